@@ -1,0 +1,237 @@
+/*
+ * tfrs_hip.h -- C ABI of libtfrs_hip.so, the MI355X (gfx950) implementation of the
+ * tensorflow/recommenders retrieval hot path.
+ *
+ * The reference's boundary for this path is a Python class API (Keras layers), not
+ * an FFI; each entry point below names the reference method whose arithmetic it
+ * replaces (paths relative to tensorflow_recommenders/).  The Python host classes in
+ * recommenders_amd/ bind these with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _h;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); calls only
+ *     enqueue work, they never synchronise the device or allocate in launch paths:
+ *     the caller supplies outputs and a workspace sized by the matching
+ *     *_workspace_bytes() query (index handles own their packed corpus);
+ *   - return value: 0 = OK, <0 = error (TFRS_E*); the message is available through
+ *     tfrs_last_error() (thread-local);
+ *   - float32 arithmetic throughout; candidate indices are int32 row numbers
+ *     (the reference's default identifiers are an int32 range/counter,
+ *     layers/factorized_top_k.py:380-382,544-545); identifier lookup stays on the host side;
+ *   - functions are re-entrant on distinct streams/workspaces; an index handle is
+ *     read-only while queries run.
+ *
+ * Numerics contract: a score is ONE float32 fma chain over d = 0..D-1 in increasing d
+ * starting from +0 (what v_mfma_f32_32x32x2_f32 computes); top-K order is score
+ * descending, ties to the lower row index (tf.math.top_k); results are therefore
+ * reproducible bit for bit and comparable with == against oracle/.
+ */
+#ifndef TFRS_HIP_H_
+#define TFRS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFRS_OK 0
+#define TFRS_EINVAL (-1)   /* bad argument (shape, k, alignment, NULL) */
+#define TFRS_ENOTIMPL (-2) /* valid request outside the implemented envelope */
+#define TFRS_EHIP (-3)     /* a HIP runtime call failed */
+#define TFRS_ENOMEM (-4)   /* workspace too small / allocation failed */
+#define TFRS_ESTATE (-5)   /* handle not indexed yet */
+
+#define TFRS_MAX_DIM 128 /* embedding dims above this are TFRS_ENOTIMPL for top-K */
+#define TFRS_MAX_K 1024
+
+int tfrs_version(void);
+const char *tfrs_last_error(void);
+/* Fills compute-unit count, LDS bytes per CU and the gcnArchName of device `dev`. */
+int tfrs_device_info(int dev, int *cu_count_h, int *lds_bytes_h, char *arch_h,
+                     int arch_len);
+
+/* Measurement hook (bench.py): while enabled, every launch of the fused score+filter scan
+ * kernel is bracketed by HIP events on its launch stream.  tfrs_profile_read returns the
+ * summed kernel time, the number of launches and their algorithmic flop (2*nq*rows*d) since
+ * the last read, after waiting for the recorded events. */
+int tfrs_profile_enable(int on);
+int tfrs_profile_read(double *scan_ms_h, int *launches_h, double *flop_h);
+
+/* ------------------------------------------------------------------------- *
+ * Candidate index (BruteForce.index, layers/factorized_top_k.py:540-584).
+ * The handle owns a device copy of the candidates in an MFMA/LDS-friendly packed
+ * layout (even/odd feature planes, one 16-byte pad slot per row so that
+ * ds_read_b128 of 16 consecutive rows is bank-conflict free).  Re-indexing drops
+ * and recreates the copy, as the reference does (:163-164).
+ * ------------------------------------------------------------------------- */
+typedef struct tfrs_index tfrs_index_t;
+
+int tfrs_index_create(tfrs_index_t **out_h);
+int tfrs_index_destroy(tfrs_index_t *index);
+/* Copies+packs candidates[n, d] (row-major f32).  May (re)allocate device memory. */
+int tfrs_index_set(tfrs_index_t *index, const float *candidates, int64_t n, int d,
+                   void *stream);
+/* Incremental ingestion for TopK.index_from_dataset (:179-215): reserve once, then
+ * append blocks in dataset order. */
+int tfrs_index_reserve(tfrs_index_t *index, int64_t capacity, int d, void *stream);
+int tfrs_index_append(tfrs_index_t *index, const float *block, int64_t nb, void *stream);
+int64_t tfrs_index_size(const tfrs_index_t *index);
+int tfrs_index_dim(const tfrs_index_t *index);
+/* Writes the original row-major candidates[n, d] back (checkpoint/state_dict). */
+int tfrs_index_unpack(const tfrs_index_t *index, float *candidates_out, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * BruteForce.call (layers/factorized_top_k.py:586-607; scores :320-333):
+ *   scores = q @ candidates^T ; values, indices = tf.math.top_k(scores, k)
+ * out_scores[nq, k] f32, out_idx[nq, k] i32 (row numbers; identifiers[idx] is a
+ * host-side gather, :607).  Requires k <= index size (TopKV2 raises otherwise).
+ * The [nq, n] score matrix is never materialised.
+ * ------------------------------------------------------------------------- */
+size_t tfrs_bruteforce_topk_workspace_bytes(int64_t nq, int64_t n, int d, int k);
+int tfrs_bruteforce_topk(const tfrs_index_t *index, const float *queries, int64_t nq,
+                         int k, float *out_scores, int32_t *out_idx, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Streaming.call (layers/factorized_top_k.py:404-509): one candidate block.
+ * Replaces top_scores (:424-438) + the reduce step top_k (:440-472) for the block
+ * cand_block[nb, d], whose rows carry the global row numbers base_row..base_row+nb-1
+ * (enumerate_rows :474-480).  The running state is state_scores/state_idx[nq, k]
+ * with state_len valid, sorted entries per row; it is updated in place and the new
+ * length min(k, state_len + nb) is returned through *new_len_h
+ * (handle_incomplete_batches=True semantics, :431-434,:465-468).
+ * ------------------------------------------------------------------------- */
+size_t tfrs_streaming_topk_workspace_bytes(int64_t nq, int64_t nb, int d, int k);
+int tfrs_streaming_topk_update(const float *queries, int64_t nq, int d,
+                               const float *cand_block, int64_t nb, int64_t base_row,
+                               int k, float *state_scores, int32_t *state_idx,
+                               int32_t state_len, int32_t *new_len_h, void *workspace,
+                               size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Merge of partial top-K lists (the multi-GPU exchange step and the general form of
+ * the Streaming reduce, :459-472): parts are scores[nparts, nq, k_in] /
+ * idx[nparts, nq, k_in] (each sorted or not), result out[nq, k_out] under
+ * (score desc, idx asc).  k_out <= nparts * k_in.
+ * ------------------------------------------------------------------------- */
+size_t tfrs_topk_merge_workspace_bytes(int64_t nq, int nparts, int k_in, int k_out);
+int tfrs_topk_merge(const float *scores_parts, const int32_t *idx_parts, int nparts,
+                    int64_t nq, int k_in, int k_out, float *out_scores,
+                    int32_t *out_idx, void *workspace, size_t workspace_bytes,
+                    void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * _exclude (layers/factorized_top_k.py:83-115) on int32 identifiers:
+ *   isin = any(ids[:, :, None] == exclude[:, None, :]); adjusted = scores - 1e5*isin;
+ *   top_k(adjusted, min(k, kin)); gather ORIGINAL scores and ids.
+ * scores/ids[nq, kin], exclude[nq, ne] -> out_scores/out_ids[nq, kout=min(k,kin)].
+ * ------------------------------------------------------------------------- */
+int tfrs_topk_exclude(const float *scores, const int32_t *ids, int64_t nq, int kin,
+                      const int32_t *exclude, int ne, int k, float *out_scores,
+                      int32_t *out_ids, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * FactorizedTopK.update_state, score-based branch
+ * (metrics/factorized_top_k.py:133-134,181-192):
+ *   pos = sum_d q*c (same fma chain as the scores);
+ *   hit[b, j] = in_top_k(target 0, concat([pos, topk]), ks[j])
+ *             = (#{topk[b, :] > pos[b]} < ks[j]) && isfinite(pos[b]).
+ * out_hits[nks, nq] f32 (0/1).  ks_h is a HOST array.
+ * ------------------------------------------------------------------------- */
+int tfrs_rank_of_positive(const float *queries, const float *true_candidates,
+                          int64_t nq, int d, const float *topk_scores, int kmax,
+                          const int32_t *ks_h, int nks, float *out_hits, void *stream);
+/* id-based branch (:141-180): hit = any(ids[b, :ks[j]] == true_id[b]). */
+int tfrs_id_match_topk(const int32_t *retrieved_ids, const int32_t *true_ids,
+                       int64_t nq, int kmax, const int32_t *ks_h, int nks,
+                       float *out_hits, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Embedding lookup (tf.keras.layers.Embedding as called at README.md:62-66,77-78;
+ * TPUEmbedding CPU branch layers/embedding/tpu_embedding_layer.py:913-919).
+ * ids are int32 or int64 (ids_are_i64).  Out-of-range ids set *err_flag (device
+ * int32, may be NULL) and produce a zero row.
+ * ------------------------------------------------------------------------- */
+int tfrs_embedding_gather_fwd(const float *table, int64_t vocab, int d, const void *ids,
+                              int ids_are_i64, int64_t n, float *out, int32_t *err_flag,
+                              void *stream);
+/* combiner: 0 = sum, 1 = mean, 2 = sqrtn.  CSR segments row_splits[nrows + 1] (i32/i64
+ * like ids); weights may be NULL.  out[nrows, d]. */
+int tfrs_embedding_segment_reduce_fwd(const float *table, int64_t vocab, int d,
+                                      const void *ids, const void *row_splits,
+                                      int ids_are_i64, const float *weights,
+                                      int64_t nrows, int combiner, float *out,
+                                      int32_t *err_flag, void *stream);
+/* Backward of gather: deterministic, atomics-free scatter-add.  `perm`/`sorted_ids`
+ * are caller-provided sort results (ids sorted ascending, perm = source positions).
+ * Produces the dense grad_table[vocab, d] rows for the touched ids only (other rows
+ * untouched) -- or, when adagrad != 0, applies the fused row-wise Adagrad update
+ * (models/base.py:77-78 with Adagrad, README.md:84):
+ *   g = sum of duplicate grads; acc += g*g; row -= lr * g / sqrt(acc + eps). */
+int tfrs_embedding_scatter_add_bwd(const float *grad_out, const int64_t *sorted_ids,
+                                   const int64_t *perm, int64_t n, int d,
+                                   float *grad_table_or_table, float *accum, float lr,
+                                   float eps, int adagrad, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Retrieval.call loss (tasks/retrieval.py:172-210, layers/loss.py:114-158):
+ * in-batch sampled softmax without materialising the [nq, nc] logits.
+ *   S = q c^T [/ temperature] [- log clip(p_c, 1e-6, 1)]
+ *       [+ MIN_FLOAT where cand_ids[c] == cand_ids[b], c != b] [MIN_FLOAT where !mask]
+ *   loss = sum_b w_b * (logsumexp_c S_bc - S_bb)
+ * out_loss: device float; out_lse[nq], out_pos[nq] saved for backward.  Optional
+ * inputs may be NULL (sample_weight, log_q_correction = log clip(p), cand_ids, mask).
+ * Requires nc >= nq (labels = eye(nq, nc)) and d <= 128.  Forward and backward share one
+ * workspace size query.
+ * ------------------------------------------------------------------------- */
+size_t tfrs_inbatch_softmax_workspace_bytes(int64_t nq, int64_t nc, int d);
+int tfrs_inbatch_softmax_ce_fwd(const float *q, const float *c, int64_t nq, int64_t nc,
+                                int d, const float *sample_weight, float inv_temperature,
+                                const float *log_q_correction, const int64_t *cand_ids,
+                                const uint8_t *score_mask, float *out_loss,
+                                float *out_lse, float *out_pos, void *workspace,
+                                size_t workspace_bytes, void *stream);
+/* dq[nq, d], dc[nc, d] for upstream scalar gradient `gloss` (device float, NULL = 1). */
+int tfrs_inbatch_softmax_ce_bwd(const float *q, const float *c, int64_t nq, int64_t nc,
+                                int d, const float *sample_weight, float inv_temperature,
+                                const float *log_q_correction, const int64_t *cand_ids,
+                                const uint8_t *score_mask, const float *lse,
+                                const float *gloss, float *dq, float *dc, void *workspace,
+                                size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Cross.call (layers/feature_interaction/dcn.py:151-186), full rank, linear
+ * preactivation:  y = x0 * (x @ kernel + bias + diag_scale * x) + x
+ * kernel[d, d] is Keras Dense layout [in, out]; bias may be NULL.
+ * ------------------------------------------------------------------------- */
+int tfrs_cross_fwd(const float *x0, const float *x, const float *kernel,
+                   const float *bias, float diag_scale, int64_t batch, int d, float *y,
+                   void *stream);
+/* Low-rank form (dcn.py:131-148, multi_layer_dcn.py:147-153): a[batch, ka] = x @ U is
+ * computed first (tfrs_dense_fwd); this call does  y = x0 * (a @ kernel[ka, d] + bias +
+ * diag_scale * x) + x  with the same fused epilogue. */
+int tfrs_cross_fwd_ex(const float *x0, const float *x, const float *a, int ka,
+                      const float *kernel, const float *bias, float diag_scale,
+                      int64_t batch, int d, float *y, void *stream);
+/* z = x @ kernel (+bias) only (used for low-rank U/V and activations): out[batch, dout]. */
+int tfrs_dense_fwd(const float *x, const float *kernel, const float *bias, int64_t batch,
+                   int din, int dout, float *out, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * DotInteraction.call (layers/feature_interaction/dot_interaction.py:53-104):
+ * x[batch, f, d] -> lower-triangle pairwise dots, row-major; self_interaction adds the
+ * diagonal; skip_gather emits the full f*f matrix with the upper part zeroed.
+ * ------------------------------------------------------------------------- */
+int tfrs_dot_interaction_fwd(const float *x, int64_t batch, int f, int d,
+                             int self_interaction, int skip_gather, float *out,
+                             void *stream);
+int tfrs_dot_interaction_bwd(const float *x, const float *dout, int64_t batch, int f,
+                             int d, int self_interaction, int skip_gather, float *dx,
+                             void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFRS_HIP_H_ */

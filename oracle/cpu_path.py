@@ -1,0 +1,51 @@
+"""CPU reference path for timing (test infrastructure only; used by bench.py's
+``cpu_baseline`` leg).
+
+TensorFlow cannot be installed here, so the "reference CPU path" is this restatement of
+``BruteForce.call`` (``layers/factorized_top_k.py:586-607``) executed with torch-CPU:
+oneDNN/MKL ``sgemm`` for ``tf.matmul`` (:333/:603) and ``torch.topk`` for
+``tf.math.top_k`` (:605) -- the same class of multithreaded kernels TF-CPU dispatches
+to.  Queries are processed in blocks so the ``[block, N]`` score matrix fits in RAM.
+Labelled "CPU reference restatement (not TensorFlow)" wherever it is reported.
+"""
+
+import time
+from typing import Tuple
+
+import numpy as np
+import torch
+
+
+def brute_force_topk(queries: np.ndarray, candidates: np.ndarray, k: int,
+                     block: int = 256) -> Tuple[np.ndarray, np.ndarray]:
+  q = torch.from_numpy(np.ascontiguousarray(queries, dtype=np.float32))
+  c = torch.from_numpy(np.ascontiguousarray(candidates, dtype=np.float32))
+  vals, idx = [], []
+  with torch.no_grad():
+    for lo in range(0, q.shape[0], block):
+      s = q[lo:lo + block] @ c.t()            # :603 (scores :333)
+      v, i = torch.topk(s, k, dim=1)          # :605
+      vals.append(v)
+      idx.append(i)
+  return torch.cat(vals).numpy(), torch.cat(idx).numpy()
+
+
+def time_brute_force(candidates: np.ndarray, queries: np.ndarray, k: int,
+                     budget_s: float = 15.0, block: int = 256) -> dict:
+  """Times the CPU path on as many query blocks as fit in ``budget_s`` seconds (at
+  least one block after one warm-up block); returns queries/s and what was sampled."""
+  q = torch.from_numpy(np.ascontiguousarray(queries, dtype=np.float32))
+  c = torch.from_numpy(np.ascontiguousarray(candidates, dtype=np.float32))
+  ct = c.t()
+  with torch.no_grad():
+    torch.topk(q[:block] @ ct, k, dim=1)      # warm-up (thread pool, page faults)
+    done, t0 = 0, time.perf_counter()
+    while True:
+      lo = done % max(q.shape[0] - block + 1, 1)
+      torch.topk(q[lo:lo + block] @ ct, k, dim=1)
+      done += min(block, q.shape[0])
+      dt = time.perf_counter() - t0
+      if dt >= budget_s or done >= 16 * block:
+        break
+  return {"value": done / dt, "seconds": dt, "queries": done,
+          "threads": torch.get_num_threads()}

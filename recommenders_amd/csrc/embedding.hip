@@ -1,0 +1,281 @@
+// embedding.hip -- embedding row gather, segment (combiner) reduce, and the
+// deterministic scatter-add backward with optional fused row-wise Adagrad.
+//
+// Replaces tf.gather behind tf.keras.layers.Embedding (README.md:62-66,77-78), the
+// combiner lookup of the TPUEmbedding CPU branch
+// (layers/embedding/tpu_embedding_layer.py:913-919) and the IndexedSlices gradient +
+// optimizer.apply_gradients of tfrs.Model.train_step (models/base.py:77-78).
+//
+// All three are HBM-bound byte movers.  Layout rule: a table row is read/written as
+// 16-byte pieces by D/4 consecutive lanes, so a wave touches 64/(D/4) whole rows per
+// instruction (full 128..512-byte lines), with several independent row loads in flight
+// per lane to cover the ~2 us random-HBM latency.  Algorithmic bytes per gathered row:
+// D*4 read + D*4 written + the id.
+#include "common.h"
+
+namespace tfrs {
+
+template <typename IdT>
+__device__ __forceinline__ int64_t load_id(const void *ids, int64_t i) {
+  return (int64_t) reinterpret_cast<const IdT *>(ids)[i];
+}
+
+// ---- dense gather ---------------------------------------------------------------------
+// VEC = 4: d % 4 == 0 (16-byte pieces); VEC = 1: any d.
+template <typename IdT, int VEC>
+__global__ void __launch_bounds__(256) gather_kernel(const float *__restrict__ table,
+                                                     int64_t vocab, int d,
+                                                     const void *__restrict__ ids, int64_t n,
+                                                     float *__restrict__ out,
+                                                     int32_t *err_flag) {
+  const int per_row = d / VEC;
+  const int64_t total = n * per_row;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  constexpr int UNROLL = 4;
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; t + (UNROLL - 1) * stride < total; t += UNROLL * stride) {
+    int64_t src[UNROLL];
+    bool ok[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t e = t + u * stride;
+      const int64_t row = e / per_row;
+      const int c = (int)(e - row * per_row);
+      const int64_t id = load_id<IdT>(ids, row);
+      ok[u] = (id >= 0 && id < vocab);
+      src[u] = (ok[u] ? id : 0) * per_row + c;
+    }
+    if (VEC == 4) {
+      float4 v[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) v[u] = reinterpret_cast<const float4 *>(table)[src[u]];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        if (!ok[u]) {
+          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (err_flag) *err_flag = 1;
+        }
+        reinterpret_cast<float4 *>(out)[t + u * stride] = v[u];
+      }
+    } else {
+      float v[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) v[u] = table[src[u]];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        if (!ok[u]) {
+          v[u] = 0.f;
+          if (err_flag) *err_flag = 1;
+        }
+        out[t + u * stride] = v[u];
+      }
+    }
+  }
+  for (; t < total; t += stride) {
+    const int64_t row = t / per_row;
+    const int c = (int)(t - row * per_row);
+    const int64_t id = load_id<IdT>(ids, row);
+    const bool ok = (id >= 0 && id < vocab);
+    if (!ok && err_flag) *err_flag = 1;
+    if (VEC == 4) {
+      float4 v = ok ? reinterpret_cast<const float4 *>(table)[id * per_row + c]
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      reinterpret_cast<float4 *>(out)[t] = v;
+    } else {
+      out[t] = ok ? table[id * per_row + c] : 0.f;
+    }
+  }
+}
+
+// ---- segment reduce (sum / mean / sqrtn combiner) -------------------------------------
+// One group of `per_row` lanes per output row; the group walks the row's id segment in
+// order (so the float32 sum order is the id order, like the oracle).
+template <typename IdT, int VEC>
+__global__ void __launch_bounds__(256) segment_reduce_kernel(
+    const float *__restrict__ table, int64_t vocab, int d, const void *__restrict__ ids,
+    const void *__restrict__ row_splits, const float *__restrict__ weights, int64_t nrows,
+    int combiner, float *__restrict__ out, int32_t *err_flag) {
+  const int per_row = d / VEC;
+  const int64_t total = nrows * per_row;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = t / per_row;
+    const int c = (int)(t - row * per_row);
+    const int64_t lo = load_id<IdT>(row_splits, row), hi = load_id<IdT>(row_splits, row + 1);
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    float wsum = 0.f, wsq = 0.f;
+    for (int64_t p = lo; p < hi; ++p) {
+      const int64_t id = load_id<IdT>(ids, p);
+      const float w = weights ? weights[p] : 1.0f;
+      wsum += w;
+      wsq = __builtin_fmaf(w, w, wsq);
+      if (id < 0 || id >= vocab) {
+        if (err_flag) *err_flag = 1;
+        continue;
+      }
+      if (VEC == 4) {
+        const float4 e = reinterpret_cast<const float4 *>(table)[id * per_row + c];
+        acc[0] += w * e.x;
+        acc[1 % VEC] += w * e.y;
+        acc[2 % VEC] += w * e.z;
+        acc[3 % VEC] += w * e.w;
+      } else {
+        acc[0] += w * table[id * per_row + c];
+      }
+    }
+    float scale = 1.0f;
+    if (hi > lo) {
+      if (combiner == 1) scale = 1.0f / wsum;
+      if (combiner == 2) scale = 1.0f / sqrtf(wsq);
+    }
+    if (VEC == 4) {
+      float4 o;
+      if (combiner == 0) {
+        o = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
+      } else {  // divide (not multiply by the reciprocal) to match acc / sum(w)
+        const float den = (hi > lo) ? (combiner == 1 ? wsum : sqrtf(wsq)) : 1.0f;
+        o = make_float4(acc[0] / den, acc[1 % VEC] / den, acc[2 % VEC] / den, acc[3 % VEC] / den);
+      }
+      reinterpret_cast<float4 *>(out)[t] = o;
+    } else {
+      const float den = (hi > lo && combiner != 0) ? (combiner == 1 ? wsum : sqrtf(wsq)) : 1.0f;
+      out[t] = acc[0] / den;
+    }
+    (void)scale;
+  }
+}
+
+// ---- scatter-add backward (+ fused Adagrad) --------------------------------------------
+// Input: ids sorted ascending (stable) with perm[i] = original position.  A lane group
+// owns every position that starts a run of equal ids and sums the run's gradient rows in
+// occurrence order: no atomics, bit-reproducible, duplicates summed BEFORE the optimizer
+// update as Keras does for IndexedSlices.
+template <int VEC>
+__global__ void __launch_bounds__(256) scatter_add_kernel(
+    const float *__restrict__ grad_out, const int64_t *__restrict__ sorted_ids,
+    const int64_t *__restrict__ perm, int64_t n, int d, float *__restrict__ dst,
+    float *__restrict__ accum, float lr, float eps, int adagrad) {
+  const int per_row = d / VEC;
+  const int64_t total = n * per_row;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / per_row;
+    const int c = (int)(t - i * per_row);
+    const int64_t id = sorted_ids[i];
+    if (i > 0 && sorted_ids[i - 1] == id) continue;  // not the start of a run
+    float g[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) g[v] = 0.f;
+    for (int64_t p = i; p < n && sorted_ids[p] == id; ++p) {
+      const int64_t src = perm[p];
+      if (VEC == 4) {
+        const float4 e = reinterpret_cast<const float4 *>(grad_out)[src * per_row + c];
+        g[0] += e.x;
+        g[1 % VEC] += e.y;
+        g[2 % VEC] += e.z;
+        g[3 % VEC] += e.w;
+      } else {
+        g[0] += grad_out[src * per_row + c];
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const int64_t o = (id * per_row + c) * VEC + v;
+      if (adagrad) {
+        const float a = accum[o] + g[v] * g[v];
+        accum[o] = a;
+        dst[o] = dst[o] - lr * g[v] / sqrtf(a + eps);
+      } else {
+        dst[o] = g[v];
+      }
+    }
+  }
+}
+
+static unsigned grid_for(int64_t total_threads) {
+  int64_t blocks = (total_threads + 255) / 256;
+  const int64_t cap = 256 * 8;  // 8 workgroups per CU, grid-stride beyond
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+}  // namespace tfrs
+
+using namespace tfrs;
+
+extern "C" int tfrs_embedding_gather_fwd(const float *table, int64_t vocab, int d,
+                                         const void *ids, int ids_are_i64, int64_t n,
+                                         float *out, int32_t *err_flag, void *stream) {
+  TFRS_CHECK_ARG(vocab >= 1 && d >= 1 && n >= 0, "embedding_gather: bad shape");
+  if (n == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(table && ids && out, "embedding_gather: NULL pointer");
+  const bool vec = (d % 4 == 0) && (((uintptr_t)table | (uintptr_t)out) % 16 == 0);
+  const int64_t total = n * (vec ? d / 4 : d);
+  const dim3 grid(grid_for((total + 3) / 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (ids_are_i64) {
+    if (vec)
+      hipLaunchKernelGGL((gather_kernel<int64_t, 4>), grid, block, 0, s, table, vocab, d, ids, n, out, err_flag);
+    else
+      hipLaunchKernelGGL((gather_kernel<int64_t, 1>), grid, block, 0, s, table, vocab, d, ids, n, out, err_flag);
+  } else {
+    if (vec)
+      hipLaunchKernelGGL((gather_kernel<int32_t, 4>), grid, block, 0, s, table, vocab, d, ids, n, out, err_flag);
+    else
+      hipLaunchKernelGGL((gather_kernel<int32_t, 1>), grid, block, 0, s, table, vocab, d, ids, n, out, err_flag);
+  }
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+extern "C" int tfrs_embedding_segment_reduce_fwd(const float *table, int64_t vocab, int d,
+                                                 const void *ids, const void *row_splits,
+                                                 int ids_are_i64, const float *weights,
+                                                 int64_t nrows, int combiner, float *out,
+                                                 int32_t *err_flag, void *stream) {
+  TFRS_CHECK_ARG(vocab >= 1 && d >= 1 && nrows >= 0, "embedding_segment_reduce: bad shape");
+  TFRS_CHECK_ARG(combiner >= 0 && combiner <= 2,
+                 "embedding_segment_reduce: combiner must be 0 (sum), 1 (mean) or 2 (sqrtn)");
+  if (nrows == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(table && row_splits && out, "embedding_segment_reduce: NULL pointer");
+  const bool vec = (d % 4 == 0) && (((uintptr_t)table | (uintptr_t)out) % 16 == 0);
+  const int64_t total = nrows * (vec ? d / 4 : d);
+  const dim3 grid(grid_for(total)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (ids_are_i64) {
+    if (vec)
+      hipLaunchKernelGGL((segment_reduce_kernel<int64_t, 4>), grid, block, 0, s, table, vocab, d, ids, row_splits, weights, nrows, combiner, out, err_flag);
+    else
+      hipLaunchKernelGGL((segment_reduce_kernel<int64_t, 1>), grid, block, 0, s, table, vocab, d, ids, row_splits, weights, nrows, combiner, out, err_flag);
+  } else {
+    if (vec)
+      hipLaunchKernelGGL((segment_reduce_kernel<int32_t, 4>), grid, block, 0, s, table, vocab, d, ids, row_splits, weights, nrows, combiner, out, err_flag);
+    else
+      hipLaunchKernelGGL((segment_reduce_kernel<int32_t, 1>), grid, block, 0, s, table, vocab, d, ids, row_splits, weights, nrows, combiner, out, err_flag);
+  }
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+extern "C" int tfrs_embedding_scatter_add_bwd(const float *grad_out, const int64_t *sorted_ids,
+                                              const int64_t *perm, int64_t n, int d,
+                                              float *grad_table_or_table, float *accum,
+                                              float lr, float eps, int adagrad, void *stream) {
+  TFRS_CHECK_ARG(n >= 0 && d >= 1, "embedding_scatter_add: bad shape");
+  if (n == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(grad_out && sorted_ids && perm && grad_table_or_table,
+                 "embedding_scatter_add: NULL pointer");
+  TFRS_CHECK_ARG(!adagrad || accum, "embedding_scatter_add: Adagrad needs an accumulator");
+  const bool vec = (d % 4 == 0) && (((uintptr_t)grad_out) % 16 == 0);
+  const int64_t total = n * (vec ? d / 4 : d);
+  const dim3 grid(grid_for(total)), block(256);
+  if (vec)
+    hipLaunchKernelGGL((scatter_add_kernel<4>), grid, block, 0, (hipStream_t)stream, grad_out, sorted_ids, perm, n, d, grad_table_or_table, accum, lr, eps, adagrad);
+  else
+    hipLaunchKernelGGL((scatter_add_kernel<1>), grid, block, 0, (hipStream_t)stream, grad_out, sorted_ids, perm, n, d, grad_table_or_table, accum, lr, eps, adagrad);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}

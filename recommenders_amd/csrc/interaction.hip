@@ -1,0 +1,355 @@
+// interaction.hip -- feature-interaction layers: DCN Cross and DLRM DotInteraction.
+//
+// Cross.call (layers/feature_interaction/dcn.py:151-186):
+//     y = x0 * (x @ kernel + bias + diag_scale * x) + x
+//   one LDS-tiled f32-MFMA GEMM (Keras Dense kernel layout [in, out]) with the whole
+//   cross formula fused into the epilogue: the [B, d] product is never written to HBM, so
+//   the layer moves 3*B*d*4 + d*d*4 bytes instead of the reference's GEMM + three
+//   elementwise passes.  MFMA-bound for the DCN-v2 shapes (2*B*d*d flop).
+//   The same GEMM with a bias-only epilogue is exported as tfrs_dense_fwd (low-rank U/V
+//   projections, MultiLayerDCN multi_layer_dcn.py:147-153).
+//
+// DotInteraction.call (layers/feature_interaction/dot_interaction.py:53-104):
+//   per sample X[F, D] -> lower triangle of X X^T in row-major order (or the full F*F with
+//   the upper part zeroed for skip_gather).  One wave per sample, X staged in LDS, pairs
+//   spread over lanes; the output is written exactly once, coalesced (HBM-bound target:
+//   B*F*D*4 read + B*out_dim*4 written, vs 4-5x that for the reference's
+//   ones_like/band_part/boolean_mask temporaries).
+#include <algorithm>
+
+#include "mfma_tile.h"
+
+namespace tfrs {
+
+// ------------------------------------------------------------------------------------------
+// GEMM  C[M, N] = A[M, K] @ B[K, N]  (+ epilogue), all row-major f32.
+// Block tile 128 x 128 x 16, 4 waves (2 x 2), each wave 64 x 64 = 2 x 2 MFMA 32x32 tiles.
+// k order inside a 16-wide K step is the "half split" (lane half h owns k in [8h, 8h+8)),
+// so a lane's A fragment is 8 contiguous floats of an LDS row (two ds_read_b128).
+// ------------------------------------------------------------------------------------------
+constexpr int kBM = 128, kBN = 128, kBK = 16;
+constexpr int kLdA = kBK + 4;   // 20 floats = 5 x 16 B: odd number of 16-B slots per row
+constexpr int kLdB = kBN + 4;   // row of B tile
+
+enum { kEpiBias = 0, kEpiCross = 1 };
+
+struct GemmArgs {
+  const float *a, *b;
+  int64_t m;
+  int n, k;
+  const float *bias;  // [n] or NULL
+  // cross epilogue
+  const float *x0;    // [m, n]
+  const float *x;     // [m, n] (== a, n == k)
+  float diag;
+  float *out;         // [m, n]
+};
+
+template <int EPI>
+__global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float as[2][kBM * kLdA];
+  __shared__ __attribute__((aligned(16))) float bs[2][kBK * kLdB];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;  // wave position in the 2 x 2 grid
+  const int j = lane & 31, h = lane >> 5;
+
+  // block coordinates; consecutive blocks share the same A rows (x) for L2 reuse
+  const int nbn = (g.n + kBN - 1) / kBN;
+  const int64_t bm = (int64_t)(blockIdx.x / nbn) * kBM;
+  const int bn = (int)(blockIdx.x % nbn) * kBN;
+
+  const bool a_vec = (g.k % 4 == 0) && (((uintptr_t)g.a) % 16 == 0);
+  const bool b_vec = (g.n % 4 == 0) && (((uintptr_t)g.b) % 16 == 0);
+
+  // staging: A tile 128 x 16 = 512 float4 -> 2 per thread; B tile 16 x 128 = 512 float4 -> 2
+  f32x4 sa[2], sb[2];
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * 256;      // 0..511
+      const int ar = e >> 2, ac = (e & 3) * 4;          // A: row 0..127, col 0,4,8,12
+      const int64_t gr = bm + ar;
+      const int gk = k0 + ac;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gr < g.m) {
+        if (a_vec && gk + 3 < g.k) {
+          v = *reinterpret_cast<const f32x4 *>(g.a + gr * g.k + gk);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (gk + t < g.k) v[t] = g.a[gr * g.k + gk + t];
+        }
+      }
+      sa[i] = v;
+      const int br = e >> 5, bc = (e & 31) * 4;         // B: row 0..15, col 0..124
+      const int gkb = k0 + br;
+      const int gn = bn + bc;
+      f32x4 u = {0.f, 0.f, 0.f, 0.f};
+      if (gkb < g.k) {
+        if (b_vec && gn + 3 < g.n) {
+          u = *reinterpret_cast<const f32x4 *>(g.b + (int64_t)gkb * g.n + gn);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (gn + t < g.n) u[t] = g.b[(int64_t)gkb * g.n + gn + t];
+        }
+      }
+      sb[i] = u;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * 256;
+      const int ar = e >> 2, ac = (e & 3) * 4;
+      *reinterpret_cast<f32x4 *>(&as[buf][ar * kLdA + ac]) = sa[i];
+      const int br = e >> 5, bc = (e & 31) * 4;
+      *reinterpret_cast<f32x4 *>(&bs[buf][br * kLdB + bc]) = sb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
+
+  const int nk = (g.k + kBK - 1) / kBK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tiles((kt + 1) * kBK);
+
+    // fragments: A rows (wm*64 + i*32 + j), k = 8h .. 8h+7; B cols (wn*64 + jn*32 + j)
+    f32x4 af[2][2];
+    float bf[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float *ap = &as[cur][(wm * 64 + i * 32 + j) * kLdA + 8 * h];
+      af[i][0] = *reinterpret_cast<const f32x4 *>(ap);
+      af[i][1] = *reinterpret_cast<const f32x4 *>(ap + 4);
+    }
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) bf[jn][s] = bs[cur][(8 * h + s) * kLdB + wn * 64 + jn * 32 + j];
+
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s >> 2][s & 3], bf[jn][s],
+                                                            acc[i][jn], 0, 0, 0);
+
+    if (kt + 1 < nk) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: acc[i][jn][r] = C[row = bm + wm*64 + i*32 + tile_row_of_reg(r, h)][col = bn + wn*64 + jn*32 + j]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+      const int col = bn + wn * 64 + jn * 32 + j;
+      if (col >= g.n) continue;
+      const float bias = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = bm + wm * 64 + i * 32 + tile_row_of_reg(r, h);
+        if (row >= g.m) continue;
+        float v = acc[i][jn][r] + bias;
+        const int64_t o = row * g.n + col;
+        if (EPI == kEpiCross) {
+          const float xv = g.x[o];
+          v = g.x0[o] * (v + g.diag * xv) + xv;
+        }
+        g.out[o] = v;
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// DotInteraction
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pair_of_index(int p, bool self, int *pi, int *pj) {
+  // row-major lower triangle: rows i = 0.., columns j <= i (self) or j < i.
+  // self:  p = i(i+1)/2 + j ;  no self: p = i(i-1)/2 + j
+  int i = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+  while ((i + 1) * (i + 2) / 2 <= p) ++i;   // fix float rounding
+  while (i * (i + 1) / 2 > p) --i;
+  const int j = p - i * (i + 1) / 2;
+  if (self) {
+    *pi = i;
+    *pj = j;
+  } else {
+    *pi = i + 1;
+    *pj = j;
+  }
+}
+
+__global__ void __launch_bounds__(256) dot_interaction_fwd_kernel(const float *__restrict__ x,
+                                                                  int64_t batch, int f, int d,
+                                                                  int self, int skip_gather,
+                                                                  float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+  if (b >= batch) return;
+  const int ld = d + 1;  // odd-ish stride: lanes read different rows at the same column
+  float *xs = smem_f + (size_t)wave * f * ld;
+  const float *xb = x + b * (int64_t)f * d;
+  for (int e = lane; e < f * d; e += 64) xs[(e / d) * ld + (e % d)] = xb[e];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  if (skip_gather) {
+    float *ob = out + b * (int64_t)f * f;
+    for (int p = lane; p < f * f; p += 64) {
+      const int i = p / f, jx = p - i * f;
+      float acc = 0.0f;
+      if (jx < i || (self && jx == i)) {
+        for (int k = 0; k < d; ++k) acc = __builtin_fmaf(xs[i * ld + k], xs[jx * ld + k], acc);
+      }
+      ob[p] = acc;
+    }
+  } else {
+    const int npairs = self ? f * (f + 1) / 2 : f * (f - 1) / 2;
+    float *ob = out + b * (int64_t)npairs;
+    for (int p = lane; p < npairs; p += 64) {
+      int i, jx;
+      pair_of_index(p, self != 0, &i, &jx);
+      float acc = 0.0f;
+      for (int k = 0; k < d; ++k) acc = __builtin_fmaf(xs[i * ld + k], xs[jx * ld + k], acc);
+      ob[p] = acc;
+    }
+  }
+}
+
+// dX[i] = sum_{j != i} dY[pair(i, j)] X[j]  (+ 2 dY[i, i] X[i] with self interaction)
+__global__ void __launch_bounds__(256) dot_interaction_bwd_kernel(
+    const float *__restrict__ x, const float *__restrict__ dout, int64_t batch, int f, int d,
+    int self, int skip_gather, float *__restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+  if (b >= batch) return;
+  float *xs = smem_f + (size_t)wave * f * d;
+  const float *xb = x + b * (int64_t)f * d;
+  for (int e = lane; e < f * d; e += 64) xs[e] = xb[e];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int npairs = self ? f * (f + 1) / 2 : f * (f - 1) / 2;
+  const float *dy = dout + b * (int64_t)(skip_gather ? f * f : npairs);
+  // one (feature row i, column k) element per lane-iteration; xs[j][k] reads are
+  // conflict-free across consecutive k
+  for (int e = lane; e < f * d; e += 64) {
+    const int i = e / d, k = e - i * d;
+    float acc = 0.0f;
+    for (int jx = 0; jx < f; ++jx) {
+      if (jx == i && !self) continue;
+      const int hi = jx > i ? jx : i, lo = jx > i ? i : jx;
+      float gy;
+      if (skip_gather) {
+        gy = dy[hi * f + lo];
+      } else {
+        gy = self ? dy[hi * (hi + 1) / 2 + lo] : dy[hi * (hi - 1) / 2 + lo];
+      }
+      if (jx == i) gy *= 2.0f;
+      acc = __builtin_fmaf(gy, xs[jx * d + k], acc);
+    }
+    dx[b * (int64_t)f * d + e] = acc;
+  }
+}
+
+}  // namespace tfrs
+
+using namespace tfrs;
+
+static int launch_gemm(const GemmArgs &g, int epi, hipStream_t s) {
+  const int64_t nbm = (g.m + kBM - 1) / kBM;
+  const int nbn = (g.n + kBN - 1) / kBN;
+  const dim3 grid((unsigned)(nbm * nbn));
+  if (epi == kEpiCross)
+    hipLaunchKernelGGL((gemm_kernel<kEpiCross>), grid, dim3(256), 0, s, g);
+  else
+    hipLaunchKernelGGL((gemm_kernel<kEpiBias>), grid, dim3(256), 0, s, g);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+extern "C" int tfrs_cross_fwd_ex(const float *x0, const float *x, const float *a, int ka,
+                                 const float *kernel, const float *bias, float diag_scale,
+                                 int64_t batch, int d, float *y, void *stream) {
+  TFRS_CHECK_ARG(batch >= 0 && d >= 1 && ka >= 1, "cross_fwd: bad shape");
+  TFRS_CHECK_ARG(diag_scale >= 0.0f, "`diag_scale` should be non-negative. Got `diag_scale` = %g",
+                 (double)diag_scale);
+  if (batch == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(x0 && x && a && kernel && y, "cross_fwd: NULL pointer");
+  GemmArgs g = {};
+  g.a = a; g.b = kernel; g.m = batch; g.n = d; g.k = ka;
+  g.bias = bias; g.x0 = x0; g.x = x; g.diag = diag_scale; g.out = y;
+  return launch_gemm(g, kEpiCross, (hipStream_t)stream);
+}
+
+extern "C" int tfrs_cross_fwd(const float *x0, const float *x, const float *kernel,
+                              const float *bias, float diag_scale, int64_t batch, int d,
+                              float *y, void *stream) {
+  return tfrs_cross_fwd_ex(x0, x, x, d, kernel, bias, diag_scale, batch, d, y, stream);
+}
+
+extern "C" int tfrs_dense_fwd(const float *x, const float *kernel, const float *bias,
+                              int64_t batch, int din, int dout, float *out, void *stream) {
+  TFRS_CHECK_ARG(batch >= 0 && din >= 1 && dout >= 1, "dense_fwd: bad shape");
+  if (batch == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(x && kernel && out, "dense_fwd: NULL pointer");
+  GemmArgs g = {};
+  g.a = x; g.b = kernel; g.m = batch; g.n = dout; g.k = din;
+  g.bias = bias; g.out = out;
+  return launch_gemm(g, kEpiBias, (hipStream_t)stream);
+}
+
+extern "C" int tfrs_dot_interaction_fwd(const float *x, int64_t batch, int f, int d,
+                                        int self_interaction, int skip_gather, float *out,
+                                        void *stream) {
+  TFRS_CHECK_ARG(batch >= 0 && f >= 1 && d >= 1, "dot_interaction_fwd: bad shape");
+  if (batch == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(x && out, "dot_interaction_fwd: NULL pointer");
+  const size_t lds = (size_t)4 * f * (d + 1) * sizeof(float);
+  if (lds > 64 * 1024) {
+    set_error("dot_interaction_fwd: %d features x %d dims do not fit the LDS staging", f, d);
+    return TFRS_ENOTIMPL;
+  }
+  hipLaunchKernelGGL(dot_interaction_fwd_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), lds,
+                     (hipStream_t)stream, x, batch, f, d, self_interaction, skip_gather, out);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+extern "C" int tfrs_dot_interaction_bwd(const float *x, const float *dout, int64_t batch, int f,
+                                        int d, int self_interaction, int skip_gather, float *dx,
+                                        void *stream) {
+  TFRS_CHECK_ARG(batch >= 0 && f >= 1 && d >= 1, "dot_interaction_bwd: bad shape");
+  if (batch == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(x && dout && dx, "dot_interaction_bwd: NULL pointer");
+  const size_t lds = (size_t)4 * f * d * sizeof(float);
+  if (lds > 64 * 1024) {
+    set_error("dot_interaction_bwd: %d features x %d dims do not fit the LDS staging", f, d);
+    return TFRS_ENOTIMPL;
+  }
+  hipLaunchKernelGGL(dot_interaction_bwd_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), lds,
+                     (hipStream_t)stream, x, dout, batch, f, d, self_interaction, skip_gather, dx);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}

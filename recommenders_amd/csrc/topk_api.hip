@@ -1,0 +1,585 @@
+// topk_api.hip -- C-ABI entry points of the top-K retrieval path and the round driver.
+//
+// A query batch is answered in "rounds" over growing candidate ranges:
+//   round 0  : rows [0, n0)   scores materialised ([nq, n0], n0 ~ 4096) -> select top-K
+//              (establishes a per-query threshold = current K-th best score)
+//   round i>0: rows [lo, hi) with hi - lo ~ (rho - 1) * lo: fused MFMA scan that keeps
+//              only scores above the threshold (expected K*(rho-1) per query) -> merge
+// Every round is exact (a threshold taken from a subset is a lower bound of the final
+// K-th score), the [nq, n] matrix never exists, nothing synchronises with the host, and
+// per-query lists that overflow (adversarial candidate order) are recomputed exactly
+// inside the merge kernel.  Streaming.call blocks reuse the same driver with the
+// carried-in state as round "-1".
+#include <stdlib.h>
+
+#include <algorithm>
+#include <new>
+
+#include "common.h"
+
+namespace tfrs {
+
+static int64_t env_i64(const char *name, int64_t dflt) {
+  const char *v = getenv(name);
+  if (!v || !*v) return dflt;
+  return atoll(v);
+}
+
+struct TopkTuning {
+  int64_t prefix;  // rows scored densely before filtering starts
+  int64_t rho;     // geometric growth of the filtered ranges
+  int64_t target_wgs;
+};
+
+static TopkTuning tuning() {
+  TopkTuning t;
+  t.prefix = std::max<int64_t>(kTileN, env_i64("TFRS_TOPK_PREFIX", 4096));
+  t.prefix = padded_rows(t.prefix);
+  t.rho = std::max<int64_t>(2, env_i64("TFRS_TOPK_RHO", 8));
+  t.target_wgs = std::max<int64_t>(1, env_i64("TFRS_TOPK_WGS", 1024));
+  return t;
+}
+
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// ---- optional per-launch timing of the scan kernel (tfrs_profile_*) ---------------------
+// HIP events recorded on the launch stream around every scan launch while enabled; read
+// back (after the caller synchronised) as total milliseconds / launches / algorithmic flop.
+struct ScanProfile {
+  bool enabled = false;
+  static constexpr int kMax = 4096;
+  hipEvent_t start[kMax], stop[kMax];
+  double flop[kMax];
+  int created = 0;
+  int used = 0;
+};
+static ScanProfile g_prof;
+
+static bool prof_begin(hipStream_t stream, double flop, int *slot) {
+  if (!g_prof.enabled || g_prof.used >= ScanProfile::kMax) return false;
+  const int i = g_prof.used;
+  if (i >= g_prof.created) {
+    if (hipEventCreate(&g_prof.start[i]) != hipSuccess) return false;
+    if (hipEventCreate(&g_prof.stop[i]) != hipSuccess) return false;
+    g_prof.created = i + 1;
+  }
+  g_prof.flop[i] = flop;
+  (void)hipEventRecord(g_prof.start[i], stream);
+  *slot = i;
+  g_prof.used = i + 1;
+  return true;
+}
+static void prof_end(hipStream_t stream, int slot) { (void)hipEventRecord(g_prof.stop[slot], stream); }
+
+static int timed_scan(const ScanArgs &sa, bool materialize, hipStream_t stream) {
+  int slot = 0;
+  const bool on = prof_begin(stream, 2.0 * (double)sa.nq * (double)(sa.c_end - sa.c_begin) * sa.d, &slot);
+  const int rc = launch_scan(sa, materialize, stream);
+  if (on) prof_end(stream, slot);
+  return rc;
+}
+
+static int64_t dense_rows(int64_t n, int k, const TopkTuning &t) {
+  const int64_t want = std::max<int64_t>(t.prefix, padded_rows(k));
+  return std::min<int64_t>(padded_rows(n), want);
+}
+
+static uint32_t list_cap(int k, const TopkTuning &t) {
+  const int64_t c = std::max<int64_t>(1024, 4 * (int64_t)k * (t.rho - 1));
+  return (uint32_t)align_up((size_t)c, 256);
+}
+
+struct RoundWs {
+  float *thr;
+  uint32_t *cnt;
+  uint32_t *overflow;
+  float *dense;
+  int64_t ld_dense;
+  uint2 *buf;
+  uint32_t cap;
+  char *end;
+};
+
+static size_t round_ws_bytes(int64_t nq, int64_t n, int k, const TopkTuning &t) {
+  size_t b = 0;
+  b += align_up((size_t)nq * 4);                           // thr
+  b += align_up((size_t)nq * 8);                           // cnt + overflow (contiguous)
+  b += align_up((size_t)nq * dense_rows(n, k, t) * 4);     // dense
+  b += align_up((size_t)nq * list_cap(k, t) * 8);          // buf
+  return b;
+}
+
+static RoundWs carve_round_ws(char *p, int64_t nq, int64_t n, int k, const TopkTuning &t) {
+  RoundWs w;
+  w.thr = reinterpret_cast<float *>(p);
+  p += align_up((size_t)nq * 4);
+  w.cnt = reinterpret_cast<uint32_t *>(p);
+  w.overflow = w.cnt + nq;
+  p += align_up((size_t)nq * 8);
+  w.ld_dense = dense_rows(n, k, t);
+  w.dense = reinterpret_cast<float *>(p);
+  p += align_up((size_t)nq * w.ld_dense * 4);
+  w.cap = list_cap(k, t);
+  w.buf = reinterpret_cast<uint2 *>(p);
+  p += align_up((size_t)nq * w.cap * 8);
+  w.end = p;
+  return w;
+}
+
+__global__ void thr_from_state_kernel(const float *state_scores, int64_t nq, int k,
+                                      float *thr) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < nq) thr[r] = state_scores[r * k + (k - 1)];
+}
+
+static void plan_splits(int64_t rows, int n_qtiles, const TopkTuning &t, int64_t *split_len,
+                        int *n_splits) {
+  const int64_t stages = (rows + kTileN - 1) / kTileN;
+  int64_t want = (t.target_wgs + n_qtiles - 1) / n_qtiles;
+  want = std::max<int64_t>(1, std::min<int64_t>(want, (stages + 3) / 4));
+  const int64_t per = (stages + want - 1) / want;
+  *split_len = per * kTileN;
+  *n_splits = (int)((stages + per - 1) / per);
+}
+
+// Answers one block of `n` packed candidate rows (global row numbers idx_base + row).
+// state_*[nq, k] holds `state_len` sorted entries drawn from `seen` earlier candidates.
+static int run_rounds(const float *q, int64_t nq, int d, const char *packed, int64_t n,
+                      int64_t idx_base, int64_t seen, int k, float *state_scores,
+                      int32_t *state_idx, int state_len, const RoundWs &w,
+                      const TopkTuning &t, hipStream_t stream, int *new_len) {
+  int len = state_len;
+  if (n <= 0 || nq <= 0) {
+    *new_len = len;
+    return TFRS_OK;
+  }
+  const int n_qtiles = (int)((nq + 255) / 256);
+  int64_t lo = 0;
+  int rc;
+
+  ScanArgs sa = {};
+  sa.q = q;
+  sa.nq = nq;
+  sa.d = d;
+  sa.packed = packed;
+  sa.n_qtiles = n_qtiles;
+  sa.thr = w.thr;
+  sa.cnt = w.cnt;
+  sa.buf = w.buf;
+  sa.cap = w.cap;
+  sa.overflow = w.overflow;
+  sa.dense = w.dense;
+  sa.ld_dense = w.ld_dense;
+
+  SelectArgs se = {};
+  se.nq = nq;
+  se.k = k;
+  se.state_scores = state_scores;
+  se.state_idx = state_idx;
+  se.q = q;
+  se.d = d;
+  se.packed = packed;
+  se.idx_base = idx_base;
+  se.out_scores = state_scores;
+  se.out_idx = state_idx;
+  se.out_thr = w.thr;
+
+  if (len < k) {
+    // dense round: every score of rows [0, n0) is a candidate
+    const int64_t n0 = std::min<int64_t>(n, w.ld_dense);
+    sa.c_begin = 0;
+    sa.c_end = n0;
+    plan_splits(n0, n_qtiles, t, &sa.split_len, &sa.n_splits);
+    if ((rc = timed_scan(sa, /*materialize=*/true, stream)) != TFRS_OK) return rc;
+    se.state_len = len;
+    se.source = kSrcDense;
+    se.dense = w.dense;
+    se.ld_dense = w.ld_dense;
+    se.n_dense = n0;
+    se.idx_base = idx_base;  // dense column e is packed row e
+    if ((rc = launch_select(se, stream)) != TFRS_OK) return rc;
+    len = (int)std::min<int64_t>(k, (int64_t)len + n0);
+    seen += n0;
+    lo = n0;
+  } else if (lo < n) {
+    hipLaunchKernelGGL(thr_from_state_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256),
+                       0, stream, state_scores, nq, k, w.thr);
+    TFRS_LAUNCH_CHECK();
+  }
+
+  while (lo < n) {  // state is full here (len == k), w.thr is current
+    int64_t span = std::max<int64_t>((t.rho - 1) * std::max<int64_t>(seen, 1), kTileN);
+    span = padded_rows(span);
+    const int64_t hi = (n - lo <= span) ? n : lo + span;
+    TFRS_HIP(hipMemsetAsync(w.cnt, 0, (size_t)nq * 8, stream));  // cnt + overflow
+    sa.c_begin = lo;
+    sa.c_end = hi;
+    plan_splits(hi - lo, n_qtiles, t, &sa.split_len, &sa.n_splits);
+    if ((rc = timed_scan(sa, /*materialize=*/false, stream)) != TFRS_OK) return rc;
+    se.state_len = len;
+    se.source = kSrcList;
+    se.buf = w.buf;
+    se.cnt = w.cnt;
+    se.cap = w.cap;
+    se.overflow = w.overflow;
+    se.rc_begin = lo;
+    se.rc_end = hi;
+    if ((rc = launch_select(se, stream)) != TFRS_OK) return rc;
+    seen += hi - lo;
+    lo = hi;
+  }
+  *new_len = len;
+  return TFRS_OK;
+}
+
+}  // namespace tfrs
+
+using namespace tfrs;
+
+extern "C" int tfrs_profile_enable(int on) {
+  g_prof.enabled = on != 0;
+  g_prof.used = 0;
+  return TFRS_OK;
+}
+
+extern "C" int tfrs_profile_read(double *scan_ms_h, int *launches_h, double *flop_h) {
+  double ms = 0.0, flop = 0.0;
+  for (int i = 0; i < g_prof.used; ++i) {
+    float t = 0.f;
+    TFRS_HIP(hipEventSynchronize(g_prof.stop[i]));
+    TFRS_HIP(hipEventElapsedTime(&t, g_prof.start[i], g_prof.stop[i]));
+    ms += t;
+    flop += g_prof.flop[i];
+  }
+  if (scan_ms_h) *scan_ms_h = ms;
+  if (launches_h) *launches_h = g_prof.used;
+  if (flop_h) *flop_h = flop;
+  g_prof.used = 0;
+  return TFRS_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// index handle
+// ----------------------------------------------------------------------------------------
+struct tfrs_index {
+  char *packed = nullptr;
+  int64_t n = 0;         // valid rows
+  int64_t capacity = 0;  // rows allocated (multiple of kTileN)
+  int d = 0;
+};
+
+extern "C" int tfrs_index_create(tfrs_index_t **out_h) {
+  TFRS_CHECK_ARG(out_h != nullptr, "index_create: NULL output");
+  *out_h = new (std::nothrow) tfrs_index();
+  if (!*out_h) {
+    set_error("index_create: out of host memory");
+    return TFRS_ENOMEM;
+  }
+  return TFRS_OK;
+}
+
+extern "C" int tfrs_index_destroy(tfrs_index_t *index) {
+  if (!index) return TFRS_OK;
+  if (index->packed) (void)hipFree(index->packed);
+  delete index;
+  return TFRS_OK;
+}
+
+extern "C" int tfrs_index_reserve(tfrs_index_t *index, int64_t capacity, int d, void *stream) {
+  TFRS_CHECK_ARG(index != nullptr, "index_reserve: NULL index");
+  TFRS_CHECK_ARG(capacity >= 0 && d >= 1, "index_reserve: bad shape [%lld, %d]",
+                 (long long)capacity, d);
+  if (d > TFRS_MAX_DIM) {
+    set_error("index: embedding dim %d > %d is not implemented", d, TFRS_MAX_DIM);
+    return TFRS_ENOTIMPL;
+  }
+  if (index->packed) {
+    TFRS_HIP(hipFree(index->packed));
+    index->packed = nullptr;
+  }
+  index->n = 0;
+  index->d = d;
+  index->capacity = padded_rows(std::max<int64_t>(capacity, 1));
+  const size_t bytes = (size_t)index->capacity * row_bytes(padded_dim(d));
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&index->packed), bytes);
+  if (e != hipSuccess) {
+    index->packed = nullptr;
+    index->capacity = 0;
+    set_error("index: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return TFRS_ENOMEM;
+  }
+  (void)stream;
+  return TFRS_OK;
+}
+
+extern "C" int tfrs_index_append(tfrs_index_t *index, const float *block, int64_t nb,
+                                 void *stream) {
+  TFRS_CHECK_ARG(index && index->packed, "index_append: reserve first");
+  TFRS_CHECK_ARG(nb >= 0 && (nb == 0 || block), "index_append: bad block");
+  TFRS_CHECK_ARG(index->n + nb <= index->capacity, "index_append: %lld + %lld rows exceed capacity %lld",
+                 (long long)index->n, (long long)nb, (long long)index->capacity);
+  // zero-fill up to the next stage boundary so whole stages can always be read
+  const int64_t zero_to = padded_rows(index->n + nb);
+  int rc = launch_pack(block, nb, index->d, index->packed, index->n, zero_to,
+                       (hipStream_t)stream);
+  if (rc != TFRS_OK) return rc;
+  index->n += nb;
+  return TFRS_OK;
+}
+
+extern "C" int tfrs_index_set(tfrs_index_t *index, const float *candidates, int64_t n, int d,
+                              void *stream) {
+  TFRS_CHECK_ARG(candidates != nullptr || n == 0, "index_set: NULL candidates");
+  int rc = tfrs_index_reserve(index, n, d, stream);
+  if (rc != TFRS_OK) return rc;
+  return tfrs_index_append(index, candidates, n, stream);
+}
+
+extern "C" int64_t tfrs_index_size(const tfrs_index_t *index) { return index ? index->n : -1; }
+extern "C" int tfrs_index_dim(const tfrs_index_t *index) { return index ? index->d : -1; }
+
+extern "C" int tfrs_index_unpack(const tfrs_index_t *index, float *out, void *stream) {
+  TFRS_CHECK_ARG(index && index->packed, "index_unpack: not indexed");
+  return launch_unpack(index->packed, index->n, index->d, out, (hipStream_t)stream);
+}
+
+// ----------------------------------------------------------------------------------------
+// BruteForce.call
+// ----------------------------------------------------------------------------------------
+extern "C" size_t tfrs_bruteforce_topk_workspace_bytes(int64_t nq, int64_t n, int d, int k) {
+  (void)d;
+  if (nq <= 0 || n <= 0 || k <= 0) return 256;
+  return round_ws_bytes(nq, n, k, tuning());
+}
+
+extern "C" int tfrs_bruteforce_topk(const tfrs_index_t *index, const float *queries,
+                                    int64_t nq, int k, float *out_scores, int32_t *out_idx,
+                                    void *workspace, size_t workspace_bytes, void *stream) {
+  if (!index || !index->packed) {
+    set_error("bruteforce_topk: the index has not been built");
+    return TFRS_ESTATE;
+  }
+  TFRS_CHECK_ARG(nq >= 0, "bruteforce_topk: nq < 0");
+  TFRS_CHECK_ARG(k >= 1 && k <= TFRS_MAX_K, "bruteforce_topk: k=%d outside [1, %d]", k,
+                 TFRS_MAX_K);
+  TFRS_CHECK_ARG((int64_t)k <= index->n,
+                 "input must have at least k columns (k=%d, candidates=%lld)", k,
+                 (long long)index->n);
+  if (nq == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(queries && out_scores && out_idx && workspace, "bruteforce_topk: NULL pointer");
+  const TopkTuning t = tuning();
+  const size_t need = round_ws_bytes(nq, index->n, k, t);
+  if (workspace_bytes < need) {
+    set_error("bruteforce_topk: workspace %zu < required %zu", workspace_bytes, need);
+    return TFRS_ENOMEM;
+  }
+  const RoundWs w = carve_round_ws(static_cast<char *>(workspace), nq, index->n, k, t);
+  int new_len = 0;
+  return run_rounds(queries, nq, index->d, index->packed, index->n, /*idx_base=*/0,
+                    /*seen=*/0, k, out_scores, out_idx, /*state_len=*/0, w, t,
+                    (hipStream_t)stream, &new_len);
+}
+
+// ----------------------------------------------------------------------------------------
+// Streaming.call, one candidate block
+// ----------------------------------------------------------------------------------------
+extern "C" size_t tfrs_streaming_topk_workspace_bytes(int64_t nq, int64_t nb, int d, int k) {
+  if (nq <= 0 || nb <= 0 || k <= 0 || d <= 0 || d > TFRS_MAX_DIM) return 256;
+  return round_ws_bytes(nq, nb, k, tuning()) +
+         align_up((size_t)padded_rows(nb) * row_bytes(padded_dim(d)));
+}
+
+extern "C" int tfrs_streaming_topk_update(const float *queries, int64_t nq, int d,
+                                          const float *cand_block, int64_t nb,
+                                          int64_t base_row, int k, float *state_scores,
+                                          int32_t *state_idx, int32_t state_len,
+                                          int32_t *new_len_h, void *workspace,
+                                          size_t workspace_bytes, void *stream) {
+  TFRS_CHECK_ARG(nq >= 0 && nb >= 0 && d >= 1, "streaming_topk_update: bad shape");
+  if (d > TFRS_MAX_DIM) {
+    set_error("streaming_topk_update: embedding dim %d > %d is not implemented", d,
+              TFRS_MAX_DIM);
+    return TFRS_ENOTIMPL;
+  }
+  TFRS_CHECK_ARG(k >= 1 && k <= TFRS_MAX_K, "streaming_topk_update: k=%d outside [1, %d]", k,
+                 TFRS_MAX_K);
+  TFRS_CHECK_ARG(state_len >= 0 && state_len <= k, "streaming_topk_update: bad state_len");
+  TFRS_CHECK_ARG(base_row >= 0 && base_row + nb <= 0x7FFFFFFFll,
+                 "streaming_topk_update: row numbers exceed int32");
+  if (new_len_h) *new_len_h = state_len;
+  if (nq == 0 || nb == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(queries && cand_block && state_scores && state_idx && workspace,
+                 "streaming_topk_update: NULL pointer");
+  const TopkTuning t = tuning();
+  const size_t need = tfrs_streaming_topk_workspace_bytes(nq, nb, d, k);
+  if (workspace_bytes < need) {
+    set_error("streaming_topk_update: workspace %zu < required %zu", workspace_bytes, need);
+    return TFRS_ENOMEM;
+  }
+  const RoundWs w = carve_round_ws(static_cast<char *>(workspace), nq, nb, k, t);
+  char *packed = w.end;
+  int rc = launch_pack(cand_block, nb, d, packed, 0, padded_rows(nb), (hipStream_t)stream);
+  if (rc != TFRS_OK) return rc;
+  int new_len = state_len;
+  rc = run_rounds(queries, nq, d, packed, nb, /*idx_base=*/base_row, /*seen=*/base_row, k,
+                  state_scores, state_idx, state_len, w, t, (hipStream_t)stream, &new_len);
+  if (new_len_h) *new_len_h = new_len;
+  return rc;
+}
+
+// ----------------------------------------------------------------------------------------
+// merge of partial lists
+// ----------------------------------------------------------------------------------------
+extern "C" size_t tfrs_topk_merge_workspace_bytes(int64_t, int, int, int) { return 256; }
+
+extern "C" int tfrs_topk_merge(const float *scores_parts, const int32_t *idx_parts, int nparts,
+                               int64_t nq, int k_in, int k_out, float *out_scores,
+                               int32_t *out_idx, void *, size_t, void *stream) {
+  TFRS_CHECK_ARG(nparts >= 1 && k_in >= 1 && nq >= 0, "topk_merge: bad shape");
+  TFRS_CHECK_ARG(k_out >= 1 && k_out <= TFRS_MAX_K && (int64_t)k_out <= (int64_t)nparts * k_in,
+                 "topk_merge: k_out=%d must be in [1, min(%d, nparts*k_in=%lld)]", k_out,
+                 TFRS_MAX_K, (long long)nparts * k_in);
+  if (nq == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(scores_parts && idx_parts && out_scores && out_idx, "topk_merge: NULL pointer");
+  SelectArgs se = {};
+  se.nq = nq;
+  se.k = k_out;
+  se.state_len = 0;
+  se.source = kSrcParts;
+  se.part_scores = scores_parts;
+  se.part_idx = idx_parts;
+  se.nparts = nparts;
+  se.k_in = k_in;
+  se.d = 8;
+  se.out_scores = out_scores;
+  se.out_idx = out_idx;
+  se.out_thr = nullptr;
+  return launch_select(se, (hipStream_t)stream);
+}
+
+// ----------------------------------------------------------------------------------------
+// _exclude, rank-of-positive, id match: small per-query kernels
+// ----------------------------------------------------------------------------------------
+namespace tfrs {
+
+// One wave per query: adjusted = score - 1e5 * isin (float32, like the reference),
+// then an exact top-kout by (adjusted desc, column asc) via rank counting (kin <= 1029).
+__global__ void __launch_bounds__(256) exclude_kernel(const float *scores, const int32_t *ids,
+                                                      int64_t nq, int kin,
+                                                      const int32_t *exclude, int ne, int kout,
+                                                      float *out_scores, int32_t *out_ids) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= nq) return;
+  float *adj = reinterpret_cast<float *>(smem) + (size_t)wave * kin;
+  for (int c = lane; c < kin; c += 64) {
+    const int32_t id = ids[row * kin + c];
+    bool isin = false;
+    for (int e = 0; e < ne; ++e) isin = isin || (exclude[row * ne + e] == id);
+    adj[c] = scores[row * kin + c] - (isin ? 1.0e5f : 0.0f);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int c = lane; c < kin; c += 64) {
+    const float v = adj[c];
+    int rank = 0;
+    for (int o = 0; o < kin; ++o) {
+      const float u = adj[o];
+      rank += (u > v) || (u == v && o < c);
+    }
+    if (rank < kout) {
+      out_scores[row * kout + rank] = scores[row * kin + c];
+      out_ids[row * kout + rank] = ids[row * kin + c];
+    }
+  }
+}
+
+struct KsArg {
+  int32_t v[16];
+};
+
+__global__ void __launch_bounds__(256) rank_of_positive_kernel(
+    const float *q, const float *c, int64_t nq, int d, const float *topk, int kmax,
+    const KsArg ks, int nks, float *out_hits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nq) return;
+  // positive score: the same d-ordered fma chain as the scoring kernels, so the positive
+  // ties exactly with its own copy in the corpus.
+  float pos = 0.0f;
+  for (int k = 0; k < d; ++k) pos = __builtin_fmaf(q[row * d + k], c[row * d + k], pos);
+  // sorted descending: #greater within the first kk columns == #greater overall, capped
+  int greater = 0;
+  for (int j = lane; j < kmax; j += 64) greater += (topk[row * kmax + j] > pos) ? 1 : 0;
+  for (int off = 32; off > 0; off >>= 1) greater += __shfl_xor(greater, off);
+  const bool finite = __builtin_isfinite(pos);
+  if (lane < nks) out_hits[(int64_t)lane * nq + row] = (finite && greater < ks.v[lane & 15]) ? 1.0f : 0.0f;
+}
+
+__global__ void __launch_bounds__(256) id_match_kernel(const int32_t *ids, const int32_t *true_ids,
+                                                       int64_t nq, int kmax, const KsArg ks,
+                                                       int nks, float *out_hits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nq) return;
+  const int32_t t = true_ids[row];
+  int first = kmax;  // first column that matches
+  for (int j = lane; j < kmax; j += 64)
+    if (ids[row * kmax + j] == t) first = min(first, j);
+  for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off));
+  if (lane < nks) out_hits[(int64_t)lane * nq + row] = (first < ks.v[lane & 15]) ? 1.0f : 0.0f;
+}
+
+}  // namespace tfrs
+
+extern "C" int tfrs_topk_exclude(const float *scores, const int32_t *ids, int64_t nq, int kin,
+                                 const int32_t *exclude, int ne, int k, float *out_scores,
+                                 int32_t *out_ids, void *stream) {
+  TFRS_CHECK_ARG(nq >= 0 && kin >= 1 && ne >= 0 && k >= 1, "topk_exclude: bad shape");
+  TFRS_CHECK_ARG(kin <= 4096, "topk_exclude: kin=%d too large", kin);
+  if (nq == 0) return TFRS_OK;
+  const int kout = k < kin ? k : kin;
+  hipLaunchKernelGGL(exclude_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256),
+                     (size_t)4 * kin * sizeof(float), (hipStream_t)stream, scores, ids, nq, kin,
+                     exclude, ne, kout, out_scores, out_ids);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+static int make_ks(const int32_t *ks_h, int nks, tfrs::KsArg *out) {
+  TFRS_CHECK_ARG(ks_h && nks >= 1 && nks <= 16, "need between 1 and 16 values of k");
+  for (int i = 0; i < 16; ++i) out->v[i] = (i < nks) ? ks_h[i] : 0;
+  return TFRS_OK;
+}
+
+extern "C" int tfrs_rank_of_positive(const float *queries, const float *true_candidates,
+                                     int64_t nq, int d, const float *topk_scores, int kmax,
+                                     const int32_t *ks_h, int nks, float *out_hits,
+                                     void *stream) {
+  TFRS_CHECK_ARG(nq >= 0 && d >= 1 && kmax >= 1, "rank_of_positive: bad shape");
+  tfrs::KsArg ks_d;
+  int rc = make_ks(ks_h, nks, &ks_d);
+  if (rc != TFRS_OK) return rc;
+  if (nq == 0) return TFRS_OK;
+  hipLaunchKernelGGL(rank_of_positive_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, queries, true_candidates, nq, d, topk_scores, kmax,
+                     ks_d, nks, out_hits);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+extern "C" int tfrs_id_match_topk(const int32_t *retrieved_ids, const int32_t *true_ids,
+                                  int64_t nq, int kmax, const int32_t *ks_h, int nks,
+                                  float *out_hits, void *stream) {
+  TFRS_CHECK_ARG(nq >= 0 && kmax >= 1, "id_match_topk: bad shape");
+  tfrs::KsArg ks_d;
+  int rc = make_ks(ks_h, nks, &ks_d);
+  if (rc != TFRS_OK) return rc;
+  if (nq == 0) return TFRS_OK;
+  hipLaunchKernelGGL(id_match_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, retrieved_ids, true_ids, nq, kmax, ks_d, nks, out_hits);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}

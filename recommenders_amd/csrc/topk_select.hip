@@ -1,0 +1,214 @@
+// topk_select.hip -- exact per-query top-K selection / merge.
+//
+// Restates tf.math.top_k (values descending, ties -> lower index) for:
+//   * the Streaming reduce step  concat(state, new) -> top_k  (layers/factorized_top_k.py:459-472)
+//   * the final top_k of BruteForce.call (:605) over the survivors of the scan filter
+//   * the multi-GPU merge of per-shard top-K lists.
+//
+// One wave per query.  Candidates are turned into 64-bit keys (common.h) whose
+// descending order is (score desc, index asc).  The wave keeps `best[KP]` sorted in LDS,
+// streams the source items 64 at a time, drops everything that cannot beat the current
+// K-th key (ballot/mbcnt compaction into `chunk`), and only when `chunk` fills does it
+// pay for a bitonic sort + bitonic merge-prune.  LDS ops of one wave execute in order,
+// so no workgroup barrier is needed; rows are independent.
+//
+// Integer/compare work on L2-resident lists: not a roofline-relevant kernel (a few % of
+// the scan time); it is kept simple and exact.
+#include "common.h"
+
+namespace tfrs {
+
+constexpr int kSelWaves = 4;
+
+__device__ __forceinline__ uint32_t sel_mbcnt(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                   __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Sorts x[0..KP) descending (bitonic network, one wave).
+template <int KP>
+__device__ __forceinline__ void bitonic_sort_desc(uint64_t *x, int lane) {
+#pragma unroll 1
+  for (int size = 2; size <= KP; size <<= 1) {
+#pragma unroll 1
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = lane; t < KP / 2; t += 64) {
+        const int i = 2 * t - (t & (stride - 1));
+        const int jx = i + stride;
+        const bool desc = ((i & size) == 0);
+        const uint64_t va = x[i], vb = x[jx];
+        if ((va < vb) == desc) {
+          x[i] = vb;
+          x[jx] = va;
+        }
+      }
+      wave_lds_sync();
+    }
+  }
+}
+
+// x[0..KP) is bitonic -> sorted descending.
+template <int KP>
+__device__ __forceinline__ void bitonic_merge_desc(uint64_t *x, int lane) {
+#pragma unroll 1
+  for (int stride = KP >> 1; stride > 0; stride >>= 1) {
+    for (int t = lane; t < KP / 2; t += 64) {
+      const int i = 2 * t - (t & (stride - 1));
+      const int jx = i + stride;
+      const uint64_t va = x[i], vb = x[jx];
+      if (va < vb) {
+        x[i] = vb;
+        x[jx] = va;
+      }
+    }
+    wave_lds_sync();
+  }
+}
+
+// best (sorted desc) <- top KP of best U chunk[0..fill); chunk is consumed.
+template <int KP>
+__device__ __forceinline__ void absorb_chunk(uint64_t *best, uint64_t *chunk, int fill,
+                                             int lane) {
+  for (int i = fill + lane; i < KP; i += 64) chunk[i] = 0ull;
+  wave_lds_sync();
+  bitonic_sort_desc<KP>(chunk, lane);
+  // element-wise max of a descending and an ascending (reversed) sequence is bitonic and
+  // holds the KP largest of the union
+  for (int i = lane; i < KP; i += 64) {
+    const uint64_t o = chunk[KP - 1 - i];
+    if (o > best[i]) best[i] = o;
+  }
+  wave_lds_sync();
+  bitonic_merge_desc<KP>(best, lane);
+}
+
+// Exact score of one candidate from the packed corpus: the same d-ordered fma chain as
+// the MFMA path (used only for queries whose scan list overflowed).
+__device__ __forceinline__ float packed_score(const char *packed, int64_t row, int dp,
+                                              const float *q, int d) {
+  const float *r = reinterpret_cast<const float *>(packed + row * (int64_t)row_bytes(dp));
+  const int half = dp / 2;
+  float acc = 0.0f;
+  for (int k = 0; k < d; ++k) acc = __builtin_fmaf(r[(k & 1) * half + (k >> 1)], q[k], acc);
+  return acc;
+}
+
+template <int KP>
+__global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t row = (int64_t)blockIdx.x * kSelWaves + wave;
+  if (row >= a.nq) return;  // whole wave
+
+  uint64_t *best = reinterpret_cast<uint64_t *>(smem) + (size_t)wave * 2 * KP;
+  uint64_t *chunk = best + KP;
+  const int K = a.k;
+
+  // ---- seed with the prior state (already sorted by construction) -----------------
+  for (int i = lane; i < KP; i += 64) {
+    uint64_t key = 0ull;
+    if (i < a.state_len) key = make_key(a.state_scores[row * K + i], a.state_idx[row * K + i]);
+    best[i] = key;
+  }
+  wave_lds_sync();
+
+  // ---- source description ------------------------------------------------------------
+  int source = a.source;
+  int64_t m = 0;
+  bool recompute = false;
+  if (source == kSrcDense) {
+    m = a.n_dense;
+  } else if (source == kSrcList) {
+    if (a.overflow[row]) {
+      recompute = true;
+      m = a.rc_end - a.rc_begin;
+    } else {
+      m = a.cnt[row];
+    }
+  } else {
+    m = (int64_t)a.nparts * a.k_in;
+  }
+  const int dp = padded_dim(a.d);
+
+  int fill = 0;                      // wave-uniform
+  uint64_t kth = best[K - 1];        // 0 while fewer than K entries: everything passes
+  for (int64_t base = 0; base < m; base += 64) {
+    const int64_t e = base + lane;
+    uint64_t key = 0ull;
+    if (e < m) {
+      if (recompute) {
+        const int64_t crow = a.rc_begin + e;
+        key = make_key(packed_score(a.packed, crow, dp, a.q + row * a.d, a.d),
+                       (int32_t)(crow + a.idx_base));
+      } else if (source == kSrcDense) {
+        key = make_key(a.dense[row * a.ld_dense + e], (int32_t)(a.idx_base + e));
+      } else if (source == kSrcList) {
+        const uint2 ent = a.buf[row * (int64_t)a.cap + e];
+        key = make_key(__uint_as_float(ent.x), (int32_t)((int64_t)ent.y + a.idx_base));
+      } else {
+        const int64_t part = e / a.k_in, jj = e - part * a.k_in;
+        const int64_t off = (part * a.nq + row) * a.k_in + jj;
+        key = make_key(a.part_scores[off], a.part_idx[off]);
+      }
+    }
+    const bool p = key > kth;  // key 0 (empty) never passes
+    const uint64_t mask = __ballot(p);
+    if (mask == 0ull) continue;
+    if (fill + 64 > KP) {
+      absorb_chunk<KP>(best, chunk, fill, lane);
+      fill = 0;
+      kth = best[K - 1];
+    }
+    // re-test against the (possibly raised) threshold is unnecessary for correctness
+    if (p) chunk[fill + sel_mbcnt(mask)] = key;
+    fill += (int)__popcll(mask);
+  }
+  if (fill > 0) absorb_chunk<KP>(best, chunk, fill, lane);
+
+  // ---- write the new state --------------------------------------------------------------
+  for (int i = lane; i < K; i += 64) {
+    const uint64_t key = best[i];
+    a.out_scores[row * K + i] = key ? key_score(key) : 0.0f;
+    a.out_idx[row * K + i] = key ? key_index(key) : 0;
+  }
+  if (a.out_thr && lane == 0) {
+    const uint64_t key = best[K - 1];
+    a.out_thr[row] = key ? key_score(key) : -__builtin_inff();
+  }
+}
+
+template <int KP>
+static int launch_select_kp(const SelectArgs &a, hipStream_t stream) {
+  const size_t lds = (size_t)kSelWaves * 2 * KP * sizeof(uint64_t);
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    TFRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_kernel<KP>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)((a.nq + kSelWaves - 1) / kSelWaves));
+  hipLaunchKernelGGL((select_kernel<KP>), grid, dim3(kSelWaves * 64), lds, stream, a);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+int launch_select(const SelectArgs &a, hipStream_t stream) {
+  if (a.nq <= 0) return TFRS_OK;
+  TFRS_CHECK_ARG(a.k >= 1 && a.k <= TFRS_MAX_K, "select: k=%d outside [1, %d]", a.k,
+                 TFRS_MAX_K);
+  TFRS_CHECK_ARG(a.state_len >= 0 && a.state_len <= a.k, "select: bad state_len %d",
+                 a.state_len);
+  if (a.k <= 64) return launch_select_kp<64>(a, stream);
+  if (a.k <= 128) return launch_select_kp<128>(a, stream);
+  if (a.k <= 256) return launch_select_kp<256>(a, stream);
+  if (a.k <= 512) return launch_select_kp<512>(a, stream);
+  return launch_select_kp<1024>(a, stream);
+}
+
+}  // namespace tfrs

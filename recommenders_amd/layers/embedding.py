@@ -1,0 +1,142 @@
+"""Embedding lookup on MI355X.
+
+``Embedding`` mirrors ``tf.keras.layers.Embedding`` as the reference uses it
+(``README.md:62-66,77-78``): ``Embedding(input_dim, output_dim)``, called on integer
+ids of any shape, returning ``ids.shape + [output_dim]`` float32; default initialiser
+uniform(-0.05, 0.05).  ``embedding_lookup_sparse`` is the combiner lookup of the
+``TPUEmbedding`` CPU branch (``layers/embedding/tpu_embedding_layer.py:913-919``) on
+CSR-form ragged ids with ``sum`` / ``mean`` / ``sqrtn`` combiners.
+
+Forward = HBM-bound gather kernel; backward = deterministic sort + segmented
+scatter-add (no atomics), optionally fused with the row-wise Adagrad update.
+"""
+
+from typing import Optional
+
+import torch
+
+from recommenders_amd import _lib
+
+_COMBINERS = {"sum": 0, "mean": 1, "sqrtn": 2}
+
+
+def _check_device(t: torch.Tensor) -> None:
+  if not t.is_cuda:
+    raise RuntimeError("recommenders_amd ops need tensors on the GPU; there is no CPU fallback.")
+
+
+def gather_rows(table: torch.Tensor, ids: torch.Tensor, validate: bool = False) -> torch.Tensor:
+  """out[...] = table[ids[...]] through ``tfrs_embedding_gather_fwd``."""
+  _check_device(table)
+  table = table.contiguous()
+  if ids.dtype not in (torch.int32, torch.int64):
+    ids = ids.long()
+  flat = ids.to(table.device).reshape(-1).contiguous()
+  out = torch.empty((flat.numel(), table.shape[1]), dtype=torch.float32, device=table.device)
+  err = torch.zeros((1,), dtype=torch.int32, device=table.device) if validate else None
+  _lib.check(_lib.load().tfrs_embedding_gather_fwd(
+      _lib.ptr(table), table.shape[0], table.shape[1], _lib.ptr(flat),
+      1 if flat.dtype == torch.int64 else 0, flat.numel(), _lib.ptr(out), _lib.ptr(err),
+      _lib.current_stream()))
+  if validate and int(err.item()):
+    raise IndexError("embedding id out of range [0, %d)" % table.shape[0])
+  return out.reshape(tuple(ids.shape) + (table.shape[1],))
+
+
+def scatter_add_rows(grad_out: torch.Tensor, ids: torch.Tensor, vocab: int) -> torch.Tensor:
+  """Dense ``[vocab, d]`` gradient of ``gather_rows`` (duplicates summed in occurrence
+  order; bit-reproducible)."""
+  d = grad_out.shape[-1]
+  g = grad_out.reshape(-1, d).contiguous()
+  flat = ids.reshape(-1).long()
+  sorted_ids, perm = torch.sort(flat, stable=True)
+  table_grad = torch.zeros((vocab, d), dtype=torch.float32, device=g.device)
+  _lib.check(_lib.load().tfrs_embedding_scatter_add_bwd(
+      _lib.ptr(g), _lib.ptr(sorted_ids), _lib.ptr(perm), flat.numel(), d,
+      _lib.ptr(table_grad), None, 0.0, 0.0, 0, _lib.current_stream()))
+  return table_grad
+
+
+def adagrad_sparse_update_(table: torch.Tensor, accum: torch.Tensor, grad_out: torch.Tensor,
+                           ids: torch.Tensor, lr: float, eps: float = 1e-7) -> None:
+  """In-place fused scatter-add + Keras Adagrad on the touched rows only
+  (``models/base.py:77-78`` with ``Adagrad``, ``README.md:84``):
+  g = sum of duplicate grads; acc += g*g; row -= lr * g / sqrt(acc + eps)."""
+  d = grad_out.shape[-1]
+  g = grad_out.reshape(-1, d).contiguous()
+  flat = ids.reshape(-1).long()
+  sorted_ids, perm = torch.sort(flat, stable=True)
+  _lib.check(_lib.load().tfrs_embedding_scatter_add_bwd(
+      _lib.ptr(g), _lib.ptr(sorted_ids), _lib.ptr(perm), flat.numel(), d,
+      _lib.ptr(table), _lib.ptr(accum), float(lr), float(eps), 1, _lib.current_stream()))
+
+
+class _GatherFn(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, table, ids):
+    ctx.save_for_backward(ids)
+    ctx.vocab = table.shape[0]
+    return gather_rows(table, ids)
+
+  @staticmethod
+  def backward(ctx, grad_out):
+    (ids,) = ctx.saved_tensors
+    return scatter_add_rows(grad_out.contiguous(), ids, ctx.vocab), None
+
+
+def embedding_lookup_sparse(table: torch.Tensor, ids: torch.Tensor, row_splits: torch.Tensor,
+                            weights: Optional[torch.Tensor] = None, combiner: str = "mean",
+                            validate: bool = False) -> torch.Tensor:
+  """Per-row combiner over ragged ids in CSR form (row b owns
+  ``ids[row_splits[b]:row_splits[b+1]]``); empty rows give zeros."""
+  if combiner not in _COMBINERS:
+    raise ValueError(f"combiner must be one of {sorted(_COMBINERS)}; got {combiner!r}")
+  _check_device(table)
+  table = table.contiguous()
+  ids = ids.to(table.device).long().contiguous()
+  row_splits = row_splits.to(table.device).long().contiguous()
+  nrows = row_splits.numel() - 1
+  w = None if weights is None else weights.to(table.device, torch.float32).contiguous()
+  out = torch.empty((nrows, table.shape[1]), dtype=torch.float32, device=table.device)
+  err = torch.zeros((1,), dtype=torch.int32, device=table.device) if validate else None
+  _lib.check(_lib.load().tfrs_embedding_segment_reduce_fwd(
+      _lib.ptr(table), table.shape[0], table.shape[1], _lib.ptr(ids), _lib.ptr(row_splits), 1,
+      _lib.ptr(w), nrows, _COMBINERS[combiner], _lib.ptr(out), _lib.ptr(err),
+      _lib.current_stream()))
+  if validate and int(err.item()):
+    raise IndexError("embedding id out of range [0, %d)" % table.shape[0])
+  return out
+
+
+class Embedding(torch.nn.Module):
+  """``tf.keras.layers.Embedding(input_dim, output_dim)`` on HBM-resident tables."""
+
+  def __init__(self, input_dim: int, output_dim: int, validate_ids: bool = False,
+               device: Optional[torch.device] = None):
+    super().__init__()
+    self.input_dim = input_dim
+    self.output_dim = output_dim
+    self.validate_ids = validate_ids
+    dev = device if device is not None else (
+        torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu"))
+    w = torch.empty((input_dim, output_dim), dtype=torch.float32, device=dev)
+    w.uniform_(-0.05, 0.05)  # Keras "uniform" initialiser
+    self.embeddings = torch.nn.Parameter(w)
+
+  def forward(self, ids: torch.Tensor) -> torch.Tensor:
+    if not isinstance(ids, torch.Tensor):
+      ids = torch.as_tensor(ids)
+    ids = ids.to(self.embeddings.device)
+    if self.validate_ids:
+      return _ValidatedGather.apply(self.embeddings, ids)
+    return _GatherFn.apply(self.embeddings, ids)
+
+
+class _ValidatedGather(_GatherFn):
+
+  @staticmethod
+  def forward(ctx, table, ids):
+    ctx.save_for_backward(ids)
+    ctx.vocab = table.shape[0]
+    return gather_rows(table, ids, validate=True)

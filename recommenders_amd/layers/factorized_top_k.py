@@ -1,0 +1,501 @@
+"""Top-K retrieval layers on MI355X.
+
+Host-side mirror of ``tensorflow_recommenders/layers/factorized_top_k.py``
+(``TopK`` :140-333, ``Streaming`` :336-512, ``BruteForce`` :515-610): same class
+names, constructor/call arguments and error behaviour.  The arithmetic
+(``tf.matmul`` + ``tf.math.top_k`` + the Streaming reduce) runs in
+``libtfrs_hip.so`` -- an f32-MFMA scan with the top-K selection fused behind it.
+
+Deviations forced by the host framework (documented in DESIGN.md):
+  * tensors are ``torch.Tensor`` on a CUDA(ROCm) device; NumPy inputs are uploaded;
+  * a ``tf.data.Dataset`` of candidates becomes any re-iterable of candidate blocks
+    ``[nb, d]`` or ``(identifiers[nb], candidates[nb, d])`` tuples;
+  * identifiers of non-numeric dtype (e.g. strings) stay on the host as NumPy arrays:
+    the device returns row numbers and the final ``identifiers[idx]`` gather
+    (:607, :438) is done host-side; numeric identifiers are gathered on the device;
+  * ``ScaNN`` (approximate search in an external C++ library) is not provided.
+"""
+
+import abc
+import ctypes
+from typing import Any, Callable, Dict, Iterable, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from recommenders_amd import _lib
+
+Tensor = torch.Tensor
+ArrayLike = Union[torch.Tensor, np.ndarray, Sequence]
+
+BATCH_TOO_SMALL_MESSAGE = (
+    "Tried to retrieve k={k} top items, but the candidate "
+    "dataset batch size is too small. This may be because "
+    "your candidate batch size is too small or the last "
+    "batch of your dataset is too small. "
+    "To resolve this, increase your batch size, set the "
+    "drop_remainder argument to True when batching your "
+    "candidates, or set the handle_incomplete_batches "
+    "argument to True in the constructor. ")
+
+NOT_INDEXED_MESSAGE = ("The `index` method must be called first to "
+                       "create the retrieval index.")
+
+
+def _device() -> torch.device:
+  if not torch.cuda.is_available():
+    raise RuntimeError(
+        "recommenders_amd needs a ROCm GPU (MI355X): no device is visible and "
+        "there is no CPU fallback.")
+  return torch.device("cuda", torch.cuda.current_device())
+
+
+def _as_f32_matrix(x: ArrayLike, what: str) -> Tensor:
+  """Float32, contiguous, 2-D, on the GPU."""
+  if not isinstance(x, torch.Tensor):
+    x = torch.as_tensor(np.asarray(x))
+  if x.dim() != 2:
+    raise ValueError(f"The {what} tensor must be 2D (got {tuple(x.shape)}).")
+  return x.to(device=_device(), dtype=torch.float32).contiguous()
+
+
+def _workspace(nbytes: int) -> Tensor:
+  return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=_device())
+
+
+def _check_candidates_with_identifiers(candidates: Iterable) -> None:
+  """Precondition of the dataset used for indexing (reference :118-137), checked on
+  the first element: either blocks, or 2-tuples with equal leading dimensions."""
+  for first in candidates:
+    if isinstance(first, (tuple, list)):
+      if len(first) != 2:
+        raise ValueError(
+            "The dataset must yield candidate embeddings or "
+            "tuples of (candidate identifiers, candidate embeddings). "
+            f"Got a {len(first)}-tuple instead.")
+      ids, cand = first
+      if len(ids) != len(cand):
+        raise ValueError(
+            "Candidates and identifiers have to have the same batch dimension. "
+            f"Got {len(cand)} and {len(ids)}.")
+    break
+
+
+class _Identifiers:
+  """Identifier table: maps device row numbers to user identifiers (:607, :438) and
+  user identifiers to comparable int32 codes for exclusions (:101-104)."""
+
+  def __init__(self, values: Optional[ArrayLike], n: int):
+    self.n = n
+    self.host: Optional[np.ndarray] = None     # non-numeric identifiers
+    self.device: Optional[Tensor] = None       # numeric identifiers
+    self._code_of: Optional[Dict[Any, int]] = None
+    self._codes_dev: Optional[Tensor] = None
+    if values is None:
+      return                                   # identifiers = arange(n), int32 (:544-545)
+    if isinstance(values, torch.Tensor):
+      self.device = values.to(_device())
+    else:
+      arr = np.asarray(values)
+      if arr.dtype.kind in "iufb":
+        self.device = torch.as_tensor(arr).to(_device())
+      else:
+        self.host = arr
+
+  @property
+  def is_range(self) -> bool:
+    return self.host is None and self.device is None
+
+  def gather(self, idx: Tensor):
+    """identifiers[idx] for an int32 index tensor."""
+    if self.is_range:
+      return idx
+    if self.device is not None:
+      return self.device[idx.long()]
+    return self.host[idx.cpu().numpy()]
+
+  def _build_codes(self) -> None:
+    if self._code_of is not None:
+      return
+    vals = self.host if self.host is not None else self.device.cpu().numpy()
+    uniq, inverse = np.unique(vals, return_inverse=True)
+    self._uniq_host = uniq
+    self._uniq_dev = (torch.as_tensor(uniq).to(_device())
+                      if self.device is not None else None)
+    self._code_of = {v.item() if hasattr(v, "item") else v: i for i, v in enumerate(uniq)}
+    self._codes_dev = torch.as_tensor(inverse.astype(np.int32)).to(_device())
+
+  def codes_of_rows(self, idx: Tensor) -> Tensor:
+    """int32 code (rank among the distinct identifiers) of each retrieved row."""
+    if self.is_range:
+      return idx
+    self._build_codes()
+    return self._codes_dev[idx.long()].contiguous()
+
+  def codes_of_values(self, values: ArrayLike) -> Tensor:
+    """int32 codes of user-supplied identifiers (-1 = not in the index)."""
+    if isinstance(values, torch.Tensor):
+      values = values.cpu().numpy()
+    arr = np.asarray(values)
+    if self.is_range:
+      codes = np.where((arr >= 0) & (arr < self.n), arr, -1).astype(np.int32)
+    else:
+      self._build_codes()
+      flat = [self._code_of.get(v.item() if hasattr(v, "item") else v, -1)
+              for v in arr.reshape(-1)]
+      codes = np.asarray(flat, dtype=np.int32).reshape(arr.shape)
+    return torch.as_tensor(codes).to(_device()).contiguous()
+
+  def values_of_codes(self, codes: Tensor):
+    if self.is_range:
+      return codes
+    if self._uniq_dev is not None:
+      return self._uniq_dev[codes.long()]
+    return self._uniq_host[codes.cpu().numpy()]
+
+
+def _exclude(scores: Tensor, row_idx: Tensor, identifiers: _Identifiers,
+             exclude: ArrayLike, k: int):
+  """``_exclude`` (:83-115) through ``tfrs_topk_exclude``: candidates whose
+  identifier is in the query's exclusion row are pushed down by 1e5, the top-k is
+  re-taken, and the ORIGINAL scores / identifiers of the winners are returned.
+  Identifiers are compared through int32 codes (rank among distinct identifiers)."""
+  nq, kin = scores.shape
+  codes = identifiers.codes_of_rows(row_idx).to(torch.int32).contiguous()
+  excl = identifiers.codes_of_values(exclude)
+  if excl.dim() != 2 or excl.shape[0] != nq:
+    raise ValueError(
+        f"exclusions must be [num_queries, num_to_exclude]; got {tuple(excl.shape)}")
+  kout = min(k, kin)
+  out_scores = torch.empty((nq, kout), dtype=torch.float32, device=scores.device)
+  out_codes = torch.empty((nq, kout), dtype=torch.int32, device=scores.device)
+  scores = scores.contiguous()
+  _lib.check(_lib.load().tfrs_topk_exclude(
+      _lib.ptr(scores), _lib.ptr(codes), nq, kin, _lib.ptr(excl), excl.shape[1], k,
+      _lib.ptr(out_scores), _lib.ptr(out_codes), _lib.current_stream()))
+  return out_scores, identifiers.values_of_codes(out_codes)
+
+
+class TopK(torch.nn.Module, abc.ABC):
+  """Interface for top K layers (reference :140-333).
+
+  Implementers provide ``index`` (build the retrieval index from a candidate
+  matrix) and ``call`` (top K candidates for a batch of queries).
+  """
+
+  def __init__(self, k: int, **kwargs) -> None:
+    name = kwargs.pop("name", None)
+    super().__init__()
+    self.name = name if name is not None else type(self).__name__.lower()
+    self._k = k
+
+  @abc.abstractmethod
+  def index(self, candidates: ArrayLike, identifiers: Optional[ArrayLike] = None) -> "TopK":
+    """Builds the retrieval index; an existing index is dropped (:158-177)."""
+    raise NotImplementedError()
+
+  def index_from_dataset(self, candidates: Iterable) -> "TopK":
+    """Builds the index from an iterable of candidate blocks or (identifier block,
+    candidate block) pairs (:179-215)."""
+    _check_candidates_with_identifiers(candidates)
+    blocks, ids = [], []
+    has_ids = None
+    for element in candidates:
+      if isinstance(element, (tuple, list)):
+        i, c = element
+        has_ids = True
+        ids.append(i.cpu().numpy() if isinstance(i, torch.Tensor) else np.asarray(i))
+      else:
+        c = element
+        has_ids = False
+      blocks.append(_as_f32_matrix(c, "candidates"))
+    if not blocks:
+      raise ValueError("The candidate dataset is empty.")
+    cand = torch.cat(blocks, dim=0)
+    return self.index(cand, np.concatenate(ids, axis=0) if has_ids else None)
+
+  @abc.abstractmethod
+  def call(self, queries, k: Optional[int] = None):
+    """Returns (top scores [B, k], top identifiers [B, k]) (:217-240)."""
+    raise NotImplementedError()
+
+  def forward(self, queries, k: Optional[int] = None):
+    return self.call(queries, k=k)
+
+  def query_with_exclusions(self, queries, exclusions: ArrayLike, k: Optional[int] = None):
+    """Top-k with per-query excluded identifiers (:242-288): query ``k + E``, then
+    ``_exclude``."""
+    k = k if k is not None else self._k
+    num_excl = (exclusions.shape[1] if hasattr(exclusions, "shape")
+                else np.asarray(exclusions).shape[1])
+    adjusted_k = k + num_excl                                         # :286
+    scores, rows = self._query_rows(queries, adjusted_k)               # :287
+    return _exclude(scores, rows, self._identifier_table(), exclusions, k)   # :288
+
+  @abc.abstractmethod
+  def is_exact(self) -> bool:
+    raise NotImplementedError()
+
+  # -- implementation hooks -------------------------------------------------------------
+  @abc.abstractmethod
+  def _query_rows(self, queries, k: int) -> Tuple[Tensor, Tensor]:
+    """(scores, int32 row numbers) before the identifier gather."""
+
+  @abc.abstractmethod
+  def _identifier_table(self) -> _Identifiers:
+    pass
+
+  def _embed(self, queries) -> Tensor:
+    query_model = getattr(self, "query_model", None)
+    if query_model is not None:
+      queries = query_model(queries)
+    return _as_f32_matrix(queries, "queries")
+
+
+class _IndexHandle:
+  """RAII wrapper of ``tfrs_index_t``."""
+
+  def __init__(self):
+    self._lib = _lib.load()
+    h = ctypes.c_void_p()
+    _lib.check(self._lib.tfrs_index_create(ctypes.byref(h)))
+    self.handle = h
+
+  def __del__(self):
+    h, self.handle = getattr(self, "handle", None), None
+    if h:
+      try:
+        self._lib.tfrs_index_destroy(h)
+      except Exception:  # interpreter shutdown
+        pass
+
+
+class BruteForce(TopK):
+  """Brute force retrieval (reference :515-610): exact top-K of ``q @ candidates^T``.
+
+  ``index`` copies the candidates into a layer-owned, MFMA-friendly packed corpus in
+  HBM (:559-584); ``call`` is one fused scan, the ``[B, N]`` score matrix is never
+  materialised.
+  """
+
+  def __init__(self, query_model: Optional[Callable] = None, k: int = 10,
+               name: Optional[str] = None):
+    super().__init__(k=k, name=name)
+    self.query_model = query_model
+    self._index: Optional[_IndexHandle] = None
+    self._ids: Optional[_Identifiers] = None
+    self._n = 0
+    self._d = 0
+
+  def index(self, candidates: ArrayLike, identifiers: Optional[ArrayLike] = None) -> "BruteForce":
+    if isinstance(candidates, torch.Tensor):
+      ndim, nrows = candidates.dim(), candidates.shape[0] if candidates.dim() else 0
+    else:
+      candidates = np.asarray(candidates)
+      ndim, nrows = candidates.ndim, candidates.shape[0] if candidates.ndim else 0
+    if ndim != 2:                                                       # :547-550
+      raise ValueError(f"The candidates tensor must be 2D (got {tuple(candidates.shape)}).")
+    if identifiers is not None and len(identifiers) != nrows:          # :552-557
+      raise ValueError(
+          "The candidates and identifiers tensors must have the same number of"
+          f" rows (got {nrows} candidates rows and"
+          f" {len(identifiers)} identifier rows). ")
+    cand = _as_f32_matrix(candidates, "candidates")
+    handle = _IndexHandle()
+    _lib.check(handle._lib.tfrs_index_set(handle.handle, _lib.ptr(cand), cand.shape[0],
+                                          cand.shape[1], _lib.current_stream()))
+    torch.cuda.current_stream().synchronize()  # `cand` may be a temporary upload
+    self._index = handle                       # the previous index (if any) is dropped
+    self._ids = _Identifiers(identifiers, cand.shape[0])
+    self._n, self._d = cand.shape
+    return self
+
+  def _identifier_table(self) -> _Identifiers:
+    return self._ids
+
+  def _query_rows(self, queries, k: int) -> Tuple[Tensor, Tensor]:
+    if self._index is None:                                             # :594-598
+      raise ValueError(NOT_INDEXED_MESSAGE)
+    q = self._embed(queries)                                            # :600-601
+    if q.shape[1] != self._d:
+      raise ValueError(f"Query dimension {q.shape[1]} does not match the index ({self._d}).")
+    lib = _lib.load()
+    nq = q.shape[0]
+    scores = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+    rows = torch.empty((nq, k), dtype=torch.int32, device=q.device)
+    ws = _workspace(lib.tfrs_bruteforce_topk_workspace_bytes(nq, self._n, self._d, k))
+    _lib.check(lib.tfrs_bruteforce_topk(
+        self._index.handle, _lib.ptr(q), nq, k, _lib.ptr(scores), _lib.ptr(rows),
+        _lib.ptr(ws), ws.numel(), _lib.current_stream()))               # :603-605
+    return scores, rows
+
+  def call(self, queries, k: Optional[int] = None):
+    k = k if k is not None else self._k
+    scores, rows = self._query_rows(queries, k)
+    return scores, self._ids.gather(rows)                               # :607
+
+  def candidates(self) -> Tensor:
+    """The indexed candidate matrix (unpacked copy), for checkpointing."""
+    if self._index is None:
+      raise ValueError(NOT_INDEXED_MESSAGE)
+    out = torch.empty((self._n, self._d), dtype=torch.float32, device=_device())
+    _lib.check(_lib.load().tfrs_index_unpack(self._index.handle, _lib.ptr(out),
+                                             _lib.current_stream()))
+    return out
+
+  def is_exact(self) -> bool:
+    return True
+
+
+class Streaming(TopK):
+  """Retrieves the K highest scoring items from a large candidate stream
+  (reference :336-512).  Keeps only a reference to the candidate iterable and
+  re-reads it on every call; the running state is ``[B, <=K]`` in HBM.
+  """
+
+  def __init__(self, query_model: Optional[Callable] = None, k: int = 10,
+               handle_incomplete_batches: bool = True,
+               num_parallel_calls: Optional[int] = None, sorted_order: bool = True) -> None:
+    super().__init__(k=k)
+    self.query_model = query_model
+    self._candidates = None
+    self._handle_incomplete_batches = handle_incomplete_batches
+    self._num_parallel_calls = num_parallel_calls  # accepted for API parity; unused
+    self._sorted = sorted_order                    # results are always sorted
+    self._last_ids: Optional[_Identifiers] = None
+
+  def index_from_dataset(self, candidates: Iterable) -> "Streaming":
+    _check_candidates_with_identifiers(candidates)                     # :386
+    self._candidates = candidates                                      # :388
+    return self
+
+  def index(self, candidates, identifiers=None) -> "Streaming":
+    """Not implemented. Please call `index_from_dataset` instead (:392-402)."""
+    raise NotImplementedError(
+        "The streaming top k class only accepts datasets. "
+        "Please call `index_from_dataset` instead.")
+
+  def _identifier_table(self) -> _Identifiers:
+    return self._last_ids
+
+  def _query_rows(self, queries, k: int) -> Tuple[Tensor, Tensor]:
+    if self._candidates is None:                                        # :412-416
+      raise ValueError(NOT_INDEXED_MESSAGE)
+    q = self._embed(queries)                                            # :418-419
+    lib = _lib.load()
+    nq, d = q.shape
+    state_scores = torch.zeros((nq, k), dtype=torch.float32, device=q.device)
+    state_rows = torch.zeros((nq, k), dtype=torch.int32, device=q.device)
+    state_len = 0
+    counter = 0                                                         # :421-422
+    ids = []
+    has_ids = False
+    new_len = ctypes.c_int32(0)
+    ws = None
+    for element in self._candidates:
+      if isinstance(element, (tuple, list)):
+        block_ids, block = element
+        has_ids = True
+        ids.append(block_ids.cpu().numpy() if isinstance(block_ids, torch.Tensor)
+                   else np.asarray(block_ids))
+      else:
+        block = element
+      block = _as_f32_matrix(block, "candidates")
+      nb = block.shape[0]
+      if block.shape[1] != d:
+        raise ValueError(f"Candidate dimension {block.shape[1]} does not match queries ({d}).")
+      if not self._handle_incomplete_batches and nb < k:               # :431-436, :34-54
+        raise ValueError(BATCH_TOO_SMALL_MESSAGE.format(k=k))
+      need = lib.tfrs_streaming_topk_workspace_bytes(nq, nb, d, k)
+      if ws is None or ws.numel() < need:
+        ws = _workspace(need)
+      _lib.check(lib.tfrs_streaming_topk_update(
+          _lib.ptr(q), nq, d, _lib.ptr(block), nb, counter, k, _lib.ptr(state_scores),
+          _lib.ptr(state_rows), state_len, ctypes.byref(new_len), _lib.ptr(ws),
+          ws.numel(), _lib.current_stream()))                          # :424-472
+      state_len = int(new_len.value)
+      counter += nb                                                     # :477-478
+    self._last_ids = _Identifiers(np.concatenate(ids, axis=0) if has_ids else None, counter)
+    return state_scores[:, :state_len], state_rows[:, :state_len]
+
+  def call(self, queries, k: Optional[int] = None):
+    k = k if k is not None else self._k
+    scores, rows = self._query_rows(queries, k)
+    return scores, self._last_ids.gather(rows)                          # :438
+
+  def is_exact(self) -> bool:
+    return True
+
+
+class ShardedBruteForce(TopK):
+  """Brute-force retrieval over a corpus that is row-sharded across the GPUs of a node
+  (one process per GPU, ``torch.distributed`` backend ``nccl`` = RCCL over xGMI).
+
+  Rank r owns candidate rows ``[base_row, base_row + n_local)`` of the global corpus.
+  ``call`` scores the (replicated) query batch against the local shard, all-gathers the
+  per-shard ``(score, global row)[B, K]`` lists -- the only exchange step of the path,
+  ``2 * B * K * 4`` bytes per rank -- and merges them with the same
+  (score desc, row asc) rule, so every rank holds exactly the single-GPU result.
+  Not part of the reference (which has no multi-device top-K); see DESIGN.md.
+  """
+
+  def __init__(self, query_model: Optional[Callable] = None, k: int = 10,
+               process_group=None, name: Optional[str] = None,
+               local_search: Optional[Callable] = None, merge: Optional[Callable] = None):
+    super().__init__(k=k, name=name)
+    self.query_model = query_model
+    self._group = process_group
+    self._local = BruteForce(k=k)
+    self._base_row = 0
+    self._ids = _Identifiers(None, 0)
+    # injection points so the collective logic can be exercised on CPU (gloo) in tests
+    self._local_search = local_search
+    self._merge = merge
+
+  def index(self, candidates: ArrayLike, identifiers: Optional[ArrayLike] = None,
+            base_row: int = 0) -> "ShardedBruteForce":
+    if identifiers is not None:
+      raise NotImplementedError("ShardedBruteForce returns global row numbers; map "
+                                "identifiers on the host.")
+    self._base_row = int(base_row)
+    if self._local_search is None:
+      self._local.index(candidates)
+    else:
+      self._cand = candidates
+    return self
+
+  def _identifier_table(self) -> _Identifiers:
+    return self._ids
+
+  def _query_rows(self, queries, k: int) -> Tuple[Tensor, Tensor]:
+    import torch.distributed as dist
+    if self._local_search is None:
+      scores, rows = self._local._query_rows(self._embed(queries), k)
+    else:
+      scores, rows = self._local_search(queries, self._cand, k)
+    rows = rows + self._base_row
+    if not (dist.is_available() and dist.is_initialized()):
+      return scores, rows
+    world = dist.get_world_size(self._group)
+    if world == 1:
+      return scores, rows
+    nq = scores.shape[0]
+    all_s = torch.empty((world, nq, k), dtype=scores.dtype, device=scores.device)
+    all_i = torch.empty((world, nq, k), dtype=rows.dtype, device=rows.device)
+    dist.all_gather_into_tensor(all_s, scores.contiguous(), group=self._group)
+    dist.all_gather_into_tensor(all_i, rows.contiguous(), group=self._group)
+    if self._merge is not None:
+      return self._merge(all_s, all_i, k)
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
+    out_i = torch.empty((nq, k), dtype=torch.int32, device=scores.device)
+    _lib.check(_lib.load().tfrs_topk_merge(
+        _lib.ptr(all_s), _lib.ptr(all_i), world, nq, k, k, _lib.ptr(out_s),
+        _lib.ptr(out_i), None, 0, _lib.current_stream()))
+    return out_s, out_i
+
+  def call(self, queries, k: Optional[int] = None):
+    k = k if k is not None else self._k
+    return self._query_rows(queries, k)
+
+  def is_exact(self) -> bool:
+    return True

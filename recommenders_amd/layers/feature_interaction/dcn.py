@@ -1,0 +1,238 @@
+"""DCN ``Cross`` layer on MI355X.
+
+Mirror of ``tensorflow_recommenders/layers/feature_interaction/dcn.py:23-208``: same
+constructor arguments, ``call(x0, x=None)``, error messages and ``get_config``.
+``x_{i+1} = x0 * (W x_i + bias + diag_scale * x_i) + x_i`` runs as ONE fused kernel
+(f32-MFMA GEMM with the cross formula in its epilogue, ``tfrs_cross_fwd``); the
+low-rank form runs the ``U`` projection through ``tfrs_dense_fwd`` and the ``V``
+projection through the same fused epilogue (``tfrs_cross_fwd_ex``).
+"""
+
+import math
+from typing import Callable, Optional, Union
+
+import torch
+
+from recommenders_amd import _lib
+
+_ACTIVATIONS = {
+    None: None, "linear": None, "relu": torch.relu, "sigmoid": torch.sigmoid,
+    "tanh": torch.tanh, "swish": torch.nn.functional.silu, "silu": torch.nn.functional.silu,
+    "gelu": torch.nn.functional.gelu,
+}
+
+
+def _get_activation(spec):
+  if callable(spec):
+    return spec
+  if spec in _ACTIVATIONS:
+    return _ACTIVATIONS[spec]
+  raise ValueError(f"Unknown activation: {spec!r}")
+
+
+def _initialize(spec: Union[str, Callable], shape, device) -> torch.Tensor:
+  """Keras initialiser names used by the reference: truncated_normal (stddev 0.05,
+  resampled beyond 2 sigma), zeros, ones, glorot_uniform."""
+  t = torch.empty(shape, dtype=torch.float32, device=device)
+  if callable(spec):
+    return spec(t)
+  if spec == "truncated_normal":
+    return torch.nn.init.trunc_normal_(t, mean=0.0, std=0.05, a=-0.1, b=0.1)
+  if spec == "zeros":
+    return t.zero_()
+  if spec == "ones":
+    return t.fill_(1.0)
+  if spec == "glorot_uniform":
+    fan = sum(shape) if len(shape) == 2 else shape[0]
+    lim = math.sqrt(6.0 / fan)
+    return t.uniform_(-lim, lim)
+  raise ValueError(f"Unknown initializer: {spec!r}")
+
+
+def dense(x: torch.Tensor, kernel: torch.Tensor, bias: Optional[torch.Tensor] = None
+          ) -> torch.Tensor:
+  """``x @ kernel + bias`` (Keras Dense layout ``[in, out]``) via ``tfrs_dense_fwd``."""
+  x = x.contiguous()
+  kernel = kernel.contiguous()
+  out = torch.empty((x.shape[0], kernel.shape[1]), dtype=torch.float32, device=x.device)
+  _lib.check(_lib.load().tfrs_dense_fwd(
+      _lib.ptr(x), _lib.ptr(kernel), _lib.ptr(bias), x.shape[0], kernel.shape[0],
+      kernel.shape[1], _lib.ptr(out), _lib.current_stream()))
+  return out
+
+
+class _DenseFn(torch.autograd.Function):
+  """Dense with gradients, every GEMM on the HIP kernel."""
+
+  @staticmethod
+  def forward(ctx, x, kernel, bias):
+    ctx.save_for_backward(x, kernel)
+    ctx.has_bias = bias is not None
+    return dense(x, kernel, bias)
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, kernel = ctx.saved_tensors
+    dy = dy.contiguous()
+    dx = dense(dy, kernel.t().contiguous())
+    dk = dense(x.t().contiguous(), dy)
+    db = dy.sum(dim=0) if ctx.has_bias else None
+    return dx, dk, db
+
+
+class _CrossFn(torch.autograd.Function):
+  """Fused full-rank cross:  y = x0 * (x @ W + b + diag * x) + x."""
+
+  @staticmethod
+  def forward(ctx, x0, x, kernel, bias, diag):
+    x0, x, kernel = x0.contiguous(), x.contiguous(), kernel.contiguous()
+    y = torch.empty_like(x0)
+    _lib.check(_lib.load().tfrs_cross_fwd(
+        _lib.ptr(x0), _lib.ptr(x), _lib.ptr(kernel), _lib.ptr(bias), float(diag),
+        x0.shape[0], x0.shape[1], _lib.ptr(y), _lib.current_stream()))
+    ctx.save_for_backward(x0, x, kernel, bias)
+    ctx.diag = float(diag)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    x0, x, kernel, bias = ctx.saved_tensors
+    dy = dy.contiguous()
+    z = dense(x, kernel, bias)                     # recomputed, not stored
+    if ctx.diag:
+      z = z + ctx.diag * x
+    dz = dy * x0
+    dx0 = dy * z
+    dx = dense(dz, kernel.t().contiguous()) + dy
+    if ctx.diag:
+      dx = dx + ctx.diag * dz
+    dk = dense(x.t().contiguous(), dz)
+    db = dz.sum(dim=0) if bias is not None else None
+    return dx0, dx, dk, db, None
+
+
+class Cross(torch.nn.Module):
+  """Cross layer of the Deep & Cross Network (reference dcn.py:23-208)."""
+
+  def __init__(self, projection_dim: Optional[int] = None, diag_scale: Optional[float] = 0.0,
+               use_bias: bool = True, preactivation=None,
+               kernel_initializer="truncated_normal", bias_initializer="zeros",
+               kernel_regularizer=None, bias_regularizer=None, **kwargs):
+    super().__init__()
+    self._projection_dim = projection_dim
+    self._diag_scale = diag_scale
+    self._use_bias = use_bias
+    self._preactivation_spec = preactivation
+    self._preactivation = _get_activation(preactivation)
+    self._kernel_initializer = kernel_initializer
+    self._bias_initializer = bias_initializer
+    self._kernel_regularizer = kernel_regularizer
+    self._bias_regularizer = bias_regularizer
+    self.name = kwargs.get("name", "cross")
+    self.built = False
+    if self._diag_scale < 0:                                           # :112-115
+      raise ValueError(
+          "`diag_scale` should be non-negative. Got `diag_scale` = {}".format(self._diag_scale))
+
+  def build(self, input_shape, device=None) -> None:                   # :117-149
+    last_dim = int(input_shape[-1])
+    dev = device if device is not None else torch.device("cuda")
+    if self._projection_dim is None:
+      self.kernel = torch.nn.Parameter(
+          _initialize(self._kernel_initializer, (last_dim, last_dim), dev))
+    else:
+      p = int(self._projection_dim)
+      self.kernel_u = torch.nn.Parameter(_initialize(self._kernel_initializer, (last_dim, p), dev))
+      self.kernel_v = torch.nn.Parameter(_initialize(self._kernel_initializer, (p, last_dim), dev))
+    self.bias = (torch.nn.Parameter(_initialize(self._bias_initializer, (last_dim,), dev))
+                 if self._use_bias else None)
+    self.built = True
+
+  def regularization_losses(self):
+    """Keras ``layer.losses`` equivalent: regulariser callables applied to the weights."""
+    out = []
+    if self._kernel_regularizer is not None:
+      for name in ("kernel", "kernel_u", "kernel_v"):
+        if hasattr(self, name):
+          out.append(self._kernel_regularizer(getattr(self, name)))
+    if self._bias_regularizer is not None and self.bias is not None:
+      out.append(self._bias_regularizer(self.bias))
+    return out
+
+  def forward(self, x0: torch.Tensor, x: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if not self.built:
+      self.build(x0.shape, x0.device)                                  # :161-162
+    if x is None:
+      x = x0                                                           # :164-165
+    if x0.shape[-1] != x.shape[-1]:                                    # :167-171
+      raise ValueError(
+          "`x0` and `x` dimension mismatch! Got `x0` dimension {}, and x "
+          "dimension {}. This case is not supported yet.".format(x0.shape[-1], x.shape[-1]))
+    x0 = x0.to(torch.float32)
+    x = x.to(torch.float32)
+    diag = float(self._diag_scale or 0.0)
+    if self._preactivation is None:
+      if self._projection_dim is None:
+        return _CrossFn.apply(x0, x, self.kernel, self.bias, diag)     # :173-186 fused
+      h = _DenseFn.apply(x, self.kernel_u, None)                       # :176
+      return _LowRankCrossFn.apply(x0, x, h, self.kernel_v, self.bias, diag)
+    # non-linear preactivation: GEMM on the HIP kernel, activation + cross formula
+    # element-wise (the reference's unfused order, :173-186)
+    if self._projection_dim is None:
+      prod = self._preactivation(_DenseFn.apply(x, self.kernel, self.bias))
+    else:
+      prod = self._preactivation(
+          _DenseFn.apply(_DenseFn.apply(x, self.kernel_u, None), self.kernel_v, self.bias))
+    if diag:
+      prod = prod + diag * x
+    return x0 * prod + x
+
+  call = forward
+
+  def get_config(self):                                                # :188-208
+    return {
+        "projection_dim": self._projection_dim,
+        "diag_scale": self._diag_scale,
+        "use_bias": self._use_bias,
+        "preactivation": self._preactivation_spec,
+        "kernel_initializer": self._kernel_initializer,
+        "bias_initializer": self._bias_initializer,
+        "kernel_regularizer": self._kernel_regularizer,
+        "bias_regularizer": self._bias_regularizer,
+        "name": self.name,
+    }
+
+  @classmethod
+  def from_config(cls, config):
+    return cls(**config)
+
+
+class _LowRankCrossFn(torch.autograd.Function):
+  """y = x0 * (h @ V + b + diag * x) + x  with h = x @ U computed by the caller."""
+
+  @staticmethod
+  def forward(ctx, x0, x, h, kernel_v, bias, diag):
+    x0, x, h, kernel_v = x0.contiguous(), x.contiguous(), h.contiguous(), kernel_v.contiguous()
+    y = torch.empty_like(x0)
+    _lib.check(_lib.load().tfrs_cross_fwd_ex(
+        _lib.ptr(x0), _lib.ptr(x), _lib.ptr(h), h.shape[1], _lib.ptr(kernel_v),
+        _lib.ptr(bias), float(diag), x0.shape[0], x0.shape[1], _lib.ptr(y),
+        _lib.current_stream()))
+    ctx.save_for_backward(x0, x, h, kernel_v, bias)
+    ctx.diag = float(diag)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    x0, x, h, kernel_v, bias = ctx.saved_tensors
+    dy = dy.contiguous()
+    z = dense(h, kernel_v, bias)
+    if ctx.diag:
+      z = z + ctx.diag * x
+    dz = dy * x0
+    dx0 = dy * z
+    dx = dy + (ctx.diag * dz if ctx.diag else 0.0)
+    dh = dense(dz, kernel_v.t().contiguous())
+    dv = dense(h.t().contiguous(), dz)
+    db = dz.sum(dim=0) if bias is not None else None
+    return dx0, dx, dh, dv, db, None

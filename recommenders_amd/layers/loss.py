@@ -1,0 +1,50 @@
+"""Logit post-processing of the retrieval loss (reference ``layers/loss.py``).
+
+In the fused training path these transforms are folded into the softmax kernel's logit
+function (``csrc/softmax.hip``: ``make_logit``).  The classes below keep the reference's
+public layer names for code that applies them to an explicit ``[B, C]`` logits tensor
+(e.g. batch metrics); they are element-wise / tiny-top-k glue on torch tensors.
+"""
+
+from typing import Tuple
+
+import numpy as np
+import torch
+
+MAX_FLOAT = float(np.finfo(np.float32).max / 100.0)   # loss.py:22
+MIN_FLOAT = float(np.finfo(np.float32).min / 100.0)   # loss.py:23
+
+
+class HardNegativeMining(torch.nn.Module):
+  """Keeps the positive and the ``num_hard_negatives`` highest negatives per row
+  (loss.py:61-111)."""
+
+  def __init__(self, num_hard_negatives: int) -> None:
+    super().__init__()
+    self._num_hard_negatives = num_hard_negatives
+
+  def forward(self, logits: torch.Tensor, labels: torch.Tensor
+              ) -> Tuple[torch.Tensor, torch.Tensor]:
+    num_sampled = min(self._num_hard_negatives + 1, logits.shape[1])   # :91
+    _, cols = torch.topk(logits + labels * MAX_FLOAT, k=num_sampled, dim=1)   # :104-105
+    return torch.gather(logits, 1, cols), torch.gather(labels, 1, cols)       # :108-109
+
+
+class RemoveAccidentalHits(torch.nn.Module):
+  """Pushes logits of negatives that share the positive's id to MIN_FLOAT
+  (loss.py:114-147)."""
+
+  def forward(self, labels: torch.Tensor, logits: torch.Tensor,
+              candidate_ids: torch.Tensor) -> torch.Tensor:
+    ids = candidate_ids.reshape(-1)
+    pos_ids = ids[torch.argmax(labels, dim=1)]                         # :139-140
+    dup = (pos_ids.unsqueeze(1) == ids.unsqueeze(0)).to(labels.dtype) - labels   # :142-146
+    return logits + dup * MIN_FLOAT                                    # :147
+
+
+class SamplingProbablityCorrection(torch.nn.Module):
+  """``logits - log(clip(p, 1e-6, 1))`` (loss.py:150-158)."""
+
+  def forward(self, logits: torch.Tensor, candidate_sampling_probability: torch.Tensor
+              ) -> torch.Tensor:
+    return logits - torch.log(torch.clamp(candidate_sampling_probability, 1e-6, 1.0))

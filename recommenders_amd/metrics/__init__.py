@@ -1,0 +1,3 @@
+"""Metrics (mirrors tensorflow_recommenders/metrics/__init__.py:17-18)."""
+
+from recommenders_amd.metrics.factorized_top_k import Factorized, FactorizedTopK, Mean  # noqa: F401

@@ -1,0 +1,235 @@
+"""The factorized retrieval task on MI355X.
+
+Mirror of ``tensorflow_recommenders/tasks/retrieval.py:29-235``: same constructor and
+``call`` arguments.  The default loss -- in-batch sampled softmax, i.e. Keras
+``CategoricalCrossentropy(from_logits=True, reduction=SUM)`` on ``labels = eye`` (:86-87,
+:185, :210) -- runs as a fused f32-MFMA kernel pair that never materialises the
+``[num_queries, num_candidates]`` logits (``tfrs_inbatch_softmax_ce_fwd/_bwd``), with
+temperature (:187), sampling-probability correction (:190), accidental-hit removal
+(:194-200) and ``score_mask`` (:202) folded into the logit function.
+
+Paths that need the explicit logits matrix -- ``batch_metrics`` (:228-232), a
+user-supplied ``loss``, ``num_hard_negatives`` (:205-208) and multi-head (3-D) queries
+(:173-176) -- compute it with the HIP dense GEMM and then follow the reference's op
+sequence on that tensor.
+"""
+
+from typing import Callable, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from recommenders_amd import _lib
+from recommenders_amd.layers import loss as loss_layers
+from recommenders_amd.layers.feature_interaction.dcn import _DenseFn
+from recommenders_amd.metrics import factorized_top_k as tfrs_metrics
+from recommenders_amd.tasks import base
+
+MIN_FLOAT = float(np.finfo(np.float32).min / 100.0)   # retrieval.py:26
+
+
+class _InBatchSoftmaxFn(torch.autograd.Function):
+  """loss = sum_b w_b (logsumexp_c S_bc - S_bb), gradients wrt both embedding matrices."""
+
+  @staticmethod
+  def forward(ctx, q, c, sample_weight, inv_t, log_corr, cand_ids, score_mask):
+    lib = _lib.load()
+    q = q.contiguous()
+    c = c.contiguous()
+    nq, d = q.shape
+    nc = c.shape[0]
+    ws = torch.empty((lib.tfrs_inbatch_softmax_workspace_bytes(nq, nc, d),),
+                     dtype=torch.uint8, device=q.device)
+    loss = torch.empty((), dtype=torch.float32, device=q.device)
+    lse = torch.empty((nq,), dtype=torch.float32, device=q.device)
+    pos = torch.empty((nq,), dtype=torch.float32, device=q.device)
+    _lib.check(lib.tfrs_inbatch_softmax_ce_fwd(
+        _lib.ptr(q), _lib.ptr(c), nq, nc, d, _lib.ptr(sample_weight), float(inv_t),
+        _lib.ptr(log_corr), _lib.ptr(cand_ids), _lib.ptr(score_mask), _lib.ptr(loss),
+        _lib.ptr(lse), _lib.ptr(pos), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+    ctx.save_for_backward(q, c, sample_weight, log_corr, cand_ids, score_mask, lse)
+    ctx.inv_t = float(inv_t)
+    return loss
+
+  @staticmethod
+  def backward(ctx, gloss):
+    q, c, sample_weight, log_corr, cand_ids, score_mask, lse = ctx.saved_tensors
+    lib = _lib.load()
+    nq, d = q.shape
+    nc = c.shape[0]
+    ws = torch.empty((lib.tfrs_inbatch_softmax_workspace_bytes(nq, nc, d),),
+                     dtype=torch.uint8, device=q.device)
+    dq = torch.empty_like(q)
+    dc = torch.empty_like(c)
+    g = gloss.to(torch.float32).contiguous()
+    _lib.check(lib.tfrs_inbatch_softmax_ce_bwd(
+        _lib.ptr(q), _lib.ptr(c), nq, nc, d, _lib.ptr(sample_weight), ctx.inv_t,
+        _lib.ptr(log_corr), _lib.ptr(cand_ids), _lib.ptr(score_mask), _lib.ptr(lse),
+        _lib.ptr(g), _lib.ptr(dq), _lib.ptr(dc), _lib.ptr(ws), ws.numel(),
+        _lib.current_stream()))
+    return dq, dc, None, None, None, None, None
+
+
+def in_batch_softmax_loss(query_embeddings: torch.Tensor, candidate_embeddings: torch.Tensor,
+                          sample_weight: Optional[torch.Tensor] = None,
+                          temperature: Optional[float] = None,
+                          candidate_sampling_probability: Optional[torch.Tensor] = None,
+                          candidate_ids: Optional[torch.Tensor] = None,
+                          score_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+  """Functional form of the fused default loss (retrieval.py:172-210)."""
+  dev = query_embeddings.device
+  inv_t = 1.0 if temperature is None else 1.0 / float(temperature)
+  w = None if sample_weight is None else sample_weight.reshape(-1).to(dev, torch.float32).contiguous()
+  corr = None
+  if candidate_sampling_probability is not None:                      # loss.py:157-158
+    corr = torch.log(torch.clamp(candidate_sampling_probability.to(dev, torch.float32),
+                                 1e-6, 1.0)).contiguous()
+  ids = None if candidate_ids is None else candidate_ids.reshape(-1).to(dev).long().contiguous()
+  mask = None if score_mask is None else score_mask.to(dev).to(torch.uint8).contiguous()
+  return _InBatchSoftmaxFn.apply(query_embeddings.to(torch.float32),
+                                 candidate_embeddings.to(torch.float32), w, inv_t, corr, ids, mask)
+
+
+class TopKCategoricalAccuracy:
+  """``tf.keras.metrics.TopKCategoricalAccuracy(k)`` for ``batch_metrics``: weighted
+  mean of ``in_top_k(argmax(labels), logits, k)`` (ties count for the target)."""
+
+  def __init__(self, k: int = 5, name: str = "top_k_categorical_accuracy"):
+    self.k = k
+    self.name = name
+    self._mean = tfrs_metrics.Mean(name)
+
+  def update_state(self, labels, logits, sample_weight=None):
+    target = torch.gather(logits, 1, torch.argmax(labels, dim=1, keepdim=True))
+    greater = (logits > target).sum(dim=1)
+    hit = ((greater < self.k) & torch.isfinite(target.squeeze(1))).to(torch.float32)
+    self._mean.update_state(hit, sample_weight)
+
+  def result(self):
+    return self._mean.result()
+
+  def reset_states(self):
+    self._mean.reset_states()
+
+
+class Retrieval(torch.nn.Module, base.Task):
+  """A factorized retrieval task (reference :29-235)."""
+
+  def __init__(self, loss: Optional[Callable] = None,
+               metrics: Optional[Union[Sequence[tfrs_metrics.Factorized],
+                                       tfrs_metrics.Factorized]] = None,
+               batch_metrics: Optional[List] = None, loss_metrics: Optional[List] = None,
+               temperature: Optional[float] = None, num_hard_negatives: Optional[int] = None,
+               remove_accidental_hits: bool = False, name: Optional[str] = None) -> None:
+    super().__init__()
+    self.name = name or "retrieval"
+    self._loss = loss            # None -> fused in-batch softmax (:86-87)
+    if metrics is None:
+      metrics = []
+    if not isinstance(metrics, Sequence):
+      metrics = [metrics]
+    self._factorized_metrics = list(metrics)
+    self._batch_metrics = batch_metrics or []
+    self._loss_metrics = loss_metrics or []
+    self._temperature = temperature
+    self._num_hard_negatives = num_hard_negatives
+    self._remove_accidental_hits = remove_accidental_hits
+
+  @property
+  def factorized_metrics(self):
+    return self._factorized_metrics                                     # :101-106
+
+  @factorized_metrics.setter
+  def factorized_metrics(self, value) -> None:                          # :108-119
+    if not isinstance(value, Sequence):
+      value = []
+    self._factorized_metrics = list(value)
+
+  @property
+  def metrics(self):
+    """All metric objects, like Keras' ``layer.metrics``."""
+    out = []
+    for m in self._factorized_metrics:
+      out.extend(m.metrics)
+    return out + list(self._batch_metrics) + list(self._loss_metrics)
+
+  def _logits_and_labels(self, q, c, candidate_sampling_probability, candidate_ids,
+                         score_mask):
+    """Explicit logits following :172-208 (only for paths that need the matrix)."""
+    if q.dim() == 3:                                                    # :172-176 maxsim
+      nq, heads, d = q.shape
+      flat = _DenseFn.apply(q.reshape(nq * heads, d).contiguous(), c.t().contiguous(), None)
+      scores = flat.reshape(nq, heads, -1).max(dim=1).values
+    else:
+      scores = _DenseFn.apply(q.contiguous(), c.t().contiguous(), None)  # :178-180
+    nq, nc = scores.shape
+    labels = torch.eye(nq, nc, dtype=torch.float32, device=scores.device)   # :185
+    if self._temperature is not None:
+      scores = scores / self._temperature                               # :187-188
+    if candidate_sampling_probability is not None:
+      scores = loss_layers.SamplingProbablityCorrection()(
+          scores, candidate_sampling_probability.to(scores.device))     # :190-192
+    if self._remove_accidental_hits:
+      scores = loss_layers.RemoveAccidentalHits()(labels, scores,
+                                                  candidate_ids.to(scores.device))  # :200
+    if score_mask is not None:
+      scores = torch.where(score_mask.to(scores.device).bool(), scores,
+                           torch.full_like(scores, MIN_FLOAT))          # :202-203
+    if self._num_hard_negatives is not None:
+      scores, labels = loss_layers.HardNegativeMining(self._num_hard_negatives)(
+          scores, labels)                                               # :205-208
+    return scores, labels
+
+  def forward(self, query_embeddings: torch.Tensor, candidate_embeddings: torch.Tensor,
+              sample_weight: Optional[torch.Tensor] = None,
+              candidate_sampling_probability: Optional[torch.Tensor] = None,
+              candidate_ids: Optional[torch.Tensor] = None, compute_metrics: bool = True,
+              compute_batch_metrics: bool = True,
+              score_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if self._remove_accidental_hits and candidate_ids is None:          # :194-199
+      raise ValueError("When accidental hit removal is enabled, candidate ids "
+                       "must be supplied.")
+    q, c = query_embeddings, candidate_embeddings
+    if sample_weight is not None and not isinstance(sample_weight, torch.Tensor):
+      sample_weight = torch.as_tensor(np.asarray(sample_weight, dtype=np.float32))
+    if sample_weight is not None:
+      sample_weight = sample_weight.to(q.device)
+
+    need_matrix = (q.dim() == 3 or self._loss is not None
+                   or self._num_hard_negatives is not None
+                   or (compute_batch_metrics and len(self._batch_metrics) > 0))
+    scores = labels = None
+    if need_matrix:
+      scores, labels = self._logits_and_labels(
+          q, c, candidate_sampling_probability, candidate_ids, score_mask)
+
+    if self._loss is None and q.dim() == 2 and self._num_hard_negatives is None:
+      loss = in_batch_softmax_loss(                                     # fused :172-210
+          q, c, sample_weight, self._temperature, candidate_sampling_probability,
+          candidate_ids if self._remove_accidental_hits else None, score_mask)
+    elif self._loss is None:
+      # CategoricalCrossentropy(from_logits, SUM) on the explicit logits (:86-87, :210)
+      per_row = -(labels * torch.log_softmax(scores, dim=1)).sum(dim=1)
+      if sample_weight is not None:
+        per_row = per_row * sample_weight.reshape(-1)
+      loss = per_row.sum()
+    else:
+      loss = self._loss(y_true=labels, y_pred=scores, sample_weight=sample_weight)
+
+    for metric in self._loss_metrics:                                   # :213-214
+      metric.update_state(loss.detach())
+
+    if compute_metrics and q.dim() == 2:                                # :216-226
+      with torch.no_grad():
+        for metric in self._factorized_metrics:
+          metric.update_state(q.detach(), c.detach()[:q.shape[0]],
+                              true_candidate_ids=candidate_ids, sample_weight=sample_weight)
+
+    if compute_batch_metrics:                                           # :228-232
+      with torch.no_grad():
+        for metric in self._batch_metrics:
+          metric.update_state(labels, scores.detach(), sample_weight=sample_weight)
+
+    return loss
+
+  call = forward
