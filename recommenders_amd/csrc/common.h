@@ -89,12 +89,15 @@ struct ScanArgs {
   int64_t split_len;     // rows per split (multiple of kTileN)
   int n_qtiles;          // ceil(nq / 256)
   int n_splits;
-  // FILTER mode
+  // FILTER mode: every lane (query j, lane half h) of the wave that owns a query appends the
+  // scores above thr[query] to its PRIVATE segment seg = 2*split + h of that query's list:
+  //   buf[(query * nseg + seg) * cap_l + e],  cnt[query * nseg + seg] = number appended
+  // (counts may exceed cap_l: the excess was dropped and the query is recomputed exactly).
   const float *thr;      // [nq] current K-th best score per query
-  uint32_t *cnt;         // [nq] number of appended passers
-  uint2 *buf;            // [nq, cap] (score bits, row index)
-  uint32_t cap;
-  uint32_t *overflow;    // [nq] set to 1 when a passer was dropped
+  uint32_t *cnt;         // [nq, nseg]
+  uint2 *buf;            // [nq, nseg, cap_l] (score bits, row index)
+  uint32_t cap_l;        // entries per segment
+  int nseg;              // 2 * n_splits
   // MATERIALIZE mode
   float *dense;          // [nq, ld_dense] scores for rows c_begin..c_end
   int64_t ld_dense;
@@ -116,11 +119,12 @@ struct SelectArgs {
   const float *dense;
   int64_t ld_dense;
   int64_t n_dense;
-  // kSrcList: buf[nq, cap] with cnt[nq] entries; overflow rows are recomputed exactly
+  // kSrcList: segmented survivor lists written by scan_kernel (see ScanArgs); a query with
+  // any cnt > cap_l lost entries and is recomputed exactly from the packed corpus
   const uint2 *buf;
   const uint32_t *cnt;
-  uint32_t cap;
-  const uint32_t *overflow;
+  uint32_t cap_l;
+  int nseg;
   // recompute fallback inputs (rows [rc_begin, rc_end) of the packed corpus)
   const float *q;
   int d;

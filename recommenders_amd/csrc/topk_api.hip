@@ -84,28 +84,36 @@ static int64_t dense_rows(int64_t n, int k, const TopkTuning &t) {
   return std::min<int64_t>(padded_rows(n), want);
 }
 
-static uint32_t list_cap(int k, const TopkTuning &t) {
-  const int64_t c = std::max<int64_t>(1024, 4 * (int64_t)k * (t.rho - 1));
-  return (uint32_t)align_up((size_t)c, 256);
+// Expected survivors per query per round (x4 safety): K * (rho - 1).
+static int64_t list_expect(int k, const TopkTuning &t) {
+  return std::max<int64_t>(1024, 4 * (int64_t)k * (t.rho - 1));
+}
+static int max_splits(int64_t nq, const TopkTuning &t) {
+  const int64_t n_qtiles = (nq + 255) / 256;
+  return (int)std::max<int64_t>(1, (t.target_wgs + n_qtiles - 1) / n_qtiles);
+}
+// Survivor-list entries reserved per query: every round uses nseg = 2 * n_splits segments
+// of cap_l = max(16, ceil(expect / nseg)) entries, so nseg * cap_l <= expect + 16 * nseg.
+static int64_t list_entries_per_query(int64_t nq, int k, const TopkTuning &t) {
+  return list_expect(k, t) + 16 * 2 * (int64_t)max_splits(nq, t) + 64;
 }
 
 struct RoundWs {
   float *thr;
   uint32_t *cnt;
-  uint32_t *overflow;
   float *dense;
   int64_t ld_dense;
   uint2 *buf;
-  uint32_t cap;
+  int64_t entries;  // per query
   char *end;
 };
 
 static size_t round_ws_bytes(int64_t nq, int64_t n, int k, const TopkTuning &t) {
   size_t b = 0;
-  b += align_up((size_t)nq * 4);                           // thr
-  b += align_up((size_t)nq * 8);                           // cnt + overflow (contiguous)
-  b += align_up((size_t)nq * dense_rows(n, k, t) * 4);     // dense
-  b += align_up((size_t)nq * list_cap(k, t) * 8);          // buf
+  b += align_up((size_t)nq * 4);                                        // thr
+  b += align_up((size_t)nq * 2 * max_splits(nq, t) * 4);                 // cnt[nq, nseg]
+  b += align_up((size_t)nq * dense_rows(n, k, t) * 4);                   // dense
+  b += align_up((size_t)nq * list_entries_per_query(nq, k, t) * 8);      // buf
   return b;
 }
 
@@ -114,14 +122,13 @@ static RoundWs carve_round_ws(char *p, int64_t nq, int64_t n, int k, const TopkT
   w.thr = reinterpret_cast<float *>(p);
   p += align_up((size_t)nq * 4);
   w.cnt = reinterpret_cast<uint32_t *>(p);
-  w.overflow = w.cnt + nq;
-  p += align_up((size_t)nq * 8);
+  p += align_up((size_t)nq * 2 * max_splits(nq, t) * 4);
   w.ld_dense = dense_rows(n, k, t);
   w.dense = reinterpret_cast<float *>(p);
   p += align_up((size_t)nq * w.ld_dense * 4);
-  w.cap = list_cap(k, t);
+  w.entries = list_entries_per_query(nq, k, t);
   w.buf = reinterpret_cast<uint2 *>(p);
-  p += align_up((size_t)nq * w.cap * 8);
+  p += align_up((size_t)nq * w.entries * 8);
   w.end = p;
   return w;
 }
@@ -166,8 +173,6 @@ static int run_rounds(const float *q, int64_t nq, int d, const char *packed, int
   sa.thr = w.thr;
   sa.cnt = w.cnt;
   sa.buf = w.buf;
-  sa.cap = w.cap;
-  sa.overflow = w.overflow;
   sa.dense = w.dense;
   sa.ld_dense = w.ld_dense;
 
@@ -211,17 +216,22 @@ static int run_rounds(const float *q, int64_t nq, int d, const char *packed, int
     int64_t span = std::max<int64_t>((t.rho - 1) * std::max<int64_t>(seen, 1), kTileN);
     span = padded_rows(span);
     const int64_t hi = (n - lo <= span) ? n : lo + span;
-    TFRS_HIP(hipMemsetAsync(w.cnt, 0, (size_t)nq * 8, stream));  // cnt + overflow
     sa.c_begin = lo;
     sa.c_end = hi;
     plan_splits(hi - lo, n_qtiles, t, &sa.split_len, &sa.n_splits);
+    sa.nseg = 2 * sa.n_splits;
+    sa.cap_l = (uint32_t)std::max<int64_t>(16, (list_expect(k, t) + sa.nseg - 1) / sa.nseg);
+    if ((int64_t)sa.nseg * sa.cap_l > w.entries) {
+      set_error("topk: survivor workspace too small (%d segments x %u)", sa.nseg, sa.cap_l);
+      return TFRS_ENOMEM;
+    }
     if ((rc = timed_scan(sa, /*materialize=*/false, stream)) != TFRS_OK) return rc;
     se.state_len = len;
     se.source = kSrcList;
     se.buf = w.buf;
     se.cnt = w.cnt;
-    se.cap = w.cap;
-    se.overflow = w.overflow;
+    se.cap_l = sa.cap_l;
+    se.nseg = sa.nseg;
     se.rc_begin = lo;
     se.rc_end = hi;
     if ((rc = launch_select(se, stream)) != TFRS_OK) return rc;

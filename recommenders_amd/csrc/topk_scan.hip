@@ -18,15 +18,18 @@
 //               threshold is a single VGPR and the common case "nothing in this
 //               32x32 tile beats the current K-th score" costs 8 v_max3 + 1 compare
 //               per 16 scores.
-//   filter    = scores > thr[query] are appended to a per-wave LDS queue
-//               (ballot/mbcnt compaction, no atomics) that is drained to the
-//               per-query global lists with one atomic slot grab per entry.
+//   filter    = scores > thr[query] are appended by the owning lane to its PRIVATE segment
+//               of the query's survivor list in global memory (counter in a VGPR):
+//               plain fire-and-forget stores -- no atomics, no LDS queue, no memset,
+//               nothing that makes the wave wait on a memory round trip.
 //   exactness = the accumulator is bit-for-bit an fmaf chain over d = 0..D-1
 //               (packed layout feeds features 2s / 2s+1 to lanes 0-31 / 32-63 of step
 //               s), so scores compare == with oracle/c/oracle_core.c.
 //
 // Roofline: MFMA-bound (f32 matrix rate 157.3 TFLOP/s): 2*DP flop per score;
 // LDS traffic is 8 KiB per wave per 32*DP/2 MFMAs (<15 % of the LDS rate).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace tfrs {
@@ -37,7 +40,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stay
 constexpr int kWaves = 8;          // waves per workgroup
 constexpr int kThreads = kWaves * 64;
 constexpr int kQueriesPerWg = kWaves * 32;
-constexpr int kQueueCap = 256;     // entries per wave queue (8 B each)
 
 template <int DP>
 struct ScanGeom {
@@ -46,36 +48,31 @@ struct ScanGeom {
   static constexpr int kStageB = kTileN * kRowB;
   static constexpr int kChunks = kStageB / 16;                        // 16-B chunks per stage
   static constexpr int kLoads = (kChunks + kThreads - 1) / kThreads;  // per thread
-  static constexpr int kLdsBytes = 2 * kStageB + kWaves * kQueueCap * 8;
+  static constexpr int kLdsBytes = 2 * kStageB;
 };
 
-__device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
-  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                   __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
+// Stage copy HBM/L2 -> LDS.  GLDS = true uses the gfx950 direct-to-LDS load
+// (global_load_lds_dwordx4: per-lane global address, LDS destination = wave-uniform base +
+// lane * 16): the packed corpus image is already in its final LDS layout, so the copy is
+// linear, needs no staging VGPRs and no ds_write pass.  GLDS = false stages through
+// registers (global_load_dwordx4 -> ds_write_b128).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-// Drains this wave's LDS queue into the per-query global lists.
-__device__ __forceinline__ void flush_queue(const uint2 *queue, uint32_t qcnt, int lane,
-                                            int64_t q_row0, int64_t c0,
-                                            const ScanArgs &a) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  for (uint32_t e = lane; e < qcnt; e += 64) {
-    const uint2 ent = queue[e];
-    const int64_t row = q_row0 + (ent.y >> 27);
-    const uint32_t idx = (uint32_t)(c0 + (int64_t)(ent.y & 0x07FFFFFFu));
-    const uint32_t slot = atomicAdd(&a.cnt[row], 1u);
-    if (slot < a.cap) {
-      a.buf[row * (int64_t)a.cap + slot] = make_uint2(ent.x, idx);
-    } else {
-      a.overflow[row] = 1u;  // select_kernel recomputes this row exactly
+template <int CHUNKS, int LOADS>
+__device__ __forceinline__ void stage_glds(const char *gsrc, char *lds_dst, int tid, int wave) {
+#pragma unroll
+  for (int i = 0; i < LOADS; ++i) {
+    const int ch0 = i * kThreads + wave * 64;  // first chunk of this wave's instruction
+    if (ch0 < CHUNKS) {                         // wave-uniform (CHUNKS is a multiple of 64)
+      __builtin_amdgcn_global_load_lds((gbl_void_t *)(gsrc + (size_t)(i * kThreads + tid) * 16),
+                                       (lds_void_t *)(lds_dst + ch0 * 16), 16, 0, 0);
     }
   }
-  __builtin_amdgcn_wave_barrier();
 }
 
-template <int DP, bool MATERIALIZE>
-__global__ void __launch_bounds__(kThreads, 2) scan_kernel(const ScanArgs a) {
+template <int DP, bool MATERIALIZE, bool GLDS>
+__global__ void __launch_bounds__(kThreads, DP <= 64 ? 4 : 2) scan_kernel(const ScanArgs a) {
   using G = ScanGeom<DP>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -113,62 +110,81 @@ __global__ void __launch_bounds__(kThreads, 2) scan_kernel(const ScanArgs a) {
   float thr = 0.0f;
   if (!MATERIALIZE) thr = qvalid ? a.thr[qrow] : __builtin_inff();
 
-  uint2 *queue = reinterpret_cast<uint2 *>(smem + 2 * G::kStageB) + wave * kQueueCap;
-  uint32_t qcnt = 0;  // wave-uniform
+  // this lane's private survivor segment
+  const int64_t seg = qrow * a.nseg + 2 * split + h;
+  uint2 *mybuf = MATERIALIZE ? nullptr : a.buf + seg * (int64_t)a.cap_l;
+  uint32_t mycnt = 0;
 
   // ---- stage 0 -> LDS ------------------------------------------------------------
   const char *gsrc = a.packed + c0 * (int64_t)G::kRowB;
   // Every thread moves kLoads 16-byte chunks per stage; chunk numbers past the stage end are
   // clamped for the load (harmless re-read) and skipped for the LDS write, which keeps
   // the staging registers unconditionally defined (no scratch).
-  f32x4 stg[G::kLoads];
+  static_assert(G::kChunks % 64 == 0, "stage size must be a whole number of wave copies");
+  f32x4 stg[GLDS ? 1 : G::kLoads];
+  if (GLDS) {
+    stage_glds<G::kChunks, G::kLoads>(gsrc, smem, tid, wave);
+  } else {
 #pragma unroll
-  for (int i = 0; i < G::kLoads; ++i) {
-    const int ch = min(tid + i * kThreads, G::kChunks - 1);
-    stg[i] = *reinterpret_cast<const f32x4 *>(gsrc + ch * 16);
-  }
+    for (int i = 0; i < G::kLoads; ++i) {
+      const int ch = min(tid + i * kThreads, G::kChunks - 1);
+      stg[i] = *reinterpret_cast<const f32x4 *>(gsrc + ch * 16);
+    }
 #pragma unroll
-  for (int i = 0; i < G::kLoads; ++i) {
-    const int ch = tid + i * kThreads;
-    if (i + 1 < G::kLoads || ch < G::kChunks) *reinterpret_cast<f32x4 *>(smem + ch * 16) = stg[i];
+    for (int i = 0; i < G::kLoads; ++i) {
+      const int ch = tid + i * kThreads;
+      if (i + 1 < G::kLoads || ch < G::kChunks) *reinterpret_cast<f32x4 *>(smem + ch * 16) = stg[i];
+    }
   }
   __syncthreads();
 
   for (int st = 0; st < nstages; ++st) {
     const char *tile = smem + (st & 1) * G::kStageB;
     const bool more = (st + 1 < nstages);
-    if (more) {  // prefetch the next stage into registers; written to LDS after compute
+    if (more) {  // prefetch the next stage (other LDS buffer: its readers passed the last barrier)
       const char *g = gsrc + (int64_t)(st + 1) * G::kStageB;
+      if (GLDS) {
+        stage_glds<G::kChunks, G::kLoads>(g, smem + ((st + 1) & 1) * G::kStageB, tid, wave);
+      } else {
 #pragma unroll
-      for (int i = 0; i < G::kLoads; ++i) {
-        const int ch = min(tid + i * kThreads, G::kChunks - 1);
-        stg[i] = *reinterpret_cast<const f32x4 *>(g + ch * 16);
+        for (int i = 0; i < G::kLoads; ++i) {
+          const int ch = min(tid + i * kThreads, G::kChunks - 1);
+          stg[i] = *reinterpret_cast<const f32x4 *>(g + ch * 16);
+        }
       }
     }
 
     const int64_t stage_c = c0 + (int64_t)st * kTileN;  // first candidate row of this stage
+
+    // A operand of sub-tile 0: candidate row j, plane h: DP/8 slots of 4 consecutive steps.
+    // The fragment registers are refilled IN PLACE with the next sub-tile's slots as soon as
+    // the four MFMAs that consume a slot have issued, so the LDS reads of sub-tile t+1 run
+    // under the MFMA chain of sub-tile t at no extra register cost.
+    const char *ap = tile + j * G::kRowB + h * (DP / 8) * 16;
+    f32x4 a4[G::kSteps / 4];
+#pragma unroll
+    for (int m = 0; m < G::kSteps / 4; ++m) a4[m] = *reinterpret_cast<const f32x4 *>(ap + m * 16);
+
 #pragma unroll 1
     for (int sub = 0; sub < kTileN / 32; ++sub) {
       const int64_t sub_c = stage_c + sub * 32;
       if (sub_c >= c1) break;  // wave-uniform: nothing valid left in this stage
-
-      // A operand: candidate row (sub*32 + j), plane h: DP/8 slots of 4 consecutive steps
-      const char *ap = tile + (sub * 32 + j) * G::kRowB + h * (DP / 8) * 16;
-      f32x4 a4[G::kSteps / 4];
-#pragma unroll
-      for (int m = 0; m < G::kSteps / 4; ++m)
-        a4[m] = *reinterpret_cast<const f32x4 *>(ap + m * 16);
+      // refill source: the next sub-tile, or (harmlessly) this one again on the last pass
+      const bool has_next = (sub + 1 < kTileN / 32) && (sub_c + 32 < c1);
+      const char *an = ap + (has_next ? 32 * G::kRowB : 0);
 
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
       for (int m = 0; m < G::kSteps / 4; ++m) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m].x, bq[4 * m + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m].y, bq[4 * m + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m].z, bq[4 * m + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m].w, bq[4 * m + 3], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m][0], bq[4 * m + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m][1], bq[4 * m + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m][2], bq[4 * m + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m][3], bq[4 * m + 3], acc, 0, 0, 0);
+        a4[m] = *reinterpret_cast<const f32x4 *>(an + m * 16);
       }
+      ap = an;
       // acc[r] = score(query j, candidate sub_c + (r&3) + 8*(r>>2) + 4*h)
 
       if (MATERIALIZE) {
@@ -181,40 +197,37 @@ __global__ void __launch_bounds__(kThreads, 2) scan_kernel(const ScanArgs a) {
           }
         }
       } else {
-        float m0 = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
-        float m1 = fmaxf(fmaxf(acc[3], acc[4]), acc[5]);
-        float m2 = fmaxf(fmaxf(acc[6], acc[7]), acc[8]);
-        float m3 = fmaxf(fmaxf(acc[9], acc[10]), acc[11]);
-        float m4 = fmaxf(fmaxf(acc[12], acc[13]), acc[14]);
-        m0 = fmaxf(fmaxf(m0, m1), m2);
-        m3 = fmaxf(fmaxf(m3, m4), acc[15]);
-        m0 = fmaxf(m0, m3);
+        // group maxima (registers 4g..4g+3 = 4 consecutive candidates of this lane)
+        const float g0 = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+        const float g1 = fmaxf(fmaxf(acc[4], acc[5]), fmaxf(acc[6], acc[7]));
+        const float g2 = fmaxf(fmaxf(acc[8], acc[9]), fmaxf(acc[10], acc[11]));
+        const float g3 = fmaxf(fmaxf(acc[12], acc[13]), fmaxf(acc[14], acc[15]));
+        const float m0 = fmaxf(fmaxf(g0, g1), fmaxf(g2, g3));
         if (__ballot(m0 > thr) != 0ull) {  // rare after warm-up: something may enter the top-K
           const bool ragged = (sub_c + 32 > c1);
           const uint32_t off0 = (uint32_t)(sub_c - c0) + 4u * h;
+          const float gm[4] = {g0, g1, g2, g3};
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const uint32_t off = off0 + (r & 3) + 8 * (r >> 2);
-            bool p = acc[r] > thr;
-            if (ragged) p = p && (c0 + (int64_t)off < c1);
-            const uint64_t mask = __ballot(p);
-            if (mask != 0ull) {
-              if (qcnt + 64 > kQueueCap) {
-                flush_queue(queue, qcnt, lane, q_row0, c0, a);
-                qcnt = 0;
-              }
+          for (int g4 = 0; g4 < 4; ++g4) {
+            if (__ballot(gm[g4] > thr) == 0ull) continue;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              const int r = 4 * g4 + rr;
+              const uint32_t off = off0 + rr + 8 * g4;
+              bool p = acc[r] > thr;
+              if (ragged) p = p && (c0 + (int64_t)off < c1);
               if (p) {
-                queue[qcnt + mbcnt64(mask)] =
-                    make_uint2(__float_as_uint(acc[r]), ((uint32_t)j << 27) | off);
+                if (mycnt < a.cap_l)
+                  mybuf[mycnt] = make_uint2(__float_as_uint(acc[r]), (uint32_t)(c0 + (int64_t)off));
+                ++mycnt;
               }
-              qcnt += (uint32_t)__popcll(mask);
             }
           }
         }
       }
     }
 
-    if (more) {
+    if (more && !GLDS) {
       char *dst = smem + ((st + 1) & 1) * G::kStageB;
 #pragma unroll
       for (int i = 0; i < G::kLoads; ++i) {
@@ -225,42 +238,45 @@ __global__ void __launch_bounds__(kThreads, 2) scan_kernel(const ScanArgs a) {
     __syncthreads();
   }
 
-  if (!MATERIALIZE) {
-    if (qcnt) flush_queue(queue, qcnt, lane, q_row0, c0, a);
+  if (!MATERIALIZE && qvalid) a.cnt[seg] = mycnt;  // every segment is written: no memset needed
+}
+
+template <int DP, bool MAT, bool GLDS>
+static int launch_scan_variant(const ScanArgs &a, hipStream_t stream) {
+  using G = ScanGeom<DP>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    TFRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<DP, MAT, GLDS>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
+    attr_set = true;
   }
+  const dim3 grid((unsigned)(a.n_qtiles * a.n_splits));
+  hipLaunchKernelGGL((scan_kernel<DP, MAT, GLDS>), grid, dim3(kThreads), G::kLdsBytes, stream, a);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+static int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
 }
 
 template <int DP>
 static int launch_scan_dp(const ScanArgs &a, bool materialize, hipStream_t stream) {
-  using G = ScanGeom<DP>;
-  static bool attr_set[2] = {false, false};
-  const dim3 grid((unsigned)(a.n_qtiles * a.n_splits));
+  const bool glds = env_int("TFRS_SCAN_GLDS", 1) != 0;
   if (materialize) {
-    if (!attr_set[0]) {
-      TFRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<DP, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   G::kLdsBytes));
-      attr_set[0] = true;
-    }
-    hipLaunchKernelGGL((scan_kernel<DP, true>), grid, dim3(kThreads), G::kLdsBytes, stream, a);
-  } else {
-    if (!attr_set[1]) {
-      TFRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<DP, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   G::kLdsBytes));
-      attr_set[1] = true;
-    }
-    hipLaunchKernelGGL((scan_kernel<DP, false>), grid, dim3(kThreads), G::kLdsBytes, stream, a);
+    return glds ? launch_scan_variant<DP, true, true>(a, stream)
+                : launch_scan_variant<DP, true, false>(a, stream);
   }
-  TFRS_LAUNCH_CHECK();
-  return TFRS_OK;
+  return glds ? launch_scan_variant<DP, false, true>(a, stream)
+              : launch_scan_variant<DP, false, false>(a, stream);
 }
 
 int launch_scan(const ScanArgs &a, bool materialize, hipStream_t stream) {
   if (a.nq <= 0 || a.c_end <= a.c_begin) return TFRS_OK;
   TFRS_CHECK_ARG(a.c_begin % kTileN == 0 && a.split_len % kTileN == 0,
                  "scan: c_begin/split_len must be multiples of %d", kTileN);
-  TFRS_CHECK_ARG(a.split_len <= (1 << 27), "scan: split too long");
+  TFRS_CHECK_ARG(materialize || a.nseg == 2 * a.n_splits, "scan: nseg must be 2 * n_splits");
   switch (padded_dim(a.d)) {
     case 8: return launch_scan_dp<8>(a, materialize, stream);
     case 16: return launch_scan_dp<16>(a, materialize, stream);

@@ -119,55 +119,83 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
   wave_lds_sync();
 
   // ---- source description ------------------------------------------------------------
-  int source = a.source;
-  int64_t m = 0;
-  bool recompute = false;
-  if (source == kSrcDense) {
-    m = a.n_dense;
-  } else if (source == kSrcList) {
-    if (a.overflow[row]) {
-      recompute = true;
-      m = a.rc_end - a.rc_begin;
-    } else {
-      m = a.cnt[row];
-    }
-  } else {
-    m = (int64_t)a.nparts * a.k_in;
-  }
+  const int source = a.source;
   const int dp = padded_dim(a.d);
-
   int fill = 0;                      // wave-uniform
   uint64_t kth = best[K - 1];        // 0 while fewer than K entries: everything passes
-  for (int64_t base = 0; base < m; base += 64) {
-    const int64_t e = base + lane;
-    uint64_t key = 0ull;
-    if (e < m) {
-      if (recompute) {
-        const int64_t crow = a.rc_begin + e;
-        key = make_key(packed_score(a.packed, crow, dp, a.q + row * a.d, a.d),
-                       (int32_t)(crow + a.idx_base));
-      } else if (source == kSrcDense) {
-        key = make_key(a.dense[row * a.ld_dense + e], (int32_t)(a.idx_base + e));
-      } else if (source == kSrcList) {
-        const uint2 ent = a.buf[row * (int64_t)a.cap + e];
-        key = make_key(__uint_as_float(ent.x), (int32_t)((int64_t)ent.y + a.idx_base));
-      } else {
-        const int64_t part = e / a.k_in, jj = e - part * a.k_in;
-        const int64_t off = (part * a.nq + row) * a.k_in + jj;
-        key = make_key(a.part_scores[off], a.part_idx[off]);
-      }
-    }
+
+  // Offers one key per lane: keys that cannot beat the current K-th are dropped, the rest
+  // are compacted into `chunk`, which is sorted and merged into `best` when it fills.
+  auto consume = [&](uint64_t key) {
     const bool p = key > kth;  // key 0 (empty) never passes
     const uint64_t mask = __ballot(p);
-    if (mask == 0ull) continue;
+    if (mask == 0ull) return;
     if (fill + 64 > KP) {
       absorb_chunk<KP>(best, chunk, fill, lane);
       fill = 0;
       kth = best[K - 1];
     }
-    // re-test against the (possibly raised) threshold is unnecessary for correctness
     if (p) chunk[fill + sel_mbcnt(mask)] = key;
     fill += (int)__popcll(mask);
+  };
+
+  bool recompute = false;
+  if (source == kSrcList) {
+    // a segment whose count exceeds its capacity lost entries: recompute the query exactly
+    bool ovf = false;
+    for (int sg = lane; sg < a.nseg; sg += 64) ovf = ovf || (a.cnt[row * a.nseg + sg] > a.cap_l);
+    recompute = (__ballot(ovf) != 0ull);
+  }
+
+  if (recompute) {
+    const int64_t m = a.rc_end - a.rc_begin;
+    for (int64_t base = 0; base < m; base += 64) {
+      const int64_t e = base + lane;
+      uint64_t key = 0ull;
+      if (e < m) {
+        const int64_t crow = a.rc_begin + e;
+        key = make_key(packed_score(a.packed, crow, dp, a.q + row * a.d, a.d),
+                       (int32_t)(crow + a.idx_base));
+      }
+      consume(key);
+    }
+  } else if (source == kSrcList) {
+    // 4 segments at a time, 16 lanes each
+    for (int sb = 0; sb < a.nseg; sb += 4) {
+      const int sg = sb + (lane >> 4);
+      const uint32_t c = (sg < a.nseg) ? a.cnt[row * a.nseg + sg] : 0u;
+      uint32_t cmax = c;
+      cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, 16));
+      cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, 32));
+      const uint2 *seg = a.buf + (row * a.nseg + sg) * (int64_t)a.cap_l;
+      for (uint32_t e0 = 0; e0 < cmax; e0 += 16) {
+        const uint32_t e = e0 + (lane & 15);
+        uint64_t key = 0ull;
+        if (e < c) {
+          const uint2 ent = seg[e];
+          key = make_key(__uint_as_float(ent.x), (int32_t)((int64_t)ent.y + a.idx_base));
+        }
+        consume(key);
+      }
+    }
+  } else if (source == kSrcDense) {
+    for (int64_t base = 0; base < a.n_dense; base += 64) {
+      const int64_t e = base + lane;
+      consume(e < a.n_dense ? make_key(a.dense[row * a.ld_dense + e], (int32_t)(a.idx_base + e))
+                            : 0ull);
+    }
+  } else {
+    const int64_t m = (int64_t)a.nparts * a.k_in;
+    for (int64_t base = 0; base < m; base += 64) {
+      const int64_t e = base + lane;
+      uint64_t key = 0ull;
+      if (e < m) {
+        const int64_t part = e / a.k_in, jj = e - part * a.k_in;
+        const int64_t off = (part * a.nq + row) * a.k_in + jj;
+        key = make_key(a.part_scores[off], a.part_idx[off]);
+      }
+      consume(key);
+    }
   }
   if (fill > 0) absorb_chunk<KP>(best, chunk, fill, lane);
 

@@ -480,10 +480,13 @@ class ShardedBruteForce(TopK):
     if world == 1:
       return scores, rows
     nq = scores.shape[0]
-    all_s = torch.empty((world, nq, k), dtype=scores.dtype, device=scores.device)
-    all_i = torch.empty((world, nq, k), dtype=rows.dtype, device=rows.device)
+    # concatenated-along-dim-0 output form: accepted by both RCCL and gloo
+    all_s = torch.empty((world * nq, k), dtype=scores.dtype, device=scores.device)
+    all_i = torch.empty((world * nq, k), dtype=rows.dtype, device=rows.device)
     dist.all_gather_into_tensor(all_s, scores.contiguous(), group=self._group)
     dist.all_gather_into_tensor(all_i, rows.contiguous(), group=self._group)
+    all_s = all_s.view(world, nq, k)
+    all_i = all_i.view(world, nq, k)
     if self._merge is not None:
       return self._merge(all_s, all_i, k)
     out_s = torch.empty((nq, k), dtype=torch.float32, device=scores.device)

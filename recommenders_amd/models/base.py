@@ -40,8 +40,10 @@ class Model(torch.nn.Module):
   def metrics(self) -> List[Any]:
     seen, out = set(), []
     for module in self.modules():
+      if module is self:
+        continue
       ms = getattr(module, "metrics", None)
-      if module is self or ms is None or callable(ms):
+      if ms is None or callable(ms):
         continue
       for m in ms:
         if id(m) not in seen:

@@ -1,0 +1,187 @@
+"""CPU-only checks of the boundary and the host logic (no GPU compute):
+the C-ABI library loads and exports every symbol include/tfrs_hip.h declares, argument
+validation returns the documented error codes, host classes raise the reference's
+errors, the product path refuses to run without a GPU, and the multi-GPU exchange logic
+works across 2 gloo ranks."""
+
+import ctypes
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "tfrs_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+  import __graft_entry__
+  __graft_entry__.build()
+  from recommenders_amd import _lib
+  return _lib.load()
+
+
+def _declared_symbols():
+  text = open(HEADER).read()
+  text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+  return sorted(set(re.findall(r"\b(tfrs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound(lib):
+  from recommenders_amd import _lib
+  declared = _declared_symbols()
+  assert len(declared) >= 30
+  so = ctypes.CDLL(_lib.LIB_PATH)
+  missing = [s for s in declared if not hasattr(so, s)]
+  assert not missing, f"declared in tfrs_hip.h but not exported: {missing}"
+  unbound = [s for s in declared if s not in _lib.SIGNATURES]
+  assert not unbound, f"declared but no ctypes prototype in _lib.SIGNATURES: {unbound}"
+  extra = [s for s in _lib.SIGNATURES if s not in declared]
+  assert not extra, f"bound but not declared in the header: {extra}"
+  assert lib.tfrs_version() >= 100
+
+
+def test_argument_validation_without_gpu(lib):
+  """Validation happens before any HIP call, so it is testable on a CPU-only box."""
+  from recommenders_amd import _lib
+  rc = lib.tfrs_topk_merge(None, None, 0, 4, 10, 10, None, None, None, 0, None)
+  assert rc == _lib.TFRS_EINVAL
+  assert "topk_merge" in _lib.last_error()
+  with pytest.raises(ValueError, match="topk_merge"):
+    _lib.check(rc)
+  rc = lib.tfrs_bruteforce_topk(None, None, 4, 10, None, None, None, 0, None)
+  assert rc == _lib.TFRS_ESTATE
+  with pytest.raises(ValueError, match="has not been built"):
+    _lib.check(rc)
+  rc = lib.tfrs_streaming_topk_update(None, 4, 4096, None, 8, 0, 5, None, None, 0, None, None, 0, None)
+  assert rc == _lib.TFRS_ENOTIMPL
+  with pytest.raises(NotImplementedError):
+    _lib.check(rc)
+  assert lib.tfrs_cross_fwd(None, None, None, None, ctypes.c_float(-1.0), 4, 4, None, None) == _lib.TFRS_EINVAL
+  assert "non-negative" in _lib.last_error()
+  assert lib.tfrs_embedding_segment_reduce_fwd(None, 10, 4, None, None, 1, None, 3, 7, None, None, None) == _lib.TFRS_EINVAL
+  assert lib.tfrs_inbatch_softmax_ce_fwd(None, None, 8, 4, 16, None, ctypes.c_float(1.0), None, None, None,
+                                         None, None, None, None, 0, None) == _lib.TFRS_EINVAL
+  assert lib.tfrs_bruteforce_topk_workspace_bytes(8192, 1_000_000, 64, 100) > 8192 * 4096 * 4
+  assert lib.tfrs_inbatch_softmax_workspace_bytes(4096, 4096, 64) > 0
+
+
+def test_host_classes_reference_errors():
+  import recommenders_amd as tfrs
+  ftk = tfrs.layers.factorized_top_k
+  q = np.zeros((2, 4), np.float32)
+  with pytest.raises(NotImplementedError, match="index_from_dataset"):
+    ftk.Streaming().index(q)
+  with pytest.raises(ValueError, match="must be called first"):
+    ftk.Streaming()(q)
+  with pytest.raises(ValueError, match="must be called first"):
+    ftk.BruteForce()(q)
+  with pytest.raises(ValueError, match="must be 2D"):
+    ftk.BruteForce().index(np.zeros((3,), np.float32))
+  with pytest.raises(ValueError, match="same number of"):
+    ftk.BruteForce().index(np.zeros((3, 2), np.float32), np.arange(2))
+  with pytest.raises(ValueError, match="tuples of"):
+    ftk.BruteForce().index_from_dataset([(1, 2, 3)])
+  with pytest.raises(ValueError, match="same batch dimension"):
+    ftk.Streaming().index_from_dataset([(np.arange(3), np.zeros((2, 4), np.float32))])
+  assert ftk.BruteForce().is_exact() and ftk.Streaming().is_exact()
+  with pytest.raises(ValueError, match="should be non-negative"):
+    tfrs.layers.feature_interaction.Cross(diag_scale=-1.0)
+  with pytest.raises(ValueError, match="dimensions must be equal"):
+    tfrs.layers.feature_interaction.DotInteraction()([torch.zeros(1, 3), torch.zeros(1, 2)])
+  with pytest.raises(ValueError, match="candidate ids"):
+    tfrs.tasks.Retrieval(remove_accidental_hits=True)(torch.zeros(2, 3), torch.zeros(2, 3))
+  with pytest.raises(NotImplementedError, match="compute_loss"):
+    tfrs.Model().compute_loss(None)
+  m = tfrs.metrics.FactorizedTopK(candidates=[np.zeros((4, 2), np.float32)], ks=(1, 5))
+  assert [x.name for x in m.metrics] == ["factorized_top_k/top_1_categorical_accuracy",
+                                         "factorized_top_k/top_5_categorical_accuracy"]
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_product_path_fails_loudly_without_gpu():
+  import recommenders_amd as tfrs
+  with pytest.raises(RuntimeError, match="no CPU fallback"):
+    tfrs.layers.factorized_top_k.BruteForce(k=2).index(np.zeros((8, 4), np.float32))
+  with pytest.raises(RuntimeError, match="no CPU fallback"):
+    tfrs.layers.embedding.gather_rows(torch.zeros(4, 4), torch.zeros(2, dtype=torch.long))
+
+
+def test_product_package_never_imports_oracle():
+  """The oracle is test infrastructure: nothing under recommenders_amd/ may reference it."""
+  pkg = os.path.join(ROOT, "recommenders_amd")
+  offenders = []
+  for base, _, files in os.walk(pkg):
+    for f in files:
+      if f.endswith((".py", ".hip", ".cpp", ".h")):
+        text = open(os.path.join(base, f), errors="ignore").read()
+        if re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M) or "oracle/" in text and f.endswith(".py"):
+          offenders.append(os.path.join(base, f))
+  assert not offenders, offenders
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from oracle import topk as o_topk
+from recommenders_amd.layers import factorized_top_k as ftk
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+rng = np.random.default_rng(123)
+n, nq, d, k = 4000, 37, 16, 25
+cand = rng.integers(-3, 4, size=(n, d)).astype(np.float32)      # integer valued: many ties
+qry = rng.integers(-3, 4, size=(nq, d)).astype(np.float32)
+per = n // world
+lo, hi = rank * per, (rank + 1) * per if rank < world - 1 else n
+
+def local_search(q, c, kk):                                      # oracle stands in for the GPU scan
+  s, i = o_topk.brute_force(np.asarray(q), np.asarray(c), kk)
+  return torch.from_numpy(s), torch.from_numpy(i.astype(np.int32))
+
+def merge(all_s, all_i, kk):                                     # oracle stands in for tfrs_topk_merge
+  w, b, _ = all_s.shape
+  fs = all_s.permute(1, 0, 2).reshape(b, -1).numpy()
+  fi = all_i.permute(1, 0, 2).reshape(b, -1).numpy()
+  out_s, out_i = np.empty((b, kk), np.float32), np.empty((b, kk), np.int32)
+  for r in range(b):
+    order = np.lexsort((fi[r], -fs[r]))[:kk]
+    out_s[r], out_i[r] = fs[r][order], fi[r][order]
+  return torch.from_numpy(out_s), torch.from_numpy(out_i)
+
+layer = ftk.ShardedBruteForce(k=k, local_search=local_search, merge=merge).index(cand[lo:hi], base_row=lo)
+s, i = layer(qry)
+es, ei = o_topk.brute_force(qry, cand, k)
+assert np.array_equal(i.numpy(), ei), "sharded indices differ from the single-shard oracle"
+assert np.array_equal(s.numpy(), es)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_topk_two_ranks_gloo(tmp_path):
+  """world_size-2 gloo run of ShardedBruteForce: shard -> local top-K -> all_gather ->
+  merge gives exactly the single-shard answer on every rank (ties included)."""
+  script = tmp_path / "worker.py"
+  script.write_text(_WORKER.format(root=ROOT))
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  port = s.getsockname()[1]
+  s.close()
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2",
+             OMP_NUM_THREADS="2")
+  procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+           for r in range(2)]
+  outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+  for r, (p, o) in enumerate(zip(procs, outs)):
+    assert p.returncode == 0, f"rank {r} failed:\n{o}"
+    assert f"rank {r} ok" in o

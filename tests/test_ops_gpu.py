@@ -1,0 +1,345 @@
+"""GPU parity tests of the embedding, in-batch softmax (Retrieval), metric, Cross /
+MultiLayerDCN and DotInteraction kernels against the oracle and the reference's golden
+vectors.  Float tolerances are written next to each check.  Run with `pytest -m gpu`."""
+
+import numpy as np
+import pytest
+
+from oracle import embedding as o_emb
+from oracle import feature_interaction as o_fi
+from oracle import metrics as o_metrics
+from oracle import retrieval as o_ret
+from oracle import topk as o_topk
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _t(a, **kw):
+  return torch.as_tensor(np.asarray(a), **kw).cuda()
+
+
+def _np(x):
+  return x.detach().cpu().numpy()
+
+
+# ---------------------------------------------------------------------------- embedding
+@pytest.mark.parametrize("d,dtype", [(64, np.int64), (64, np.int32), (7, np.int64), (128, np.int32)])
+def test_embedding_gather_and_grad(d, dtype):
+  from recommenders_amd.layers import embedding as emb
+  rng = np.random.default_rng(d)
+  vocab, n = 2000, 4096
+  table = rng.uniform(-0.05, 0.05, size=(vocab, d)).astype(np.float32)
+  ids = rng.integers(0, vocab, size=(n,)).astype(dtype)
+  out = emb.gather_rows(_t(table), _t(ids))
+  np.testing.assert_array_equal(_np(out), o_emb.gather(table, ids))       # byte copy: exact
+  ids2 = ids.reshape(64, 64)
+  assert tuple(emb.gather_rows(_t(table), _t(ids2)).shape) == (64, 64, d)
+  # backward: deterministic scatter-add, bit-exact vs occurrence-order float32 sums
+  g = rng.normal(size=(n, d)).astype(np.float32)
+  got = emb.scatter_add_rows(_t(g), _t(ids), vocab)
+  np.testing.assert_array_equal(_np(got), o_emb.scatter_add_grad(g, ids, vocab))
+  with pytest.raises(IndexError):
+    emb.gather_rows(_t(table), _t(np.array([vocab], dtype)), validate=True)
+
+
+def test_embedding_layer_autograd_and_adagrad():
+  from recommenders_amd.layers import embedding as emb
+  rng = np.random.default_rng(1)
+  layer = emb.Embedding(2000, 64)
+  assert float(layer.embeddings.abs().max()) <= 0.05
+  ids = _t(rng.integers(0, 2000, size=(4096,)))
+  out = layer(ids)
+  w = _t(rng.normal(size=(4096, 64)).astype(np.float32))
+  (out * w).sum().backward()
+  ref = o_emb.scatter_add_grad(_np(w), _np(ids), 2000)
+  np.testing.assert_array_equal(_np(layer.embeddings.grad), ref)
+  # fused sparse Adagrad vs the oracle formula (float tolerance 1e-6 rel)
+  table = _np(layer.embeddings).copy()
+  accum = np.full_like(table, 0.1)
+  t_dev, a_dev = _t(table.copy()), _t(accum.copy())
+  emb.adagrad_sparse_update_(t_dev, a_dev, w, ids, lr=0.5)
+  t_ref, a_ref = o_emb.adagrad_sparse_update(table, accum, _np(w), _np(ids), lr=0.5)
+  np.testing.assert_allclose(_np(a_dev), a_ref, rtol=1e-6)
+  np.testing.assert_allclose(_np(t_dev), t_ref, rtol=1e-5, atol=1e-7)
+
+
+def test_embedding_combiners():
+  from recommenders_amd.layers import embedding as emb
+  g = load_golden("embedding.json")
+  video, user = np.asarray(g["video_table"], np.float32), np.asarray(g["user_table"], np.float32)
+  for feat, table, comb in (("watched", video, "sum"), ("favorited", video, "sum"),
+                            ("friends", user, "mean")):
+    out = emb.embedding_lookup_sparse(_t(table), _t(g[feat]["ids"]), _t(g[feat]["row_splits"]),
+                                      combiner=comb)
+    np.testing.assert_allclose(_np(out), g[feat]["expected"], rtol=1e-6)
+  rng = np.random.default_rng(2)
+  table = rng.normal(size=(500, 32)).astype(np.float32)
+  lens = rng.integers(0, 6, size=300)
+  splits = np.concatenate([[0], np.cumsum(lens)])
+  ids = rng.integers(0, 500, size=splits[-1])
+  wts = rng.uniform(0.5, 2.0, size=splits[-1]).astype(np.float32)
+  for comb in ("sum", "mean", "sqrtn"):
+    for w in (None, wts):
+      out = emb.embedding_lookup_sparse(_t(table), _t(ids), _t(splits),
+                                        None if w is None else _t(w), combiner=comb)
+      ref = o_emb.lookup_sparse(table, ids, splits, w, comb)
+      np.testing.assert_allclose(_np(out), ref, rtol=2e-6, atol=1e-6)   # fma contraction only
+  with pytest.raises(ValueError, match="combiner"):
+    emb.embedding_lookup_sparse(_t(table), _t(ids), _t(splits), combiner="max")
+
+
+# ---------------------------------------------------------------------------- retrieval
+def test_retrieval_golden_cases():
+  """tasks/retrieval_test.py:33-71,112-137,181-213,257-298 on the HIP path."""
+  import recommenders_amd as tfrs
+  g = load_golden("retrieval.json")
+  for case in g["cases"]:
+    corpus = np.zeros(case["corpus_zeros"], np.float32)
+    bs = case["corpus_batch"]
+    batches = [corpus[i:i + bs] for i in range(0, corpus.shape[0], bs)]
+    from recommenders_amd.tasks.retrieval import TopKCategoricalAccuracy
+    task = tfrs.tasks.Retrieval(
+        metrics=tfrs.metrics.FactorizedTopK(candidates=batches, ks=case["ks"]),
+        batch_metrics=[TopKCategoricalAccuracy(k=1, name="batch_categorical_accuracy_at_1")],
+        loss_metrics=[tfrs.metrics.Mean(name="batch_loss")])
+    q, c = _t(case["query"], dtype=torch.float32), _t(case["candidate"], dtype=torch.float32)
+    w = None if case["sample_weight"] is None else _t(case["sample_weight"], dtype=torch.float32)
+    loss = task(query_embeddings=q, candidate_embeddings=c, sample_weight=w)
+    np.testing.assert_allclose(float(loss), case["expected_loss"], rtol=1e-6, err_msg=case["source"])
+    got = {m.name: float(m.result()) for m in task.metrics}
+    assert got["factorized_top_k/top_5_categorical_accuracy"] == pytest.approx(case["expected_top5"])
+    assert got["batch_categorical_accuracy_at_1"] == pytest.approx(case["expected_batch_top1"])
+    assert got["batch_loss"] == pytest.approx(case["expected_loss"], rel=1e-6)
+    # metric switches (:73-110)
+    for m in task.metrics:
+      m.reset_states()
+    task(query_embeddings=q, candidate_embeddings=c, compute_metrics=False)
+    assert float(task.metrics[0].result()) == 0.0
+  with pytest.raises(ValueError, match="candidate ids"):
+    tfrs.tasks.Retrieval(remove_accidental_hits=True)(q, c)
+
+
+@pytest.mark.parametrize("nq,nc,d", [(2, 2, 3), (64, 64, 64), (100, 333, 20), (257, 300, 128),
+                                     (512, 512, 32), (1000, 1024, 64)])
+def test_inbatch_softmax_options_vs_oracle(nq, nc, d):
+  """loss within 1e-5 relative, gradients within 1e-4 relative (+1e-6 abs) of the
+  float64 oracle, for every fused logit option."""
+  from recommenders_amd.tasks.retrieval import in_batch_softmax_loss
+  rng = np.random.default_rng(nq * 7 + d)
+  q = (rng.normal(size=(nq, d)) / np.sqrt(d) * 3).astype(np.float32)
+  c = (rng.normal(size=(nc, d)) / np.sqrt(d) * 3).astype(np.float32)
+  w = rng.uniform(0.1, 2.0, size=nq).astype(np.float32)
+  p = rng.uniform(0.0, 1.0, size=nc).astype(np.float32)
+  p[::7] = 0.0                                          # exercises the 1e-6 clip
+  ids = rng.integers(0, max(nc // 3, 2), size=nc)       # duplicates -> accidental hits
+  mask = rng.uniform(size=(nq, nc)) > 0.2
+  mask[np.arange(nq), np.arange(nq)] = True
+  variants = [
+      dict(),
+      dict(sample_weight=w),
+      dict(temperature=0.7),
+      dict(candidate_sampling_probability=p),
+      dict(candidate_ids=ids, remove_accidental_hits_flag=True),
+      dict(score_mask=mask),
+      dict(sample_weight=w, temperature=1.3, candidate_sampling_probability=p,
+           candidate_ids=ids, remove_accidental_hits_flag=True, score_mask=mask),
+  ]
+  for kw in variants:
+    ref = o_ret.loss(q, c, **kw)
+    dq_ref, dc_ref = o_ret.loss_grads(q, c, **kw)
+    tq = _t(q).requires_grad_(True)
+    tc = _t(c).requires_grad_(True)
+    loss = in_batch_softmax_loss(
+        tq, tc,
+        sample_weight=None if "sample_weight" not in kw else _t(kw["sample_weight"]),
+        temperature=kw.get("temperature"),
+        candidate_sampling_probability=(None if "candidate_sampling_probability" not in kw
+                                        else _t(kw["candidate_sampling_probability"])),
+        candidate_ids=None if "candidate_ids" not in kw else _t(kw["candidate_ids"]),
+        score_mask=None if "score_mask" not in kw else _t(kw["score_mask"]))
+    np.testing.assert_allclose(float(loss), float(ref), rtol=1e-5, err_msg=str(sorted(kw)))
+    (loss * 2.0).backward()   # upstream gradient 2: exercises gloss
+    scale = max(np.abs(dq_ref).max(), 1e-6)
+    np.testing.assert_allclose(_np(tq.grad) / 2.0, dq_ref, rtol=1e-4, atol=1e-5 * scale,
+                               err_msg=str(sorted(kw)))
+    scale = max(np.abs(dc_ref).max(), 1e-6)
+    np.testing.assert_allclose(_np(tc.grad) / 2.0, dc_ref, rtol=1e-4, atol=1e-5 * scale,
+                               err_msg=str(sorted(kw)))
+
+
+def test_retrieval_hard_negatives_and_custom_paths():
+  import recommenders_amd as tfrs
+  rng = np.random.default_rng(4)
+  q = rng.normal(size=(32, 16)).astype(np.float32)
+  c = rng.normal(size=(40, 16)).astype(np.float32)
+  task = tfrs.tasks.Retrieval(num_hard_negatives=5, temperature=0.5)
+  loss = task(_t(q), _t(c), compute_metrics=False)
+  ref = o_ret.loss(q, c, num_hard_negatives=5, temperature=0.5)
+  np.testing.assert_allclose(float(loss), float(ref), rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------- metrics
+def test_factorized_top_k_metric_golden():
+  """metrics/factorized_top_k_test.py:39-86 and :93-131."""
+  import recommenders_amd as tfrs
+  ftk = tfrs.layers.factorized_top_k
+  g = load_golden("metric.json")["weighted"]
+  rng = np.random.RandomState(g["seed"])
+  nc, nq, d = g["num_candidates"], g["num_queries"], g["dim"]
+  cand_ids = np.arange(0, nc).astype(str)
+  cands = rng.normal(size=(nc, d)).astype(np.float32)
+  query = rng.normal(size=(nq, d)).astype(np.float32)
+  sw = rng.uniform(size=(nq, 1)).astype(np.float32)
+  true_idx = rng.randint(0, nc, size=nq)
+  batches = [(cand_ids[i:i + 32], cands[i:i + 32]) for i in range(0, nc, 32)]
+  for layer in (ftk.Streaming, ftk.BruteForce, None):
+    for use_ids in (True, False):
+      src = batches if layer is None else layer().index_from_dataset(batches)
+      metric = tfrs.metrics.FactorizedTopK(candidates=src, ks=g["ks"])
+      metric.update_state(query_embeddings=query, true_candidate_embeddings=cands[true_idx],
+                          true_candidate_ids=cand_ids[true_idx] if use_ids else None,
+                          sample_weight=sw)
+      got = [float(v) for v in metric.result()]
+      np.testing.assert_allclose(got, g["expected"], rtol=1e-5, err_msg=f"{layer} ids={use_ids}")
+  names = [m.name for m in metric.metrics]
+  assert names == [f"factorized_top_k/top_{k}_categorical_accuracy" for k in g["ks"]]
+
+  g = load_golden("metric.json")["id_based"]
+  rng = np.random.default_rng(g["seed"])
+  nc, nq, d, k = g["num_candidates"], g["num_queries"], g["dim"], g["k"]
+  cands = rng.normal(size=(nc, d)).astype(np.float32)
+  queries = rng.normal(size=(nq, d)).astype(np.float32)
+  true_idx = rng.integers(0, nc, size=nq).astype(np.int32)
+  for layer in (ftk.Streaming, ftk.BruteForce):
+    index = layer(k=k).index_from_dataset([cands[i:i + 32] for i in range(0, nc, 32)])
+    metric = tfrs.metrics.FactorizedTopK(candidates=index, ks=[k])
+    metric.update_state(queries, cands[true_idx], true_idx)
+    assert float(metric.result()[0]) == pytest.approx(g["expected_metric"])
+
+
+# ---------------------------------------------------------------------------- cross / dcn
+def test_cross_golden():
+  from recommenders_amd.layers.feature_interaction import Cross, MultiLayerDCN
+  g = load_golden("feature_interaction.json")
+  for case in g["cross"]:
+    pre = (lambda z: torch.zeros_like(z)) if case.get("preactivation") == "zeros_like" else None
+    layer = Cross(projection_dim=case["projection_dim"], diag_scale=case["diag_scale"],
+                  kernel_initializer=case["kernel"], bias_initializer=case["bias"],
+                  preactivation=pre)
+    x0 = _t(case["x0"], dtype=torch.float32)
+    x = None if case["x"] is None else _t(case["x"], dtype=torch.float32)
+    out = layer(x0, x) if x is not None else layer(x0)
+    np.testing.assert_allclose(_np(out), case["expected"], rtol=1e-6, atol=1e-6,
+                               err_msg=case["source"])
+  for case in g["multi_layer_dcn"]:
+    layer = MultiLayerDCN(projection_dim=case["projection_dim"], num_layers=case["num_layers"],
+                          use_bias=case["use_bias"], kernel_initializer=case["kernel"],
+                          bias_initializer=case["bias"])
+    out = layer(_t(case["x0"], dtype=torch.float32))
+    np.testing.assert_allclose(_np(out), case["expected"], rtol=1e-5, err_msg=case["source"])
+  with pytest.raises(ValueError, match="dimension mismatch"):
+    Cross()(torch.zeros((12, 5), device="cuda"), torch.zeros((12, 7), device="cuda"))
+  with pytest.raises(ValueError, match="should be non-negative"):
+    Cross(diag_scale=-1.0)
+  layer = Cross(projection_dim=None, preactivation="swish")
+  assert Cross.from_config(layer.get_config()).get_config() == layer.get_config()
+
+
+@pytest.mark.parametrize("b,d,p", [(5, 3, None), (300, 96, None), (1000, 257, None),
+                                   (4096, 512, None), (300, 96, 24), (513, 130, 7)])
+def test_cross_random_fwd_bwd(b, d, p):
+  """y and all gradients within 2e-5 relative of the float64 oracle (f32 MFMA GEMM)."""
+  from recommenders_amd.layers.feature_interaction import Cross
+  rng = np.random.default_rng(b + d)
+  x0 = rng.normal(size=(b, d)).astype(np.float32)
+  x = rng.normal(size=(b, d)).astype(np.float32)
+  dy = rng.normal(size=(b, d)).astype(np.float32)
+  layer = Cross(projection_dim=p, diag_scale=0.3, bias_initializer="ones")
+  tx0, tx = _t(x0).requires_grad_(True), _t(x).requires_grad_(True)
+  y = layer(tx0, tx)
+  if p is None:
+    kern, bias = _np(layer.kernel), _np(layer.bias)
+    ref = o_fi.cross(x0, x, kernel=kern, bias=bias, diag_scale=0.3)
+  else:
+    ref = o_fi.cross(x0, x, u=_np(layer.kernel_u), v=_np(layer.kernel_v), bias=_np(layer.bias),
+                     diag_scale=0.3)
+  tol = 2e-5 * np.abs(ref).max()
+  np.testing.assert_allclose(_np(y), ref, rtol=2e-5, atol=tol)
+  y.backward(_t(dy))
+  if p is None:
+    dx0, dx, dw, db = o_fi.cross_grads(x0, x, kern, bias, dy, diag_scale=0.3)
+    for got, want in ((tx0.grad, dx0), (tx.grad, dx), (layer.kernel.grad, dw), (layer.bias.grad, db)):
+      np.testing.assert_allclose(_np(got), want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
+
+
+# ---------------------------------------------------------------------------- dot interaction
+def test_dot_interaction_golden_and_random():
+  from recommenders_amd.layers.feature_interaction import DotInteraction
+  g = load_golden("feature_interaction.json")["dot_interaction"]
+  feats = [_t(f, dtype=torch.float32) for f in g["features"]]
+  for (si, sg), key in {(True, False): "self_gather", (True, True): "self_skip",
+                        (False, False): "noself_gather", (False, True): "noself_skip"}.items():
+    out = DotInteraction(self_interaction=si, skip_gather=sg)(feats)
+    np.testing.assert_allclose(_np(out), g["expected"][key], rtol=1e-5, atol=1e-5, err_msg=key)
+  with pytest.raises(ValueError, match="dimensions must be equal"):
+    DotInteraction()([torch.zeros((1, 3), device="cuda"), torch.zeros((1, 2), device="cuda")])
+  rng = np.random.default_rng(9)
+  for b, f, d in ((7, 5, 8), (130, 27, 16), (64, 101, 32)):
+    xs = [rng.normal(size=(b, d)).astype(np.float32) for _ in range(f)]
+    for si in (False, True):
+      for sg in (False, True):
+        txs = [_t(a).requires_grad_(True) for a in xs]
+        out = DotInteraction(self_interaction=si, skip_gather=sg)(txs)
+        ref = o_fi.dot_interaction(xs, si, sg)
+        np.testing.assert_allclose(_np(out), ref, rtol=1e-5, atol=1e-5)
+        dy = rng.normal(size=ref.shape).astype(np.float32)
+        out.backward(_t(dy))
+        dref = o_fi.dot_interaction_grad(xs, dy, si, sg)          # [b, f, d]
+        got = np.stack([_np(t.grad) for t in txs], axis=1)
+        np.testing.assert_allclose(got, dref, rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------- model
+def test_model_train_step_contract():
+  """models/base.py:64-104: metrics dict keys and a decreasing loss on a toy two-tower."""
+  import recommenders_amd as tfrs
+  rng = np.random.default_rng(0)
+
+  class TwoTower(tfrs.Model):
+    def __init__(self):
+      super().__init__()
+      self.user_model = tfrs.layers.embedding.Embedding(200, 32)
+      self.item_model = tfrs.layers.embedding.Embedding(300, 32)
+      items = torch.arange(300, device="cuda")
+      self.task = tfrs.tasks.Retrieval(metrics=tfrs.metrics.FactorizedTopK(
+          candidates=_Items(self.item_model, items), ks=(1, 5, 10)))
+
+    def compute_loss(self, features, training=False):
+      u = self.user_model(features["user_id"])
+      v = self.item_model(features["movie_id"])
+      return self.task(u, v, compute_metrics=not training)
+
+  class _Items:
+    def __init__(self, model, ids):
+      self.model, self.ids = model, ids
+    def __iter__(self):
+      for lo in range(0, self.ids.numel(), 128):
+        with torch.no_grad():
+          yield self.model(self.ids[lo:lo + 128])
+
+  model = TwoTower()
+  model.compile(optimizer=torch.optim.Adagrad(model.parameters(), lr=0.5,
+                                              initial_accumulator_value=0.1, eps=1e-7))
+  users = rng.integers(0, 200, size=2048)
+  items = (users * 7 + rng.integers(0, 3, size=2048)) % 300
+  batch = {"user_id": _t(users), "movie_id": _t(items)}
+  first = model.train_step(batch)
+  assert {"loss", "regularization_loss", "total_loss"} <= set(first)
+  for _ in range(20):
+    last = model.train_step(batch)
+  assert float(last["loss"]) < float(first["loss"])
+  ev = model.test_step(batch)
+  assert "factorized_top_k/top_10_categorical_accuracy" in ev
+  assert 0.0 <= float(ev["factorized_top_k/top_10_categorical_accuracy"]) <= 1.0
