@@ -58,6 +58,9 @@ int tfrs_device_info(int dev, int *cu_count_h, int *lds_bytes_h, char *arch_h,
  * the last read, after waiting for the recorded events. */
 int tfrs_profile_enable(int on);
 int tfrs_profile_read(double *scan_ms_h, int *launches_h, double *flop_h);
+/* Same sums restricted to one scan kernel (0 = exact f32 scan, 1 = fp16 prefilter scan);
+ * does not reset -- call before tfrs_profile_read. */
+int tfrs_profile_read_kind(int kind, double *scan_ms_h, int *launches_h, double *flop_h);
 
 /* ------------------------------------------------------------------------- *
  * Candidate index (BruteForce.index, layers/factorized_top_k.py:540-584).
@@ -93,6 +96,14 @@ size_t tfrs_bruteforce_topk_workspace_bytes(int64_t nq, int64_t n, int d, int k)
 int tfrs_bruteforce_topk(const tfrs_index_t *index, const float *queries, int64_t nq,
                          int k, float *out_scores, int32_t *out_idx, void *workspace,
                          size_t workspace_bytes, void *stream);
+
+/* Test hook: raw scores of the fp16 PREFILTER (never returned by the product path) for rows
+ * [row_begin, row_end) of the index, row_begin a multiple of 128: out[nq, ld] with
+ * ld = (row_end - row_begin) rounded up to 128; scratch: 2 * nq floats.  tests/ check
+ * |s_16 - s_f32| against the bound ||q|| ||c|| * 0.0011 that the filter relies on. */
+int tfrs_debug_fp16_scores(const tfrs_index_t *index, const float *queries, int64_t nq,
+                           int64_t row_begin, int64_t row_end, float *out, float *scratch,
+                           void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Streaming.call (layers/factorized_top_k.py:404-509): one candidate block.

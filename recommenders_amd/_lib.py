@@ -24,6 +24,7 @@ SIGNATURES = {
     "tfrs_device_info": (c_int, [c_int, P, P, P, c_int]),
     "tfrs_profile_enable": (c_int, [c_int]),
     "tfrs_profile_read": (c_int, [P, P, P]),
+    "tfrs_profile_read_kind": (c_int, [c_int, P, P, P]),
     "tfrs_index_create": (c_int, [P]),
     "tfrs_index_destroy": (c_int, [P]),
     "tfrs_index_set": (c_int, [P, P, c_i64, c_int, P]),
@@ -34,6 +35,7 @@ SIGNATURES = {
     "tfrs_index_unpack": (c_int, [P, P, P]),
     "tfrs_bruteforce_topk_workspace_bytes": (c_size_t, [c_i64, c_i64, c_int, c_int]),
     "tfrs_bruteforce_topk": (c_int, [P, P, c_i64, c_int, P, P, P, c_size_t, P]),
+    "tfrs_debug_fp16_scores": (c_int, [P, P, c_i64, c_i64, c_i64, P, P, P]),
     "tfrs_streaming_topk_workspace_bytes": (c_size_t, [c_i64, c_i64, c_int, c_int]),
     "tfrs_streaming_topk_update": (c_int, [P, c_i64, c_int, P, c_i64, c_i64, c_int, P, P,
                                            ctypes.c_int32, P, P, c_size_t, P]),

@@ -23,12 +23,18 @@ SOURCES = [
     "api.cpp",
     "topk_pack.hip",
     "topk_scan.hip",
+    "topk_scan16.hip",
     "topk_select.hip",
     "topk_api.hip",
     "embedding.hip",
     "softmax.hip",
     "interaction.hip",
 ]
+
+
+# topk_scan16.hip: its max trees must compile to bare v_max3_f32 (no sNaN-quieting
+# canonicalisation of the MFMA results); NaN inputs are outside the top-K contract anyway.
+EXTRA_FLAGS = {"topk_scan16.hip": ["-fno-honor-nans"]}
 
 
 def hipcc() -> str:
@@ -50,7 +56,7 @@ def _compile(src: str, force: bool) -> str:
   deps = [os.path.join(HERE, src), os.path.join(HERE, "common.h"),
           os.path.join(PKG, "..", "include", "tfrs_hip.h")]
   if force or _newer(deps, obj):
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
+    cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(src, []) + [
            "-x", "hip", "-c", os.path.join(HERE, src), "-o", obj]
     subprocess.check_call(cmd)
   return obj

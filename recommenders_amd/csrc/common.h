@@ -57,6 +57,57 @@ __host__ __device__ inline int64_t padded_rows(int64_t n) {
   return (n + kTileN - 1) / kTileN * kTileN;
 }
 
+// ---- fp16 prefilter image -------------------------------------------------------
+// A second, half-size image of the corpus feeds the 16-bit matrix cores (16x the f32 MFMA
+// rate).  Its scores only FILTER: every prefilter score carries a rigorous error bound
+//   |s_16 - s_f32| <= ||q|| * ||c|| * kF16Kappa + kF16Tiny,
+// candidates whose prefilter score is within the bound of the running K-th best are kept and
+// re-scored with the exact f32 fma chain before anything is returned.
+//
+// fp16 (11-bit significand) rather than bf16 (8-bit) because the bound is 8x tighter at the
+// same MFMA rate; its narrow exponent range is handled by power-of-two scales that are
+// folded into the filter threshold (no per-score work): every stage of kTileN rows stores
+// x / s_stage with s_stage = 2^ceil(log2(max |x| in the stage)), every query is scaled by its
+// own 2^ceil(log2(max |q_d|)).  With |x/s| <= 1:
+//   element error <= 2^-11 |x| (normal range) or 2^-25 s (fp16 subnormal range)
+//   => sum over d: 2^-10 sum|q_d c_d| + 2^-25 (s_c ||q||_1 + s_q ||c||_1)
+//                  <= ||q|| * N * (2^-10 + 2^-23 sqrt(D)),  N = max row norm of the stage
+//   + D * 2^-21 ||q|| ||c|| for the f32 accumulation orders (matrix core vs. fma chain)
+// so kappa = 2^-10 + 2^-19.5 + 2^-14 (D = 128) = 1.04e-3; kF16Kappa adds 5 %.
+// Row r of the image occupies row_bytes16(dp16) bytes: dp16 halves in natural feature order
+// + one 16-byte zero pad slot (odd number of 16-B slots per row -> conflict-free
+// ds_read_b128, same argument as the f32 image).  Per stage: StageMeta {norm, scale}.
+constexpr float kF16Kappa = 0.0011f;
+constexpr float kF16Tiny = 1.0e-30f;    // absolute slack (f32 subnormal flushes)
+constexpr float kNormSlack = 1.0002f;   // covers the rounding of the f32 norm computation
+
+struct StageMeta {
+  float norm;       // max row 2-norm of the stage's rows (rounded up)
+  float scale;      // power of two >= max |x| of the stage (1 for an all-zero stage)
+  float inv_scale;  // 1 / scale (exact)
+  float pad_;
+};
+
+__host__ __device__ inline int padded_dim16(int d) {
+  if (d <= 16) return 16;
+  if (d <= 32) return 32;
+  if (d <= 64) return 64;
+  return 128;
+}
+__host__ __device__ inline int row_bytes16(int dp16) { return dp16 * 2 + 16; }
+
+// smallest power of two >= x for finite x > 0 (1 for x == 0 or non-finite), clamped so
+// that both the scale and its reciprocal are normal floats
+__device__ inline float pow2_ceil(float x) {
+  if (!(x > 0.0f) || !(x < __builtin_inff())) return 1.0f;
+  const uint32_t b = __float_as_uint(x);
+  int e = (int)(b >> 23) - 127;           // floor(log2 x) for normal x, -127 for subnormal
+  if ((b & 0x7FFFFFu) != 0u) e += 1;
+  if (e < -120) e = -120;
+  if (e > 120) e = 120;
+  return __uint_as_float((uint32_t)(e + 127) << 23);
+}
+
 // ---- ordered keys ------------------------------------------------------------
 // 64-bit key whose unsigned order is (score descending-first, index ascending-first)
 // when sorted in DESCENDING key order: high word = monotone map of the f32 score,
@@ -90,12 +141,13 @@ struct ScanArgs {
   int n_qtiles;          // ceil(nq / 256)
   int n_splits;
   // FILTER mode: every lane (query j, lane half h) of the wave that owns a query appends the
-  // scores above thr[query] to its PRIVATE segment seg = 2*split + h of that query's list:
-  //   buf[(query * nseg + seg) * cap_l + e],  cnt[query * nseg + seg] = number appended
+  // scores above thr[query] to its PRIVATE segment seg = 2*split + h of that query's list
+  // (entry-major, so that the select kernel reads entry e of 64 segments as one 512-byte row):
+  //   buf[(query * cap_l + e) * nseg + seg],  cnt[query * nseg + seg] = number appended
   // (counts may exceed cap_l: the excess was dropped and the query is recomputed exactly).
   const float *thr;      // [nq] current K-th best score per query
   uint32_t *cnt;         // [nq, nseg]
-  uint2 *buf;            // [nq, nseg, cap_l] (score bits, row index)
+  uint2 *buf;            // [nq, cap_l, nseg] (score bits, row index)
   uint32_t cap_l;        // entries per segment
   int nseg;              // 2 * n_splits
   // MATERIALIZE mode
@@ -104,6 +156,44 @@ struct ScanArgs {
 };
 
 int launch_scan(const ScanArgs &a, bool materialize, hipStream_t stream);
+
+// fp16 prefilter scan (topk_scan16.hip).  A launch covers the stage list
+// stage0 + i * stage_stride, i < n_stages, cut into n_splits slices of stages_per_split;
+// a workgroup owns 512 queries (8 waves x 2 groups of 32) x one slice.
+//   FILTER (default): a score survives when s_16 > lower[q] - qk[q] * meta[stage].norm - tiny
+//     (lower[q]: proven lower bound of the query's final exact K-th score; qk = ||q|| * kappa)
+//     and is appended to the query's survivor list (layout: see SelectArgs).
+//   BINMAX (binmax != NULL): binmax[q * ld_binmax + 2 * i + h] = max prefilter score of lane
+//     half h over stage i (64 candidates).
+//   MATERIALIZE (dense != NULL): dense[q * ld_dense + i * 128 + r] = prefilter score of row r
+//     of stage i.
+struct Scan16Args {
+  const float *q;        // [nq, d] row-major f32 (scaled + converted to fp16 in registers)
+  int64_t nq;
+  int d;
+  const char *packed16;  // fp16 image base (row 0)
+  const StageMeta *meta; // [rows / kTileN]
+  int64_t stage0;
+  int n_stages;
+  int stage_stride;
+  int stages_per_split;
+  int64_t row_limit;     // rows >= row_limit (zero padding of the last stage) never survive
+  int n_qtiles;          // ceil(nq / 512)
+  int n_splits;
+  const float *lower;    // [nq]
+  const float *qk;       // [nq]
+  const float *qscale;   // [nq] power of two >= max |q_d|
+  uint32_t *cnt;         // [nq, nseg]
+  uint2 *buf;            // [nq, cap_l, nseg] (prefilter score bits, row index)
+  uint32_t cap_l;
+  int nseg;              // 2 * n_splits
+  float *dense;
+  int64_t ld_dense;
+  float *binmax;
+  int64_t ld_binmax;
+};
+int launch_scan16(const Scan16Args &a, hipStream_t stream);
+constexpr int kScan16QueriesPerWg = 512;
 
 enum SelectSource { kSrcDense = 0, kSrcList = 1, kSrcParts = 2 };
 
@@ -140,11 +230,31 @@ struct SelectArgs {
   float *out_scores;   // [nq, k]
   int32_t *out_idx;    // [nq, k]
   float *out_thr;      // [nq] K-th best score, or -inf while fewer than k entries (may be NULL)
+  // ---- fp16 prefilter support ----
+  // thr_eps: out_thr = K-th score - eps[q] (the source scores are prefilter scores, so this is
+  //   the proven lower bound of the exact K-th score), eps[q] = qk[q] * norm_max + tiny.
+  // approx (kSrcList only): the list holds prefilter scores.  Every entry within 2*eps of the
+  //   K-th prefilter score is retained (it may still belong to the exact top-K); after the last
+  //   list entry the retained ones are re-scored with the exact f32 fma chain from the packed
+  //   corpus and the exact top-K is written.  A query whose retained set does not fit the
+  //   kernel's KP slots is recomputed exactly over rows [rc_begin, rc_end) instead.
+  int thr_eps;
+  int approx;
+  const float *qk;        // [nq] ||q|| * kappa
+  const float *norm_max;  // device scalar: max row norm of the corpus
 };
 
 int launch_select(const SelectArgs &a, hipStream_t stream);
 int launch_pack(const float *cand, int64_t n, int d, char *packed, int64_t dst_row,
                 int64_t zero_rows_to, hipStream_t stream);
 int launch_unpack(const char *packed, int64_t n, int d, float *out, hipStream_t stream);
+// (Re)builds the fp16 image, StageMeta and the global max row norm for the stages that hold
+// rows [row_begin, row_end) from the f32 image (stage-local and idempotent: a partially
+// filled tail stage is simply rebuilt by the next append).  norm_max: atomicMax on float bits.
+int launch_pack16(const char *packed, int d, int64_t row_begin, int64_t row_end, char *packed16,
+                  StageMeta *meta, float *norm_max, hipStream_t stream);
+// qk[q] = ||q||_2 * kNormSlack * kF16Kappa;  qscale[q] = 2^ceil(log2 max|q_d|)
+int launch_query_kappa(const float *q, int64_t nq, int d, float *qk, float *qscale,
+                       hipStream_t stream);
 
 }  // namespace tfrs

@@ -29,6 +29,9 @@ struct TopkTuning {
   int64_t prefix;  // rows scored densely before filtering starts
   int64_t rho;     // geometric growth of the filtered ranges
   int64_t target_wgs;
+  bool f16_filter;  // TFRS_TOPK_FILTER=f16 (default) | f32
+  int64_t sample;   // fp16 path: the threshold pass scans every `sample`-th stage
+  int64_t min_bins; // fp16 path: sampled bins required per query, in units of K
 };
 
 static TopkTuning tuning() {
@@ -37,6 +40,10 @@ static TopkTuning tuning() {
   t.prefix = padded_rows(t.prefix);
   t.rho = std::max<int64_t>(2, env_i64("TFRS_TOPK_RHO", 8));
   t.target_wgs = std::max<int64_t>(1, env_i64("TFRS_TOPK_WGS", 1024));
+  const char *f = getenv("TFRS_TOPK_FILTER");
+  t.f16_filter = !(f && (f[0] == 'f' || f[0] == 'F') && f[1] == '3');
+  t.sample = std::max<int64_t>(1, env_i64("TFRS_TOPK_SAMPLE", 4));
+  t.min_bins = std::max<int64_t>(1, env_i64("TFRS_TOPK_MINBINS", 8));
   return t;
 }
 
@@ -50,12 +57,13 @@ struct ScanProfile {
   static constexpr int kMax = 4096;
   hipEvent_t start[kMax], stop[kMax];
   double flop[kMax];
+  int kind[kMax];  // 0 = f32 scan, 1 = fp16 prefilter scan
   int created = 0;
   int used = 0;
 };
 static ScanProfile g_prof;
 
-static bool prof_begin(hipStream_t stream, double flop, int *slot) {
+static bool prof_begin(hipStream_t stream, double flop, int kind, int *slot) {
   if (!g_prof.enabled || g_prof.used >= ScanProfile::kMax) return false;
   const int i = g_prof.used;
   if (i >= g_prof.created) {
@@ -64,6 +72,7 @@ static bool prof_begin(hipStream_t stream, double flop, int *slot) {
     g_prof.created = i + 1;
   }
   g_prof.flop[i] = flop;
+  g_prof.kind[i] = kind;
   (void)hipEventRecord(g_prof.start[i], stream);
   *slot = i;
   g_prof.used = i + 1;
@@ -73,29 +82,68 @@ static void prof_end(hipStream_t stream, int slot) { (void)hipEventRecord(g_prof
 
 static int timed_scan(const ScanArgs &sa, bool materialize, hipStream_t stream) {
   int slot = 0;
-  const bool on = prof_begin(stream, 2.0 * (double)sa.nq * (double)(sa.c_end - sa.c_begin) * sa.d, &slot);
+  const bool on = prof_begin(stream, 2.0 * (double)sa.nq * (double)(sa.c_end - sa.c_begin) * sa.d, 0, &slot);
   const int rc = launch_scan(sa, materialize, stream);
   if (on) prof_end(stream, slot);
   return rc;
 }
 
-static int64_t dense_rows(int64_t n, int k, const TopkTuning &t) {
-  const int64_t want = std::max<int64_t>(t.prefix, padded_rows(k));
-  return std::min<int64_t>(padded_rows(n), want);
+static int timed_scan16(const Scan16Args &sa, double flop, hipStream_t stream) {
+  int slot = 0;
+  const bool on = prof_begin(stream, flop, 1, &slot);
+  const int rc = launch_scan16(sa, stream);
+  if (on) prof_end(stream, slot);
+  return rc;
 }
 
-// Expected survivors per query per round (x4 safety): K * (rho - 1).
-static int64_t list_expect(int k, const TopkTuning &t) {
-  return std::max<int64_t>(1024, 4 * (int64_t)k * (t.rho - 1));
+// fp16 path: stages scanned by the threshold pass (only full stages are sampled) and the
+// stride actually used: the requested one, reduced until min_bins * K bins are available.
+struct SamplePlan {
+  int64_t stride;
+  int64_t n_stages;  // 0: the fp16 path is not applicable
+};
+static SamplePlan plan_sample(int64_t n, int k, const TopkTuning &t) {
+  const int64_t full = n / kTileN;
+  const int64_t want_bins = t.min_bins * (int64_t)k;
+  SamplePlan p = {t.sample, 0};
+  while (p.stride > 1 && 2 * (full / p.stride) < want_bins) --p.stride;
+  const int64_t ns = full / p.stride;
+  if (2 * ns >= std::max<int64_t>(want_bins, k)) p.n_stages = ns;
+  return p;
 }
+static int64_t dense_rows(int64_t n, int k, const TopkTuning &t) {
+  const int64_t want = std::max<int64_t>(t.prefix, padded_rows(k));
+  int64_t cols = std::min<int64_t>(padded_rows(n), want);
+  if (t.f16_filter && k <= 512) cols = std::max<int64_t>(cols, padded_rows(2 * plan_sample(n, k, t).n_stages));
+  return cols;
+}
+
+// Survivor lists.  A filtered round keeps, per query, about K * (rho - 1) scores (the rows of
+// the round that beat the K-th best of the rows before it) plus, on the fp16 path, the band
+// within eps of the bound: list_mean() budgets 1.5x that.  The list is cut into nseg private
+// segments (2 per candidate split); a segment's load is ~Poisson(mean / nseg), so its capacity
+// is mean + 8 sigma + 8 -- overflow probability < 1e-12 per segment on exchangeable data, and
+// an overflow only costs time (the query's range is recomputed exactly), never correctness.
+static int64_t list_mean(int k, const TopkTuning &t) {
+  // f32 rounds: K * (rho - 1); fp16 path: K * sample (threshold from 1/sample of the rows)
+  return std::max<int64_t>(256, (3 * (int64_t)k * std::max<int64_t>(t.rho - 1, t.sample)) / 2);
+}
+static uint32_t segment_cap(int k, int nseg, const TopkTuning &t) {
+  const double m = (double)list_mean(k, t) / nseg;
+  return (uint32_t)(m + 8.0 * __builtin_sqrt(m) + 8.0);
+}
+// (sized for the fp16 prefilter geometry, 512 queries per workgroup: it has the fewer query
+// tiles and therefore the more splits)
 static int max_splits(int64_t nq, const TopkTuning &t) {
-  const int64_t n_qtiles = (nq + 255) / 256;
+  const int64_t n_qtiles = (nq + kScan16QueriesPerWg - 1) / kScan16QueriesPerWg;
   return (int)std::max<int64_t>(1, (t.target_wgs + n_qtiles - 1) / n_qtiles);
 }
-// Survivor-list entries reserved per query: every round uses nseg = 2 * n_splits segments
-// of cap_l = max(16, ceil(expect / nseg)) entries, so nseg * cap_l <= expect + 16 * nseg.
+constexpr int kMaxKF16 = 512;
+// Survivor-list entries reserved per query: nseg * segment_cap(nseg) grows with nseg, so the
+// largest segment count bounds every round.
 static int64_t list_entries_per_query(int64_t nq, int k, const TopkTuning &t) {
-  return list_expect(k, t) + 16 * 2 * (int64_t)max_splits(nq, t) + 64;
+  const int nseg = 2 * max_splits(nq, t);
+  return (int64_t)nseg * segment_cap(k, nseg, t);
 }
 
 struct RoundWs {
@@ -105,6 +153,8 @@ struct RoundWs {
   int64_t ld_dense;
   uint2 *buf;
   int64_t entries;  // per query
+  float *qk;        // [nq]
+  float *qscale;    // [nq]
   char *end;
 };
 
@@ -114,6 +164,7 @@ static size_t round_ws_bytes(int64_t nq, int64_t n, int k, const TopkTuning &t) 
   b += align_up((size_t)nq * 2 * max_splits(nq, t) * 4);                 // cnt[nq, nseg]
   b += align_up((size_t)nq * dense_rows(n, k, t) * 4);                   // dense
   b += align_up((size_t)nq * list_entries_per_query(nq, k, t) * 8);      // buf
+  b += 2 * align_up((size_t)nq * 4);                                     // qk, qscale
   return b;
 }
 
@@ -129,6 +180,10 @@ static RoundWs carve_round_ws(char *p, int64_t nq, int64_t n, int k, const TopkT
   w.entries = list_entries_per_query(nq, k, t);
   w.buf = reinterpret_cast<uint2 *>(p);
   p += align_up((size_t)nq * w.entries * 8);
+  w.qk = reinterpret_cast<float *>(p);
+  p += align_up((size_t)nq * 4);
+  w.qscale = reinterpret_cast<float *>(p);
+  p += align_up((size_t)nq * 4);
   w.end = p;
   return w;
 }
@@ -137,6 +192,11 @@ __global__ void thr_from_state_kernel(const float *state_scores, int64_t nq, int
                                       float *thr) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r < nq) thr[r] = state_scores[r * k + (k - 1)];
+}
+
+__global__ void fill_kernel(float *p, int64_t n, float v) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) p[r] = v;
 }
 
 static void plan_splits(int64_t rows, int n_qtiles, const TopkTuning &t, int64_t *split_len,
@@ -220,7 +280,7 @@ static int run_rounds(const float *q, int64_t nq, int d, const char *packed, int
     sa.c_end = hi;
     plan_splits(hi - lo, n_qtiles, t, &sa.split_len, &sa.n_splits);
     sa.nseg = 2 * sa.n_splits;
-    sa.cap_l = (uint32_t)std::max<int64_t>(16, (list_expect(k, t) + sa.nseg - 1) / sa.nseg);
+    sa.cap_l = segment_cap(k, sa.nseg, t);
     if ((int64_t)sa.nseg * sa.cap_l > w.entries) {
       set_error("topk: survivor workspace too small (%d segments x %u)", sa.nseg, sa.cap_l);
       return TFRS_ENOMEM;
@@ -242,6 +302,112 @@ static int run_rounds(const float *q, int64_t nq, int d, const char *packed, int
   return TFRS_OK;
 }
 
+// ---- fp16-prefiltered path (BruteForce.call) ---------------------------------------------
+// Four launches, no rounds:
+//   1. query_kappa: ||q|| * kappa and the power-of-two query scales;
+//   2. threshold pass: BINMAX scan of every `stride`-th stage of the fp16 image -> the largest
+//      prefilter score per 64-candidate bin; bin maxima belong to distinct candidates, so
+//      (K-th largest bin maximum) - eps is a proven lower bound of the final K-th score
+//      (select kernel, kSrcDense + thr_eps);
+//   3. filter pass: FILTER scan of ALL rows against that bound (about K * stride survivors
+//      per query instead of a [nq, n] score matrix);
+//   4. select: prefilter top-K with its 2*eps retention band, exact f32 re-scoring of the
+//      retained entries, exact top-K (bit-identical to the f32 path).
+struct F16Image {
+  const char *packed16;
+  const StageMeta *meta;
+  const float *norm_max;
+};
+
+static void plan_stage_splits(int64_t n_stages, int n_qtiles, const TopkTuning &t, int *per,
+                              int *n_splits) {
+  int64_t want = (t.target_wgs + n_qtiles - 1) / n_qtiles;
+  want = std::max<int64_t>(1, std::min<int64_t>(want, (n_stages + 3) / 4));
+  *per = (int)((n_stages + want - 1) / want);
+  *n_splits = (int)((n_stages + *per - 1) / *per);
+}
+
+static int run_f16(const float *q, int64_t nq, int d, const char *packed, const F16Image &img,
+                   int64_t n, int k, const SamplePlan &sp, float *out_scores, int32_t *out_idx,
+                   const RoundWs &w, const TopkTuning &t, hipStream_t stream) {
+  const int n_qtiles = (int)((nq + kScan16QueriesPerWg - 1) / kScan16QueriesPerWg);
+  int rc;
+  if ((rc = launch_query_kappa(q, nq, d, w.qk, w.qscale, stream)) != TFRS_OK) return rc;
+
+  Scan16Args s16 = {};
+  s16.q = q;
+  s16.nq = nq;
+  s16.d = d;
+  s16.packed16 = img.packed16;
+  s16.meta = img.meta;
+  s16.n_qtiles = n_qtiles;
+  s16.qk = w.qk;
+  s16.qscale = w.qscale;
+  s16.row_limit = n;
+
+  SelectArgs se = {};
+  se.nq = nq;
+  se.k = k;
+  se.q = q;
+  se.d = d;
+  se.packed = packed;
+  se.qk = w.qk;
+  se.norm_max = img.norm_max;
+
+  // threshold pass
+  s16.stage0 = 0;
+  s16.n_stages = (int)sp.n_stages;
+  s16.stage_stride = (int)sp.stride;
+  plan_stage_splits(sp.n_stages, n_qtiles, t, &s16.stages_per_split, &s16.n_splits);
+  s16.binmax = w.dense;
+  s16.ld_binmax = w.ld_dense;
+  if ((rc = timed_scan16(s16, 2.0 * (double)nq * (double)sp.n_stages * kTileN * d, stream)) != TFRS_OK)
+    return rc;
+  se.source = kSrcDense;
+  se.dense = w.dense;
+  se.ld_dense = w.ld_dense;
+  se.n_dense = 2 * sp.n_stages;
+  se.thr_eps = 1;
+  se.out_thr = w.thr;
+  if ((rc = launch_select(se, stream)) != TFRS_OK) return rc;
+
+  // filter pass over all rows
+  const int64_t all_stages = (n + kTileN - 1) / kTileN;
+  s16.binmax = nullptr;
+  s16.n_stages = (int)all_stages;
+  s16.stage_stride = 1;
+  plan_stage_splits(all_stages, n_qtiles, t, &s16.stages_per_split, &s16.n_splits);
+  s16.lower = w.thr;
+  if (env_i64("TFRS_DEBUG_NO_SURVIVORS", 0) != 0) {  // timing experiment only: results are wrong
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream,
+                       w.thr, nq, __builtin_inff());
+  }
+  s16.cnt = w.cnt;
+  s16.buf = w.buf;
+  s16.nseg = 2 * s16.n_splits;
+  s16.cap_l = segment_cap(k, s16.nseg, t);
+  if ((int64_t)s16.nseg * s16.cap_l > w.entries) {
+    set_error("topk: survivor workspace too small (%d segments x %u)", s16.nseg, s16.cap_l);
+    return TFRS_ENOMEM;
+  }
+  if ((rc = timed_scan16(s16, 2.0 * (double)nq * (double)n * d, stream)) != TFRS_OK) return rc;
+
+  // prefilter top-K + exact re-scoring
+  se.source = kSrcList;
+  se.approx = 1;
+  se.thr_eps = 0;
+  se.out_thr = nullptr;
+  se.buf = w.buf;
+  se.cnt = w.cnt;
+  se.cap_l = s16.cap_l;
+  se.nseg = s16.nseg;
+  se.rc_begin = 0;
+  se.rc_end = n;
+  se.out_scores = out_scores;
+  se.out_idx = out_idx;
+  return launch_select(se, stream);
+}
+
 }  // namespace tfrs
 
 using namespace tfrs;
@@ -252,31 +418,57 @@ extern "C" int tfrs_profile_enable(int on) {
   return TFRS_OK;
 }
 
-extern "C" int tfrs_profile_read(double *scan_ms_h, int *launches_h, double *flop_h) {
+static int profile_sum(int kind, double *scan_ms_h, int *launches_h, double *flop_h) {
   double ms = 0.0, flop = 0.0;
+  int cnt = 0;
   for (int i = 0; i < g_prof.used; ++i) {
+    if (kind >= 0 && g_prof.kind[i] != kind) continue;
     float t = 0.f;
     TFRS_HIP(hipEventSynchronize(g_prof.stop[i]));
     TFRS_HIP(hipEventElapsedTime(&t, g_prof.start[i], g_prof.stop[i]));
     ms += t;
     flop += g_prof.flop[i];
+    ++cnt;
   }
   if (scan_ms_h) *scan_ms_h = ms;
-  if (launches_h) *launches_h = g_prof.used;
+  if (launches_h) *launches_h = cnt;
   if (flop_h) *flop_h = flop;
-  g_prof.used = 0;
   return TFRS_OK;
+}
+
+extern "C" int tfrs_profile_read_kind(int kind, double *scan_ms_h, int *launches_h,
+                                      double *flop_h) {
+  TFRS_CHECK_ARG(kind == 0 || kind == 1, "profile_read_kind: kind must be 0 (f32) or 1 (fp16)");
+  return profile_sum(kind, scan_ms_h, launches_h, flop_h);
+}
+
+extern "C" int tfrs_profile_read(double *scan_ms_h, int *launches_h, double *flop_h) {
+  const int rc = profile_sum(-1, scan_ms_h, launches_h, flop_h);
+  g_prof.used = 0;
+  return rc;
 }
 
 // ----------------------------------------------------------------------------------------
 // index handle
 // ----------------------------------------------------------------------------------------
 struct tfrs_index {
-  char *packed = nullptr;
+  char *packed = nullptr;    // f32 image (exact scores)
+  char *packed16 = nullptr;  // fp16 image (prefilter), meta[capacity / kTileN], norm_max
+  StageMeta *meta = nullptr;
+  float *norm_max = nullptr;
   int64_t n = 0;         // valid rows
   int64_t capacity = 0;  // rows allocated (multiple of kTileN)
   int d = 0;
 };
+
+static void index_free(tfrs_index *index) {
+  if (index->packed) (void)hipFree(index->packed);
+  if (index->packed16) (void)hipFree(index->packed16);
+  if (index->meta) (void)hipFree(index->meta);  // norm_max lives in the same block
+  index->packed = index->packed16 = nullptr;
+  index->meta = nullptr;
+  index->norm_max = nullptr;
+}
 
 extern "C" int tfrs_index_create(tfrs_index_t **out_h) {
   TFRS_CHECK_ARG(out_h != nullptr, "index_create: NULL output");
@@ -290,7 +482,7 @@ extern "C" int tfrs_index_create(tfrs_index_t **out_h) {
 
 extern "C" int tfrs_index_destroy(tfrs_index_t *index) {
   if (!index) return TFRS_OK;
-  if (index->packed) (void)hipFree(index->packed);
+  index_free(index);
   delete index;
   return TFRS_OK;
 }
@@ -303,22 +495,26 @@ extern "C" int tfrs_index_reserve(tfrs_index_t *index, int64_t capacity, int d, 
     set_error("index: embedding dim %d > %d is not implemented", d, TFRS_MAX_DIM);
     return TFRS_ENOTIMPL;
   }
-  if (index->packed) {
-    TFRS_HIP(hipFree(index->packed));
-    index->packed = nullptr;
-  }
+  index_free(index);
   index->n = 0;
   index->d = d;
   index->capacity = padded_rows(std::max<int64_t>(capacity, 1));
   const size_t bytes = (size_t)index->capacity * row_bytes(padded_dim(d));
+  const size_t bytes16 = (size_t)index->capacity * row_bytes16(padded_dim16(d));
+  const size_t nstages = (size_t)(index->capacity / kTileN);
   hipError_t e = hipMalloc(reinterpret_cast<void **>(&index->packed), bytes);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&index->packed16), bytes16);
+  if (e == hipSuccess)
+    e = hipMalloc(reinterpret_cast<void **>(&index->meta), (nstages + 1) * sizeof(StageMeta));
   if (e != hipSuccess) {
-    index->packed = nullptr;
+    index_free(index);
     index->capacity = 0;
-    set_error("index: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    set_error("index: hipMalloc(%zu + %zu) failed: %s", bytes, bytes16, hipGetErrorString(e));
     return TFRS_ENOMEM;
   }
-  (void)stream;
+  index->norm_max = reinterpret_cast<float *>(index->meta + nstages);
+  TFRS_HIP(hipMemsetAsync(index->meta, 0, (nstages + 1) * sizeof(StageMeta),
+                          (hipStream_t)stream));
   return TFRS_OK;
 }
 
@@ -332,6 +528,10 @@ extern "C" int tfrs_index_append(tfrs_index_t *index, const float *block, int64_
   const int64_t zero_to = padded_rows(index->n + nb);
   int rc = launch_pack(block, nb, index->d, index->packed, index->n, zero_to,
                        (hipStream_t)stream);
+  if (rc != TFRS_OK) return rc;
+  // (re)build the fp16 image of every stage this block touched, from the f32 image
+  rc = launch_pack16(index->packed, index->d, index->n, zero_to, index->packed16, index->meta,
+                     index->norm_max, (hipStream_t)stream);
   if (rc != TFRS_OK) return rc;
   index->n += nb;
   return TFRS_OK;
@@ -384,10 +584,52 @@ extern "C" int tfrs_bruteforce_topk(const tfrs_index_t *index, const float *quer
     return TFRS_ENOMEM;
   }
   const RoundWs w = carve_round_ws(static_cast<char *>(workspace), nq, index->n, k, t);
+  if (t.f16_filter && k <= kMaxKF16) {
+    const SamplePlan sp = plan_sample(index->n, k, t);
+    if (sp.n_stages > 0) {
+      const F16Image img = {index->packed16, index->meta, index->norm_max};
+      return run_f16(queries, nq, index->d, index->packed, img, index->n, k, sp, out_scores,
+                     out_idx, w, t, (hipStream_t)stream);
+    }
+  }
   int new_len = 0;
   return run_rounds(queries, nq, index->d, index->packed, index->n, /*idx_base=*/0,
                     /*seen=*/0, k, out_scores, out_idx, /*state_len=*/0, w, t,
                     (hipStream_t)stream, &new_len);
+}
+
+// Test hook: the raw fp16 prefilter scores of rows [row_begin, row_end) (multiples of 128
+// except at the corpus end), so that tests can check the error bound the filter relies on.
+extern "C" int tfrs_debug_fp16_scores(const tfrs_index_t *index, const float *queries,
+                                      int64_t nq, int64_t row_begin, int64_t row_end,
+                                      float *out, float *scratch, void *stream) {
+  if (!index || !index->packed16) {
+    set_error("debug_fp16_scores: the index has not been built");
+    return TFRS_ESTATE;
+  }
+  TFRS_CHECK_ARG(queries && out && scratch && nq >= 0, "debug_fp16_scores: NULL pointer");
+  TFRS_CHECK_ARG(row_begin >= 0 && row_begin % kTileN == 0 && row_end >= row_begin &&
+                     row_end <= index->n, "debug_fp16_scores: bad row range");
+  const TopkTuning t = tuning();
+  Scan16Args a = {};
+  a.q = queries;
+  a.nq = nq;
+  a.d = index->d;
+  a.packed16 = index->packed16;
+  a.meta = index->meta;
+  int rc = launch_query_kappa(queries, nq, index->d, scratch, scratch + nq, (hipStream_t)stream);
+  if (rc != TFRS_OK) return rc;
+  a.qk = scratch;
+  a.qscale = scratch + nq;
+  a.n_qtiles = (int)((nq + kScan16QueriesPerWg - 1) / kScan16QueriesPerWg);
+  a.stage0 = row_begin / kTileN;
+  a.n_stages = (int)((row_end - row_begin + kTileN - 1) / kTileN);
+  a.stage_stride = 1;
+  a.row_limit = row_end;
+  plan_stage_splits(a.n_stages, a.n_qtiles, t, &a.stages_per_split, &a.n_splits);
+  a.dense = out;
+  a.ld_dense = (int64_t)a.n_stages * kTileN;
+  return launch_scan16(a, (hipStream_t)stream);
 }
 
 // ----------------------------------------------------------------------------------------

@@ -74,4 +74,118 @@ int launch_unpack(const char *packed, int64_t n, int d, float *out, hipStream_t 
   return TFRS_OK;
 }
 
+// ---- fp16 prefilter image (common.h) ------------------------------------------------
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+  union {
+    f16x2_t h;
+    uint32_t u;
+  } v;
+  v.h[0] = (_Float16)lo;  // v_cvt_pk_f16_f32, round to nearest even
+  v.h[1] = (_Float16)hi;
+  return v.u;
+}
+
+// One workgroup (256 threads) per stage of kTileN rows, reading the f32 image:
+//   pass 1: threads 0..127 own one row each -> row norm, row max |x|; block max of both;
+//   pass 2: every thread converts 16-byte slots (8 halves, natural feature order) of x / scale.
+// Rows >= the valid row count are zero in the f32 image and stay zero here.
+__global__ void __launch_bounds__(256) pack16_stage_kernel(const char *__restrict__ packed, int dp,
+                                                           int dp16, int64_t stage0,
+                                                           char *__restrict__ packed16,
+                                                           StageMeta *__restrict__ meta,
+                                                           float *__restrict__ norm_max) {
+  __shared__ float s_norm[kTileN], s_amax[kTileN];
+  __shared__ float s_scale;
+  const int64_t stage = stage0 + blockIdx.x;
+  const int64_t row0 = stage * kTileN;
+  const int half = dp / 2;  // floats per parity plane of the f32 image
+  const int tid = threadIdx.x;
+  if (tid < kTileN) {
+    const float *row = reinterpret_cast<const float *>(packed + (row0 + tid) * (int64_t)row_bytes(dp));
+    float ssq = 0.0f, amax = 0.0f;
+    for (int k = 0; k < dp; ++k) {  // plane order; the sum of squares does not depend on it
+      const float x = row[k];
+      ssq = __builtin_fmaf(x, x, ssq);
+      amax = fmaxf(amax, __builtin_fabsf(x));
+    }
+    s_norm[tid] = __builtin_sqrtf(ssq) * kNormSlack;
+    s_amax[tid] = amax;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float nm = fmaxf(s_norm[tid], s_norm[tid + 64]);
+    float am = fmaxf(s_amax[tid], s_amax[tid + 64]);
+    for (int off = 32; off > 0; off >>= 1) {
+      nm = fmaxf(nm, __shfl_xor(nm, off));
+      am = fmaxf(am, __shfl_xor(am, off));
+    }
+    if (tid == 0) {
+      const float sc = pow2_ceil(am);
+      s_scale = sc;
+      meta[stage].norm = nm;
+      meta[stage].scale = sc;
+      meta[stage].inv_scale = 1.0f / sc;
+      meta[stage].pad_ = 0.0f;
+      atomicMax(reinterpret_cast<uint32_t *>(norm_max), __float_as_uint(nm));  // nm >= 0
+    }
+  }
+  __syncthreads();
+  const float inv = 1.0f / s_scale;  // exact: power of two
+  const int slots = dp16 / 8 + 1;
+  for (int t = tid; t < kTileN * slots; t += 256) {
+    const int r = t / slots;
+    const int s = t - r * slots;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    if (s < slots - 1) {
+      const float *row = reinterpret_cast<const float *>(packed + (row0 + r) * (int64_t)row_bytes(dp));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = 8 * s + 2 * i;  // features k (even plane) and k + 1 (odd plane)
+        const float x0 = (k < dp) ? row[k >> 1] * inv : 0.0f;
+        const float x1 = (k + 1 < dp) ? row[half + (k >> 1)] * inv : 0.0f;
+        w[i] = pack_f16x2(x0, x1);
+      }
+    }
+    *reinterpret_cast<uint4 *>(packed16 + (row0 + r) * (int64_t)row_bytes16(dp16) + (int64_t)s * 16) =
+        make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+__global__ void __launch_bounds__(256) query_kappa_kernel(const float *__restrict__ q, int64_t nq,
+                                                          int d, float *__restrict__ qk,
+                                                          float *__restrict__ qscale) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nq) return;
+  const float *row = q + r * d;
+  float ssq = 0.0f, amax = 0.0f;
+  for (int k = 0; k < d; ++k) {
+    ssq = __builtin_fmaf(row[k], row[k], ssq);
+    amax = fmaxf(amax, __builtin_fabsf(row[k]));
+  }
+  qk[r] = __builtin_sqrtf(ssq) * kNormSlack * kF16Kappa;
+  qscale[r] = pow2_ceil(amax);
+}
+
+int launch_pack16(const char *packed, int d, int64_t row_begin, int64_t row_end, char *packed16,
+                  StageMeta *meta, float *norm_max, hipStream_t stream) {
+  if (row_end <= row_begin) return TFRS_OK;
+  const int64_t s0 = row_begin / kTileN;
+  const int64_t s1 = (row_end + kTileN - 1) / kTileN;
+  hipLaunchKernelGGL(pack16_stage_kernel, dim3((unsigned)(s1 - s0)), dim3(256), 0, stream, packed,
+                     padded_dim(d), padded_dim16(d), s0, packed16, meta, norm_max);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+int launch_query_kappa(const float *q, int64_t nq, int d, float *qk, float *qscale,
+                       hipStream_t stream) {
+  if (nq <= 0) return TFRS_OK;
+  hipLaunchKernelGGL(query_kappa_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0,
+                     stream, q, nq, d, qk, qscale);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
 }  // namespace tfrs

@@ -112,7 +112,8 @@ __global__ void __launch_bounds__(kThreads, DP <= 64 ? 4 : 2) scan_kernel(const 
 
   // this lane's private survivor segment
   const int64_t seg = qrow * a.nseg + 2 * split + h;
-  uint2 *mybuf = MATERIALIZE ? nullptr : a.buf + seg * (int64_t)a.cap_l;
+  // entry-major list: entry e of this segment lives at buf[(qrow * cap_l + e) * nseg + seg]
+  uint2 *mybuf = MATERIALIZE ? nullptr : a.buf + (qrow * (int64_t)a.cap_l) * a.nseg + (2 * split + h);
   uint32_t mycnt = 0;
 
   // ---- stage 0 -> LDS ------------------------------------------------------------
@@ -218,7 +219,8 @@ __global__ void __launch_bounds__(kThreads, DP <= 64 ? 4 : 2) scan_kernel(const 
               if (ragged) p = p && (c0 + (int64_t)off < c1);
               if (p) {
                 if (mycnt < a.cap_l)
-                  mybuf[mycnt] = make_uint2(__float_as_uint(acc[r]), (uint32_t)(c0 + (int64_t)off));
+                  mybuf[(size_t)mycnt * a.nseg] =
+                      make_uint2(__float_as_uint(acc[r]), (uint32_t)(c0 + (int64_t)off));
                 ++mycnt;
               }
             }

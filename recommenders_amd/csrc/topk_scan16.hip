@@ -1,0 +1,316 @@
+// topk_scan16.hip -- fp16 PREFILTER scan: S~ = fp16(Q) x fp16(Cand)^T on the 16-bit matrix
+// cores (v_mfma_f32_32x32x16_f16, 16x the f32 MFMA rate) with the top-K filter fused
+// behind it.  Nothing computed here is ever returned: a prefilter score only decides whether
+// a candidate can still reach a query's top-K, under the rigorous error bound of common.h
+//   |s~ - s| <= ||q|| * ||c|| * kappa (+tiny),
+// and every survivor is later re-scored with the exact f32 fma chain (select kernel).
+// Same role in BruteForce.call (layers/factorized_top_k.py:603-605) as topk_scan.hip.
+//
+// Work decomposition (one launch covers a list of 128-row stages: stage0 + i * stride):
+//   grid      = n_splits x n_qtiles workgroups of 512 threads (8 waves), XCD-aware remap so
+//               that the workgroups resident on one XCD stream the same candidate split.
+//   workgroup = 512 queries x one split of the stage list; stages (18 KiB at D=64) are
+//               double-buffered in LDS by global_load_lds and shared by the 8 waves.
+//   wave      = 2 groups of 32 queries, resident as MFMA B operands (DP/16 x 4 VGPRs each);
+//               per 32-candidate sub-tile: DP/16 ds_read_b128 (A operand, shared by both
+//               groups) and 2 x DP/16 MFMAs.  A = candidates, B = queries, so a lane's 16
+//               accumulator registers belong to ONE query: the per-tile test is a
+//               v_max3 tree (8 VALU) + one compare per 16 scores.
+// Modes:
+//   BINMAX      (threshold pass over a SAMPLE of the stages, no thresholds, no branches): the
+//               maximum prefilter score per (query, stage, lane half) -> binmax[nq, 2*stages].
+//               Bin maxima belong to distinct candidates, so the K-th largest of them minus
+//               eps is a proven lower bound of the query's final K-th score.
+//   FILTER      keep s~ > lower[q] - qk[q] * norm[stage] - tiny, appended by the owning lane
+//               to its private segment of the query's survivor list (no atomics).
+//   MATERIALIZE raw prefilter scores (test hook).
+// The image holds x / scale[stage] and the queries q / qscale[q] (powers of two, so fp16's
+// narrow exponent range is never the limit): the scales are folded into the threshold once
+// per stage, the MFMA results are compared as they are.
+//
+// Roofline: fp16/bf16 MFMA (2.5 PFLOP/s dense): 2*DP flop per score.
+// Built with -fno-honor-nans (build.py): fmaxf trees become bare v_max3_f32.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace tfrs {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWaves16 = 8;
+constexpr int kThreads16 = kWaves16 * 64;
+constexpr int kQG = 2;  // query groups (of 32) per wave
+static_assert(kWaves16 * kQG * 32 == kScan16QueriesPerWg, "queries per workgroup");
+
+enum Scan16Mode { kModeFilter = 0, kModeMaterialize = 1, kModeBinMax = 2 };
+
+template <int DP>
+struct Scan16Geom {
+  static constexpr int kSteps = DP / 16;
+  static constexpr int kRowB = DP * 2 + 16;
+  static constexpr int kStageB = kTileN * kRowB;
+  static constexpr int kChunks = kStageB / 16;
+  static constexpr int kLoads = (kChunks + kThreads16 - 1) / kThreads16;
+  static constexpr int kLdsBytes = 2 * kStageB;
+};
+
+typedef __attribute__((address_space(3))) void lds_void16_t;
+typedef __attribute__((address_space(1))) const void gbl_void16_t;
+
+// Linear stage copy HBM/L2 -> LDS with the direct-to-LDS load (the fp16 image already has
+// its LDS layout): every wave-instruction moves 1 KiB.
+template <int CHUNKS, int LOADS>
+__device__ __forceinline__ void stage16_glds(const char *gsrc, char *lds_dst, int tid, int wave) {
+#pragma unroll
+  for (int i = 0; i < LOADS; ++i) {
+    const int ch0 = i * kThreads16 + wave * 64;
+    if (ch0 < CHUNKS) {  // wave-uniform (CHUNKS is a multiple of 64)
+      __builtin_amdgcn_global_load_lds((gbl_void16_t *)(gsrc + (size_t)(i * kThreads16 + tid) * 16),
+                                       (lds_void16_t *)(lds_dst + ch0 * 16), 16, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ f16x8 as_f16x8(u32x4 v) {
+  union {
+    u32x4 u;
+    f16x8 b;
+  } x;
+  x.u = v;
+  return x.b;
+}
+__device__ __forceinline__ uint32_t cvt_f16x2(float lo, float hi) {
+  union {
+    f16x2 h;
+    uint32_t u;
+  } v;
+  v.h[0] = (_Float16)lo;  // v_cvt_pk_f16_f32 (round to nearest even)
+  v.h[1] = (_Float16)hi;
+  return v.u;
+}
+__device__ __forceinline__ float mx3(float a, float b, float c) {
+  return __builtin_fmaxf(__builtin_fmaxf(a, b), c);
+}
+__device__ __forceinline__ float max16(const f32x16 &c) {
+  const float a = mx3(c[0], c[1], c[2]), b = mx3(c[3], c[4], c[5]), d = mx3(c[6], c[7], c[8]),
+              e = mx3(c[9], c[10], c[11]), f = mx3(c[12], c[13], c[14]);
+  return __builtin_fmaxf(mx3(a, b, d), mx3(e, f, c[15]));
+}
+
+template <int DP, int MODE>
+__global__ void __launch_bounds__(kThreads16, 2) scan16_kernel(const Scan16Args a) {
+  using G = Scan16Geom<DP>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31;  // query column of this lane
+  const int h = lane >> 5;  // k half of the MFMA step / upper candidate half of the C layout
+
+  // ---- XCD-aware workgroup remap (bijective for any grid size) -----------------
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int xcd = bid & 7, pos = bid >> 3;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + pos;
+  const int split = logical / a.n_qtiles;
+  const int qt = logical - split * a.n_qtiles;
+
+  // this split's slice of the stage list
+  const int i0 = split * a.stages_per_split;
+  int i1 = i0 + a.stages_per_split;
+  if (i1 > a.n_stages) i1 = a.n_stages;
+  if (i0 >= i1) return;
+  const int nst = i1 - i0;
+  const int64_t stride = a.stage_stride;
+  const int64_t first_stage = a.stage0 + (int64_t)i0 * stride;
+
+  // ---- this wave's 2 x 32 queries -> fp16 MFMA B operands (resident) -------------
+  f16x8 bq[kQG][G::kSteps];
+  float lower[kQG], qk[kQG], qs[kQG], qinv[kQG];
+  bool qvalid[kQG];
+  int64_t qrow[kQG];
+  uint2 *wp[kQG];  // FILTER: next free slot of this lane's segment (stride nseg entries)
+  uint32_t mycnt[kQG];
+#pragma unroll
+  for (int g = 0; g < kQG; ++g) {
+    qrow[g] = (int64_t)qt * kScan16QueriesPerWg + wave * (kQG * 32) + g * 32 + j;
+    qvalid[g] = qrow[g] < a.nq;
+    const float *qp = a.q + qrow[g] * a.d;
+    qs[g] = qvalid[g] ? a.qscale[qrow[g]] : 1.0f;
+    qinv[g] = 1.0f / qs[g];  // exact: power of two
+#pragma unroll
+    for (int m = 0; m < G::kSteps; ++m) {
+      u32x4 w;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = 16 * m + 8 * h + 2 * i;
+        const float x0 = (qvalid[g] && k < a.d) ? qp[k] : 0.0f;
+        const float x1 = (qvalid[g] && k + 1 < a.d) ? qp[k + 1] : 0.0f;
+        w[i] = cvt_f16x2(x0 * qinv[g], x1 * qinv[g]);
+      }
+      bq[g][m] = as_f16x8(w);
+    }
+    lower[g] = (MODE == kModeFilter && qvalid[g]) ? a.lower[qrow[g]] : __builtin_inff();
+    qk[g] = (MODE == kModeFilter && qvalid[g]) ? a.qk[qrow[g]] : 0.0f;
+    // survivor lists are entry-major: buf[(q * cap_l + e) * nseg + seg], seg = 2 * split + h
+    wp[g] = (MODE == kModeFilter)
+                ? a.buf + (qrow[g] * (int64_t)a.cap_l) * a.nseg + (2 * split + h)
+                : nullptr;
+    mycnt[g] = 0;
+  }
+  const uint32_t row_limit = (uint32_t)a.row_limit;
+
+  // ---- stage 0 -> LDS ------------------------------------------------------------
+  static_assert(G::kChunks % 64 == 0, "stage size must be a whole number of wave copies");
+  const char *gsrc = a.packed16 + first_stage * (int64_t)G::kStageB;
+  const int64_t gstep = stride * (int64_t)G::kStageB;
+  stage16_glds<G::kChunks, G::kLoads>(gsrc, smem, tid, wave);
+  const StageMeta *mp = a.meta + first_stage;
+  StageMeta sm = mp[0];
+  __syncthreads();
+
+  for (int st = 0; st < nst; ++st) {
+    const char *tile = smem + (st & 1) * G::kStageB;
+    const bool more = (st + 1 < nst);
+    StageMeta sm_next = sm;
+    if (more) {  // prefetch the next stage into the other buffer (its readers passed the barrier)
+      stage16_glds<G::kChunks, G::kLoads>(gsrc + (int64_t)(st + 1) * gstep,
+                                          smem + ((st + 1) & 1) * G::kStageB, tid, wave);
+      sm_next = mp[(int64_t)(st + 1) * stride];
+    }
+    // MFMA result = true prefilter score / (qscale * stage scale): compare against the
+    // threshold divided by the same powers of two; `unscale` restores survivors' scores.
+    float thr[kQG], unscale[kQG];
+#pragma unroll
+    for (int g = 0; g < kQG; ++g) {
+      thr[g] = (__builtin_fmaf(-qk[g], sm.norm, lower[g]) - kF16Tiny) * qinv[g] * sm.inv_scale;
+      unscale[g] = qs[g] * sm.scale;
+    }
+    float binmax[kQG];
+#pragma unroll
+    for (int g = 0; g < kQG; ++g) binmax[g] = -__builtin_inff();
+
+    const uint32_t stage_row = (uint32_t)((first_stage + (int64_t)st * stride) * kTileN);
+    const char *ap = tile + j * G::kRowB + h * 16;
+
+#pragma unroll
+    for (int sub = 0; sub < kTileN / 32; ++sub) {
+      u32x4 af[G::kSteps];
+#pragma unroll
+      for (int m = 0; m < G::kSteps; ++m)
+        af[m] = *reinterpret_cast<const u32x4 *>(ap + sub * 32 * G::kRowB + m * 32);
+
+      f32x16 acc[kQG];
+#pragma unroll
+      for (int g = 0; g < kQG; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.0f;
+#pragma unroll
+      for (int m = 0; m < G::kSteps; ++m) {
+#pragma unroll
+        for (int g = 0; g < kQG; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(af[m]), bq[g][m], acc[g], 0, 0, 0);
+      }
+      // acc[g][r] = s~(query g*32 + j, candidate stage_row + sub*32 + (r&3) + 8*(r>>2) + 4*h)
+
+#pragma unroll
+      for (int g = 0; g < kQG; ++g) {
+        const f32x16 &c = acc[g];
+        if (MODE == kModeMaterialize) {
+          if (qvalid[g]) {
+            float *drow = a.dense + qrow[g] * a.ld_dense +
+                          ((int64_t)(i0 + st) * kTileN + sub * 32 + 4 * h);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+              *reinterpret_cast<float4 *>(drow + 8 * g4) =
+                  make_float4(c[4 * g4 + 0] * unscale[g], c[4 * g4 + 1] * unscale[g],
+                              c[4 * g4 + 2] * unscale[g], c[4 * g4 + 3] * unscale[g]);
+          }
+          continue;
+        }
+        const float m0 = max16(c);
+        if (MODE == kModeBinMax) {
+          binmax[g] = __builtin_fmaxf(binmax[g], m0);
+          continue;
+        }
+        if (__ballot(m0 > thr[g]) != 0ull) {  // some lane of the wave has a survivor in this tile
+          const uint32_t rbase = stage_row + sub * 32 + 4u * h;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const float gm = __builtin_fmaxf(mx3(c[4 * g4], c[4 * g4 + 1], c[4 * g4 + 2]), c[4 * g4 + 3]);
+            if (__ballot(gm > thr[g]) == 0ull) continue;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              const float v = c[4 * g4 + rr];
+              const uint32_t row = rbase + rr + 8 * g4;
+              if (v > thr[g] && row < row_limit) {
+                if (mycnt[g] < a.cap_l) *wp[g] = make_uint2(__float_as_uint(v * unscale[g]), row);
+                wp[g] += a.nseg;
+                ++mycnt[g];
+              }
+            }
+          }
+        }
+      }
+    }
+    if (MODE == kModeBinMax) {
+#pragma unroll
+      for (int g = 0; g < kQG; ++g)
+        if (qvalid[g]) a.binmax[qrow[g] * a.ld_binmax + 2 * (i0 + st) + h] = binmax[g] * unscale[g];
+    }
+    sm = sm_next;
+    __syncthreads();
+  }
+
+  if (MODE == kModeFilter) {
+#pragma unroll
+    for (int g = 0; g < kQG; ++g)
+      if (qvalid[g]) a.cnt[qrow[g] * a.nseg + 2 * split + h] = mycnt[g];  // every segment is written
+  }
+}
+
+template <int DP, int MODE>
+static int launch_scan16_variant(const Scan16Args &a, hipStream_t stream) {
+  using G = Scan16Geom<DP>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    TFRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan16_kernel<DP, MODE>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)(a.n_qtiles * a.n_splits));
+  hipLaunchKernelGGL((scan16_kernel<DP, MODE>), grid, dim3(kThreads16), G::kLdsBytes, stream, a);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+template <int DP>
+static int launch_scan16_dp(const Scan16Args &a, hipStream_t stream) {
+  if (a.dense) return launch_scan16_variant<DP, kModeMaterialize>(a, stream);
+  if (a.binmax) return launch_scan16_variant<DP, kModeBinMax>(a, stream);
+  return launch_scan16_variant<DP, kModeFilter>(a, stream);
+}
+
+int launch_scan16(const Scan16Args &a, hipStream_t stream) {
+  if (a.nq <= 0 || a.n_stages <= 0) return TFRS_OK;
+  TFRS_CHECK_ARG(a.stage_stride >= 1 && a.stages_per_split >= 1 &&
+                     (int64_t)a.n_splits * a.stages_per_split >= a.n_stages,
+                 "scan16: bad stage split");
+  TFRS_CHECK_ARG(a.dense || a.binmax || a.nseg == 2 * a.n_splits, "scan16: nseg must be 2 * n_splits");
+  switch (padded_dim16(a.d)) {
+    case 16: return launch_scan16_dp<16>(a, stream);
+    case 32: return launch_scan16_dp<32>(a, stream);
+    case 64: return launch_scan16_dp<64>(a, stream);
+    case 128: return launch_scan16_dp<128>(a, stream);
+  }
+  set_error("scan16: unsupported dim %d", a.d);
+  return TFRS_ENOTIMPL;
+}
+
+}  // namespace tfrs

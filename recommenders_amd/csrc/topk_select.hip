@@ -14,6 +14,8 @@
 //
 // Integer/compare work on L2-resident lists: not a roofline-relevant kernel (a few % of
 // the scan time); it is kept simple and exact.
+#include <algorithm>
+
 #include "common.h"
 
 namespace tfrs {
@@ -87,14 +89,28 @@ __device__ __forceinline__ void absorb_chunk(uint64_t *best, uint64_t *chunk, in
   bitonic_merge_desc<KP>(best, lane);
 }
 
-// Exact score of one candidate from the packed corpus: the same d-ordered fma chain as
-// the MFMA path (used only for queries whose scan list overflowed).
+// Exact score of one candidate from the packed corpus: the same d-ordered fma chain as the
+// MFMA path (re-scoring of prefilter survivors; queries whose scan list overflowed).  `qs`
+// is the query, zero-padded to dp floats, in LDS (all lanes read the same address:
+// broadcast); the candidate row is fetched with 16-byte loads, 4 even + 4 odd features each.
 __device__ __forceinline__ float packed_score(const char *packed, int64_t row, int dp,
-                                              const float *q, int d) {
-  const float *r = reinterpret_cast<const float *>(packed + row * (int64_t)row_bytes(dp));
-  const int half = dp / 2;
+                                              const float *qs) {
+  const float4 *ev = reinterpret_cast<const float4 *>(packed + row * (int64_t)row_bytes(dp));
+  const float4 *od = ev + dp / 8;
+  const float4 *q4 = reinterpret_cast<const float4 *>(qs);
   float acc = 0.0f;
-  for (int k = 0; k < d; ++k) acc = __builtin_fmaf(r[(k & 1) * half + (k >> 1)], q[k], acc);
+  for (int m = 0; m < dp / 8; ++m) {
+    const float4 e = ev[m], o = od[m];
+    const float4 qa = q4[2 * m], qb = q4[2 * m + 1];  // features 8m .. 8m+7
+    acc = __builtin_fmaf(e.x, qa.x, acc);
+    acc = __builtin_fmaf(o.x, qa.y, acc);
+    acc = __builtin_fmaf(e.y, qa.z, acc);
+    acc = __builtin_fmaf(o.y, qa.w, acc);
+    acc = __builtin_fmaf(e.z, qb.x, acc);
+    acc = __builtin_fmaf(o.z, qb.y, acc);
+    acc = __builtin_fmaf(e.w, qb.z, acc);
+    acc = __builtin_fmaf(o.w, qb.w, acc);
+  }
   return acc;
 }
 
@@ -108,7 +124,15 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
 
   uint64_t *best = reinterpret_cast<uint64_t *>(smem) + (size_t)wave * 2 * KP;
   uint64_t *chunk = best + KP;
+  float *qs = reinterpret_cast<float *>(smem + (size_t)kSelWaves * 2 * KP * sizeof(uint64_t)) +
+              (size_t)wave * TFRS_MAX_DIM;
   const int K = a.k;
+  const int source = a.source;
+  const bool approx = a.approx != 0;
+  const int dp = padded_dim(a.d);
+  // eps bounds |prefilter score - exact score| for every candidate of this query
+  float eps = 0.0f;
+  if (approx || a.thr_eps) eps = a.qk[row] * a.norm_max[0] + kF16Tiny;
 
   // ---- seed with the prior state (already sorted by construction) -----------------
   for (int i = lane; i < KP; i += 64) {
@@ -116,15 +140,25 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
     if (i < a.state_len) key = make_key(a.state_scores[row * K + i], a.state_idx[row * K + i]);
     best[i] = key;
   }
+  if (source == kSrcList) {  // the query, zero-padded, for exact (re-)scoring
+    for (int i = lane; i < dp; i += 64) qs[i] = (i < a.d) ? a.q[row * a.d + i] : 0.0f;
+  }
   wave_lds_sync();
 
-  // ---- source description ------------------------------------------------------------
-  const int source = a.source;
-  const int dp = padded_dim(a.d);
-  int fill = 0;                      // wave-uniform
-  uint64_t kth = best[K - 1];        // 0 while fewer than K entries: everything passes
+  // Pass bound derived from the K-th key.  Exact mode: the K-th key itself.  Approximate mode:
+  // everything whose score is within 2*eps of the K-th score must be retained (it may still
+  // belong to the exact top-K), so the bound is the lowest key of score t - 2*eps.
+  auto bound_of = [&](uint64_t kkey) -> uint64_t {
+    if (!approx || kkey == 0ull) return kkey;
+    if (!(eps < __builtin_inff())) return 0ull;
+    const float b = key_score(kkey) - 2.0f * eps;
+    return (uint64_t)f32_orderable(b) << 32;
+  };
 
-  // Offers one key per lane: keys that cannot beat the current K-th are dropped, the rest
+  int fill = 0;                           // wave-uniform
+  uint64_t kth = bound_of(best[K - 1]);   // 0 while fewer than K entries: everything passes
+
+  // Offers one key per lane: keys that cannot beat the current bound are dropped, the rest
   // are compacted into `chunk`, which is sorted and merged into `best` when it fills.
   auto consume = [&](uint64_t key) {
     const bool p = key > kth;  // key 0 (empty) never passes
@@ -133,49 +167,64 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
     if (fill + 64 > KP) {
       absorb_chunk<KP>(best, chunk, fill, lane);
       fill = 0;
-      kth = best[K - 1];
+      kth = bound_of(best[K - 1]);
     }
     if (p) chunk[fill + sel_mbcnt(mask)] = key;
     fill += (int)__popcll(mask);
   };
 
-  bool recompute = false;
-  if (source == kSrcList) {
-    // a segment whose count exceeds its capacity lost entries: recompute the query exactly
-    bool ovf = false;
-    for (int sg = lane; sg < a.nseg; sg += 64) ovf = ovf || (a.cnt[row * a.nseg + sg] > a.cap_l);
-    recompute = (__ballot(ovf) != 0ull);
-  }
-
-  if (recompute) {
+  // exact keys of rows [rc_begin, rc_end): the slow but always-correct path
+  auto recompute_range = [&]() {
     const int64_t m = a.rc_end - a.rc_begin;
     for (int64_t base = 0; base < m; base += 64) {
       const int64_t e = base + lane;
       uint64_t key = 0ull;
       if (e < m) {
         const int64_t crow = a.rc_begin + e;
-        key = make_key(packed_score(a.packed, crow, dp, a.q + row * a.d, a.d),
-                       (int32_t)(crow + a.idx_base));
+        key = make_key(packed_score(a.packed, crow, dp, qs), (int32_t)(crow + a.idx_base));
       }
       consume(key);
     }
-  } else if (source == kSrcList) {
-    // 4 segments at a time, 16 lanes each
-    for (int sb = 0; sb < a.nseg; sb += 4) {
-      const int sg = sb + (lane >> 4);
-      const uint32_t c = (sg < a.nseg) ? a.cnt[row * a.nseg + sg] : 0u;
-      uint32_t cmax = c;
-      cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, 16));
-      cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, 32));
-      const uint2 *seg = a.buf + (row * a.nseg + sg) * (int64_t)a.cap_l;
-      for (uint32_t e0 = 0; e0 < cmax; e0 += 16) {
-        const uint32_t e = e0 + (lane & 15);
-        uint64_t key = 0ull;
-        if (e < c) {
-          const uint2 ent = seg[e];
-          key = make_key(__uint_as_float(ent.x), (int32_t)((int64_t)ent.y + a.idx_base));
+  };
+
+  bool exact_done = false;  // approx: true when the keys in `best` are already exact
+  if (source == kSrcList) {
+    // a segment whose count exceeds its capacity lost entries: recompute the query exactly
+    bool ovf = false;
+    for (int sg = lane; sg < a.nseg; sg += 64) ovf = ovf || (a.cnt[row * a.nseg + sg] > a.cap_l);
+    if (__ballot(ovf) != 0ull) {
+      if (approx) {  // exact keys must not be mixed with the +-eps retention logic: start over
+        for (int i = lane; i < KP; i += 64) best[i] = 0ull;
+        wave_lds_sync();
+        kth = 0ull;
+      }
+      // exact scores from here on: the exact bound (K-th key) applies
+      eps = 0.0f;
+      recompute_range();
+      exact_done = true;
+    } else {
+      // lanes <-> segments, 64 at a time; entry e of 64 consecutive segments is one 512-B row
+      const uint2 *qbuf = a.buf + (row * (int64_t)a.cap_l) * a.nseg;
+      for (int sb = 0; sb < a.nseg; sb += 64) {
+        const int sg = sb + lane;
+        const uint32_t c = (sg < a.nseg) ? a.cnt[row * a.nseg + sg] : 0u;
+        uint32_t cmax = c;
+        for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, off));
+        for (uint32_t e0 = 0; e0 < cmax; e0 += 4) {
+          uint2 ent[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            ent[u] = make_uint2(0u, 0u);
+            if (e0 + u < c) ent[u] = qbuf[(int64_t)(e0 + u) * a.nseg + sg];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            uint64_t key = 0ull;
+            if (e0 + u < c)
+              key = make_key(__uint_as_float(ent[u].x), (int32_t)((int64_t)ent[u].y + a.idx_base));
+            consume(key);
+          }
         }
-        consume(key);
       }
     }
   } else if (source == kSrcDense) {
@@ -197,23 +246,59 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
       consume(key);
     }
   }
-  if (fill > 0) absorb_chunk<KP>(best, chunk, fill, lane);
+  if (fill > 0) {
+    absorb_chunk<KP>(best, chunk, fill, lane);
+    fill = 0;
+  }
+
+  if (approx && !exact_done) {
+    // ---- exact re-scoring of the retained prefilter entries --------------------------------
+    const uint64_t kk = best[K - 1];
+    const uint64_t last = best[KP - 1];
+    float lo = -__builtin_inff();
+    if (kk != 0ull && eps < __builtin_inff()) lo = key_score(kk) - 2.0f * eps;
+    // the retained set (scores >= lo) must fit the KP slots, else entries were lost
+    const bool lost = (last != 0ull) && !(key_score(last) < lo);
+    if (lost) {
+      for (int i = lane; i < KP; i += 64) best[i] = 0ull;
+      wave_lds_sync();
+      kth = 0ull;
+      eps = 0.0f;
+      recompute_range();
+      if (fill > 0) absorb_chunk<KP>(best, chunk, fill, lane);
+    } else {
+      for (int i = lane; i < KP; i += 64) {
+        const uint64_t ak = best[i];
+        uint64_t key = 0ull;
+        if (ak != 0ull && key_score(ak) >= lo) {
+          const int32_t gidx = key_index(ak);
+          key = make_key(packed_score(a.packed, (int64_t)gidx - a.idx_base, dp, qs), gidx);
+        }
+        chunk[i] = key;
+      }
+      wave_lds_sync();
+      bitonic_sort_desc<KP>(chunk, lane);
+      best = chunk;  // sorted exact keys
+    }
+  }
 
   // ---- write the new state --------------------------------------------------------------
-  for (int i = lane; i < K; i += 64) {
-    const uint64_t key = best[i];
-    a.out_scores[row * K + i] = key ? key_score(key) : 0.0f;
-    a.out_idx[row * K + i] = key ? key_index(key) : 0;
+  if (a.out_scores) {
+    for (int i = lane; i < K; i += 64) {
+      const uint64_t key = best[i];
+      a.out_scores[row * K + i] = key ? key_score(key) : 0.0f;
+      a.out_idx[row * K + i] = key ? key_index(key) : 0;
+    }
   }
   if (a.out_thr && lane == 0) {
     const uint64_t key = best[K - 1];
-    a.out_thr[row] = key ? key_score(key) : -__builtin_inff();
+    a.out_thr[row] = key ? key_score(key) - (a.thr_eps ? eps : 0.0f) : -__builtin_inff();
   }
 }
 
 template <int KP>
 static int launch_select_kp(const SelectArgs &a, hipStream_t stream) {
-  const size_t lds = (size_t)kSelWaves * 2 * KP * sizeof(uint64_t);
+  const size_t lds = (size_t)kSelWaves * (2 * KP * sizeof(uint64_t) + TFRS_MAX_DIM * sizeof(float));
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
     TFRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_kernel<KP>),
@@ -232,10 +317,13 @@ int launch_select(const SelectArgs &a, hipStream_t stream) {
                  TFRS_MAX_K);
   TFRS_CHECK_ARG(a.state_len >= 0 && a.state_len <= a.k, "select: bad state_len %d",
                  a.state_len);
-  if (a.k <= 64) return launch_select_kp<64>(a, stream);
-  if (a.k <= 128) return launch_select_kp<128>(a, stream);
-  if (a.k <= 256) return launch_select_kp<256>(a, stream);
-  if (a.k <= 512) return launch_select_kp<512>(a, stream);
+  // approximate lists need room for the 2*eps retention band next to the K best
+  int need = a.k;
+  if (a.approx) need = std::min(1024, 2 * a.k);
+  if (need <= 64) return launch_select_kp<64>(a, stream);
+  if (need <= 128) return launch_select_kp<128>(a, stream);
+  if (need <= 256) return launch_select_kp<256>(a, stream);
+  if (need <= 512) return launch_select_kp<512>(a, stream);
   return launch_select_kp<1024>(a, stream);
 }
 

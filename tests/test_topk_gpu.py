@@ -14,6 +14,23 @@ torch = pytest.importorskip("torch")
 GRID = load_golden("topk_grid.json")
 
 
+# Every test of this file runs three times: the default configuration (fp16 prefilter path for
+# corpora with at least 8*K sampled 64-row bins, all-f32 rounds below that), "f16-eager" which
+# sends every corpus with at least K bins through the fp16 path (threshold pass over all
+# stages), and the all-f32 scan path.  All three must give bit-identical results.
+@pytest.fixture(autouse=True, params=["f16", "f16-eager", "f32"])
+def filter_mode(request, monkeypatch):
+  mode = request.param
+  monkeypatch.setenv("TFRS_TOPK_FILTER", "f32" if mode == "f32" else "f16")
+  if mode == "f16-eager":
+    monkeypatch.setenv("TFRS_TOPK_MINBINS", "1")
+    monkeypatch.setenv("TFRS_TOPK_SAMPLE", "1")
+  return mode
+
+
+_ORACLE_CACHE = {}
+
+
 def _layers():
   from recommenders_amd.layers import factorized_top_k
   return factorized_top_k
@@ -79,7 +96,7 @@ def test_reference_grid(layer_name, case):
 def test_bruteforce_bit_exact_dims(d):
   ftk = _layers()
   rng = np.random.default_rng(d)
-  n, nq, k = 6000, 300, 100
+  n, nq, k = 8000, 300, 100
   c = (rng.normal(size=(n, d)) / np.sqrt(d)).astype(np.float32)
   q = (rng.normal(size=(nq, d)) / np.sqrt(d)).astype(np.float32)
   es, ei = o_topk.brute_force(q, c, k)
@@ -104,12 +121,29 @@ def test_bruteforce_k_values(k):
   np.testing.assert_array_equal(_np(s), es)
 
 
+@pytest.mark.parametrize("d", [7, 16, 40, 64, 128])
+@pytest.mark.parametrize("k", [1, 10, 100, 300, 512])
+def test_bruteforce_f16_sized(d, k):
+  """Corpora large enough for the default fp16 prefilter path (>= 8*K sampled bins)."""
+  ftk = _layers()
+  rng = np.random.default_rng(1000 * d + k)
+  n, nq = (70000 if k <= 100 else 300000), 64
+  c = (rng.normal(size=(n, d)) * np.exp(0.3 * rng.normal(size=(n, 1)))).astype(np.float32)
+  q = rng.normal(size=(nq, d)).astype(np.float32)
+  if (d, k) not in _ORACLE_CACHE:     # the three filter modes share one oracle evaluation
+    _ORACLE_CACHE[(d, k)] = o_topk.brute_force(q, c, k)
+  es, ei = _ORACLE_CACHE[(d, k)]
+  s, i = ftk.BruteForce(k=k).index(c)(q)
+  np.testing.assert_array_equal(_np(i), ei)
+  np.testing.assert_array_equal(_np(s), es)
+
+
 def test_integer_ties_kat():
   """Integer-valued embeddings: every dot product is exact, ties are massive; the tie
   rule (lower row first) decides."""
   ftk = _layers()
   rng = np.random.default_rng(7)
-  n, nq, d, k = 20000, 130, 64, 100
+  n, nq, d, k = 60000, 130, 64, 100
   c = rng.integers(-4, 5, size=(n, d)).astype(np.float32)
   q = rng.integers(-4, 5, size=(nq, d)).astype(np.float32)
   es, ei = o_topk.brute_force(q, c, k)
@@ -236,3 +270,76 @@ def test_full_size_properties():
   es, ei = o_topk.brute_force(q[sample].cpu().numpy(), c.cpu().numpy(), k)
   np.testing.assert_array_equal(_np(i)[sample], ei)
   np.testing.assert_array_equal(_np(s)[sample], es)
+
+
+def _pow2_ceil(x):
+  x = np.asarray(x, np.float64)
+  out = np.ones_like(x)
+  nz = x > 0
+  out[nz] = 2.0 ** np.ceil(np.log2(x[nz]))
+  return out
+
+
+@pytest.mark.parametrize("d", [5, 16, 48, 64, 128])
+def test_f16_prefilter_error_bound(d, filter_mode):
+  """The fp16 prefilter never returns a score, but the exactness of the path rests on
+  |s_16 - s_f32| <= ||q|| ||c|| * kappa (kappa = 0.0011 in common.h): measure the raw
+  prefilter scores against the oracle's f32 chain, and against a float64 evaluation of the
+  scaled, fp16-rounded operands (what the matrix core should compute up to its accumulation
+  order).  Rows span many orders of magnitude and contain elements far below fp16's normal
+  range relative to the stage maximum (subnormal handling of the matrix core)."""
+  if filter_mode != "f16":
+    pytest.skip("property of the fp16 image only")
+  from recommenders_amd import _lib
+  ftk = _layers()
+  rng = np.random.default_rng(100 + d)
+  n, nq = 1280, 200
+  scale = np.exp(rng.normal(size=(n, 1)) * 3.0)       # row norms spread over orders of magnitude
+  c = (rng.normal(size=(n, d)) * scale).astype(np.float32)
+  c[:, ::3] *= np.float32(1e-5)                        # tiny elements next to large ones
+  q = (rng.normal(size=(nq, d)) * np.exp(rng.normal(size=(nq, 1)))).astype(np.float32)
+  q[:, 1::4] *= np.float32(3e-6)
+  layer = ftk.BruteForce(k=10).index(c)
+  out = torch.empty((nq, n), dtype=torch.float32, device="cuda")
+  scratch = torch.empty((2 * nq,), dtype=torch.float32, device="cuda")
+  tq = torch.as_tensor(q).cuda()
+  lib = _lib.load()
+  _lib.check(lib.tfrs_debug_fp16_scores(layer._index.handle, _lib.ptr(tq), nq, 0, n, _lib.ptr(out),
+                                        _lib.ptr(scratch), _lib.current_stream()))
+  got = _np(out).astype(np.float64)
+  exact = o_topk.scores(q, c).astype(np.float64)
+  qn = np.linalg.norm(q.astype(np.float64), axis=1, keepdims=True)
+  cn = np.linalg.norm(c.astype(np.float64), axis=1, keepdims=True).T
+  # the bound is stated with the max row norm of the candidate's 128-row stage
+  sn = np.repeat(cn.reshape(-1, 128).max(axis=1), 128)[None, :]
+  ratio = np.abs(got - exact) / (qn * sn)
+  assert ratio.max() <= 0.00104, ratio.max()            # kappa before its 5 % slack
+  # emulation: power-of-two scales per stage / per query, RNE to fp16 (subnormals kept)
+  sc = np.repeat(_pow2_ceil(np.abs(c).reshape(-1, 128 * d).max(axis=1)), 128)[:, None]
+  sq = _pow2_ceil(np.abs(q).max(axis=1))[:, None]
+  ch = (c.astype(np.float64) / sc).astype(np.float16).astype(np.float64) * sc
+  qh = (q.astype(np.float64) / sq).astype(np.float16).astype(np.float64) * sq
+  emu = qh @ ch.T
+  acc_err = np.abs(got - emu) / (qn * sn)
+  assert acc_err.max() <= d * 2.0 ** -22, acc_err.max()  # accumulation-order term of the bound
+
+
+def test_f16_prefilter_adversarial_norms_and_clusters():
+  """Cases built to stress the prefilter's margins: one huge-norm outlier row per stage
+  (inflates the per-stage bound), near-duplicate candidates whose scores differ in the last
+  bits (the whole cluster sits inside the 2*eps band: retention overflow -> exact redo), and a
+  zero query."""
+  ftk = _layers()
+  rng = np.random.default_rng(17)
+  n, nq, d, k = 60000, 64, 64, 100
+  c = (rng.normal(size=(n, d)) / 8).astype(np.float32)
+  c[::128] *= 1000.0                                     # outliers
+  base = (rng.normal(size=(1, d)) / 8).astype(np.float32)
+  c[5000:5600] = base * (1.0 + 1e-6 * rng.normal(size=(600, 1))).astype(np.float32)  # cluster
+  q = (rng.normal(size=(nq, d)) / 8).astype(np.float32)
+  q[0] = base[0] * 3.0                                   # query aligned with the cluster
+  q[1] = 0.0
+  es, ei = o_topk.brute_force(q, c, k)
+  s, i = ftk.BruteForce(k=k).index(c)(q)
+  np.testing.assert_array_equal(_np(i), ei)
+  np.testing.assert_array_equal(_np(s), es)

@@ -1,0 +1,14 @@
+"""PMC target: a few BruteForce steps with TFRS_DEBUG_NO_SURVIVORS=1 (raw scan loop, no events)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("TFRS_DEBUG_NO_SURVIVORS", "1")
+import torch
+from recommenders_amd.layers import factorized_top_k as ftk
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev).manual_seed(42)
+corpus = torch.randn((1_000_000, 64), generator=g, device=dev) / 8.0
+queries = torch.randn((8192, 64), generator=g, device=dev) / 8.0
+index = ftk.BruteForce(k=100).index(corpus)
+for _ in range(4):
+  index(queries)
+torch.cuda.synchronize()
