@@ -25,6 +25,7 @@ SOURCES = [
     "topk_scan.hip",
     "topk_scan16.hip",
     "topk_select.hip",
+    "topk_select16.hip",
     "topk_api.hip",
     "embedding.hip",
     "softmax.hip",

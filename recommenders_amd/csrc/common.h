@@ -195,7 +195,7 @@ struct Scan16Args {
 int launch_scan16(const Scan16Args &a, hipStream_t stream);
 constexpr int kScan16QueriesPerWg = 512;
 
-enum SelectSource { kSrcDense = 0, kSrcList = 1, kSrcParts = 2 };
+enum SelectSource { kSrcDense = 0, kSrcList = 1, kSrcParts = 2, kSrcRecompute = 3 };
 
 struct SelectArgs {
   int64_t nq;
@@ -230,18 +230,9 @@ struct SelectArgs {
   float *out_scores;   // [nq, k]
   int32_t *out_idx;    // [nq, k]
   float *out_thr;      // [nq] K-th best score, or -inf while fewer than k entries (may be NULL)
-  // ---- fp16 prefilter support ----
-  // thr_eps: out_thr = K-th score - eps[q] (the source scores are prefilter scores, so this is
-  //   the proven lower bound of the exact K-th score), eps[q] = qk[q] * norm_max + tiny.
-  // approx (kSrcList only): the list holds prefilter scores.  Every entry within 2*eps of the
-  //   K-th prefilter score is retained (it may still belong to the exact top-K); after the last
-  //   list entry the retained ones are re-scored with the exact f32 fma chain from the packed
-  //   corpus and the exact top-K is written.  A query whose retained set does not fit the
-  //   kernel's KP slots is recomputed exactly over rows [rc_begin, rc_end) instead.
-  int thr_eps;
-  int approx;
-  const float *qk;        // [nq] ||q|| * kappa
-  const float *norm_max;  // device scalar: max row norm of the corpus
+  // kSrcRecompute: exact keys of rows [rc_begin, rc_end) (slow, always correct).
+  // only_flagged != NULL: rows with only_flagged[row] == 0 are skipped (their outputs stay).
+  const uint32_t *only_flagged;
 };
 
 int launch_select(const SelectArgs &a, hipStream_t stream);
@@ -255,6 +246,16 @@ int launch_pack16(const char *packed, int d, int64_t row_begin, int64_t row_end,
                   StageMeta *meta, float *norm_max, hipStream_t stream);
 // qk[q] = ||q||_2 * kNormSlack * kF16Kappa;  qscale[q] = 2^ceil(log2 max|q_d|)
 int launch_query_kappa(const float *q, int64_t nq, int d, float *qk, float *qscale,
+                       hipStream_t stream);
+// topk_select16.hip: lower[q] = (K-th largest bin maximum) - eps[q]
+int launch_bin_threshold(const float *binmax, int64_t ld, int n_bins, int64_t nq, int k,
+                         const float *qk, const float *norm_max, float *lower,
+                         hipStream_t stream);
+// topk_select16.hip: survivor list of prefilter scores -> exact top-K; redo[q] = 1 for the
+// queries that need the exact recompute path (list overflow / retained set too large)
+int launch_list_topk16(const float *q, int64_t nq, int d, const char *packed, const uint2 *buf,
+                       const uint32_t *cnt, uint32_t cap_l, int nseg, int k, const float *qk,
+                       const float *norm_max, float *out_scores, int32_t *out_idx, uint32_t *redo,
                        hipStream_t stream);
 
 }  // namespace tfrs

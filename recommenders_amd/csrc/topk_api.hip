@@ -39,7 +39,7 @@ static TopkTuning tuning() {
   t.prefix = std::max<int64_t>(kTileN, env_i64("TFRS_TOPK_PREFIX", 4096));
   t.prefix = padded_rows(t.prefix);
   t.rho = std::max<int64_t>(2, env_i64("TFRS_TOPK_RHO", 8));
-  t.target_wgs = std::max<int64_t>(1, env_i64("TFRS_TOPK_WGS", 1024));
+  t.target_wgs = std::max<int64_t>(1, env_i64("TFRS_TOPK_WGS", 512));
   const char *f = getenv("TFRS_TOPK_FILTER");
   t.f16_filter = !(f && (f[0] == 'f' || f[0] == 'F') && f[1] == '3');
   t.sample = std::max<int64_t>(1, env_i64("TFRS_TOPK_SAMPLE", 4));
@@ -155,6 +155,7 @@ struct RoundWs {
   int64_t entries;  // per query
   float *qk;        // [nq]
   float *qscale;    // [nq]
+  uint32_t *redo;   // [nq]
   char *end;
 };
 
@@ -164,7 +165,7 @@ static size_t round_ws_bytes(int64_t nq, int64_t n, int k, const TopkTuning &t) 
   b += align_up((size_t)nq * 2 * max_splits(nq, t) * 4);                 // cnt[nq, nseg]
   b += align_up((size_t)nq * dense_rows(n, k, t) * 4);                   // dense
   b += align_up((size_t)nq * list_entries_per_query(nq, k, t) * 8);      // buf
-  b += 2 * align_up((size_t)nq * 4);                                     // qk, qscale
+  b += 3 * align_up((size_t)nq * 4);                                     // qk, qscale, redo
   return b;
 }
 
@@ -183,6 +184,8 @@ static RoundWs carve_round_ws(char *p, int64_t nq, int64_t n, int k, const TopkT
   w.qk = reinterpret_cast<float *>(p);
   p += align_up((size_t)nq * 4);
   w.qscale = reinterpret_cast<float *>(p);
+  p += align_up((size_t)nq * 4);
+  w.redo = reinterpret_cast<uint32_t *>(p);
   p += align_up((size_t)nq * 4);
   w.end = p;
   return w;
@@ -345,15 +348,6 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
   s16.qscale = w.qscale;
   s16.row_limit = n;
 
-  SelectArgs se = {};
-  se.nq = nq;
-  se.k = k;
-  se.q = q;
-  se.d = d;
-  se.packed = packed;
-  se.qk = w.qk;
-  se.norm_max = img.norm_max;
-
   // threshold pass
   s16.stage0 = 0;
   s16.n_stages = (int)sp.n_stages;
@@ -363,13 +357,9 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
   s16.ld_binmax = w.ld_dense;
   if ((rc = timed_scan16(s16, 2.0 * (double)nq * (double)sp.n_stages * kTileN * d, stream)) != TFRS_OK)
     return rc;
-  se.source = kSrcDense;
-  se.dense = w.dense;
-  se.ld_dense = w.ld_dense;
-  se.n_dense = 2 * sp.n_stages;
-  se.thr_eps = 1;
-  se.out_thr = w.thr;
-  if ((rc = launch_select(se, stream)) != TFRS_OK) return rc;
+  if ((rc = launch_bin_threshold(w.dense, w.ld_dense, (int)(2 * sp.n_stages), nq, k, w.qk,
+                                 img.norm_max, w.thr, stream)) != TFRS_OK)
+    return rc;
 
   // filter pass over all rows
   const int64_t all_stages = (n + kTileN - 1) / kTileN;
@@ -392,15 +382,20 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
   }
   if ((rc = timed_scan16(s16, 2.0 * (double)nq * (double)n * d, stream)) != TFRS_OK) return rc;
 
-  // prefilter top-K + exact re-scoring
-  se.source = kSrcList;
-  se.approx = 1;
-  se.thr_eps = 0;
-  se.out_thr = nullptr;
-  se.buf = w.buf;
-  se.cnt = w.cnt;
-  se.cap_l = s16.cap_l;
-  se.nseg = s16.nseg;
+  // prefilter top-K + exact re-scoring; flagged queries (list overflow, retained set too
+  // large) are answered by the exact recompute path of the generic select kernel
+  TFRS_HIP(hipMemsetAsync(w.redo, 0, (size_t)nq * 4, stream));
+  if ((rc = launch_list_topk16(q, nq, d, packed, w.buf, w.cnt, s16.cap_l, s16.nseg, k, w.qk,
+                               img.norm_max, out_scores, out_idx, w.redo, stream)) != TFRS_OK)
+    return rc;
+  SelectArgs se = {};
+  se.nq = nq;
+  se.k = k;
+  se.q = q;
+  se.d = d;
+  se.packed = packed;
+  se.source = kSrcRecompute;
+  se.only_flagged = w.redo;
   se.rc_begin = 0;
   se.rc_end = n;
   se.out_scores = out_scores;

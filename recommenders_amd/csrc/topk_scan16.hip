@@ -102,7 +102,7 @@ __device__ __forceinline__ float max16(const f32x16 &c) {
 }
 
 template <int DP, int MODE>
-__global__ void __launch_bounds__(kThreads16, 2) scan16_kernel(const Scan16Args a) {
+__global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(const Scan16Args a) {
   using G = Scan16Geom<DP>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -199,23 +199,32 @@ __global__ void __launch_bounds__(kThreads16, 2) scan16_kernel(const Scan16Args 
     const uint32_t stage_row = (uint32_t)((first_stage + (int64_t)st * stride) * kTileN);
     const char *ap = tile + j * G::kRowB + h * 16;
 
+    // A fragments are double-buffered in registers: the ds_reads of sub-tile t+1 are issued
+    // before the MFMAs of sub-tile t, so no MFMA waits on LDS latency inside a stage.
+    u32x4 af[2][G::kSteps];
+#pragma unroll
+    for (int m = 0; m < G::kSteps; ++m) af[0][m] = *reinterpret_cast<const u32x4 *>(ap + m * 32);
+
 #pragma unroll
     for (int sub = 0; sub < kTileN / 32; ++sub) {
-      u32x4 af[G::kSteps];
+      if (sub + 1 < kTileN / 32) {
 #pragma unroll
-      for (int m = 0; m < G::kSteps; ++m)
-        af[m] = *reinterpret_cast<const u32x4 *>(ap + sub * 32 * G::kRowB + m * 32);
-
+        for (int m = 0; m < G::kSteps; ++m)
+          af[(sub + 1) & 1][m] =
+              *reinterpret_cast<const u32x4 *>(ap + (sub + 1) * 32 * G::kRowB + m * 32);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this sub-tile's MFMAs
       f32x16 acc[kQG];
 #pragma unroll
       for (int g = 0; g < kQG; ++g)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[g][r] = 0.0f;
+      // chain-major order: the DP/16 MFMAs of one accumulator tile issue back to back
 #pragma unroll
-      for (int m = 0; m < G::kSteps; ++m) {
+      for (int g = 0; g < kQG; ++g) {
 #pragma unroll
-        for (int g = 0; g < kQG; ++g)
-          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(af[m]), bq[g][m], acc[g], 0, 0, 0);
+        for (int m = 0; m < G::kSteps; ++m)
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(af[sub & 1][m]), bq[g][m], acc[g], 0, 0, 0);
       }
       // acc[g][r] = s~(query g*32 + j, candidate stage_row + sub*32 + (r&3) + 8*(r>>2) + 4*h)
 
@@ -237,6 +246,9 @@ __global__ void __launch_bounds__(kThreads16, 2) scan16_kernel(const Scan16Args 
         const float m0 = max16(c);
         if (MODE == kModeBinMax) {
           binmax[g] = __builtin_fmaxf(binmax[g], m0);
+          // reduce NOW (the optimiser would otherwise sink the max trees to the end of the
+          // stage and keep all 8 accumulator tiles alive -> scratch spills)
+          asm volatile("" : "+v"(binmax[g]));
           continue;
         }
         if (__ballot(m0 > thr[g]) != 0ull) {  // some lane of the wave has a survivor in this tile
@@ -279,13 +291,16 @@ template <int DP, int MODE>
 static int launch_scan16_variant(const Scan16Args &a, hipStream_t stream) {
   using G = Scan16Geom<DP>;
   static bool attr_set = false;
+  static int lds_pad = 0;  // TFRS_DEBUG_LDS_PAD: occupancy experiments only
   if (!attr_set) {
+    const char *v = getenv("TFRS_DEBUG_LDS_PAD");
+    lds_pad = (v && *v) ? atoi(v) : 0;
     TFRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan16_kernel<DP, MODE>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes + lds_pad));
     attr_set = true;
   }
   const dim3 grid((unsigned)(a.n_qtiles * a.n_splits));
-  hipLaunchKernelGGL((scan16_kernel<DP, MODE>), grid, dim3(kThreads16), G::kLdsBytes, stream, a);
+  hipLaunchKernelGGL((scan16_kernel<DP, MODE>), grid, dim3(kThreads16), G::kLdsBytes + lds_pad, stream, a);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
 }

@@ -128,11 +128,8 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
               (size_t)wave * TFRS_MAX_DIM;
   const int K = a.k;
   const int source = a.source;
-  const bool approx = a.approx != 0;
   const int dp = padded_dim(a.d);
-  // eps bounds |prefilter score - exact score| for every candidate of this query
-  float eps = 0.0f;
-  if (approx || a.thr_eps) eps = a.qk[row] * a.norm_max[0] + kF16Tiny;
+  if (a.only_flagged && a.only_flagged[row] == 0u) return;  // whole wave
 
   // ---- seed with the prior state (already sorted by construction) -----------------
   for (int i = lane; i < KP; i += 64) {
@@ -140,23 +137,13 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
     if (i < a.state_len) key = make_key(a.state_scores[row * K + i], a.state_idx[row * K + i]);
     best[i] = key;
   }
-  if (source == kSrcList) {  // the query, zero-padded, for exact (re-)scoring
+  if (source == kSrcList || source == kSrcRecompute) {  // the query, zero-padded, for exact scoring
     for (int i = lane; i < dp; i += 64) qs[i] = (i < a.d) ? a.q[row * a.d + i] : 0.0f;
   }
   wave_lds_sync();
 
-  // Pass bound derived from the K-th key.  Exact mode: the K-th key itself.  Approximate mode:
-  // everything whose score is within 2*eps of the K-th score must be retained (it may still
-  // belong to the exact top-K), so the bound is the lowest key of score t - 2*eps.
-  auto bound_of = [&](uint64_t kkey) -> uint64_t {
-    if (!approx || kkey == 0ull) return kkey;
-    if (!(eps < __builtin_inff())) return 0ull;
-    const float b = key_score(kkey) - 2.0f * eps;
-    return (uint64_t)f32_orderable(b) << 32;
-  };
-
   int fill = 0;                           // wave-uniform
-  uint64_t kth = bound_of(best[K - 1]);   // 0 while fewer than K entries: everything passes
+  uint64_t kth = best[K - 1];             // 0 while fewer than K entries: everything passes
 
   // Offers one key per lane: keys that cannot beat the current bound are dropped, the rest
   // are compacted into `chunk`, which is sorted and merged into `best` when it fills.
@@ -167,7 +154,7 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
     if (fill + 64 > KP) {
       absorb_chunk<KP>(best, chunk, fill, lane);
       fill = 0;
-      kth = bound_of(best[K - 1]);
+      kth = best[K - 1];
     }
     if (p) chunk[fill + sel_mbcnt(mask)] = key;
     fill += (int)__popcll(mask);
@@ -187,21 +174,14 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
     }
   };
 
-  bool exact_done = false;  // approx: true when the keys in `best` are already exact
-  if (source == kSrcList) {
+  if (source == kSrcRecompute) {
+    recompute_range();
+  } else if (source == kSrcList) {
     // a segment whose count exceeds its capacity lost entries: recompute the query exactly
     bool ovf = false;
     for (int sg = lane; sg < a.nseg; sg += 64) ovf = ovf || (a.cnt[row * a.nseg + sg] > a.cap_l);
     if (__ballot(ovf) != 0ull) {
-      if (approx) {  // exact keys must not be mixed with the +-eps retention logic: start over
-        for (int i = lane; i < KP; i += 64) best[i] = 0ull;
-        wave_lds_sync();
-        kth = 0ull;
-      }
-      // exact scores from here on: the exact bound (K-th key) applies
-      eps = 0.0f;
       recompute_range();
-      exact_done = true;
     } else {
       // lanes <-> segments, 64 at a time; entry e of 64 consecutive segments is one 512-B row
       const uint2 *qbuf = a.buf + (row * (int64_t)a.cap_l) * a.nseg;
@@ -246,41 +226,7 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
       consume(key);
     }
   }
-  if (fill > 0) {
-    absorb_chunk<KP>(best, chunk, fill, lane);
-    fill = 0;
-  }
-
-  if (approx && !exact_done) {
-    // ---- exact re-scoring of the retained prefilter entries --------------------------------
-    const uint64_t kk = best[K - 1];
-    const uint64_t last = best[KP - 1];
-    float lo = -__builtin_inff();
-    if (kk != 0ull && eps < __builtin_inff()) lo = key_score(kk) - 2.0f * eps;
-    // the retained set (scores >= lo) must fit the KP slots, else entries were lost
-    const bool lost = (last != 0ull) && !(key_score(last) < lo);
-    if (lost) {
-      for (int i = lane; i < KP; i += 64) best[i] = 0ull;
-      wave_lds_sync();
-      kth = 0ull;
-      eps = 0.0f;
-      recompute_range();
-      if (fill > 0) absorb_chunk<KP>(best, chunk, fill, lane);
-    } else {
-      for (int i = lane; i < KP; i += 64) {
-        const uint64_t ak = best[i];
-        uint64_t key = 0ull;
-        if (ak != 0ull && key_score(ak) >= lo) {
-          const int32_t gidx = key_index(ak);
-          key = make_key(packed_score(a.packed, (int64_t)gidx - a.idx_base, dp, qs), gidx);
-        }
-        chunk[i] = key;
-      }
-      wave_lds_sync();
-      bitonic_sort_desc<KP>(chunk, lane);
-      best = chunk;  // sorted exact keys
-    }
-  }
+  if (fill > 0) absorb_chunk<KP>(best, chunk, fill, lane);
 
   // ---- write the new state --------------------------------------------------------------
   if (a.out_scores) {
@@ -292,7 +238,7 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
   }
   if (a.out_thr && lane == 0) {
     const uint64_t key = best[K - 1];
-    a.out_thr[row] = key ? key_score(key) - (a.thr_eps ? eps : 0.0f) : -__builtin_inff();
+    a.out_thr[row] = key ? key_score(key) : -__builtin_inff();
   }
 }
 
@@ -317,9 +263,7 @@ int launch_select(const SelectArgs &a, hipStream_t stream) {
                  TFRS_MAX_K);
   TFRS_CHECK_ARG(a.state_len >= 0 && a.state_len <= a.k, "select: bad state_len %d",
                  a.state_len);
-  // approximate lists need room for the 2*eps retention band next to the K best
-  int need = a.k;
-  if (a.approx) need = std::min(1024, 2 * a.k);
+  const int need = a.k;
   if (need <= 64) return launch_select_kp<64>(a, stream);
   if (need <= 128) return launch_select_kp<128>(a, stream);
   if (need <= 256) return launch_select_kp<256>(a, stream);

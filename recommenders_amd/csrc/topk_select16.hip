@@ -1,0 +1,313 @@
+// topk_select16.hip -- the two per-query kernels of the fp16-prefiltered BruteForce path
+// (topk_api.hip run_f16): lean replacements of the generic sort-merge select kernel for the
+// two shapes that path produces.  One wave per query, data in registers, selection by
+// MSB-first radix counting (ballot + popcount) instead of bitonic sort-merge in LDS.
+//
+//   bin_threshold_kernel : K-th largest of the threshold pass's bin maxima -> lower[q]
+//   list_topk16_kernel   : survivor list (prefilter scores) -> K-th prefilter score ->
+//                          retain everything within 2*eps -> exact f32 re-scoring (same
+//                          d-ordered fma chain as the MFMA f32 path) -> sorted exact top-K
+//                          = tf.math.top_k of BruteForce.call (layers/factorized_top_k.py:605).
+// Queries whose survivor list overflowed, or whose retained set does not fit, are flagged in
+// redo[q] and answered by the generic select kernel's exact recompute path afterwards.
+#include "common.h"
+
+namespace tfrs {
+
+constexpr int kSel16Waves = 4;
+constexpr int kSlots = 16;     // values per lane held in registers (64 * 16 = 1024 per query)
+constexpr int kRadixBits = 24; // the K-th key is resolved to its top 24 bits (rounded DOWN)
+
+__device__ __forceinline__ uint32_t sel16_mbcnt(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                   __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+__device__ __forceinline__ void sel16_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Top kRadixBits bits of the k-th largest of the wave's 64 * kSlots orderable keys (0 = empty
+// slot; returns 0 when fewer than k non-empty keys exist).  The result is <= the true k-th
+// largest key, i.e. a lower bound of the k-th largest score.
+__device__ __forceinline__ uint32_t radix_kth(const uint32_t (&key)[kSlots], int k) {
+  uint32_t prefix = 0u;
+#pragma unroll 1
+  for (int bit = 31; bit >= 32 - kRadixBits; --bit) {
+    const uint32_t test = prefix | (1u << bit);
+    const uint32_t himask = ~((1u << bit) - 1u);
+    int cnt = 0;
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) cnt += (int)__popcll(__ballot((key[s] & himask) == test));
+    if (cnt >= k) prefix = test; else k -= cnt;
+  }
+  return prefix;
+}
+
+// ---- threshold from the bin maxima ------------------------------------------------------
+// binmax[q, n_bins] (prefilter scores of DISTINCT candidates, one per 64-candidate bin).
+// Adjacent bins are first merged in groups of `group` (the maximum of a group is still the
+// score of one candidate), giving <= 1024 values per query; lower[q] = (K-th largest) - eps.
+__global__ void __launch_bounds__(kSel16Waves * 64) bin_threshold_kernel(
+    const float *__restrict__ binmax, int64_t ld, int n_bins, int group, int64_t nq, int k,
+    const float *__restrict__ qk, const float *__restrict__ norm_max, float *__restrict__ lower) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * kSel16Waves + (threadIdx.x >> 6);
+  if (row >= nq) return;
+  const float *src = binmax + row * ld;
+  uint32_t key[kSlots];
+#pragma unroll
+  for (int s = 0; s < kSlots; ++s) {
+    const int b0 = (s * 64 + lane) * group;
+    float m = -__builtin_inff();
+    if (group % 4 == 0) {
+      for (int g = 0; g < group; g += 4) {
+        if (b0 + g + 3 < n_bins) {
+          const float4 v = *reinterpret_cast<const float4 *>(src + b0 + g);
+          m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+        } else {
+          for (int e = 0; e < 4; ++e)
+            if (b0 + g + e < n_bins) m = fmaxf(m, src[b0 + g + e]);
+        }
+      }
+    } else {
+      for (int g = 0; g < group; ++g)
+        if (b0 + g < n_bins) m = fmaxf(m, src[b0 + g]);
+    }
+    key[s] = (b0 < n_bins) ? f32_orderable(m) : 0u;
+  }
+  const uint32_t kth = radix_kth(key, k);
+  if (lane == 0) {
+    const float eps = qk[row] * norm_max[0] + kF16Tiny;
+    // no K-th value (fewer than K bins, or -inf scores): no bound
+    lower[row] = (kth > f32_orderable(-__builtin_inff())) ? f32_from_orderable(kth) - eps
+                                                          : -__builtin_inff();
+  }
+}
+
+int launch_bin_threshold(const float *binmax, int64_t ld, int n_bins, int64_t nq, int k,
+                         const float *qk, const float *norm_max, float *lower,
+                         hipStream_t stream) {
+  if (nq <= 0) return TFRS_OK;
+  int group = 1;
+  if (n_bins > 64 * kSlots) group = ((n_bins + 64 * kSlots - 1) / (64 * kSlots) + 3) / 4 * 4;
+  hipLaunchKernelGGL(bin_threshold_kernel, dim3((unsigned)((nq + kSel16Waves - 1) / kSel16Waves)),
+                     dim3(kSel16Waves * 64), 0, stream, binmax, ld, n_bins, group, nq, k, qk,
+                     norm_max, lower);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+// ---- survivor list -> exact top-K ----------------------------------------------------------
+// Exact score of one candidate from the packed f32 corpus (d-ordered fma chain; `qs` is the
+// zero-padded query in LDS, read as broadcast float4).
+__device__ __forceinline__ float packed_score16(const char *packed, int64_t row, int dp,
+                                                const float *qs) {
+  const float4 *ev = reinterpret_cast<const float4 *>(packed + row * (int64_t)row_bytes(dp));
+  const float4 *od = ev + dp / 8;
+  const float4 *q4 = reinterpret_cast<const float4 *>(qs);
+  float acc = 0.0f;
+  for (int m = 0; m < dp / 8; ++m) {
+    const float4 e = ev[m], o = od[m];
+    const float4 qa = q4[2 * m], qb = q4[2 * m + 1];
+    acc = __builtin_fmaf(e.x, qa.x, acc);
+    acc = __builtin_fmaf(o.x, qa.y, acc);
+    acc = __builtin_fmaf(e.y, qa.z, acc);
+    acc = __builtin_fmaf(o.y, qa.w, acc);
+    acc = __builtin_fmaf(e.z, qb.x, acc);
+    acc = __builtin_fmaf(o.z, qb.y, acc);
+    acc = __builtin_fmaf(e.w, qb.z, acc);
+    acc = __builtin_fmaf(o.w, qb.w, acc);
+  }
+  return acc;
+}
+
+// Sorts x[0..P) descending (bitonic network in LDS, one wave).
+template <int P>
+__device__ __forceinline__ void sort_desc16(uint64_t *x, int lane) {
+#pragma unroll 1
+  for (int size = 2; size <= P; size <<= 1) {
+#pragma unroll 1
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = lane; t < P / 2; t += 64) {
+        const int i = 2 * t - (t & (stride - 1));
+        const int jx = i + stride;
+        const bool desc = ((i & size) == 0);
+        const uint64_t va = x[i], vb = x[jx];
+        if ((va < vb) == desc) {
+          x[i] = vb;
+          x[jx] = va;
+        }
+      }
+      sel16_lds_sync();
+    }
+  }
+}
+
+struct List16Args {
+  int64_t nq;
+  int k;
+  const float *q;
+  int d;
+  const char *packed;
+  const uint2 *buf;      // [nq, cap_l, nseg]
+  const uint32_t *cnt;   // [nq, nseg]
+  uint32_t cap_l;
+  int nseg;
+  const float *qk;
+  const float *norm_max;
+  float *out_scores;     // [nq, k]
+  int32_t *out_idx;      // [nq, k]
+  uint32_t *redo;        // [nq]: 1 = answer this query with the exact recompute path
+};
+
+// KP: slots for the retained set (>= K + band); the list itself may hold up to 64 * kSlots.
+template <int KP>
+__global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const List16Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t row = (int64_t)blockIdx.x * kSel16Waves + wave;
+  if (row >= a.nq) return;
+  constexpr int kCap = 64 * kSlots;
+  uint2 *ent = reinterpret_cast<uint2 *>(smem) + (size_t)wave * kCap;   // compacted list; later
+  uint64_t *ex = reinterpret_cast<uint64_t *>(ent);                      // reused for exact keys
+  float *qs = reinterpret_cast<float *>(smem + (size_t)kSel16Waves * kCap * sizeof(uint2)) +
+              (size_t)wave * TFRS_MAX_DIM;
+  const int K = a.k;
+  const int dp = padded_dim(a.d);
+  for (int i = lane; i < dp; i += 64) qs[i] = (i < a.d) ? a.q[row * a.d + i] : 0.0f;
+
+  // ---- gather the segmented list into LDS (lanes <-> segments, entry-major rows) ----------
+  const uint2 *qbuf = a.buf + (row * (int64_t)a.cap_l) * a.nseg;
+  int total = 0;       // wave-uniform
+  bool bad = false;    // overflowed segment or list longer than kCap
+  for (int sb = 0; sb < a.nseg; sb += 64) {
+    const int sg = sb + lane;
+    const uint32_t c = (sg < a.nseg) ? a.cnt[row * a.nseg + sg] : 0u;
+    bad = bad || (c > a.cap_l);
+    uint32_t cmax = c;
+    for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, off));
+    if (cmax > a.cap_l) break;  // (uniform) the query is redone anyway
+    for (uint32_t e0 = 0; e0 < cmax; e0 += 4) {
+      uint2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = make_uint2(0u, 0u);
+        if (e0 + u < c) v[u] = qbuf[(int64_t)(e0 + u) * a.nseg + sg];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool p = e0 + u < c;
+        const uint64_t mask = __ballot(p);
+        const int pos = total + (int)sel16_mbcnt(mask);
+        if (p && pos < kCap) ent[pos] = v[u];
+        total += (int)__popcll(mask);
+      }
+    }
+  }
+  if (__ballot(bad) != 0ull || total > kCap) {
+    if (lane == 0) a.redo[row] = 1u;
+    return;
+  }
+  sel16_lds_sync();
+
+  // ---- list -> registers; K-th largest prefilter score ---------------------------------------
+  uint32_t key[kSlots], rowid[kSlots];
+#pragma unroll
+  for (int s = 0; s < kSlots; ++s) {
+    const int e = s * 64 + lane;
+    key[s] = 0u;
+    rowid[s] = 0u;
+    if (e < total) {
+      const uint2 v = ent[e];
+      key[s] = f32_orderable(__uint_as_float(v.x));
+      rowid[s] = v.y;
+    }
+  }
+  const float eps = a.qk[row] * a.norm_max[0] + kF16Tiny;
+  const uint32_t kth = radix_kth(key, K);
+  // everything whose prefilter score is within 2*eps of the K-th one may belong to the exact
+  // top-K (common.h); kth == 0: fewer than K entries -> keep all of them
+  uint32_t lo_key = 0u;
+  if (kth != 0u && eps < __builtin_inff()) lo_key = f32_orderable(f32_from_orderable(kth) - 2.0f * eps);
+  sel16_lds_sync();  // all lanes have read `ent`: it can be overwritten with exact keys
+
+  // ---- retained entries: compact their row numbers into LDS --------------------------------
+  uint32_t *keep = reinterpret_cast<uint32_t *>(ent);
+  int m = 0;  // wave-uniform
+#pragma unroll
+  for (int s = 0; s < kSlots; ++s) {
+    const bool kp = key[s] != 0u && key[s] >= lo_key;
+    const uint64_t mask = __ballot(kp);
+    const int pos = m + (int)sel16_mbcnt(mask);
+    if (kp && pos < KP) keep[pos] = rowid[s];
+    m += (int)__popcll(mask);
+  }
+  if (m > KP) {  // retained set does not fit: exact redo
+    if (lane == 0) a.redo[row] = 1u;
+    return;
+  }
+  sel16_lds_sync();
+  // ---- exact re-scoring, all lanes busy: entry u*64 + lane -> ex[u*64 + lane] -----------------
+  uint32_t kid[KP / 64];
+#pragma unroll
+  for (int u = 0; u < KP / 64; ++u) kid[u] = (u * 64 + lane < m) ? keep[u * 64 + lane] : 0u;
+  sel16_lds_sync();  // `keep` is dead: the region becomes `ex`
+#pragma unroll
+  for (int u = 0; u < KP / 64; ++u) {
+    if (u * 64 < m) {  // wave-uniform
+      uint64_t kk = 0ull;
+      if (u * 64 + lane < m)
+        kk = make_key(packed_score16(a.packed, (int64_t)kid[u], dp, qs), (int32_t)kid[u]);
+      ex[u * 64 + lane] = kk;
+    }
+  }
+  for (int i = m + lane; i < KP; i += 64) ex[i] = 0ull;
+  sel16_lds_sync();
+  if (KP > 128 && m <= 128) sort_desc16<128>(ex, lane); else sort_desc16<KP>(ex, lane);
+
+  for (int i = lane; i < K; i += 64) {
+    const uint64_t kk = ex[i];
+    a.out_scores[row * K + i] = kk ? key_score(kk) : 0.0f;
+    a.out_idx[row * K + i] = kk ? key_index(kk) : 0;
+  }
+}
+
+template <int KP>
+static int launch_list16_kp(const List16Args &a, hipStream_t stream) {
+  const size_t lds = (size_t)kSel16Waves * (64 * kSlots * sizeof(uint2) + TFRS_MAX_DIM * sizeof(float));
+  const dim3 grid((unsigned)((a.nq + kSel16Waves - 1) / kSel16Waves));
+  hipLaunchKernelGGL((list_topk16_kernel<KP>), grid, dim3(kSel16Waves * 64), lds, stream, a);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+int launch_list_topk16(const float *q, int64_t nq, int d, const char *packed, const uint2 *buf,
+                       const uint32_t *cnt, uint32_t cap_l, int nseg, int k, const float *qk,
+                       const float *norm_max, float *out_scores, int32_t *out_idx, uint32_t *redo,
+                       hipStream_t stream) {
+  if (nq <= 0) return TFRS_OK;
+  List16Args a;
+  a.nq = nq;
+  a.k = k;
+  a.q = q;
+  a.d = d;
+  a.packed = packed;
+  a.buf = buf;
+  a.cnt = cnt;
+  a.cap_l = cap_l;
+  a.nseg = nseg;
+  a.qk = qk;
+  a.norm_max = norm_max;
+  a.out_scores = out_scores;
+  a.out_idx = out_idx;
+  a.redo = redo;
+  const int need = 2 * k;  // K + room for the 2*eps band
+  if (need <= 128) return launch_list16_kp<128>(a, stream);
+  if (need <= 256) return launch_list16_kp<256>(a, stream);
+  if (need <= 512) return launch_list16_kp<512>(a, stream);
+  return launch_list16_kp<1024>(a, stream);
+}
+
+}  // namespace tfrs
