@@ -163,8 +163,8 @@ int launch_scan(const ScanArgs &a, bool materialize, hipStream_t stream);
 //   FILTER (default): a score survives when s_16 > lower[q] - qk[q] * meta[stage].norm - tiny
 //     (lower[q]: proven lower bound of the query's final exact K-th score; qk = ||q|| * kappa)
 //     and is appended to the query's survivor list (layout: see SelectArgs).
-//   BINMAX (binmax != NULL): binmax[q * ld_binmax + 2 * i + h] = max prefilter score of lane
-//     half h over stage i (64 candidates).
+//   BINMAX (binmax != NULL): binmax[q * ld_binmax + 2 * (i / bin_stages) + h] = max prefilter
+//     score of lane half h over bin_stages consecutive list stages (64 * bin_stages candidates).
 //   MATERIALIZE (dense != NULL): dense[q * ld_dense + i * 128 + r] = prefilter score of row r
 //     of stage i.
 struct Scan16Args {
@@ -191,6 +191,7 @@ struct Scan16Args {
   int64_t ld_dense;
   float *binmax;
   int64_t ld_binmax;
+  int bin_stages;        // stages per bin (stages_per_split must be a multiple of it)
 };
 int launch_scan16(const Scan16Args &a, hipStream_t stream);
 constexpr int kScan16QueriesPerWg = 512;

@@ -43,7 +43,7 @@ static TopkTuning tuning() {
   const char *f = getenv("TFRS_TOPK_FILTER");
   t.f16_filter = !(f && (f[0] == 'f' || f[0] == 'F') && f[1] == '3');
   t.sample = std::max<int64_t>(1, env_i64("TFRS_TOPK_SAMPLE", 4));
-  t.min_bins = std::max<int64_t>(1, env_i64("TFRS_TOPK_MINBINS", 8));
+  t.min_bins = std::max<int64_t>(1, env_i64("TFRS_TOPK_MINBINS", 8));  // in 64-candidate bins
   return t;
 }
 
@@ -100,15 +100,18 @@ static int timed_scan16(const Scan16Args &sa, double flop, hipStream_t stream) {
 // stride actually used: the requested one, reduced until min_bins * K bins are available.
 struct SamplePlan {
   int64_t stride;
-  int64_t n_stages;  // 0: the fp16 path is not applicable
+  int64_t n_stages;    // 0: the fp16 path is not applicable
+  int64_t bin_stages;  // stages per bin: 4 when that still leaves 8 * K bins, else 1
+  int64_t n_bins() const { return 2 * ((n_stages + bin_stages - 1) / bin_stages); }
 };
 static SamplePlan plan_sample(int64_t n, int k, const TopkTuning &t) {
   const int64_t full = n / kTileN;
   const int64_t want_bins = t.min_bins * (int64_t)k;
-  SamplePlan p = {t.sample, 0};
+  SamplePlan p = {t.sample, 0, 1};
   while (p.stride > 1 && 2 * (full / p.stride) < want_bins) --p.stride;
   const int64_t ns = full / p.stride;
   if (2 * ns >= std::max<int64_t>(want_bins, k)) p.n_stages = ns;
+  if (2 * (ns / 4) >= 8 * (int64_t)k) p.bin_stages = 4;
   return p;
 }
 static int64_t dense_rows(int64_t n, int k, const TopkTuning &t) {
@@ -353,11 +356,14 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
   s16.n_stages = (int)sp.n_stages;
   s16.stage_stride = (int)sp.stride;
   plan_stage_splits(sp.n_stages, n_qtiles, t, &s16.stages_per_split, &s16.n_splits);
+  s16.bin_stages = (int)sp.bin_stages;
+  s16.stages_per_split = (int)((s16.stages_per_split + sp.bin_stages - 1) / sp.bin_stages * sp.bin_stages);
+  s16.n_splits = (int)((sp.n_stages + s16.stages_per_split - 1) / s16.stages_per_split);
   s16.binmax = w.dense;
   s16.ld_binmax = w.ld_dense;
   if ((rc = timed_scan16(s16, 2.0 * (double)nq * (double)sp.n_stages * kTileN * d, stream)) != TFRS_OK)
     return rc;
-  if ((rc = launch_bin_threshold(w.dense, w.ld_dense, (int)(2 * sp.n_stages), nq, k, w.qk,
+  if ((rc = launch_bin_threshold(w.dense, w.ld_dense, (int)sp.n_bins(), nq, k, w.qk,
                                  img.norm_max, w.thr, stream)) != TFRS_OK)
     return rc;
 

@@ -18,7 +18,7 @@
 //               v_max3 tree (8 VALU) + one compare per 16 scores.
 // Modes:
 //   BINMAX      (threshold pass over a SAMPLE of the stages, no thresholds, no branches): the
-//               maximum prefilter score per (query, stage, lane half) -> binmax[nq, 2*stages].
+//               maximum prefilter score per (query, bin_stages stages, lane half) -> binmax.
 //               Bin maxima belong to distinct candidates, so the K-th largest of them minus
 //               eps is a proven lower bound of the query's final K-th score.
 //   FILTER      keep s~ > lower[q] - qk[q] * norm[stage] - tiny, appended by the owning lane
@@ -175,6 +175,7 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
   StageMeta sm = mp[0];
   __syncthreads();
 
+  float binmax[kQG] = {-__builtin_inff(), -__builtin_inff()};
   for (int st = 0; st < nst; ++st) {
     const char *tile = smem + (st & 1) * G::kStageB;
     const bool more = (st + 1 < nst);
@@ -192,10 +193,15 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
       thr[g] = (__builtin_fmaf(-qk[g], sm.norm, lower[g]) - kF16Tiny) * qinv[g] * sm.inv_scale;
       unscale[g] = qs[g] * sm.scale;
     }
-    float binmax[kQG];
+    // BINMAX: one bin = bin_stages consecutive stages of the list x lane half h
+    if (MODE == kModeBinMax && (st % a.bin_stages) == 0) {
 #pragma unroll
-    for (int g = 0; g < kQG; ++g) binmax[g] = -__builtin_inff();
+      for (int g = 0; g < kQG; ++g) binmax[g] = -__builtin_inff();
+    }
 
+    float stagemax[kQG];
+#pragma unroll
+    for (int g = 0; g < kQG; ++g) stagemax[g] = -__builtin_inff();
     const uint32_t stage_row = (uint32_t)((first_stage + (int64_t)st * stride) * kTileN);
     const char *ap = tile + j * G::kRowB + h * 16;
 
@@ -245,10 +251,10 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
         }
         const float m0 = max16(c);
         if (MODE == kModeBinMax) {
-          binmax[g] = __builtin_fmaxf(binmax[g], m0);
+          stagemax[g] = __builtin_fmaxf(stagemax[g], m0);
           // reduce NOW (the optimiser would otherwise sink the max trees to the end of the
           // stage and keep all 8 accumulator tiles alive -> scratch spills)
-          asm volatile("" : "+v"(binmax[g]));
+          asm volatile("" : "+v"(stagemax[g]));
           continue;
         }
         if (__ballot(m0 > thr[g]) != 0ull) {  // some lane of the wave has a survivor in this tile
@@ -272,9 +278,15 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
       }
     }
     if (MODE == kModeBinMax) {
+      // scores of different stages are compared in true units
 #pragma unroll
-      for (int g = 0; g < kQG; ++g)
-        if (qvalid[g]) a.binmax[qrow[g] * a.ld_binmax + 2 * (i0 + st) + h] = binmax[g] * unscale[g];
+      for (int g = 0; g < kQG; ++g) binmax[g] = __builtin_fmaxf(binmax[g], stagemax[g] * unscale[g]);
+      if ((st % a.bin_stages) == a.bin_stages - 1 || st == nst - 1) {
+#pragma unroll
+        for (int g = 0; g < kQG; ++g)
+          if (qvalid[g])
+            a.binmax[qrow[g] * a.ld_binmax + 2 * ((i0 + st) / a.bin_stages) + h] = binmax[g];
+      }
     }
     sm = sm_next;
     __syncthreads();
@@ -318,6 +330,8 @@ int launch_scan16(const Scan16Args &a, hipStream_t stream) {
                      (int64_t)a.n_splits * a.stages_per_split >= a.n_stages,
                  "scan16: bad stage split");
   TFRS_CHECK_ARG(a.dense || a.binmax || a.nseg == 2 * a.n_splits, "scan16: nseg must be 2 * n_splits");
+  TFRS_CHECK_ARG(!a.binmax || (a.bin_stages >= 1 && a.stages_per_split % a.bin_stages == 0),
+                 "scan16: stages_per_split must be a multiple of bin_stages");
   switch (padded_dim16(a.d)) {
     case 16: return launch_scan16_dp<16>(a, stream);
     case 32: return launch_scan16_dp<32>(a, stream);
