@@ -58,8 +58,9 @@ int tfrs_device_info(int dev, int *cu_count_h, int *lds_bytes_h, char *arch_h,
  * the last read, after waiting for the recorded events. */
 int tfrs_profile_enable(int on);
 int tfrs_profile_read(double *scan_ms_h, int *launches_h, double *flop_h);
-/* Same sums restricted to one scan kernel (0 = exact f32 scan, 1 = fp16 prefilter scan);
- * does not reset -- call before tfrs_profile_read. */
+/* Same sums restricted to one scan kernel (0 = exact f32 scan, 1 = fp16 filter pass over all
+ * rows, 2 = fp16 threshold pass over the sampled stages); does not reset -- call before
+ * tfrs_profile_read. */
 int tfrs_profile_read_kind(int kind, double *scan_ms_h, int *launches_h, double *flop_h);
 
 /* ------------------------------------------------------------------------- *

@@ -57,7 +57,7 @@ struct ScanProfile {
   static constexpr int kMax = 4096;
   hipEvent_t start[kMax], stop[kMax];
   double flop[kMax];
-  int kind[kMax];  // 0 = f32 scan, 1 = fp16 prefilter scan
+  int kind[kMax];  // 0 = f32 scan, 1 = fp16 filter pass, 2 = fp16 threshold (bin-max) pass
   int created = 0;
   int used = 0;
 };
@@ -90,7 +90,7 @@ static int timed_scan(const ScanArgs &sa, bool materialize, hipStream_t stream) 
 
 static int timed_scan16(const Scan16Args &sa, double flop, hipStream_t stream) {
   int slot = 0;
-  const bool on = prof_begin(stream, flop, 1, &slot);
+  const bool on = prof_begin(stream, flop, sa.binmax ? 2 : 1, &slot);
   const int rc = launch_scan16(sa, stream);
   if (on) prof_end(stream, slot);
   return rc;
@@ -439,7 +439,7 @@ static int profile_sum(int kind, double *scan_ms_h, int *launches_h, double *flo
 
 extern "C" int tfrs_profile_read_kind(int kind, double *scan_ms_h, int *launches_h,
                                       double *flop_h) {
-  TFRS_CHECK_ARG(kind == 0 || kind == 1, "profile_read_kind: kind must be 0 (f32) or 1 (fp16)");
+  TFRS_CHECK_ARG(kind >= 0 && kind <= 2, "profile_read_kind: kind must be 0, 1 or 2");
   return profile_sum(kind, scan_ms_h, launches_h, flop_h);
 }
 

@@ -100,18 +100,28 @@ __global__ void __launch_bounds__(256) pack16_stage_kernel(const char *__restric
   __shared__ float s_scale;
   const int64_t stage = stage0 + blockIdx.x;
   const int64_t row0 = stage * kTileN;
-  const int half = dp / 2;  // floats per parity plane of the f32 image
   const int tid = threadIdx.x;
-  if (tid < kTileN) {
-    const float *row = reinterpret_cast<const float *>(packed + (row0 + tid) * (int64_t)row_bytes(dp));
+  {
+    // two threads per row (one per parity plane), 16-byte loads
+    const int r = tid >> 1, pl = tid & 1;
+    const float4 *plane = reinterpret_cast<const float4 *>(packed + (row0 + r) * (int64_t)row_bytes(dp)) +
+                          pl * (dp / 8);
     float ssq = 0.0f, amax = 0.0f;
-    for (int k = 0; k < dp; ++k) {  // plane order; the sum of squares does not depend on it
-      const float x = row[k];
-      ssq = __builtin_fmaf(x, x, ssq);
-      amax = fmaxf(amax, __builtin_fabsf(x));
+    for (int m = 0; m < dp / 8; ++m) {
+      const float4 v = plane[m];
+      ssq = __builtin_fmaf(v.x, v.x, ssq);
+      ssq = __builtin_fmaf(v.y, v.y, ssq);
+      ssq = __builtin_fmaf(v.z, v.z, ssq);
+      ssq = __builtin_fmaf(v.w, v.w, ssq);
+      amax = fmaxf(fmaxf(amax, fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y))),
+                   fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
     }
-    s_norm[tid] = __builtin_sqrtf(ssq) * kNormSlack;
-    s_amax[tid] = amax;
+    ssq += __shfl_xor(ssq, 1);
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    if (pl == 0) {
+      s_norm[r] = __builtin_sqrtf(ssq) * kNormSlack;
+      s_amax[r] = amax;
+    }
   }
   __syncthreads();
   if (tid < 64) {
@@ -138,15 +148,14 @@ __global__ void __launch_bounds__(256) pack16_stage_kernel(const char *__restric
     const int r = t / slots;
     const int s = t - r * slots;
     uint32_t w[4] = {0u, 0u, 0u, 0u};
-    if (s < slots - 1) {
-      const float *row = reinterpret_cast<const float *>(packed + (row0 + r) * (int64_t)row_bytes(dp));
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = 8 * s + 2 * i;  // features k (even plane) and k + 1 (odd plane)
-        const float x0 = (k < dp) ? row[k >> 1] * inv : 0.0f;
-        const float x1 = (k + 1 < dp) ? row[half + (k >> 1)] * inv : 0.0f;
-        w[i] = pack_f16x2(x0, x1);
-      }
+    if (s < slots - 1 && 8 * s < dp) {
+      // features 8s .. 8s+7 = float4 #s of the even plane interleaved with float4 #s of the odd one
+      const float4 *ev = reinterpret_cast<const float4 *>(packed + (row0 + r) * (int64_t)row_bytes(dp));
+      const float4 e = ev[s], o = ev[dp / 8 + s];
+      w[0] = pack_f16x2(e.x * inv, o.x * inv);
+      w[1] = pack_f16x2(e.y * inv, o.y * inv);
+      w[2] = pack_f16x2(e.z * inv, o.z * inv);
+      w[3] = pack_f16x2(e.w * inv, o.w * inv);
     }
     *reinterpret_cast<uint4 *>(packed16 + (row0 + r) * (int64_t)row_bytes16(dp16) + (int64_t)s * 16) =
         make_uint4(w[0], w[1], w[2], w[3]);

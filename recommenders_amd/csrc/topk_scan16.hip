@@ -144,16 +144,28 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
     const float *qp = a.q + qrow[g] * a.d;
     qs[g] = qvalid[g] ? a.qscale[qrow[g]] : 1.0f;
     qinv[g] = 1.0f / qs[g];  // exact: power of two
+    const bool vec_ok = (a.d == DP) && ((reinterpret_cast<uintptr_t>(a.q) & 15) == 0);  // uniform
 #pragma unroll
     for (int m = 0; m < G::kSteps; ++m) {
+      float x[8];
+      if (vec_ok) {  // 8 consecutive features = two 16-byte loads
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+        if (qvalid[g]) {
+          lo = *reinterpret_cast<const float4 *>(qp + 16 * m + 8 * h);
+          hi = *reinterpret_cast<const float4 *>(qp + 16 * m + 8 * h + 4);
+        }
+        x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w;
+        x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int k = 16 * m + 8 * h + i;
+          x[i] = (qvalid[g] && k < a.d) ? qp[k] : 0.0f;
+        }
+      }
       u32x4 w;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = 16 * m + 8 * h + 2 * i;
-        const float x0 = (qvalid[g] && k < a.d) ? qp[k] : 0.0f;
-        const float x1 = (qvalid[g] && k + 1 < a.d) ? qp[k + 1] : 0.0f;
-        w[i] = cvt_f16x2(x0 * qinv[g], x1 * qinv[g]);
-      }
+      for (int i = 0; i < 4; ++i) w[i] = cvt_f16x2(x[2 * i] * qinv[g], x[2 * i + 1] * qinv[g]);
       bq[g][m] = as_f16x8(w);
     }
     lower[g] = (MODE == kModeFilter && qvalid[g]) ? a.lower[qrow[g]] : __builtin_inff();

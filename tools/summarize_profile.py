@@ -110,6 +110,17 @@ def main() -> None:
       out.append("")
       out += ["* " + n for n in notes]
       out.append("")
+  # machine-readable HBM traffic per launch for bench.py's roofline.traffic
+  traffic = {}
+  for k, d in pmc.items():
+    g = {c: s_ / n for c, (n, s_) in d.items()}
+    if "FETCH_SIZE" in g:
+      traffic[k] = {"fetch_bytes_corrected": 2 * g["FETCH_SIZE"] * 1024,
+                    "write_bytes_uncalibrated": g.get("WRITE_SIZE", 0.0) * 1024,
+                    "note": "rocprofv3 --pmc FETCH_SIZE (KiB) x2 per MI355X_MICROARCH.md; separate pass"}
+  if traffic:
+    with open(os.path.splitext(dst)[0] + "_traffic.json", "w") as f:
+      json.dump(traffic, f, indent=1)
   os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
   with open(dst, "w") as f:
     f.write("\n".join(out) + "\n")
