@@ -221,7 +221,7 @@ struct SelectArgs {
   int d;
   const char *packed;
   int64_t rc_begin, rc_end;
-  // kSrcParts: scores/idx[nparts, nq, k_in]
+  // kSrcParts: scores/idx[nparts, nq, k_in]; idx < 0 marks an empty slot
   const float *part_scores;
   const int32_t *part_idx;
   int nparts, k_in;
@@ -257,6 +257,6 @@ int launch_bin_threshold(const float *binmax, int64_t ld, int n_bins, int64_t nq
 int launch_list_topk16(const float *q, int64_t nq, int d, const char *packed, const uint2 *buf,
                        const uint32_t *cnt, uint32_t cap_l, int nseg, int k, const float *qk,
                        const float *norm_max, float *out_scores, int32_t *out_idx, uint32_t *redo,
-                       hipStream_t stream);
+                       int64_t idx_base, hipStream_t stream);
 
 }  // namespace tfrs

@@ -333,9 +333,12 @@ static void plan_stage_splits(int64_t n_stages, int n_qtiles, const TopkTuning &
   *n_splits = (int)((n_stages + *per - 1) / *per);
 }
 
+// lower_preset: w.thr already holds a proven lower bound per query (Streaming: the carried
+// state's exact K-th score) -> the threshold pass is skipped.
 static int run_f16(const float *q, int64_t nq, int d, const char *packed, const F16Image &img,
-                   int64_t n, int k, const SamplePlan &sp, float *out_scores, int32_t *out_idx,
-                   const RoundWs &w, const TopkTuning &t, hipStream_t stream) {
+                   int64_t n, int64_t idx_base, int k, const SamplePlan &sp, bool lower_preset,
+                   float *out_scores, int32_t *out_idx, const RoundWs &w, const TopkTuning &t,
+                   hipStream_t stream) {
   const int n_qtiles = (int)((nq + kScan16QueriesPerWg - 1) / kScan16QueriesPerWg);
   int rc;
   if ((rc = launch_query_kappa(q, nq, d, w.qk, w.qscale, stream)) != TFRS_OK) return rc;
@@ -352,6 +355,7 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
   s16.row_limit = n;
 
   // threshold pass
+  if (!lower_preset) {
   s16.stage0 = 0;
   s16.n_stages = (int)sp.n_stages;
   s16.stage_stride = (int)sp.stride;
@@ -366,6 +370,7 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
   if ((rc = launch_bin_threshold(w.dense, w.ld_dense, (int)sp.n_bins(), nq, k, w.qk,
                                  img.norm_max, w.thr, stream)) != TFRS_OK)
     return rc;
+  }
 
   // filter pass over all rows
   const int64_t all_stages = (n + kTileN - 1) / kTileN;
@@ -392,7 +397,7 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
   // large) are answered by the exact recompute path of the generic select kernel
   TFRS_HIP(hipMemsetAsync(w.redo, 0, (size_t)nq * 4, stream));
   if ((rc = launch_list_topk16(q, nq, d, packed, w.buf, w.cnt, s16.cap_l, s16.nseg, k, w.qk,
-                               img.norm_max, out_scores, out_idx, w.redo, stream)) != TFRS_OK)
+                               img.norm_max, out_scores, out_idx, w.redo, idx_base, stream)) != TFRS_OK)
     return rc;
   SelectArgs se = {};
   se.nq = nq;
@@ -402,6 +407,7 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
   se.packed = packed;
   se.source = kSrcRecompute;
   se.only_flagged = w.redo;
+  se.idx_base = idx_base;
   se.rc_begin = 0;
   se.rc_end = n;
   se.out_scores = out_scores;
@@ -589,8 +595,8 @@ extern "C" int tfrs_bruteforce_topk(const tfrs_index_t *index, const float *quer
     const SamplePlan sp = plan_sample(index->n, k, t);
     if (sp.n_stages > 0) {
       const F16Image img = {index->packed16, index->meta, index->norm_max};
-      return run_f16(queries, nq, index->d, index->packed, img, index->n, k, sp, out_scores,
-                     out_idx, w, t, (hipStream_t)stream);
+      return run_f16(queries, nq, index->d, index->packed, img, index->n, /*idx_base=*/0, k, sp,
+                     /*lower_preset=*/false, out_scores, out_idx, w, t, (hipStream_t)stream);
     }
   }
   int new_len = 0;
@@ -636,10 +642,24 @@ extern "C" int tfrs_debug_fp16_scores(const tfrs_index_t *index, const float *qu
 // ----------------------------------------------------------------------------------------
 // Streaming.call, one candidate block
 // ----------------------------------------------------------------------------------------
+// Streaming blocks go through the fp16 prefilter when they are large enough: at least 16
+// stages, and -- for a block that cannot take its bound from the carried state -- enough
+// bins for the threshold pass.
+static bool stream_block_f16(int64_t nb, int k, const TopkTuning &t) {
+  return t.f16_filter && k <= kMaxKF16 && nb >= 16 * kTileN;
+}
+static size_t stream_f16_extra_bytes(int64_t nq, int64_t nb, int d, int k) {
+  return align_up((size_t)padded_rows(nb) * row_bytes16(padded_dim16(d))) +              // fp16 image
+         align_up((size_t)(padded_rows(nb) / kTileN + 1) * sizeof(StageMeta)) +           // meta + norm_max
+         2 * align_up((size_t)nq * k * 4);                                                // block top-K
+}
+
 extern "C" size_t tfrs_streaming_topk_workspace_bytes(int64_t nq, int64_t nb, int d, int k) {
   if (nq <= 0 || nb <= 0 || k <= 0 || d <= 0 || d > TFRS_MAX_DIM) return 256;
-  return round_ws_bytes(nq, nb, k, tuning()) +
-         align_up((size_t)padded_rows(nb) * row_bytes(padded_dim(d)));
+  const TopkTuning t = tuning();
+  size_t b = round_ws_bytes(nq, nb, k, t) + align_up((size_t)padded_rows(nb) * row_bytes(padded_dim(d)));
+  if (stream_block_f16(nb, k, t)) b += stream_f16_extra_bytes(nq, nb, d, k);
+  return b;
 }
 
 extern "C" int tfrs_streaming_topk_update(const float *queries, int64_t nq, int d,
@@ -674,6 +694,56 @@ extern "C" int tfrs_streaming_topk_update(const float *queries, int64_t nq, int 
   int rc = launch_pack(cand_block, nb, d, packed, 0, padded_rows(nb), (hipStream_t)stream);
   if (rc != TFRS_OK) return rc;
   int new_len = state_len;
+  if (stream_block_f16(nb, k, t)) {
+    // fp16-prefiltered block: bound from the carried state when it is full (no threshold
+    // pass at all), else from the block's own bin maxima; then merge the block's exact top-K
+    // into the state.
+    const bool preset = (state_len == k);
+    const SamplePlan sp = preset ? SamplePlan{1, 0, 1} : plan_sample(nb, k, t);
+    if (preset || sp.n_stages > 0) {
+      hipStream_t st = (hipStream_t)stream;
+      char *p = packed + align_up((size_t)padded_rows(nb) * row_bytes(padded_dim(d)));
+      char *packed16 = p;
+      p += align_up((size_t)padded_rows(nb) * row_bytes16(padded_dim16(d)));
+      StageMeta *meta = reinterpret_cast<StageMeta *>(p);
+      const size_t nstages = (size_t)(padded_rows(nb) / kTileN);
+      float *norm_max = reinterpret_cast<float *>(meta + nstages);
+      p += align_up((nstages + 1) * sizeof(StageMeta));
+      float *blk_scores = reinterpret_cast<float *>(p);
+      p += align_up((size_t)nq * k * 4);
+      int32_t *blk_idx = reinterpret_cast<int32_t *>(p);
+      TFRS_HIP(hipMemsetAsync(norm_max, 0, sizeof(float), st));
+      if ((rc = launch_pack16(packed, d, 0, padded_rows(nb), packed16, meta, norm_max, st)) != TFRS_OK)
+        return rc;
+      if (preset) {
+        hipLaunchKernelGGL(thr_from_state_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0,
+                           st, state_scores, nq, k, w.thr);
+        TFRS_LAUNCH_CHECK();
+      }
+      const F16Image img = {packed16, meta, norm_max};
+      if ((rc = run_f16(queries, nq, d, packed, img, nb, base_row, k, sp, preset, blk_scores,
+                        blk_idx, w, t, st)) != TFRS_OK)
+        return rc;
+      SelectArgs se = {};
+      se.nq = nq;
+      se.k = k;
+      se.state_scores = state_scores;
+      se.state_idx = state_idx;
+      se.state_len = state_len;
+      se.source = kSrcParts;
+      se.part_scores = blk_scores;
+      se.part_idx = blk_idx;
+      se.nparts = 1;
+      se.k_in = k;
+      se.d = 8;
+      se.out_scores = state_scores;
+      se.out_idx = state_idx;
+      if ((rc = launch_select(se, st)) != TFRS_OK) return rc;
+      new_len = (int)std::min<int64_t>(k, (int64_t)state_len + nb);
+      if (new_len_h) *new_len_h = new_len;
+      return TFRS_OK;
+    }
+  }
   rc = run_rounds(queries, nq, d, packed, nb, /*idx_base=*/base_row, /*seen=*/base_row, k,
                   state_scores, state_idx, state_len, w, t, (hipStream_t)stream, &new_len);
   if (new_len_h) *new_len_h = new_len;

@@ -221,7 +221,8 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
       if (e < m) {
         const int64_t part = e / a.k_in, jj = e - part * a.k_in;
         const int64_t off = (part * a.nq + row) * a.k_in + jj;
-        key = make_key(a.part_scores[off], a.part_idx[off]);
+        const int32_t pi = a.part_idx[off];
+        if (pi >= 0) key = make_key(a.part_scores[off], pi);
       }
       consume(key);
     }

@@ -157,8 +157,9 @@ struct List16Args {
   const float *qk;
   const float *norm_max;
   float *out_scores;     // [nq, k]
-  int32_t *out_idx;      // [nq, k]
+  int32_t *out_idx;      // [nq, k] (row + idx_base; -1 marks an empty slot: fewer than k survivors)
   uint32_t *redo;        // [nq]: 1 = answer this query with the exact recompute path
+  int64_t idx_base;      // added to the image-local row numbers
 };
 
 // KP: slots for the retained set (>= K + band); the list itself may hold up to 64 * kSlots.
@@ -259,7 +260,8 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
     if (u * 64 < m) {  // wave-uniform
       uint64_t kk = 0ull;
       if (u * 64 + lane < m)
-        kk = make_key(packed_score16(a.packed, (int64_t)kid[u], dp, qs), (int32_t)kid[u]);
+        kk = make_key(packed_score16(a.packed, (int64_t)kid[u], dp, qs),
+                      (int32_t)((int64_t)kid[u] + a.idx_base));
       ex[u * 64 + lane] = kk;
     }
   }
@@ -269,8 +271,8 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
 
   for (int i = lane; i < K; i += 64) {
     const uint64_t kk = ex[i];
-    a.out_scores[row * K + i] = kk ? key_score(kk) : 0.0f;
-    a.out_idx[row * K + i] = kk ? key_index(kk) : 0;
+    a.out_scores[row * K + i] = kk ? key_score(kk) : -__builtin_inff();
+    a.out_idx[row * K + i] = kk ? key_index(kk) : -1;
   }
 }
 
@@ -286,9 +288,10 @@ static int launch_list16_kp(const List16Args &a, hipStream_t stream) {
 int launch_list_topk16(const float *q, int64_t nq, int d, const char *packed, const uint2 *buf,
                        const uint32_t *cnt, uint32_t cap_l, int nseg, int k, const float *qk,
                        const float *norm_max, float *out_scores, int32_t *out_idx, uint32_t *redo,
-                       hipStream_t stream) {
+                       int64_t idx_base, hipStream_t stream) {
   if (nq <= 0) return TFRS_OK;
   List16Args a;
+  a.idx_base = idx_base;
   a.nq = nq;
   a.k = k;
   a.q = q;

@@ -186,6 +186,23 @@ def test_streaming_block_sizes(bs):
   np.testing.assert_array_equal(_np(s), es)
 
 
+@pytest.mark.parametrize("d,k,bs", [(64, 100, 40000), (128, 100, 65536), (32, 10, 2048), (64, 300, 100000)])
+def test_streaming_f16_blocks(d, k, bs):
+  """Blocks large enough for the fp16-prefiltered block path (threshold from the block's own
+  bin maxima for the first block, from the carried state afterwards), ragged last block."""
+  ftk = _layers()
+  rng = np.random.default_rng(d + k + bs)
+  n, nq = 230000, 70
+  c = (rng.normal(size=(n, d)) * np.exp(0.2 * rng.normal(size=(n, 1)))).astype(np.float32)
+  q = rng.normal(size=(nq, d)).astype(np.float32)
+  if (d, k, "stream") not in _ORACLE_CACHE:
+    _ORACLE_CACHE[(d, k, "stream")] = o_topk.brute_force(q, c, k)
+  es, ei = _ORACLE_CACHE[(d, k, "stream")]
+  s, i = ftk.Streaming(k=k).index_from_dataset(_Dataset(c, None, bs))(q)
+  np.testing.assert_array_equal(_np(i), ei)
+  np.testing.assert_array_equal(_np(s), es)
+
+
 def test_streaming_incomplete_and_errors():
   ftk = _layers()
   c = np.random.default_rng(0).normal(size=(7, 4)).astype(np.float32)

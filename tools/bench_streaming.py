@@ -1,0 +1,44 @@
+"""C3-shaped measurement (per-GPU shard of BASELINE.json configs[2]): Streaming top-100 over a
+12.5M x 128 shard in blocks of 65536 rows, and BruteForce over the same shard.  Evidence tool."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from recommenders_amd.layers import factorized_top_k as ftk
+
+dev = torch.device("cuda", 0)
+n, d, k, bs = int(os.environ.get("ROWS", 12_500_000)), 128, 100, 65536
+g = torch.Generator(device=dev).manual_seed(1)
+corpus = torch.randn((n, d), generator=g, device=dev) / (d ** 0.5)
+
+
+class Blocks:
+  def __iter__(self):
+    for lo in range(0, n, bs):
+      yield corpus[lo:lo + bs]
+
+
+for nq in (8192, 64, 1):
+  q = torch.randn((nq, d), generator=g, device=dev) / (d ** 0.5)
+  bf = ftk.BruteForce(k=k).index(corpus)
+  for _ in range(2):
+    out_b = bf(q)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter(); reps = 3
+  for _ in range(reps):
+    out_b = bf(q)
+  torch.cuda.synchronize()
+  tb = (time.perf_counter() - t0) / reps
+  del bf
+  st = ftk.Streaming(k=k).index_from_dataset(Blocks())
+  out_s = st(q)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  out_s = st(q)
+  torch.cuda.synchronize()
+  ts = time.perf_counter() - t0
+  same = bool(torch.equal(out_b[0], out_s[0]) and torch.equal(out_b[1].to(torch.int64), out_s[1].to(torch.int64)))
+  print(json.dumps({"rows": n, "dim": d, "batch": nq, "k": k,
+                    "bruteforce_ms": tb * 1e3, "bruteforce_qps": nq / tb,
+                    "bruteforce_pflops": 2.0 * nq * n * d / tb / 1e15,
+                    "streaming_block": bs, "streaming_ms": ts * 1e3, "streaming_qps": nq / ts,
+                    "streaming_equals_bruteforce": same}), flush=True)
