@@ -55,24 +55,32 @@ def hbm_traffic(kernel: str):
 def train_step_metric(dev) -> dict:
   """Second half of BASELINE.json's metric: train steps/sec of the in-batch-softmax two-tower
   step at the MovieLens-100K shapes of configs[0] (B=4096, D=64, 2k-row user/item tables):
-  embedding gather -> fused in-batch softmax loss (tasks/retrieval.py:172-210) -> backward ->
-  Adagrad.  Every arithmetic kernel is HIP (no torch matmul/softmax); torch runs autograd
-  bookkeeping and the dense Adagrad update of the two small tables."""
-  from recommenders_amd.layers import embedding as emb
-  from recommenders_amd.tasks.retrieval import in_batch_softmax_loss
+  ``tfrs.Model.train_step`` of the quickstart two-tower model: embedding gather -> fused
+  in-batch softmax loss (tasks/retrieval.py:172-210) -> backward -> sparse Adagrad on the
+  looked-up rows (IndexedSlices semantics).  The arithmetic kernels are HIP; torch runs the
+  autograd bookkeeping and the id sort."""
+  import recommenders_amd as tfrs
   g = torch.Generator(device=dev).manual_seed(0)
   B, D, V = 4096, 64, 2000
-  user, item = emb.Embedding(V, D), emb.Embedding(V, D)
-  uid = torch.randint(0, 943, (B,), generator=g, device=dev)
-  iid = torch.randint(0, 1682, (B,), generator=g, device=dev)
-  opt = torch.optim.Adagrad(list(user.parameters()) + list(item.parameters()), lr=0.5,
-                            initial_accumulator_value=0.1, eps=1e-7)
+
+  class TwoTower(tfrs.Model):          # the reference's quickstart model (README.md:58-82)
+    def __init__(self):
+      super().__init__()
+      self.user_model = tfrs.layers.embedding.Embedding(V, D)
+      self.item_model = tfrs.layers.embedding.Embedding(V, D)
+      self.task = tfrs.tasks.Retrieval()
+
+    def compute_loss(self, inputs, training=False):
+      return self.task(self.user_model(inputs["user_id"]), self.item_model(inputs["movie_id"]),
+                       compute_metrics=False)
+
+  model = TwoTower()
+  model.compile(optimizer=tfrs.optimizers.Adagrad(model.parameters(), learning_rate=0.5))
+  batch = {"user_id": torch.randint(0, 943, (B,), generator=g, device=dev),
+           "movie_id": torch.randint(0, 1682, (B,), generator=g, device=dev)}
 
   def step():
-    opt.zero_grad(set_to_none=True)
-    loss = in_batch_softmax_loss(user(uid), item(iid))
-    loss.backward()
-    opt.step()
+    model.train_step(batch)            # models/base.py:64-85
 
   for _ in range(5):
     step()

@@ -27,6 +27,8 @@
 // tens of microseconds, i.e. launch-latency territory.
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "mfma_tile.h"
 
 namespace tfrs {
@@ -138,11 +140,17 @@ __global__ void __launch_bounds__(256) softmax_fwd_kernel(const SoftmaxArgs a) {
 }
 
 // Combines the per-split (max, sum) pairs, writes lse/pos and the weighted loss.
-__global__ void __launch_bounds__(1024) softmax_finalize_kernel(const SoftmaxArgs a, float *out_loss,
-                                                                float *out_lse, float *out_pos) {
-  __shared__ double red[1024];
+// One thread per query row; every block leaves a partial loss in block_part[] and the LAST
+// block to finish (ticket counter) adds the partials in block order, so the result does not
+// depend on scheduling.  `ticket` must be zero on entry and is reset for the next launch.
+__global__ void __launch_bounds__(256) softmax_finalize_kernel(const SoftmaxArgs a, float *out_loss,
+                                                               float *out_lse, float *out_pos,
+                                                               double *block_part, uint32_t *ticket) {
+  __shared__ double red[256];
+  __shared__ bool is_last;
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
   double local = 0.0;
-  for (int64_t row = threadIdx.x; row < a.nq; row += 1024) {
+  if (row < a.nq) {
     float mm = -__builtin_inff();
     for (int sp = 0; sp < a.nsplit; ++sp) mm = fmaxf(mm, a.pm[(int64_t)sp * a.nq + row]);
     float ll = 0.0f;
@@ -155,15 +163,29 @@ __global__ void __launch_bounds__(1024) softmax_finalize_kernel(const SoftmaxArg
     out_lse[row] = lse;
     out_pos[row] = pos;
     const float w = a.w ? a.w[row] : 1.0f;
-    local += (double)w * ((double)lse - (double)pos);
+    local = (double)w * ((double)lse - (double)pos);
   }
   red[threadIdx.x] = local;
   __syncthreads();
-  for (int off = 512; off > 0; off >>= 1) {
+  for (int off = 128; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0) *out_loss = (float)red[0];
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&block_part[blockIdx.x], red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (is_last && threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    double total = 0.0;
+    for (unsigned b = 0; b < gridDim.x; ++b)
+      total += __hip_atomic_load(&block_part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *out_loss = (float)total;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // ROWS_ARE_QUERIES = true : wave owns 32 queries, streams candidates, emits partial dq.
@@ -283,7 +305,11 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float *parti
 static void plan(int64_t n_rows, int64_t n_stream, int *nsplit, int64_t *split_len) {
   const int64_t row_blocks = (n_rows + 31) / 32;
   const int64_t tiles = (n_stream + 31) / 32;
-  int64_t want = (2048 + row_blocks - 1) / row_blocks;  // ~2 waves per SIMD on 256 CUs
+  static const int64_t target_waves = [] {
+    const char *v = getenv("TFRS_SOFTMAX_WAVES");
+    return (v && *v) ? (int64_t)atoll(v) : (int64_t)2048;  // ~2 waves per SIMD on 256 CUs
+  }();
+  int64_t want = (target_waves + row_blocks - 1) / row_blocks;
   if (want > tiles) want = tiles;
   if (want < 1) want = 1;
   const int64_t per = (tiles + want - 1) / want;
@@ -329,7 +355,8 @@ extern "C" size_t tfrs_inbatch_softmax_workspace_bytes(int64_t nq, int64_t nc, i
   plan(nq, nc, &nsf, &len);
   plan(nq, nc, &nsq, &len);
   plan(nc, nq, &nsc, &len);
-  const size_t fwd = 2 * al((size_t)nsf * nq * 4) + al((size_t)nq * 4);
+  const size_t fwd = 2 * al((size_t)nsf * nq * 4) + al((size_t)nq * 4) +
+                     al((size_t)((nq + 255) / 256) * 8) + al(4);  // + finalize partials, ticket
   const size_t bwd = al((size_t)nsq * nq * d * 4) + al((size_t)nsc * nc * d * 4);
   return fwd > bwd ? fwd : bwd;
 }
@@ -355,8 +382,12 @@ extern "C" int tfrs_inbatch_softmax_ce_fwd(const float *q, const float *c, int64
   char *p = static_cast<char *>(workspace);
   a.pm = reinterpret_cast<float *>(p); p += al((size_t)a.nsplit * nq * 4);
   a.pl = reinterpret_cast<float *>(p); p += al((size_t)a.nsplit * nq * 4);
-  a.ppos = reinterpret_cast<float *>(p);
+  a.ppos = reinterpret_cast<float *>(p); p += al((size_t)nq * 4);
+  const unsigned fin_blocks = (unsigned)((nq + 255) / 256);
+  double *block_part = reinterpret_cast<double *>(p); p += al((size_t)fin_blocks * 8);
+  uint32_t *ticket = reinterpret_cast<uint32_t *>(p);
   hipStream_t s = (hipStream_t)stream;
+  TFRS_HIP(hipMemsetAsync(ticket, 0, 4, s));
   switch (softmax_padded_dim(d)) {
     case 8: launch_fwd<8>(a, s); break;
     case 16: launch_fwd<16>(a, s); break;
@@ -365,7 +396,8 @@ extern "C" int tfrs_inbatch_softmax_ce_fwd(const float *q, const float *c, int64
     default: launch_fwd<128>(a, s); break;
   }
   TFRS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(softmax_finalize_kernel, dim3(1), dim3(1024), 0, s, a, out_loss, out_lse, out_pos);
+  hipLaunchKernelGGL(softmax_finalize_kernel, dim3(fin_blocks), dim3(256), 0, s, a, out_loss, out_lse,
+                     out_pos, block_part, ticket);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
 }

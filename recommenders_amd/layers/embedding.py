@@ -71,18 +71,31 @@ def adagrad_sparse_update_(table: torch.Tensor, accum: torch.Tensor, grad_out: t
       _lib.ptr(table), _lib.ptr(accum), float(lr), float(eps), 1, _lib.current_stream()))
 
 
+def _emit_table_grad(ctx, grad_out):
+  """Backward of a lookup.  Default: the dense ``[vocab, d]`` gradient.  When the table is
+  owned by ``recommenders_amd.optimizers.Adagrad`` the ``(ids, grad_rows)`` slices are handed
+  to the optimizer instead (TensorFlow's ``IndexedSlices``, models/base.py:77-78) and no dense
+  gradient is ever built."""
+  (ids,) = ctx.saved_tensors
+  table = ctx.table_ref
+  if getattr(table, "_tfrs_sparse_grad", False):
+    table._tfrs_slices.append((ids, grad_out.contiguous()))
+    return None
+  return scatter_add_rows(grad_out.contiguous(), ids, ctx.vocab)
+
+
 class _GatherFn(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, table, ids):
     ctx.save_for_backward(ids)
     ctx.vocab = table.shape[0]
+    ctx.table_ref = table
     return gather_rows(table, ids)
 
   @staticmethod
   def backward(ctx, grad_out):
-    (ids,) = ctx.saved_tensors
-    return scatter_add_rows(grad_out.contiguous(), ids, ctx.vocab), None
+    return _emit_table_grad(ctx, grad_out), None
 
 
 def embedding_lookup_sparse(table: torch.Tensor, ids: torch.Tensor, row_splits: torch.Tensor,
@@ -123,6 +136,7 @@ class Embedding(torch.nn.Module):
     w = torch.empty((input_dim, output_dim), dtype=torch.float32, device=dev)
     w.uniform_(-0.05, 0.05)  # Keras "uniform" initialiser
     self.embeddings = torch.nn.Parameter(w)
+    self.embeddings._tfrs_embedding = True   # lets optimizers.Adagrad ask for sliced gradients
 
   def forward(self, ids: torch.Tensor) -> torch.Tensor:
     if not isinstance(ids, torch.Tensor):
@@ -139,4 +153,5 @@ class _ValidatedGather(_GatherFn):
   def forward(ctx, table, ids):
     ctx.save_for_backward(ids)
     ctx.vocab = table.shape[0]
+    ctx.table_ref = table
     return gather_rows(table, ids, validate=True)

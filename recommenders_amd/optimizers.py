@@ -1,0 +1,82 @@
+"""Optimizers for the training step of ``tfrs.Model`` on MI355X.
+
+``Adagrad`` restates ``tf.keras.optimizers.Adagrad`` as the reference's quickstart uses it
+(``README.md:84``: ``tfrs.Model.compile(optimizer=tf.keras.optimizers.Adagrad(0.5))``, applied
+in ``models/base.py:77-78``):
+
+    accumulator starts at ``initial_accumulator_value`` (0.1); per step
+    ``acc += g * g ;  var -= learning_rate * g / sqrt(acc + epsilon)``   (epsilon = 1e-7)
+
+and, like TensorFlow's handling of ``IndexedSlices`` gradients of embedding lookups, only
+touches the rows that were looked up: duplicate ids are summed first, then the update is
+applied once per unique row.  For parameters of :class:`recommenders_amd.layers.embedding.Embedding`
+the gradient never exists as a dense ``[vocab, dim]`` tensor -- the lookup's backward hands
+``(ids, grad_rows)`` slices to the optimizer, which runs the fused sort + segmented
+scatter-add + Adagrad kernel (``tfrs_embedding_scatter_add_bwd`` with ``adagrad=1``).
+Dense parameters (Cross kernels, MLPs) take the same formula element-wise.
+
+The reference's tests do not pin Adagrad numerics ("parity unpinned"); the
+formula above is the tf-keras one; the test oracle restates the same formula.
+"""
+
+from typing import Iterable
+
+import torch
+
+from recommenders_amd.layers import embedding as emb
+
+
+class Adagrad(torch.optim.Optimizer):
+  """``tf.keras.optimizers.Adagrad(learning_rate, initial_accumulator_value, epsilon)``."""
+
+  def __init__(self, params: Iterable, learning_rate: float = 0.001,
+               initial_accumulator_value: float = 0.1, epsilon: float = 1e-7):
+    if initial_accumulator_value < 0.0:
+      raise ValueError("initial_accumulator_value must be non-negative")
+    defaults = dict(learning_rate=float(learning_rate),
+                    initial_accumulator_value=float(initial_accumulator_value),
+                    epsilon=float(epsilon))
+    super().__init__(params, defaults)
+    for group in self.param_groups:
+      for p in group["params"]:
+        if getattr(p, "_tfrs_embedding", False):
+          p._tfrs_sparse_grad = True        # the lookup's backward now emits slices
+          p._tfrs_slices = []
+
+  def _accumulator(self, p: torch.Tensor, init: float) -> torch.Tensor:
+    state = self.state[p]
+    if "accumulator" not in state:
+      state["accumulator"] = torch.full_like(p, init)
+    return state["accumulator"]
+
+  def zero_grad(self, set_to_none: bool = True) -> None:
+    super().zero_grad(set_to_none=set_to_none)
+    for group in self.param_groups:
+      for p in group["params"]:
+        if getattr(p, "_tfrs_sparse_grad", False):
+          p._tfrs_slices.clear()
+
+  @torch.no_grad()
+  def step(self, closure=None):
+    loss = None
+    if closure is not None:
+      with torch.enable_grad():
+        loss = closure()
+    for group in self.param_groups:
+      lr, eps = group["learning_rate"], group["epsilon"]
+      for p in group["params"]:
+        acc = self._accumulator(p, group["initial_accumulator_value"])
+        slices = getattr(p, "_tfrs_slices", None)
+        if slices:
+          if len(slices) == 1:
+            ids, rows = slices[0]
+          else:   # the same table looked up several times: one combined IndexedSlices
+            ids = torch.cat([s[0].reshape(-1) for s in slices])
+            rows = torch.cat([s[1].reshape(-1, p.shape[1]) for s in slices])
+          emb.adagrad_sparse_update_(p.data, acc, rows, ids, lr, eps)
+          slices.clear()
+        if p.grad is not None:
+          g = p.grad
+          acc.addcmul_(g, g)
+          p.addcdiv_(g, torch.sqrt(acc + eps), value=-lr)
+    return loss
