@@ -273,6 +273,180 @@ __global__ void __launch_bounds__(256) dot_interaction_bwd_kernel(
   }
 }
 
+// MFMA form of the forward pass.  A wave owns one sample at a time (grid-stride over the
+// batch): the sample's whole feature matrix X[F, D] lives in registers as NB row-block
+// fragments (lane l: row 32*rb + (l & 31), feature half l >> 5; the next sample's fragments
+// are fetched under the copy-out of the current one), every 32x32 block of the lower
+// triangle of G = X X^T is one chain of DP/2 v_mfma_f32_32x32x2_f32 (exact f32).  The packed
+// row-major lower triangle is assembled in LDS (ds_write_b32 per accumulator register) and
+// leaves as one linear stream of 8-byte stores, so HBM sees full lines only.
+// Algorithmic bytes: B*(F*D + out_dim)*4.  (skip_gather keeps direct stores: F*F is too
+// large to stage and the mode is rare.)
+// (staged launches use ONE wave per workgroup so that LDS -- 20 KiB per sample at F = 101 --
+// limits residency per wave, not per 4-wave group)
+template <int DP, int NB, bool STAGE>
+__global__ void __launch_bounds__(STAGE ? 64 : 256, 2) dot_interaction_mfma_kernel(const float *__restrict__ x,
+                                                                   int64_t batch, int f, int d,
+                                                                   int self, int skip_gather_arg,
+                                                                   float *__restrict__ out) {
+  const bool skip_gather = STAGE ? false : (skip_gather_arg != 0);  // staged launches never skip
+  extern __shared__ __attribute__((aligned(16))) float smem_dot[];
+  constexpr int kWavesPerWg = STAGE ? 1 : 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const bool vec_ok = (d == DP) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((f * d) % 4 == 0);
+  const int out_dim = skip_gather ? f * f : (self ? f * (f + 1) / 2 : f * (f - 1) / 2);
+  const int stage_len = ((out_dim + 3) & ~3) + 64;  // + one dummy slot per lane
+  float *stage = smem_dot + (size_t)wave * stage_len;
+  const int dummy = stage_len - 64 + lane;
+  const int64_t wave_stride = (int64_t)gridDim.x * kWavesPerWg;
+
+  int64_t b = (int64_t)blockIdx.x * kWavesPerWg + wave;
+  float frag[NB][DP / 2];
+  if (b < batch) {
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb)
+      load_row_frag<DP>(frag[rb], x + b * (int64_t)f * d, rb * 32 + j, rb * 32 + j < f, d, h, vec_ok);
+  }
+  for (; b < batch; b += wave_stride) {
+    float *ob = out + b * (int64_t)out_dim;
+    float *dst = STAGE ? stage : ob;
+    // Opaque zero: keeps the ~160 store predicates / offsets of one sample from being hoisted
+    // out of the sample loop (they would occupy hundreds of SGPRs/VGPRs for the whole kernel).
+    int lz = 0;
+    asm volatile("" : "+v"(lz));
+    const int jv = j + lz, hv = h + lz;
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+      if (bi * 32 >= f) continue;  // uniform
+      // packed offset of (row, col): tri(row) + col with tri(row) = row(row -+ 1)/2.  For the
+      // lane's 16 rows row0 + dr (dr compile-time) tri(row0 + dr) = tri(row0) + dr*row0 +
+      // dr(dr -+ 1)/2: one multiply per block, one mad per element, 32-bit (out_dim < 2^15).
+      const int row0 = bi * 32 + 4 * hv;
+      const int tri0 = self ? row0 * (row0 + 1) / 2 : row0 * (row0 - 1) / 2;
+      const int row_lim = f - row0;          // rows row0 + dr with dr < row_lim exist
+      const int diag_t = jv - 4 * hv;        // diagonal block: col < row  <=>  diag_t < dr
+      int pre[16];                           // tri(row0 + dr) - tri(row0)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        pre[r] = dr * row0 + (self ? dr * (dr + 1) / 2 : dr * (dr - 1) / 2);
+      }
+#pragma unroll
+      for (int bj = 0; bj <= bi; ++bj) {
+        const f32x16 acc = tile_dot<DP>(frag[bi], frag[bj]);
+        // acc[r] = G[row0 + dr(r)][bj*32 + j],  dr(r) = (r & 3) + 8 * (r >> 2)
+        const int col = bj * 32 + jv;
+        const int a0 = tri0 + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          if (skip_gather) {
+            const int row = row0 + dr;
+            if (row < f && col < f) {
+              const bool in_tri = self ? (col <= row) : (col < row);
+              dst[row * f + col] = in_tri ? acc[r] : 0.0f;
+            }
+          } else {
+            // off-diagonal blocks lie entirely below the diagonal; only the last row block
+            // can hold rows >= f
+            bool keep = (bi < NB - 1) || (dr < row_lim);
+            if (bj == bi) keep = keep && (self ? diag_t <= dr : diag_t < dr);
+            if (STAGE) {  // branch-free: rejected elements land in a per-lane dummy slot
+              stage[keep ? a0 + pre[r] : dummy] = acc[r];
+            } else if (keep) {
+              dst[a0 + pre[r]] = acc[r];
+            }
+          }
+        }
+      }
+      if (skip_gather) {  // blocks right of the diagonal block: zeros
+#pragma unroll
+        for (int bj = bi + 1; bj < NB; ++bj) {
+          const int col = bj * 32 + j;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2);
+            if (row < f && col < f) dst[row * f + col] = 0.0f;
+          }
+        }
+      }
+    }
+    // the fragments are dead: fetch the next sample of this wave under the copy-out
+    const int64_t bn = b + wave_stride;
+    if (bn < batch) {
+#pragma unroll
+      for (int rb = 0; rb < NB; ++rb)
+        load_row_frag<DP>(frag[rb], x + bn * (int64_t)f * d, rb * 32 + j, rb * 32 + j < f, d, h, vec_ok);
+    }
+    if (STAGE) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // linear copy-out: sample bases are 8-byte aligned when out_dim is even, else dwords
+      if ((out_dim & 1) == 0 && ((reinterpret_cast<uintptr_t>(out) & 7) == 0)) {
+        for (int e = 2 * lane; e < out_dim; e += 128)
+          *reinterpret_cast<float2 *>(ob + e) = *reinterpret_cast<const float2 *>(stage + e);
+      } else {
+        for (int e = lane; e < out_dim; e += 64) ob[e] = stage[e];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // the staging buffer is reused by the next sample
+    }
+  }
+}
+
+template <int DP, int NB>
+static bool launch_dot_mfma_nb(const float *x, int64_t batch, int f, int d, int self, int skip,
+                               float *out, hipStream_t s) {
+  const int out_dim = skip ? f * f : (self ? f * (f + 1) / 2 : f * (f - 1) / 2);
+  const size_t lds = (size_t)(((out_dim + 3) & ~3) + 64) * sizeof(float);  // per wave
+  const bool stage = !skip && lds <= 64 * 1024;
+  if (stage) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dot_interaction_mfma_kernel<DP, NB, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      attr_set = true;
+    }
+    const int64_t per_cu = std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)lds));
+    const dim3 grid((unsigned)std::min<int64_t>(batch, 256 * per_cu * 2));
+    hipLaunchKernelGGL((dot_interaction_mfma_kernel<DP, NB, true>), grid, dim3(64), lds, s, x, batch, f, d,
+                       self, skip, out);
+  } else {
+    const dim3 grid((unsigned)std::min<int64_t>((batch + 3) / 4, 256 * 16));
+    hipLaunchKernelGGL((dot_interaction_mfma_kernel<DP, NB, false>), grid, dim3(256), 0, s, x, batch, f, d,
+                       self, skip, out);
+  }
+  return true;
+}
+
+template <int DP>
+static bool launch_dot_mfma_dp(const float *x, int64_t batch, int f, int d, int self, int skip,
+                               float *out, hipStream_t s) {
+  const int nb = (f + 31) / 32;
+  if (nb * (DP / 2) > 128) return false;  // register budget of the resident X
+  switch (nb) {
+    case 1: return launch_dot_mfma_nb<DP, 1>(x, batch, f, d, self, skip, out, s);
+    case 2: return launch_dot_mfma_nb<DP, 2>(x, batch, f, d, self, skip, out, s);
+    case 3: return launch_dot_mfma_nb<DP, 3>(x, batch, f, d, self, skip, out, s);
+    case 4: return launch_dot_mfma_nb<DP, 4>(x, batch, f, d, self, skip, out, s);
+    default: return false;
+  }
+}
+
+static bool launch_dot_mfma(const float *x, int64_t batch, int f, int d, int self, int skip,
+                            float *out, hipStream_t s) {
+  if (d > 128 || f > 128) return false;
+  switch (softmax_padded_dim(d)) {
+    case 8: return launch_dot_mfma_dp<8>(x, batch, f, d, self, skip, out, s);
+    case 16: return launch_dot_mfma_dp<16>(x, batch, f, d, self, skip, out, s);
+    case 32: return launch_dot_mfma_dp<32>(x, batch, f, d, self, skip, out, s);
+    case 64: return launch_dot_mfma_dp<64>(x, batch, f, d, self, skip, out, s);
+    default: return launch_dot_mfma_dp<128>(x, batch, f, d, self, skip, out, s);
+  }
+}
+
 }  // namespace tfrs
 
 using namespace tfrs;
@@ -326,6 +500,10 @@ extern "C" int tfrs_dot_interaction_fwd(const float *x, int64_t batch, int f, in
   TFRS_CHECK_ARG(batch >= 0 && f >= 1 && d >= 1, "dot_interaction_fwd: bad shape");
   if (batch == 0) return TFRS_OK;
   TFRS_CHECK_ARG(x && out, "dot_interaction_fwd: NULL pointer");
+  if (launch_dot_mfma(x, batch, f, d, self_interaction, skip_gather, out, (hipStream_t)stream)) {
+    TFRS_LAUNCH_CHECK();
+    return TFRS_OK;
+  }
   const size_t lds = (size_t)4 * f * (d + 1) * sizeof(float);
   if (lds > 64 * 1024) {
     set_error("dot_interaction_fwd: %d features x %d dims do not fit the LDS staging", f, d);
