@@ -187,6 +187,15 @@ int tfrs_embedding_scatter_add_bwd(const float *grad_out, const int64_t *sorted_
                                    float *grad_table_or_table, float *accum, float lr,
                                    float eps, int adagrad, void *stream);
 
+/* Same result without the sort, for small vocabularies: one wave per table row scans the id
+ * list and sums matching gradient rows in occurrence order (O(vocab * n / 64) wave steps;
+ * d <= 256).  In dense mode (adagrad == 0) EVERY row of grad_table[vocab, d] is written
+ * (zeros for untouched rows). */
+int tfrs_embedding_scatter_add_rowscan(const float *grad_out, const void *ids, int ids_are_i64,
+                                       int64_t n, int d, int64_t vocab,
+                                       float *grad_table_or_table, float *accum, float lr,
+                                       float eps, int adagrad, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Retrieval.call loss (tasks/retrieval.py:172-210, layers/loss.py:114-158):
  * in-batch sampled softmax without materialising the [nq, nc] logits.

@@ -91,10 +91,14 @@ __global__ void __launch_bounds__(256) softmax_fwd_kernel(const SoftmaxArgs a) {
   int64_t c_hi = c_lo + a.split_len;
   if (c_hi > a.nc) c_hi = a.nc;
 
+  // the next tile's fragment is fetched while the current one is multiplied
+  float af_next[DP / 2];
+  load_row_frag<DP>(af_next, a.c, c_lo + j, c_lo + j < a.nc && c_lo < c_hi, a.d, h, vec_ok);
   for (int64_t c0 = c_lo; c0 < c_hi; c0 += 32) {
-    const int64_t crow = c0 + j;
     float af[DP / 2];
-    load_row_frag<DP>(af, a.c, crow, crow < a.nc, a.d, h, vec_ok);
+#pragma unroll
+    for (int s = 0; s < DP / 2; ++s) af[s] = af_next[s];
+    if (c0 + 32 < c_hi) load_row_frag<DP>(af_next, a.c, c0 + 32 + j, c0 + 32 + j < a.nc, a.d, h, vec_ok);
     const f32x16 acc = tile_dot<DP>(af, bq);
 
     float s[16];
@@ -236,10 +240,26 @@ __global__ void __launch_bounds__(256) softmax_bwd_kernel(const SoftmaxArgs a) {
   int64_t s_hi = s_lo + a.split_len;
   if (s_hi > n_s) s_hi = n_s;
 
+  // Streamed tile (32 rows x DP features): fetched one tile ahead into registers (row j, half h
+  // = the first GEMM's A fragment) and mirrored into this wave's LDS slab so that the second
+  // GEMM can read it transposed (lane = feature) with conflict-free ds_read_b32.
+  constexpr int kLd = DP + 4;  // floats per LDS row (+16 B: rows start in different bank groups)
+  extern __shared__ __attribute__((aligned(16))) float smem_sm[];
+  float *slab = smem_sm + (size_t)wave * 32 * kLd;
+  float af_next[DP / 2];
+  load_row_frag<DP>(af_next, sdata, s_lo + j, s_lo + j < n_s && s_lo < s_hi, a.d, h, vec_ok);
+
   for (int64_t s0 = s_lo; s0 < s_hi; s0 += 32) {
-    const int64_t srow_l = s0 + j;
     float af[DP / 2];
-    load_row_frag<DP>(af, sdata, srow_l, srow_l < n_s, a.d, h, vec_ok);
+#pragma unroll
+    for (int s = 0; s < DP / 2; ++s) af[s] = af_next[s];
+    if (s0 + 32 < s_hi) load_row_frag<DP>(af_next, sdata, s0 + 32 + j, s0 + 32 + j < n_s, a.d, h, vec_ok);
+#pragma unroll
+    for (int m4 = 0; m4 < DP / 8; ++m4)
+      *reinterpret_cast<float4 *>(slab + j * kLd + h * (DP / 2) + 4 * m4) =
+          make_float4(af[4 * m4], af[4 * m4 + 1], af[4 * m4 + 2], af[4 * m4 + 3]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     const f32x16 acc = tile_dot<DP>(af, br);
 
     float g[16];
@@ -266,18 +286,20 @@ __global__ void __launch_bounds__(256) softmax_bwd_kernel(const SoftmaxArgs a) {
 
     // out^T[feature][owned row] += sum over the 32 streamed rows of X[srow][feature] * G[srow][row]
     // MFMA step r contracts the streamed-row pair (tile_row_of_reg(r,0), tile_row_of_reg(r,1)),
-    // which is exactly where g[r] lives in lane halves 0 / 1.
+    // which is exactly where g[r] lives in lane halves 0 / 1.  Rows past the end and padded
+    // features are zero in the slab.
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int64_t srow = s0 + tile_row_of_reg(r, h);
-      const bool sv = srow < n_s;
+      const float *xrow = slab + tile_row_of_reg(r, h) * kLd;
 #pragma unroll
       for (int fb = 0; fb < NFB; ++fb) {
         const int feat = fb * 32 + j;
-        const float av = (sv && feat < a.d) ? sdata[srow * a.d + feat] : 0.0f;
+        const float av = (feat < DP) ? xrow[feat] : 0.0f;
         outacc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, g[r], outacc[fb], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the slab is rewritten by the next tile
   }
 
   if (rvalid) {
@@ -329,7 +351,8 @@ template <int DP, bool RQ>
 static void launch_bwd(const SoftmaxArgs &a, hipStream_t s) {
   const int64_t rows = RQ ? a.nq : a.nc;
   const int64_t waves = ((rows + 31) / 32) * a.nsplit;
-  hipLaunchKernelGGL((softmax_bwd_kernel<DP, RQ>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+  const size_t lds = (size_t)4 * 32 * (DP + 4) * sizeof(float);
+  hipLaunchKernelGGL((softmax_bwd_kernel<DP, RQ>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, s, a);
 }
 
 }  // namespace tfrs

@@ -43,11 +43,28 @@ def gather_rows(table: torch.Tensor, ids: torch.Tensor, validate: bool = False) 
   return out.reshape(tuple(ids.shape) + (table.shape[1],))
 
 
+# vocab * n below which the sort-free row-scan kernel (one wave per table row) is used
+_ROWSCAN_MAX_WORK = 1 << 26
+
+
+def _use_rowscan(vocab: int, n: int, d: int) -> bool:
+  return d <= 256 and vocab * max(n, 1) <= _ROWSCAN_MAX_WORK
+
+
 def scatter_add_rows(grad_out: torch.Tensor, ids: torch.Tensor, vocab: int) -> torch.Tensor:
   """Dense ``[vocab, d]`` gradient of ``gather_rows`` (duplicates summed in occurrence
   order; bit-reproducible)."""
   d = grad_out.shape[-1]
   g = grad_out.reshape(-1, d).contiguous()
+  if ids.dtype not in (torch.int32, torch.int64):
+    ids = ids.long()
+  if _use_rowscan(vocab, ids.numel(), d):
+    flat = ids.reshape(-1).contiguous()
+    table_grad = torch.empty((vocab, d), dtype=torch.float32, device=g.device)
+    _lib.check(_lib.load().tfrs_embedding_scatter_add_rowscan(
+        _lib.ptr(g), _lib.ptr(flat), 1 if flat.dtype == torch.int64 else 0, flat.numel(), d,
+        vocab, _lib.ptr(table_grad), None, 0.0, 0.0, 0, _lib.current_stream()))
+    return table_grad
   flat = ids.reshape(-1).long()
   sorted_ids, perm = torch.sort(flat, stable=True)
   table_grad = torch.zeros((vocab, d), dtype=torch.float32, device=g.device)
@@ -64,6 +81,15 @@ def adagrad_sparse_update_(table: torch.Tensor, accum: torch.Tensor, grad_out: t
   g = sum of duplicate grads; acc += g*g; row -= lr * g / sqrt(acc + eps)."""
   d = grad_out.shape[-1]
   g = grad_out.reshape(-1, d).contiguous()
+  if ids.dtype not in (torch.int32, torch.int64):
+    ids = ids.long()
+  if _use_rowscan(table.shape[0], ids.numel(), d):
+    flat = ids.reshape(-1).contiguous()
+    _lib.check(_lib.load().tfrs_embedding_scatter_add_rowscan(
+        _lib.ptr(g), _lib.ptr(flat), 1 if flat.dtype == torch.int64 else 0, flat.numel(), d,
+        table.shape[0], _lib.ptr(table), _lib.ptr(accum), float(lr), float(eps), 1,
+        _lib.current_stream()))
+    return
   flat = ids.reshape(-1).long()
   sorted_ids, perm = torch.sort(flat, stable=True)
   _lib.check(_lib.load().tfrs_embedding_scatter_add_bwd(

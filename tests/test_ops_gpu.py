@@ -25,8 +25,18 @@ def _np(x):
 
 
 # ---------------------------------------------------------------------------- embedding
+@pytest.fixture(params=["rowscan", "sorted"])
+def scatter_path(request, monkeypatch):
+  """The scatter-add backward has two implementations -- the sort-free row scan (small
+  vocab * n) and stable sort + segmented sum -- which must agree bit for bit."""
+  from recommenders_amd.layers import embedding as emb
+  if request.param == "sorted":
+    monkeypatch.setattr(emb, "_ROWSCAN_MAX_WORK", 0)
+  return request.param
+
+
 @pytest.mark.parametrize("d,dtype", [(64, np.int64), (64, np.int32), (7, np.int64), (128, np.int32)])
-def test_embedding_gather_and_grad(d, dtype):
+def test_embedding_gather_and_grad(d, dtype, scatter_path):
   from recommenders_amd.layers import embedding as emb
   rng = np.random.default_rng(d)
   vocab, n = 2000, 4096
@@ -44,7 +54,7 @@ def test_embedding_gather_and_grad(d, dtype):
     emb.gather_rows(_t(table), _t(np.array([vocab], dtype)), validate=True)
 
 
-def test_embedding_layer_autograd_and_adagrad():
+def test_embedding_layer_autograd_and_adagrad(scatter_path):
   from recommenders_amd.layers import embedding as emb
   rng = np.random.default_rng(1)
   layer = emb.Embedding(2000, 64)
