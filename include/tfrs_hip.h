@@ -134,6 +134,13 @@ int tfrs_topk_merge(const float *scores_parts, const int32_t *idx_parts, int npa
                     int32_t *out_idx, void *workspace, size_t workspace_bytes,
                     void *stream);
 
+/* Same with parts that are part_stride elements apart (>= nq * k_in): lets the multi-GPU
+ * exchange gather ONE buffer [world, 2, nq, k] (scores and rows of a rank back to back)
+ * with a single all-gather and merge it in place. */
+int tfrs_topk_merge_strided(const float *scores_parts, const int32_t *idx_parts, int nparts,
+                            int64_t part_stride, int64_t nq, int k_in, int k_out,
+                            float *out_scores, int32_t *out_idx, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * _exclude (layers/factorized_top_k.py:83-115) on int32 identifiers:
  *   isin = any(ids[:, :, None] == exclude[:, None, :]); adjusted = scores - 1e5*isin;

@@ -41,6 +41,7 @@ SIGNATURES = {
                                            ctypes.c_int32, P, P, c_size_t, P]),
     "tfrs_topk_merge_workspace_bytes": (c_size_t, [c_i64, c_int, c_int, c_int]),
     "tfrs_topk_merge": (c_int, [P, P, c_int, c_i64, c_int, c_int, P, P, P, c_size_t, P]),
+    "tfrs_topk_merge_strided": (c_int, [P, P, c_int, c_i64, c_i64, c_int, c_int, P, P, P]),
     "tfrs_topk_exclude": (c_int, [P, P, c_i64, c_int, P, c_int, c_int, P, P, P]),
     "tfrs_rank_of_positive": (c_int, [P, P, c_i64, c_int, P, c_int, P, c_int, P, P]),
     "tfrs_id_match_topk": (c_int, [P, P, c_i64, c_int, P, c_int, P, P]),

@@ -225,6 +225,7 @@ struct SelectArgs {
   const float *part_scores;
   const int32_t *part_idx;
   int nparts, k_in;
+  int64_t part_stride;  // elements between consecutive parts (0 = dense: nq * k_in)
   // all sources: value added to source-local row numbers
   int64_t idx_base;
   // outputs

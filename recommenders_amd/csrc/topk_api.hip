@@ -755,13 +755,15 @@ extern "C" int tfrs_streaming_topk_update(const float *queries, int64_t nq, int 
 // ----------------------------------------------------------------------------------------
 extern "C" size_t tfrs_topk_merge_workspace_bytes(int64_t, int, int, int) { return 256; }
 
-extern "C" int tfrs_topk_merge(const float *scores_parts, const int32_t *idx_parts, int nparts,
-                               int64_t nq, int k_in, int k_out, float *out_scores,
-                               int32_t *out_idx, void *, size_t, void *stream) {
+static int topk_merge_impl(const float *scores_parts, const int32_t *idx_parts, int nparts,
+                           int64_t part_stride, int64_t nq, int k_in, int k_out, float *out_scores,
+                           int32_t *out_idx, void *stream) {
   TFRS_CHECK_ARG(nparts >= 1 && k_in >= 1 && nq >= 0, "topk_merge: bad shape");
   TFRS_CHECK_ARG(k_out >= 1 && k_out <= TFRS_MAX_K && (int64_t)k_out <= (int64_t)nparts * k_in,
                  "topk_merge: k_out=%d must be in [1, min(%d, nparts*k_in=%lld)]", k_out,
                  TFRS_MAX_K, (long long)nparts * k_in);
+  TFRS_CHECK_ARG(part_stride == 0 || part_stride >= nq * (int64_t)k_in,
+                 "topk_merge: part_stride smaller than one part");
   if (nq == 0) return TFRS_OK;
   TFRS_CHECK_ARG(scores_parts && idx_parts && out_scores && out_idx, "topk_merge: NULL pointer");
   SelectArgs se = {};
@@ -773,11 +775,27 @@ extern "C" int tfrs_topk_merge(const float *scores_parts, const int32_t *idx_par
   se.part_idx = idx_parts;
   se.nparts = nparts;
   se.k_in = k_in;
+  se.part_stride = part_stride;
   se.d = 8;
   se.out_scores = out_scores;
   se.out_idx = out_idx;
   se.out_thr = nullptr;
   return launch_select(se, (hipStream_t)stream);
+}
+
+extern "C" int tfrs_topk_merge(const float *scores_parts, const int32_t *idx_parts, int nparts,
+                               int64_t nq, int k_in, int k_out, float *out_scores,
+                               int32_t *out_idx, void *, size_t, void *stream) {
+  return topk_merge_impl(scores_parts, idx_parts, nparts, 0, nq, k_in, k_out, out_scores, out_idx,
+                         stream);
+}
+
+extern "C" int tfrs_topk_merge_strided(const float *scores_parts, const int32_t *idx_parts,
+                                       int nparts, int64_t part_stride, int64_t nq, int k_in,
+                                       int k_out, float *out_scores, int32_t *out_idx,
+                                       void *stream) {
+  return topk_merge_impl(scores_parts, idx_parts, nparts, part_stride, nq, k_in, k_out, out_scores,
+                         out_idx, stream);
 }
 
 // ----------------------------------------------------------------------------------------

@@ -220,7 +220,8 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
       uint64_t key = 0ull;
       if (e < m) {
         const int64_t part = e / a.k_in, jj = e - part * a.k_in;
-        const int64_t off = (part * a.nq + row) * a.k_in + jj;
+        const int64_t pstride = a.part_stride ? a.part_stride : a.nq * (int64_t)a.k_in;
+        const int64_t off = part * pstride + row * a.k_in + jj;
         const int32_t pi = a.part_idx[off];
         if (pi >= 0) key = make_key(a.part_scores[off], pi);
       }

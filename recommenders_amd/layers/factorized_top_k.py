@@ -480,20 +480,23 @@ class ShardedBruteForce(TopK):
     if world == 1:
       return scores, rows
     nq = scores.shape[0]
-    # concatenated-along-dim-0 output form: accepted by both RCCL and gloo
-    all_s = torch.empty((world * nq, k), dtype=scores.dtype, device=scores.device)
-    all_i = torch.empty((world * nq, k), dtype=rows.dtype, device=rows.device)
-    dist.all_gather_into_tensor(all_s, scores.contiguous(), group=self._group)
-    dist.all_gather_into_tensor(all_i, rows.contiguous(), group=self._group)
-    all_s = all_s.view(world, nq, k)
-    all_i = all_i.view(world, nq, k)
+    # ONE exchange: this rank's scores (bit pattern) and global rows back to back in one int32
+    # buffer [2, nq, k]; the all-gather delivers [world, 2, nq, k] and the merge kernel reads
+    # the parts in place (stride 2 * nq * k).  2 * nq * k * 4 bytes per rank.
+    mine = torch.empty((2, nq, k), dtype=torch.int32, device=scores.device)
+    mine[0].copy_(scores.contiguous().view(torch.int32))
+    mine[1].copy_(rows)
+    gathered = torch.empty((world, 2, nq, k), dtype=torch.int32, device=scores.device)
+    dist.all_gather_into_tensor(gathered.view(world * 2 * nq, k), mine.view(2 * nq, k),
+                                group=self._group)
     if self._merge is not None:
-      return self._merge(all_s, all_i, k)
+      return self._merge(gathered[:, 0].contiguous().view(torch.float32), gathered[:, 1].contiguous(), k)
     out_s = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
     out_i = torch.empty((nq, k), dtype=torch.int32, device=scores.device)
-    _lib.check(_lib.load().tfrs_topk_merge(
-        _lib.ptr(all_s), _lib.ptr(all_i), world, nq, k, k, _lib.ptr(out_s),
-        _lib.ptr(out_i), None, 0, _lib.current_stream()))
+    base = gathered.view(-1)
+    _lib.check(_lib.load().tfrs_topk_merge_strided(
+        base.data_ptr(), base.data_ptr() + nq * k * 4, world, 2 * nq * k, nq, k, k,
+        _lib.ptr(out_s), _lib.ptr(out_i), _lib.current_stream()))
     return out_s, out_i
 
   def call(self, queries, k: Optional[int] = None):
