@@ -435,6 +435,145 @@ static bool launch_dot_mfma_dp(const float *x, int64_t batch, int f, int d, int 
   }
 }
 
+// MFMA form of the backward pass (packed-triangle output only): with S = L + L^T, L the
+// lower-triangular matrix holding the incoming gradient of the packed pairs (diagonal kept
+// for self_interaction, so S_ii = 2 dG_ii), dX = S X.  One wave per sample (one-wave
+// workgroups, grid-stride): the packed gradient (out_dim floats) is staged in LDS with
+// linear coalesced loads; the B operand (X, lane = feature) is read once from global into
+// registers; the A operand S[i][k] is gathered from the packed LDS copy with incremental
+// triangular offsets; every 32-row block of dX is NB*16 v_mfma_f32_32x32x2_f32 per 32
+// features; rows leave as 128-byte runs per half-wave.
+template <int DP, int NB>
+__global__ void __launch_bounds__(64, 2) dot_interaction_bwd_mfma_kernel(
+    const float *__restrict__ x, const float *__restrict__ dout, int64_t batch, int f, int d,
+    int self, float *__restrict__ dx) {
+  constexpr int NFB = (DP + 31) / 32;   // 32-feature output blocks
+  constexpr int KS = NB * 16;           // MFMA steps over k = 0 .. 32*NB - 1 (2 per step)
+  extern __shared__ __attribute__((aligned(16))) float smem_db[];
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const int out_dim = self ? f * (f + 1) / 2 : f * (f - 1) / 2;
+  float *ls = smem_db;  // packed gradient, out_dim floats
+  for (int64_t b = blockIdx.x; b < batch; b += gridDim.x) {
+    const float *dy = dout + b * (int64_t)out_dim;
+    const float *xb = x + b * (int64_t)f * d;
+    // Opaque zero: keeps per-sample index math from being hoisted out of the sample loop.
+    int lz = 0;
+    asm volatile("" : "+v"(lz));
+    const int jv = j + lz, hv = h + lz;
+    // B operand straight from global (lanes = consecutive features: 128-byte runs), resident
+    // in registers for the whole sample: X[k = 2s + h][feature fb*32 + j]
+    float bx[NFB][KS];
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int row = 2 * s + hv, ft = fb * 32 + jv;
+        bx[fb][s] = (row < f && ft < d) ? xb[row * d + ft] : 0.0f;
+      }
+    for (int e = lane; e < out_dim; e += 64) ls[e] = dy[e];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+      if (bi * 32 >= f) continue;  // uniform
+      const int i = bi * 32 + jv;  // A-operand row of this lane
+      const int tri_i = self ? i * (i + 1) / 2 : i * (i - 1) / 2;
+      const bool i_ok = i < f;
+      f32x16 acc[NFB];
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[fb][r] = 0.0f;
+      // k = 2s + h; tri(k) advances by 2k + (self ? 3 : 1) per step.  The A operand S[i][k] is
+      // gathered branch-free from the packed LDS copy, 8 steps at a time ahead of their MFMAs.
+      int lzb = 0;  // (opaque zero per row block: the k / tri(k) sequences are recomputed, not
+      asm volatile("" : "+v"(lzb));  //  kept alive across the four blocks)
+      int k = hv + lzb;
+      int tri_k = self ? k * (k + 1) / 2 : k * (k - 1) / 2;
+#pragma unroll
+      for (int s0 = 0; s0 < KS; s0 += 8) {
+        float av[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const bool ok = i_ok && k < f && (self || k != i);
+          const int idx = ok ? (k < i ? tri_i + k : tri_k + i) : 0;
+          float a = ls[idx];
+          a = ok ? a : 0.0f;
+          av[u] = (k == i) ? 2.0f * a : a;
+          tri_k += 2 * k + (self ? 3 : 1);
+          k += 2;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int fb = 0; fb < NFB; ++fb)
+            acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bx[fb][s0 + u], acc[fb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);  // one chunk of gathers in flight, not all of them
+      }
+      // acc[fb][r] = dX[bi*32 + tile_row_of_reg(r, h)][fb*32 + j]
+      float *db = dx + b * (int64_t)f * d;
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb) {
+        const int ft = fb * 32 + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = bi * 32 + tile_row_of_reg(r, h);
+          if (row < f && ft < d) db[row * d + ft] = acc[fb][r];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // LDS is refilled by the next sample
+  }
+}
+
+template <int DP, int NB>
+static bool launch_dot_bwd_mfma_nb(const float *x, const float *dout, int64_t batch, int f, int d,
+                                   int self, float *dx, hipStream_t s) {
+  const int out_dim = self ? f * (f + 1) / 2 : f * (f - 1) / 2;
+  const size_t lds = (size_t)((out_dim + 3) & ~3) * sizeof(float);
+  if (lds > 64 * 1024) return false;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dot_interaction_bwd_mfma_kernel<DP, NB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    attr_set = true;
+  }
+  const int64_t per_cu = std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)lds));
+  const dim3 grid((unsigned)std::min<int64_t>(batch, 256 * per_cu * 2));
+  hipLaunchKernelGGL((dot_interaction_bwd_mfma_kernel<DP, NB>), grid, dim3(64), lds, s, x, dout, batch, f,
+                     d, self, dx);
+  return true;
+}
+
+template <int DP>
+static bool launch_dot_bwd_mfma_dp(const float *x, const float *dout, int64_t batch, int f, int d,
+                                   int self, float *dx, hipStream_t s) {
+  const int nb = (f + 31) / 32;
+  if (nb * 16 * ((DP + 31) / 32) > 128) return false;  // register budget of the resident X operand
+  switch (nb) {
+    case 1: return launch_dot_bwd_mfma_nb<DP, 1>(x, dout, batch, f, d, self, dx, s);
+    case 2: return launch_dot_bwd_mfma_nb<DP, 2>(x, dout, batch, f, d, self, dx, s);
+    case 3: return launch_dot_bwd_mfma_nb<DP, 3>(x, dout, batch, f, d, self, dx, s);
+    case 4: return launch_dot_bwd_mfma_nb<DP, 4>(x, dout, batch, f, d, self, dx, s);
+    default: return false;
+  }
+}
+
+static bool launch_dot_bwd_mfma(const float *x, const float *dout, int64_t batch, int f, int d,
+                                int self, float *dx, hipStream_t s) {
+  if (d > 128 || f > 128) return false;
+  switch (softmax_padded_dim(d)) {
+    case 8: return launch_dot_bwd_mfma_dp<8>(x, dout, batch, f, d, self, dx, s);
+    case 16: return launch_dot_bwd_mfma_dp<16>(x, dout, batch, f, d, self, dx, s);
+    case 32: return launch_dot_bwd_mfma_dp<32>(x, dout, batch, f, d, self, dx, s);
+    case 64: return launch_dot_bwd_mfma_dp<64>(x, dout, batch, f, d, self, dx, s);
+    default: return launch_dot_bwd_mfma_dp<128>(x, dout, batch, f, d, self, dx, s);
+  }
+}
+
 static bool launch_dot_mfma(const float *x, int64_t batch, int f, int d, int self, int skip,
                             float *out, hipStream_t s) {
   if (d > 128 || f > 128) return false;
@@ -521,6 +660,11 @@ extern "C" int tfrs_dot_interaction_bwd(const float *x, const float *dout, int64
   TFRS_CHECK_ARG(batch >= 0 && f >= 1 && d >= 1, "dot_interaction_bwd: bad shape");
   if (batch == 0) return TFRS_OK;
   TFRS_CHECK_ARG(x && dout && dx, "dot_interaction_bwd: NULL pointer");
+  if (!skip_gather &&
+      launch_dot_bwd_mfma(x, dout, batch, f, d, self_interaction, dx, (hipStream_t)stream)) {
+    TFRS_LAUNCH_CHECK();
+    return TFRS_OK;
+  }
   const size_t lds = (size_t)4 * f * d * sizeof(float);
   if (lds > 64 * 1024) {
     set_error("dot_interaction_bwd: %d features x %d dims do not fit the LDS staging", f, d);

@@ -83,20 +83,23 @@ def main():
 
   # ---- C1: MovieLens-shaped in-batch softmax train step ----
   B, D, V = 4096, 64, 2000
-  user, item = emb.Embedding(V, D), emb.Embedding(V, D)
-  uid = torch.randint(0, 943, (B,), generator=g, device=dev)
-  iid = torch.randint(0, 1682, (B,), generator=g, device=dev)
-  opt = torch.optim.Adagrad(list(user.parameters()) + list(item.parameters()), lr=0.5,
-                            initial_accumulator_value=0.1, eps=1e-7)
 
-  def train_step():
-    opt.zero_grad(set_to_none=True)
-    loss = in_batch_softmax_loss(user(uid), item(iid))
-    loss.backward()
-    opt.step()
+  class TwoTower(tfrs.Model):
+    def __init__(self):
+      super().__init__()
+      self.user_model = emb.Embedding(V, D)
+      self.item_model = emb.Embedding(V, D)
+      self.task = tfrs.tasks.Retrieval()
 
-  t = timeit(train_step, iters=50)
-  emit(op="C1 train step (gather + in-batch softmax fwd/bwd + Adagrad), compute_metrics=False",
+    def compute_loss(self, inputs, training=False):
+      return self.task(self.user_model(inputs[0]), self.item_model(inputs[1]), compute_metrics=False)
+
+  model = TwoTower()
+  model.compile(optimizer=tfrs.optimizers.Adagrad(model.parameters(), learning_rate=0.5))
+  batch = (torch.randint(0, 943, (B,), generator=g, device=dev),
+           torch.randint(0, 1682, (B,), generator=g, device=dev))
+  t = timeit(lambda: model.train_step(batch), iters=50)
+  emit(op="C1 tfrs.Model.train_step (gather + in-batch softmax fwd/bwd + sparse Adagrad), compute_metrics=False",
        batch=B, dim=D, ms=t * 1e3, steps_per_s=1.0 / t)
   q = torch.randn((B, D), generator=g, device=dev, requires_grad=True)
   c = torch.randn((B, D), generator=g, device=dev, requires_grad=True)
@@ -128,7 +131,17 @@ def main():
   fl = 2.0 * Bc * dc * dc
   emit(op="cross_fwd", batch=Bc, dim=dc, ms=t * 1e3, tflops=fl / t / 1e12,
        frac_mfma_peak=fl / t / F32_MFMA_PEAK)
-  del x0, layer
+  x0g = x0.clone().requires_grad_(True)
+
+  def cross_fb():
+    x0g.grad = None
+    layer.zero_grad(set_to_none=True)
+    layer(x0g, x0g).sum().backward()
+
+  t = timeit(cross_fb, warmup=1, iters=3)
+  emit(op="cross_fwd+bwd (bwd = HIP GEMMs + torch element-wise/transposes)", batch=Bc, dim=dc, ms=t * 1e3,
+       tflops=3 * fl / t / 1e12, frac_mfma_peak=3 * fl / t / F32_MFMA_PEAK)
+  del x0, x0g, layer
 
   # ---- C5: DotInteraction, B = 131072, F = 101, D = 32 ----
   Bd, F, Dd = (131072, 101, 32) if not small else (16384, 27, 16)
@@ -139,6 +152,23 @@ def main():
   byts = Bd * F * Dd * 4 + Bd * out_dim * 4
   emit(op="dot_interaction_fwd", batch=Bd, features=F, dim=Dd, ms=t * 1e3, gbps=byts / t / 1e9,
        frac_hbm_peak=byts / t / HBM_PEAK, gflop_full_gram=2.0 * Bd * F * F * Dd / 1e9)
+  xg = x.clone().requires_grad_(True)
+
+  def dot_fb():
+    xg.grad = None
+    _DotInteractionFn.apply(xg, False, False).sum().backward()
+
+  t = timeit(dot_fb, warmup=1, iters=3)
+  emit(op="dot_interaction_fwd+bwd", batch=Bd, features=F, dim=Dd, ms=t * 1e3)
+  del x, xg
+
+  # ---- FactorizedTopK metric update on a BruteForce index (C1-sized eval batch) ----
+  cand = torch.randn((1682, 64), generator=g, device=dev) / 8.0
+  metric = tfrs.metrics.FactorizedTopK(tfrs.layers.factorized_top_k.BruteForce(k=100).index(cand))
+  qe = torch.randn((4096, 64), generator=g, device=dev) / 8.0
+  ce = cand[torch.randint(0, 1682, (4096,), generator=g, device=dev)]
+  t = timeit(lambda: metric.update_state(qe, ce), iters=20)
+  emit(op="FactorizedTopK.update_state (batch 4096 vs 1682 candidates, ks=(1,5,10,50,100))", ms=t * 1e3)
 
 
 if __name__ == "__main__":
