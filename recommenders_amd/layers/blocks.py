@@ -1,0 +1,77 @@
+"""Convenience blocks (mirror of ``tensorflow_recommenders/layers/blocks.py:24-61``).
+
+``MLP(units, use_bias=True, activation="relu", final_activation=None)`` is a stack of Keras
+``Dense`` layers: ``y = act(x @ kernel + bias)`` with ``kernel`` in ``[in, out]`` layout,
+``glorot_uniform`` kernel / ``zeros`` bias initialisers and lazy building on the first call.
+Every matmul (forward and both backward GEMMs) runs on the f32-MFMA GEMM kernel
+(``tfrs_dense_fwd``); the activations are element-wise torch ops.
+"""
+
+import math
+from typing import Callable, List, Optional, Union
+
+import torch
+
+from recommenders_amd.layers.feature_interaction.dcn import _DenseFn
+
+Activation = Optional[Union[str, Callable[[torch.Tensor], torch.Tensor]]]
+
+_ACTIVATIONS = {
+    None: lambda x: x,
+    "linear": lambda x: x,
+    "relu": torch.relu,
+    "sigmoid": torch.sigmoid,
+    "tanh": torch.tanh,
+}
+
+
+def get_activation(spec: Activation) -> Callable[[torch.Tensor], torch.Tensor]:
+  if callable(spec):
+    return spec
+  if spec not in _ACTIVATIONS:
+    raise ValueError(f"Unknown activation: {spec!r}")
+  return _ACTIVATIONS[spec]
+
+
+class Dense(torch.nn.Module):
+  """``tf.keras.layers.Dense(units, activation=None, use_bias=True)``."""
+
+  def __init__(self, units: int, activation: Activation = None, use_bias: bool = True,
+               device: Optional[torch.device] = None):
+    super().__init__()
+    self.units = int(units)
+    self.use_bias = use_bias
+    self._activation = get_activation(activation)
+    self._device = device
+    self.kernel: Optional[torch.nn.Parameter] = None
+    self.bias: Optional[torch.nn.Parameter] = None
+
+  def build(self, in_dim: int, device: torch.device) -> None:
+    lim = math.sqrt(6.0 / (in_dim + self.units))          # glorot_uniform
+    k = torch.empty((in_dim, self.units), dtype=torch.float32, device=device).uniform_(-lim, lim)
+    self.kernel = torch.nn.Parameter(k)
+    if self.use_bias:
+      self.bias = torch.nn.Parameter(torch.zeros((self.units,), dtype=torch.float32, device=device))
+
+  def forward(self, x: torch.Tensor) -> torch.Tensor:
+    if self.kernel is None:
+      self.build(x.shape[-1], self._device or x.device)
+    lead = x.shape[:-1]
+    y = _DenseFn.apply(x.reshape(-1, x.shape[-1]).to(torch.float32), self.kernel, self.bias)
+    return self._activation(y).reshape(*lead, self.units)
+
+
+class MLP(torch.nn.Module):
+  """Sequential multi-layer perceptron block (reference blocks.py:24-61)."""
+
+  def __init__(self, units: List[int], use_bias: bool = True, activation: Activation = "relu",
+               final_activation: Activation = None):
+    super().__init__()
+    layers = [Dense(n, activation=activation, use_bias=use_bias) for n in units[:-1]]   # :46-49
+    layers.append(Dense(units[-1], activation=final_activation, use_bias=use_bias))      # :50-52
+    self._sublayers = torch.nn.ModuleList(layers)
+
+  def forward(self, x: torch.Tensor) -> torch.Tensor:                                   # :54-59
+    for layer in self._sublayers:
+      x = layer(x)
+    return x

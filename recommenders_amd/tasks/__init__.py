@@ -2,3 +2,4 @@
 
 from recommenders_amd.tasks.base import Task  # noqa: F401
 from recommenders_amd.tasks.retrieval import Retrieval  # noqa: F401
+from recommenders_amd.tasks.ranking import Ranking  # noqa: F401
