@@ -346,6 +346,39 @@ class BruteForce(TopK):
   def is_exact(self) -> bool:
     return True
 
+  # -- persistence (the role of SavedModel export in the reference, --------------------------
+  #    factorized_top_k_test.py:152-165, basic_retrieval.ipynb "serving") ---------------------
+  def state_dict(self) -> Dict[str, Any]:   # type: ignore[override]
+    """Everything needed to rebuild the index: the row-major float32 candidates (unpacked from
+    the device images), the identifiers (``None`` = row numbers) and ``k``."""
+    if self._index is None:
+      raise ValueError(NOT_INDEXED_MESSAGE)
+    ids = self._ids
+    identifiers = None
+    if ids.host is not None:
+      identifiers = ids.host
+    elif ids.device is not None:
+      identifiers = ids.device.cpu().numpy()
+    return {"candidates": self.candidates().cpu().numpy(), "identifiers": identifiers, "k": self._k}
+
+  def load_state_dict(self, state: Dict[str, Any]) -> "BruteForce":   # type: ignore[override]
+    self._k = int(state.get("k", self._k))
+    return self.index(state["candidates"], state.get("identifiers"))
+
+  def save(self, path: str) -> None:
+    """Writes the index to one ``.npz`` file (string identifiers are stored as a unicode array)."""
+    st = self.state_dict()
+    payload = {"candidates": st["candidates"], "k": np.asarray(st["k"])}
+    if st["identifiers"] is not None:
+      payload["identifiers"] = np.asarray(st["identifiers"])
+    np.savez(path, **payload)
+
+  @classmethod
+  def load(cls, path: str, query_model: Optional[Callable] = None) -> "BruteForce":
+    with np.load(path, allow_pickle=False) as f:
+      layer = cls(query_model=query_model, k=int(f["k"]))
+      return layer.index(f["candidates"], f["identifiers"] if "identifiers" in f.files else None)
+
 
 class Streaming(TopK):
   """Retrieves the K highest scoring items from a large candidate stream

@@ -419,3 +419,30 @@ def test_sharded_bruteforce_two_ranks_one_gpu(tmp_path, filter_mode):
   for r, (p, o) in enumerate(zip(procs, outs)):
     assert p.returncode == 0, f"rank {r} failed:\n{o}"
     assert f"rank {r} ok" in o
+
+
+@pytest.mark.parametrize("id_kind", ["range", "int", "str"])
+def test_bruteforce_save_load_roundtrip(tmp_path, id_kind, filter_mode):
+  """Persistence (the SavedModel round trip of factorized_top_k_test.py:152-165): an index
+  written to disk and loaded into a fresh layer answers identically, identifiers included."""
+  if filter_mode != "f16":
+    pytest.skip("run once")
+  ftk = _layers()
+  rng = np.random.default_rng(9)
+  n, d, k = 3000, 24, 7
+  c = rng.normal(size=(n, d)).astype(np.float32)
+  q = rng.normal(size=(40, d)).astype(np.float32)
+  ids = {"range": None, "int": (np.arange(n) * 5 + 3).astype(np.int64),
+         "str": np.array([f"item-{i}" for i in range(n)])}[id_kind]
+  layer = ftk.BruteForce(k=k).index(c, ids)
+  s0, i0 = layer(q)
+  path = str(tmp_path / "index.npz")
+  layer.save(path)
+  loaded = ftk.BruteForce.load(path)
+  s1, i1 = loaded(q)
+  np.testing.assert_array_equal(_np(s0), _np(s1))
+  np.testing.assert_array_equal(np.asarray(_np(i0)), np.asarray(_np(i1)))
+  np.testing.assert_array_equal(_np(loaded.candidates()), c)
+  fresh = ftk.BruteForce().load_state_dict(layer.state_dict())
+  s2, i2 = fresh(q)
+  np.testing.assert_array_equal(_np(s0), _np(s2))
