@@ -185,3 +185,61 @@ def test_sharded_topk_two_ranks_gloo(tmp_path):
   for r, (p, o) in enumerate(zip(procs, outs)):
     assert p.returncode == 0, f"rank {r} failed:\n{o}"
     assert f"rank {r} ok" in o
+
+
+_EMB_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from oracle import embedding as o_emb
+from recommenders_amd.layers.sharded_embedding import ShardedEmbedding
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+V, D, B = 103, 8, 57                                  # V not divisible by the world size
+rng = np.random.default_rng(7)
+full = rng.normal(size=(V, D)).astype(np.float32)     # the same full table on every rank
+
+def gather(shard, ids):                               # oracle stands in for the HIP gather
+  return torch.from_numpy(o_emb.gather(shard.detach().numpy(), ids.numpy()))
+def scatter(g, ids, vocab):                           # ... and for the scatter-add
+  return torch.from_numpy(o_emb.scatter_add_grad(g.numpy(), ids.numpy(), vocab))
+
+layer = ShardedEmbedding(V, D, device=torch.device("cpu"), local_gather=gather, local_scatter=scatter)
+lo, hi = layer.row_range
+with torch.no_grad():
+  layer.embeddings.copy_(torch.from_numpy(full[lo:hi]))
+ids = np.random.default_rng(100 + rank).integers(0, V, size=(B,))   # each rank: its own batch
+w = np.random.default_rng(200 + rank).normal(size=(B, D)).astype(np.float32)
+out = layer(torch.from_numpy(ids))
+assert np.array_equal(out.detach().numpy(), o_emb.gather(full, ids)), "sharded lookup != full-table gather"
+(out * torch.from_numpy(w)).sum().backward()
+# expected shard gradient: every rank's (ids, w) contributions that fall into my row range
+all_ids = [np.random.default_rng(100 + r).integers(0, V, size=(B,)) for r in range(world)]
+all_w = [np.random.default_rng(200 + r).normal(size=(B, D)).astype(np.float32) for r in range(world)]
+ref = o_emb.scatter_add_grad(np.concatenate(all_w), np.concatenate(all_ids), V)[lo:hi]
+np.testing.assert_allclose(layer.embeddings.grad.numpy(), ref, rtol=1e-6, atol=1e-6)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_embedding_two_ranks_gloo(tmp_path):
+  """world_size-2 gloo run of ShardedEmbedding: ids -> owners -> rows back, and gradient rows ->
+  owners, equal the full-table gather / scatter-add on every rank."""
+  script = tmp_path / "emb_worker.py"
+  script.write_text(_EMB_WORKER.format(root=ROOT))
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  port = s.getsockname()[1]
+  s.close()
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2",
+             OMP_NUM_THREADS="2")
+  procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+           for r in range(2)]
+  outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+  for r, (p, o) in enumerate(zip(procs, outs)):
+    assert p.returncode == 0, f"rank {r} failed:\n{o}"
+    assert f"rank {r} ok" in o

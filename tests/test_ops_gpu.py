@@ -394,3 +394,57 @@ def test_adagrad_optimizer_sparse_slices_match_dense_formula():
     dvec = dvec - lr * gd / np.sqrt(dacc + 1e-7)
     np.testing.assert_allclose(_np(layer.embeddings.detach()), table, rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(_np(dense.detach()), dvec, rtol=2e-5, atol=1e-6)
+
+
+_SHARDED_EMB_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from oracle import embedding as o_emb
+import recommenders_amd as tfrs
+from recommenders_amd.layers.sharded_embedding import ShardedEmbedding
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")          # exchange emulated through the host; kernels are HIP
+torch.cuda.set_device(0)
+V, D, B = 5003, 32, 4096
+full = np.random.default_rng(7).normal(size=(V, D)).astype(np.float32)
+layer = ShardedEmbedding(V, D)
+lo, hi = layer.row_range
+with torch.no_grad():
+  layer.embeddings.copy_(torch.from_numpy(full[lo:hi]).cuda())
+opt = tfrs.optimizers.Adagrad(layer.parameters(), learning_rate=0.5)
+all_ids = [np.random.default_rng(100 + r).integers(0, V, size=(B,)) for r in range(world)]
+all_w = [np.random.default_rng(200 + r).normal(size=(B, D)).astype(np.float32) for r in range(world)]
+out = layer(torch.from_numpy(all_ids[rank]).cuda())
+assert np.array_equal(out.detach().cpu().numpy(), o_emb.gather(full, all_ids[rank]))
+opt.zero_grad()
+(out * torch.from_numpy(all_w[rank]).cuda()).sum().backward()
+opt.step()                                 # fused sparse Adagrad on the shard's touched rows
+t_ref, _ = o_emb.adagrad_sparse_update(full, np.full_like(full, 0.1), np.concatenate(all_w),
+                                       np.concatenate(all_ids), lr=0.5)
+np.testing.assert_allclose(layer.embeddings.detach().cpu().numpy(), t_ref[lo:hi], rtol=2e-5, atol=1e-6)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_embedding_two_ranks_one_gpu(tmp_path):
+  """Row-sharded table, two ranks sharing cuda:0: HIP gather on the owners, all-to-all of ids /
+  rows / gradient rows (host-emulated under gloo), fused sparse Adagrad on each shard."""
+  import os, socket, subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  script = tmp_path / "worker.py"
+  script.write_text(_SHARDED_EMB_WORKER.format(root=root))
+  sock = socket.socket()
+  sock.bind(("127.0.0.1", 0))
+  port = sock.getsockname()[1]
+  sock.close()
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+  procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+  outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+  for r, (p, o) in enumerate(zip(procs, outs)):
+    assert p.returncode == 0, f"rank {r} failed:\n{o}"
+    assert f"rank {r} ok" in o
