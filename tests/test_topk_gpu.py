@@ -172,6 +172,23 @@ def test_adversarial_order_overflow_recompute():
   np.testing.assert_array_equal(_np(s), es)
 
 
+def test_f16_prefilter_segment_overflow_redo():
+  """A burst of strong matches inside stages the threshold pass does NOT sample (stage index
+  1..3 mod 4) overflows one private survivor segment of the fp16 filter pass: the query must be
+  flagged and answered exactly by the recompute path; the other queries stay on the fast path."""
+  ftk = _layers()
+  rng = np.random.default_rng(23)
+  n, nq, d, k = 120000, 48, 64, 100
+  c = (rng.normal(size=(n, d)) / 8).astype(np.float32)
+  q = (rng.normal(size=(nq, d)) / 8).astype(np.float32)
+  burst = np.arange(128 * 401, 128 * 401 + 300)                 # stage 401 (= 1 mod 4) onwards
+  c[burst] = q[3] * (4.0 + rng.uniform(size=(300, 1))).astype(np.float32)   # all beat everything for query 3
+  es, ei = o_topk.brute_force(q, c, k)
+  s, i = ftk.BruteForce(k=k).index(c)(q)
+  np.testing.assert_array_equal(_np(i), ei)
+  np.testing.assert_array_equal(_np(s), es)
+
+
 @pytest.mark.parametrize("bs", [3, 100, 128, 1000, 5000, 70000])
 def test_streaming_block_sizes(bs):
   ftk = _layers()
