@@ -226,25 +226,37 @@ __global__ void __launch_bounds__(256) scatter_rowscan_kernel(
     const float *__restrict__ grad_out, const void *__restrict__ ids, int64_t n, int d,
     int64_t vocab, float *__restrict__ dst, float *__restrict__ accum, float lr, float eps,
     int adagrad) {
+  // the id list goes through LDS in chunks shared by the workgroup's 4 rows, so a wave's scan
+  // is 64 LDS reads per 4096 ids instead of 64 dependent global loads
+  constexpr int kChunk = 4096;
+  __shared__ int64_t s_ids[kChunk];
   const int lane = threadIdx.x & 63;
   const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (v >= vocab) return;
+  const bool row_ok = v < vocab;
   float g[4] = {0.f, 0.f, 0.f, 0.f};  // features lane, lane + 64, lane + 128, lane + 192
   bool touched = false;
-  for (int64_t base = 0; base < n; base += 64) {
-    const int64_t p = base + lane;
-    const bool hit = (p < n) && (load_id<IdT>(ids, p) == v);
-    uint64_t mask = __ballot(hit);
-    touched = touched || (mask != 0ull);
-    while (mask != 0ull) {
-      const int64_t pos = base + __builtin_ctzll(mask);
-      mask &= mask - 1ull;
-      const float *row = grad_out + pos * d;
+  for (int64_t c0 = 0; c0 < n; c0 += kChunk) {
+    const int m = (int)((n - c0 < kChunk) ? (n - c0) : kChunk);
+    __syncthreads();
+    for (int e = threadIdx.x; e < m; e += 256) s_ids[e] = load_id<IdT>(ids, c0 + e);
+    __syncthreads();
+    if (!row_ok) continue;
+    for (int base = 0; base < m; base += 64) {
+      const int p = base + lane;
+      const bool hit = (p < m) && (s_ids[p] == v);
+      uint64_t mask = __ballot(hit);
+      touched = touched || (mask != 0ull);
+      while (mask != 0ull) {
+        const int64_t pos = c0 + base + __builtin_ctzll(mask);
+        mask &= mask - 1ull;
+        const float *row = grad_out + pos * d;
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-        if (lane + 64 * s < d) g[s] += row[lane + 64 * s];
+        for (int s = 0; s < 4; ++s)
+          if (lane + 64 * s < d) g[s] += row[lane + 64 * s];
+      }
     }
   }
+  if (!row_ok) return;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int f = lane + 64 * s;

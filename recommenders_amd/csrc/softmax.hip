@@ -67,8 +67,16 @@ __device__ __forceinline__ float make_logit(float dot, int64_t query, int64_t ca
   return v;
 }
 
-template <int DP>
-__global__ void __launch_bounds__(256) softmax_fwd_kernel(const SoftmaxArgs a) {
+// PLAIN: no sampling-probability correction, no accidental-hit removal, no score mask (the
+// default Retrieval configuration): those branches are compiled out of the tile epilogue.
+template <int DP, bool PLAIN>
+__global__ void __launch_bounds__(256) softmax_fwd_kernel(const SoftmaxArgs a_in) {
+  SoftmaxArgs a = a_in;
+  if (PLAIN) {
+    a.corr = nullptr;
+    a.ids = nullptr;
+    a.mask = nullptr;
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
@@ -194,8 +202,14 @@ __global__ void __launch_bounds__(256) softmax_finalize_kernel(const SoftmaxArgs
 
 // ROWS_ARE_QUERIES = true : wave owns 32 queries, streams candidates, emits partial dq.
 // ROWS_ARE_QUERIES = false: wave owns 32 candidates, streams queries, emits partial dc.
-template <int DP, bool ROWS_ARE_QUERIES>
-__global__ void __launch_bounds__(256) softmax_bwd_kernel(const SoftmaxArgs a) {
+template <int DP, bool ROWS_ARE_QUERIES, bool PLAIN>
+__global__ void __launch_bounds__(256) softmax_bwd_kernel(const SoftmaxArgs a_in) {
+  SoftmaxArgs a = a_in;
+  if (PLAIN) {
+    a.corr = nullptr;
+    a.ids = nullptr;
+    a.mask = nullptr;
+  }
   constexpr int NFB = (DP + 31) / 32;  // 32-feature output blocks
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -344,7 +358,10 @@ static size_t al(size_t x) { return (x + 255) / 256 * 256; }
 template <int DP>
 static void launch_fwd(const SoftmaxArgs &a, hipStream_t s) {
   const int64_t waves = ((a.nq + 31) / 32) * a.nsplit;
-  hipLaunchKernelGGL((softmax_fwd_kernel<DP>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+  if (!a.corr && !a.ids && !a.mask)
+    hipLaunchKernelGGL((softmax_fwd_kernel<DP, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((softmax_fwd_kernel<DP, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
 }
 
 template <int DP, bool RQ>
@@ -352,7 +369,10 @@ static void launch_bwd(const SoftmaxArgs &a, hipStream_t s) {
   const int64_t rows = RQ ? a.nq : a.nc;
   const int64_t waves = ((rows + 31) / 32) * a.nsplit;
   const size_t lds = (size_t)4 * 32 * (DP + 4) * sizeof(float);
-  hipLaunchKernelGGL((softmax_bwd_kernel<DP, RQ>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, s, a);
+  if (!a.corr && !a.ids && !a.mask)
+    hipLaunchKernelGGL((softmax_bwd_kernel<DP, RQ, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, s, a);
+  else
+    hipLaunchKernelGGL((softmax_bwd_kernel<DP, RQ, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, s, a);
 }
 
 }  // namespace tfrs

@@ -111,13 +111,19 @@ static SamplePlan plan_sample(int64_t n, int k, const TopkTuning &t) {
   while (p.stride > 1 && 2 * (full / p.stride) < want_bins) --p.stride;
   const int64_t ns = full / p.stride;
   if (2 * ns >= std::max<int64_t>(want_bins, k)) p.n_stages = ns;
-  if (2 * (ns / 4) >= 8 * (int64_t)k) p.bin_stages = 4;
+  // 4 stages per bin when that still leaves 8 * K bins; beyond 4096 bins per query the bins
+  // are widened further (the threshold kernel merges them down to <= 1024 values anyway), so
+  // the bin-maxima buffer stays at nq * 4096 floats however large the corpus is
+  if (2 * (ns / 4) >= 8 * (int64_t)k) p.bin_stages = std::max<int64_t>(4, (2 * ns + 4095) / 4096);
   return p;
 }
 static int64_t dense_rows(int64_t n, int k, const TopkTuning &t) {
   const int64_t want = std::max<int64_t>(t.prefix, padded_rows(k));
   int64_t cols = std::min<int64_t>(padded_rows(n), want);
-  if (t.f16_filter && k <= 512) cols = std::max<int64_t>(cols, padded_rows(2 * plan_sample(n, k, t).n_stages));
+  if (t.f16_filter && k <= 512) {
+    const SamplePlan sp = plan_sample(n, k, t);
+    if (sp.n_stages > 0) cols = std::max<int64_t>(cols, padded_rows(sp.n_bins()));
+  }
   return cols;
 }
 
