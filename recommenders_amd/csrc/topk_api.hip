@@ -206,11 +206,6 @@ __global__ void thr_from_state_kernel(const float *state_scores, int64_t nq, int
   if (r < nq) thr[r] = state_scores[r * k + (k - 1)];
 }
 
-__global__ void fill_kernel(float *p, int64_t n, float v) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n) p[r] = v;
-}
-
 static void plan_splits(int64_t rows, int n_qtiles, const TopkTuning &t, int64_t *split_len,
                         int *n_splits) {
   const int64_t stages = (rows + kTileN - 1) / kTileN;
@@ -385,10 +380,6 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
   s16.stage_stride = 1;
   plan_stage_splits(all_stages, n_qtiles, t, &s16.stages_per_split, &s16.n_splits);
   s16.lower = w.thr;
-  if (env_i64("TFRS_DEBUG_NO_SURVIVORS", 0) != 0) {  // timing experiment only: results are wrong
-    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream,
-                       w.thr, nq, __builtin_inff());
-  }
   s16.cnt = w.cnt;
   s16.buf = w.buf;
   s16.nseg = 2 * s16.n_splits;

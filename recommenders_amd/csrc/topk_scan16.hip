@@ -315,16 +315,13 @@ template <int DP, int MODE>
 static int launch_scan16_variant(const Scan16Args &a, hipStream_t stream) {
   using G = Scan16Geom<DP>;
   static bool attr_set = false;
-  static int lds_pad = 0;  // TFRS_DEBUG_LDS_PAD: occupancy experiments only
   if (!attr_set) {
-    const char *v = getenv("TFRS_DEBUG_LDS_PAD");
-    lds_pad = (v && *v) ? atoi(v) : 0;
     TFRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan16_kernel<DP, MODE>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes + lds_pad));
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
     attr_set = true;
   }
   const dim3 grid((unsigned)(a.n_qtiles * a.n_splits));
-  hipLaunchKernelGGL((scan16_kernel<DP, MODE>), grid, dim3(kThreads16), G::kLdsBytes + lds_pad, stream, a);
+  hipLaunchKernelGGL((scan16_kernel<DP, MODE>), grid, dim3(kThreads16), G::kLdsBytes, stream, a);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
 }

@@ -11,9 +11,9 @@ corpus = torch.randn((1_000_000, 64), generator=g, device=dev) / 8.0
 queries = torch.randn((8192, 64), generator=g, device=dev) / 8.0
 index = ftk.BruteForce(k=100).index(corpus)
 lib = _lib.load()
-for env in [{}, {"TFRS_DEBUG_NO_SURVIVORS": "1"}, {"TFRS_TOPK_WGS": "512"}, {"TFRS_TOPK_WGS": "512", "TFRS_DEBUG_NO_SURVIVORS": "1"},
+for env in [{}, {"TFRS_TOPK_WGS": "512"},
             {"TFRS_TOPK_RHO": "4"}, {"TFRS_TOPK_RHO": "2"}, {"TFRS_TOPK_RHO": "16"}, {"TFRS_TOPK_PREFIX": "16384"}]:
-  for k in ("TFRS_DEBUG_NO_SURVIVORS", "TFRS_TOPK_WGS", "TFRS_TOPK_RHO", "TFRS_TOPK_PREFIX"):
+  for k in ("TFRS_TOPK_WGS", "TFRS_TOPK_RHO", "TFRS_TOPK_PREFIX"):
     os.environ.pop(k, None)
   os.environ.update(env)
   for _ in range(2):
