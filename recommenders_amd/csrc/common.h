@@ -232,12 +232,20 @@ struct SelectArgs {
   float *out_scores;   // [nq, k]
   int32_t *out_idx;    // [nq, k]
   float *out_thr;      // [nq] K-th best score, or -inf while fewer than k entries (may be NULL)
+  // launch_recompute: optional buffer [nq, kRecomputeChunks, k] of partial key lists; when set,
+  // each query's rows are spread over kRecomputeChunks workgroups and merged afterwards
+  uint64_t *part_keys;
   // kSrcRecompute: exact keys of rows [rc_begin, rc_end) (slow, always correct).
-  // only_flagged != NULL: rows with only_flagged[row] == 0 are skipped (their outputs stay).
+  // launch_recompute only: only_flagged != NULL restricts the work to the listed queries,
+  // only_flagged[0] = count, only_flagged[1 + s] = query index of slot s.
   const uint32_t *only_flagged;
 };
 
 int launch_select(const SelectArgs &a, hipStream_t stream);
+// exact top-K of rows [rc_begin, rc_end) for the queries flagged in a.only_flagged (all queries
+// when NULL), one workgroup per query; writes out_scores / out_idx of those queries only
+int launch_recompute(const SelectArgs &a, hipStream_t stream);
+constexpr int kRecomputeChunks = 32;
 int launch_pack(const float *cand, int64_t n, int d, char *packed, int64_t dst_row,
                 int64_t zero_rows_to, hipStream_t stream);
 int launch_unpack(const char *packed, int64_t n, int d, float *out, hipStream_t stream);
@@ -253,8 +261,9 @@ int launch_query_kappa(const float *q, int64_t nq, int d, float *qk, float *qsca
 int launch_bin_threshold(const float *binmax, int64_t ld, int n_bins, int64_t nq, int k,
                          const float *qk, const float *norm_max, float *lower,
                          hipStream_t stream);
-// topk_select16.hip: survivor list of prefilter scores -> exact top-K; redo[q] = 1 for the
-// queries that need the exact recompute path (list overflow / retained set too large)
+// topk_select16.hip: survivor list of prefilter scores -> exact top-K; queries that need the
+// exact recompute path (list overflow / retained set too large) are appended to the list
+// redo[1 + slot] with redo[0] = their count (must be zero on entry)
 int launch_list_topk16(const float *q, int64_t nq, int d, const char *packed, const uint2 *buf,
                        const uint32_t *cnt, uint32_t cap_l, int nseg, int k, const float *qk,
                        const float *norm_max, float *out_scores, int32_t *out_idx, uint32_t *redo,

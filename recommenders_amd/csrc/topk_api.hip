@@ -164,7 +164,8 @@ struct RoundWs {
   int64_t entries;  // per query
   float *qk;        // [nq]
   float *qscale;    // [nq]
-  uint32_t *redo;   // [nq]
+  uint32_t *redo;   // [1 + nq] count + flagged query list
+  uint64_t *part_keys;  // [nq, kRecomputeChunks, k] partial lists of the exact-recompute fallback
   char *end;
 };
 
@@ -174,7 +175,8 @@ static size_t round_ws_bytes(int64_t nq, int64_t n, int k, const TopkTuning &t) 
   b += align_up((size_t)nq * 2 * max_splits(nq, t) * 4);                 // cnt[nq, nseg]
   b += align_up((size_t)nq * dense_rows(n, k, t) * 4);                   // dense
   b += align_up((size_t)nq * list_entries_per_query(nq, k, t) * 8);      // buf
-  b += 3 * align_up((size_t)nq * 4);                                     // qk, qscale, redo
+  b += 2 * align_up((size_t)nq * 4) + align_up((size_t)(nq + 1) * 4);    // qk, qscale, redo
+  b += align_up((size_t)nq * kRecomputeChunks * k * 8);                  // part_keys
   return b;
 }
 
@@ -195,7 +197,9 @@ static RoundWs carve_round_ws(char *p, int64_t nq, int64_t n, int k, const TopkT
   w.qscale = reinterpret_cast<float *>(p);
   p += align_up((size_t)nq * 4);
   w.redo = reinterpret_cast<uint32_t *>(p);
-  p += align_up((size_t)nq * 4);
+  p += align_up((size_t)(nq + 1) * 4);
+  w.part_keys = reinterpret_cast<uint64_t *>(p);
+  p += align_up((size_t)nq * kRecomputeChunks * k * 8);
   w.end = p;
   return w;
 }
@@ -392,7 +396,7 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
 
   // prefilter top-K + exact re-scoring; flagged queries (list overflow, retained set too
   // large) are answered by the exact recompute path of the generic select kernel
-  TFRS_HIP(hipMemsetAsync(w.redo, 0, (size_t)nq * 4, stream));
+  TFRS_HIP(hipMemsetAsync(w.redo, 0, 4, stream));  // the flagged-query counter
   if ((rc = launch_list_topk16(q, nq, d, packed, w.buf, w.cnt, s16.cap_l, s16.nseg, k, w.qk,
                                img.norm_max, out_scores, out_idx, w.redo, idx_base, stream)) != TFRS_OK)
     return rc;
@@ -404,12 +408,13 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
   se.packed = packed;
   se.source = kSrcRecompute;
   se.only_flagged = w.redo;
+  se.part_keys = w.part_keys;
   se.idx_base = idx_base;
   se.rc_begin = 0;
   se.rc_end = n;
   se.out_scores = out_scores;
   se.out_idx = out_idx;
-  return launch_select(se, stream);
+  return launch_recompute(se, stream);
 }
 
 }  // namespace tfrs

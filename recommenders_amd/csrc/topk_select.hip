@@ -99,7 +99,8 @@ __device__ __forceinline__ float packed_score(const char *packed, int64_t row, i
   const float4 *od = ev + dp / 8;
   const float4 *q4 = reinterpret_cast<const float4 *>(qs);
   float acc = 0.0f;
-  for (int m = 0; m < dp / 8; ++m) {
+#pragma unroll 4
+  for (int m = 0; m < dp / 8; ++m) {  // (unrolled: 8 independent 16-byte loads in flight)
     const float4 e = ev[m], o = od[m];
     const float4 qa = q4[2 * m], qb = q4[2 * m + 1];  // features 8m .. 8m+7
     acc = __builtin_fmaf(e.x, qa.x, acc);
@@ -129,7 +130,6 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
   const int K = a.k;
   const int source = a.source;
   const int dp = padded_dim(a.d);
-  if (a.only_flagged && a.only_flagged[row] == 0u) return;  // whole wave
 
   // ---- seed with the prior state (already sorted by construction) -----------------
   for (int i = lane; i < KP; i += 64) {
@@ -242,6 +242,162 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
     const uint64_t key = best[K - 1];
     a.out_thr[row] = key ? key_score(key) : -__builtin_inff();
   }
+}
+
+// ---- exact recompute of flagged queries, one WORKGROUP per query ---------------------------
+// The always-correct fallback of the fp16-prefiltered path (list overflow / retained set too
+// large): NW waves split rows [rc_begin, rc_end) between them, each keeps its own top-K with
+// the same consume/absorb machinery, wave 0 merges the NW partial lists.  Unflagged queries'
+// workgroups exit at once.  (A single wave per query took 16 ms for one flagged query on a
+// 1M-row corpus; 16 waves bring the worst case to ~1 ms.)
+template <int KP, int NW>
+__global__ void __launch_bounds__(NW * 64) recompute_kernel(const SelectArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nchunks = gridDim.y, chunk_id = blockIdx.y;  // the row range is cut into gridDim.y chunks
+  // flagged queries: a.only_flagged[0] = count, a.only_flagged[1 + s] = query of slot s
+  // (NULL: every query, slot = query); workgroups stride over the slots
+  const int64_t nslots = a.only_flagged ? (int64_t)a.only_flagged[0] : a.nq;
+  for (int64_t slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
+  const int64_t row = a.only_flagged ? (int64_t)a.only_flagged[1 + slot] : slot;
+  __syncthreads();  // LDS reuse across slots
+  uint64_t *best = reinterpret_cast<uint64_t *>(smem) + (size_t)wave * 2 * KP;
+  uint64_t *chunk = best + KP;
+  float *qs = reinterpret_cast<float *>(smem + (size_t)NW * 2 * KP * sizeof(uint64_t));
+  const int K = a.k;
+  const int dp = padded_dim(a.d);
+  for (int i = threadIdx.x; i < dp; i += NW * 64) qs[i] = (i < a.d) ? a.q[row * a.d + i] : 0.0f;
+  for (int i = lane; i < KP; i += 64) best[i] = 0ull;
+  __syncthreads();
+
+  int fill = 0;
+  uint64_t kth = 0ull;
+  auto consume = [&](uint64_t key) {
+    const bool p = key > kth;
+    const uint64_t mask = __ballot(p);
+    if (mask == 0ull) return;
+    if (fill + 64 > KP) {
+      absorb_chunk<KP>(best, chunk, fill, lane);
+      fill = 0;
+      kth = best[K - 1];
+    }
+    if (p) chunk[fill + sel_mbcnt(mask)] = key;
+    fill += (int)__popcll(mask);
+  };
+  const int64_t m = a.rc_end - a.rc_begin;
+  const int64_t per = ((m + (int64_t)NW * nchunks - 1) / ((int64_t)NW * nchunks) + 63) / 64 * 64;
+  const int64_t lo = ((int64_t)chunk_id * NW + wave) * per;
+  const int64_t hi = (lo + per < m) ? lo + per : m;
+  for (int64_t base = lo; base < hi; base += 64) {
+    const int64_t e = base + lane;
+    uint64_t key = 0ull;
+    if (e < hi) {
+      const int64_t crow = a.rc_begin + e;
+      key = make_key(packed_score(a.packed, crow, dp, qs), (int32_t)(crow + a.idx_base));
+    }
+    consume(key);
+  }
+  if (fill > 0) absorb_chunk<KP>(best, chunk, fill, lane);
+  fill = 0;
+  __syncthreads();
+  if (wave != 0) continue;
+  // wave 0: fold the other waves' sorted lists (their first K keys) into its own
+  kth = best[K - 1];
+  for (int w = 1; w < NW; ++w) {
+    const uint64_t *other = reinterpret_cast<const uint64_t *>(smem) + (size_t)w * 2 * KP;
+    for (int base = 0; base < K; base += 64) {
+      const int e = base + lane;
+      consume(e < K ? other[e] : 0ull);
+    }
+  }
+  if (fill > 0) absorb_chunk<KP>(best, chunk, fill, lane);
+  if (nchunks > 1) {  // partial list of this chunk: merged by recompute_merge_kernel
+    uint64_t *dst = a.part_keys + ((size_t)slot * nchunks + chunk_id) * K;
+    for (int i = lane; i < K; i += 64) dst[i] = best[i];
+    continue;
+  }
+  for (int i = lane; i < K; i += 64) {
+    const uint64_t key = best[i];
+    a.out_scores[row * K + i] = key ? key_score(key) : 0.0f;
+    a.out_idx[row * K + i] = key ? key_index(key) : 0;
+  }
+  }  // slot loop
+}
+
+// One wave per flagged query: top-K of the nchunks sorted partial key lists.
+template <int KP>
+__global__ void __launch_bounds__(64) recompute_merge_kernel(const SelectArgs a, int nchunks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  uint64_t *best = reinterpret_cast<uint64_t *>(smem);
+  uint64_t *chunk = best + KP;
+  const int K = a.k;
+  const int64_t nslots = a.only_flagged ? (int64_t)a.only_flagged[0] : a.nq;
+  for (int64_t slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
+  const int64_t row = a.only_flagged ? (int64_t)a.only_flagged[1 + slot] : slot;
+  wave_lds_sync();
+  for (int i = lane; i < KP; i += 64) best[i] = 0ull;
+  wave_lds_sync();
+  int fill = 0;
+  uint64_t kth = 0ull;
+  const uint64_t *src = a.part_keys + (size_t)slot * nchunks * K;
+  const int total = nchunks * K;
+  for (int base = 0; base < total; base += 64) {
+    const int e = base + lane;
+    const uint64_t key = e < total ? src[e] : 0ull;
+    const bool p = key > kth;
+    const uint64_t mask = __ballot(p);
+    if (mask == 0ull) continue;
+    if (fill + 64 > KP) {
+      absorb_chunk<KP>(best, chunk, fill, lane);
+      fill = 0;
+      kth = best[K - 1];
+    }
+    if (p) chunk[fill + sel_mbcnt(mask)] = key;
+    fill += (int)__popcll(mask);
+  }
+  if (fill > 0) absorb_chunk<KP>(best, chunk, fill, lane);
+  for (int i = lane; i < K; i += 64) {
+    const uint64_t key = best[i];
+    a.out_scores[row * K + i] = key ? key_score(key) : 0.0f;
+    a.out_idx[row * K + i] = key ? key_index(key) : 0;
+  }
+  }  // slot loop
+}
+
+template <int KP, int NW>
+static int launch_recompute_kp(const SelectArgs &a, hipStream_t stream) {
+  const size_t lds = (size_t)NW * 2 * KP * sizeof(uint64_t) + TFRS_MAX_DIM * sizeof(float);
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    TFRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&recompute_kernel<KP, NW>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  // with a partial-list buffer the rows of a flagged query are spread over kRecomputeChunks
+  // workgroups (a single CU streams only ~30 GB/s of candidate rows), then merged
+  const int nchunks = a.part_keys ? kRecomputeChunks : 1;
+  // small fixed grid striding over the flagged slots (usually none: the launch costs ~3 us)
+  const unsigned gx = a.only_flagged ? (unsigned)std::min<int64_t>(a.nq, 64) : (unsigned)a.nq;
+  hipLaunchKernelGGL((recompute_kernel<KP, NW>), dim3(gx, (unsigned)nchunks), dim3(NW * 64), lds, stream, a);
+  TFRS_LAUNCH_CHECK();
+  if (nchunks > 1) {
+    hipLaunchKernelGGL((recompute_merge_kernel<KP>), dim3(gx), dim3(64),
+                       (size_t)2 * KP * sizeof(uint64_t), stream, a, nchunks);
+    TFRS_LAUNCH_CHECK();
+  }
+  return TFRS_OK;
+}
+
+int launch_recompute(const SelectArgs &a, hipStream_t stream) {
+  if (a.nq <= 0) return TFRS_OK;
+  TFRS_CHECK_ARG(a.k >= 1 && a.k <= TFRS_MAX_K, "recompute: k=%d outside [1, %d]", a.k, TFRS_MAX_K);
+  if (a.k <= 64) return launch_recompute_kp<64, 4>(a, stream);
+  if (a.k <= 128) return launch_recompute_kp<128, 4>(a, stream);
+  if (a.k <= 256) return launch_recompute_kp<256, 4>(a, stream);
+  if (a.k <= 512) return launch_recompute_kp<512, 4>(a, stream);
+  return launch_recompute_kp<1024, 4>(a, stream);
 }
 
 template <int KP>

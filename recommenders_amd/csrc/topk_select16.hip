@@ -9,7 +9,7 @@
 //                          d-ordered fma chain as the MFMA f32 path) -> sorted exact top-K
 //                          = tf.math.top_k of BruteForce.call (layers/factorized_top_k.py:605).
 // Queries whose survivor list overflowed, or whose retained set does not fit, are flagged in
-// redo[q] and answered by the generic select kernel's exact recompute path afterwards.
+// a redo list and answered by the exact recompute kernels (topk_select.hip) afterwards.
 #include "common.h"
 
 namespace tfrs {
@@ -107,7 +107,8 @@ __device__ __forceinline__ float packed_score16(const char *packed, int64_t row,
   const float4 *od = ev + dp / 8;
   const float4 *q4 = reinterpret_cast<const float4 *>(qs);
   float acc = 0.0f;
-  for (int m = 0; m < dp / 8; ++m) {
+#pragma unroll 4
+  for (int m = 0; m < dp / 8; ++m) {  // (unrolled: 8 independent 16-byte loads in flight)
     const float4 e = ev[m], o = od[m];
     const float4 qa = q4[2 * m], qb = q4[2 * m + 1];
     acc = __builtin_fmaf(e.x, qa.x, acc);
@@ -158,7 +159,7 @@ struct List16Args {
   const float *norm_max;
   float *out_scores;     // [nq, k]
   int32_t *out_idx;      // [nq, k] (row + idx_base; -1 marks an empty slot: fewer than k survivors)
-  uint32_t *redo;        // [nq]: 1 = answer this query with the exact recompute path
+  uint32_t *redo;        // [1 + nq]: count, then the queries to answer with the exact recompute path
   int64_t idx_base;      // added to the image-local row numbers
 };
 
@@ -208,7 +209,7 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
     }
   }
   if (__ballot(bad) != 0ull || total > kCap) {
-    if (lane == 0) a.redo[row] = 1u;
+    if (lane == 0) a.redo[1 + atomicAdd(a.redo, 1u)] = (uint32_t)row;
     return;
   }
   sel16_lds_sync();
@@ -246,7 +247,7 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
     m += (int)__popcll(mask);
   }
   if (m > KP) {  // retained set does not fit: exact redo
-    if (lane == 0) a.redo[row] = 1u;
+    if (lane == 0) a.redo[1 + atomicAdd(a.redo, 1u)] = (uint32_t)row;
     return;
   }
   sel16_lds_sync();
