@@ -1,0 +1,78 @@
+"""End-to-end train-step timing of the two ranking configurations of BASELINE.json (evidence
+tool, one GPU):
+
+  configs[3]  DCN-v2: 26 categorical features (1M-row tables, dim 128) + 13 dense features,
+              3 full-rank Cross layers on the concatenated 27*128 = 3456-wide vector, batch 65536.
+  configs[4]  DLRM: 100 categorical features, dim 32, DotInteraction over 101 vectors, batch
+              131072 -- with one GPU's 1/8 share of the 10M-row tables (1.25M rows each), the
+              shard an 8-GPU row-sharded deployment keeps per device.
+
+Model = experimental.models.Ranking, optimizer = optimizers.Adagrad (sparse embedding updates).
+"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import recommenders_amd as tfrs
+from recommenders_amd.experimental.models import ranking as rk
+
+dev = torch.device("cuda", 0)
+
+
+def run(name, n_tables, vocab, dim, batch, interaction, steps=3):
+  g = torch.Generator(device=dev).manual_seed(0)
+  emb = rk.EmbeddingDict({str(i): vocab for i in range(n_tables)}, dim)
+  bottom = tfrs.layers.blocks.MLP(units=[512, 256, dim], final_activation="relu")
+  if interaction == "cross":
+    class CrossStack(torch.nn.Module):
+      def __init__(self):
+        super().__init__()
+        self.layers = torch.nn.ModuleList([tfrs.layers.feature_interaction.Cross() for _ in range(3)])
+      def forward(self, inputs):
+        x0 = torch.cat(list(inputs), dim=-1)
+        x = x0
+        for layer in self.layers:
+          x = layer(x0, x)
+        return x
+    fi = CrossStack()
+  else:
+    fi = tfrs.layers.feature_interaction.DotInteraction()
+  top = tfrs.layers.blocks.MLP(units=[1024, 512, 1], final_activation="sigmoid")
+  model = rk.Ranking(emb, bottom_stack=bottom, feature_interaction=fi, top_stack=top,
+                     task=tfrs.tasks.Ranking(loss=tfrs.losses.BinaryCrossentropy(reduction="none")))
+  feats = {"dense_features": torch.rand((batch, 13), generator=g, device=dev),
+           "sparse_features": {str(i): torch.randint(0, vocab, (batch,), generator=g, device=dev)
+                               for i in range(n_tables)}}
+  labels = torch.randint(0, 2, (batch,), generator=g, device=dev)
+  model(feats)                                            # builds the lazily-shaped Dense layers
+  model.compile(optimizer=tfrs.optimizers.Adagrad(model.parameters(), learning_rate=0.01))
+  for _ in range(2):
+    model.train_step((feats, labels))
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    logs = model.train_step((feats, labels))
+  torch.cuda.synchronize()
+  dt = (time.perf_counter() - t0) / steps
+  with torch.no_grad():
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+      model(feats)
+    torch.cuda.synchronize()
+    df = (time.perf_counter() - t0) / steps
+  print(json.dumps({"config": name, "tables": n_tables, "vocab": vocab, "dim": dim, "batch": batch,
+                    "interaction": interaction, "train_step_ms": round(dt * 1e3, 2),
+                    "forward_ms": round(df * 1e3, 2), "examples_per_s": round(batch / dt, 1),
+                    "loss": float(logs["loss"])}), flush=True)
+  del model, emb
+  torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+  small = len(sys.argv) > 1 and sys.argv[1] == "small"
+  if small:
+    run("dcn-v2 (small)", 4, 10000, 32, 4096, "cross")
+    run("dlrm (small)", 8, 10000, 16, 4096, "dot")
+  else:
+    run("configs[3] DCN-v2", 26, 1_000_000, 128, 65536, "cross")
+    run("configs[4] DLRM, one GPU's row shard", 100, 1_250_000, 32, 131072, "dot")
