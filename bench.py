@@ -4,8 +4,10 @@
 
 Workload (BASELINE.json configs[1]): synthetic 1M-item x dim-64 corpus, batch of 8192
 queries, exact top-100 (`BruteForce.call`, reference layers/factorized_top_k.py:586-607),
-float32 throughout, inputs resident in HBM before the timed region.  A "step" is one
-`BruteForce` call on the batch.
+inputs resident in HBM before the timed region.  Returned scores and indices are those of
+the float32 fma chain (bit-identical to the all-f32 path); the default path filters with
+fp16 MFMA scores under a rigorous error bound and re-scores the survivors exactly
+(DESIGN.md 4.1).  A "step" is one `BruteForce` call on the batch.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the corpus is
 row-sharded -- every rank owns a 1M-row shard (weak scaling: total corpus = N x 1M rows),
@@ -13,8 +15,9 @@ all ranks score the same 8192 queries against their shard, then all_gather the p
 top-100 (score, global row) lists over xGMI and merge them.  `value` counts
 shard-queries: N * 8192 / step time.
 
-Prints ONE JSON line on rank 0 with the contract fields plus `roofline` (fused
-score+filter scan kernel, f32 MFMA roof) and `cpu_baseline` (N = 1 only).
+Prints ONE JSON line on rank 0 with the contract fields plus `roofline` (the kernel the step
+spends most time in: the fp16 filter pass, priced against the dense 16-bit MFMA peak with
+its ALGORITHMIC flop 2*B*N*D), `cpu_baseline` and `secondary` (train steps/sec), N = 1 only.
 """
 
 import argparse
