@@ -116,11 +116,28 @@ def main() -> None:
   world = int(os.environ.get("WORLD_SIZE", "1"))
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs a ROCm GPU: there is no CPU fallback for the product path")
+  # Validation aid for boxes with ONE GPU (not used by the driver): TFRS_BENCH_ONE_GPU=1 runs the
+  # N > 1 code path with every rank on cuda:0 and the single all-gather of the sharded path
+  # staged through gloo/host, because RCCL refuses two ranks on one device.
+  one_gpu = os.environ.get("TFRS_BENCH_ONE_GPU", "0") == "1"
+  if one_gpu:
+    local_rank = 0
   torch.cuda.set_device(local_rank)
   dev = torch.device("cuda", local_rank)
   if world > 1:
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("nccl", device_id=dev)
+    if one_gpu:
+      dist.init_process_group("gloo")
+      real_gather = dist.all_gather_into_tensor
+
+      def staged_gather(out, inp, group=None):
+        host = torch.empty(out.shape, dtype=out.dtype)
+        real_gather(host, inp.cpu(), group=group)
+        out.copy_(host)
+
+      dist.all_gather_into_tensor = staged_gather
+    else:
+      dist.init_process_group("nccl", device_id=dev)
 
   from recommenders_amd import _lib
   from recommenders_amd.layers import factorized_top_k as ftk
