@@ -183,12 +183,21 @@ int tfrs_embedding_segment_reduce_fwd(const float *table, int64_t vocab, int d,
                                       int ids_are_i64, const float *weights,
                                       int64_t nrows, int combiner, float *out,
                                       int32_t *err_flag, void *stream);
+/* Backward of the combiner lookup: grad_rows[p, :] = (grad_out[b, :] / den_b) * w_p for every
+ * entry p of segment b (den_b = 1 | sum w | sqrt(sum w^2) as in the forward), i.e. the values
+ * of the IndexedSlices gradient whose indices are the looked-up ids; feed (ids, grad_rows) to
+ * tfrs_embedding_scatter_add_* (TPUEmbedding CPU branch, tpu_embedding_layer.py:913-919 under
+ * tape.gradient, models/base.py:77).  grad_rows[nnz, d], nnz = row_splits[nrows]. */
+int tfrs_embedding_segment_reduce_bwd(const float *grad_out, int d, const void *row_splits,
+                                      int splits_are_i64, const float *weights, int64_t nrows,
+                                      int combiner, float *grad_rows, void *stream);
 /* Backward of gather: deterministic, atomics-free scatter-add.  `perm`/`sorted_ids`
  * are caller-provided sort results (ids sorted ascending, perm = source positions).
  * Produces the dense grad_table[vocab, d] rows for the touched ids only (other rows
  * untouched) -- or, when adagrad != 0, applies the fused row-wise Adagrad update
  * (models/base.py:77-78 with Adagrad, README.md:84):
- *   g = sum of duplicate grads; acc += g*g; row -= lr * g / sqrt(acc + eps). */
+ *   g = sum of duplicate grads; acc += g*g; row -= lr * g / sqrt(acc + eps).
+ * Negative ids (the padding slots of a max_sequence_length feature) contribute nothing. */
 int tfrs_embedding_scatter_add_bwd(const float *grad_out, const int64_t *sorted_ids,
                                    const int64_t *perm, int64_t n, int d,
                                    float *grad_table_or_table, float *accum, float lr,
@@ -202,6 +211,35 @@ int tfrs_embedding_scatter_add_rowscan(const float *grad_out, const void *ids, i
                                        int64_t n, int d, int64_t vocab,
                                        float *grad_table_or_table, float *accum, float lr,
                                        float eps, int adagrad, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * tf.keras.layers.Hashing(num_bins, salt=[s0, s1]) as UnifiedEmbedding applies it per
+ * feature chunk (layers/feature_multiplexing/unified_embedding.py:116-119,155-159,198-205):
+ * bucket = SipHash-2-4_{(s0, s1)}(bytes) mod num_bins (unsigned), where bytes is the decimal
+ * string of an integer id (tf.as_string) or the string itself.  out[n] int64.
+ *   _ids:   ids[n] int32/int64 on the device.
+ *   _bytes: n strings packed back to back in `bytes`, string i = bytes[offsets[i]:offsets[i+1]].
+ * ------------------------------------------------------------------------- */
+int tfrs_hash_bucket_strong_ids(const void *ids, int ids_are_i64, int64_t n, int64_t num_bins,
+                                uint64_t salt0, uint64_t salt1, int64_t *out, void *stream);
+int tfrs_hash_bucket_strong_bytes(const unsigned char *bytes, const int64_t *offsets, int64_t n,
+                                  int64_t num_bins, uint64_t salt0, uint64_t salt1,
+                                  int64_t *out, void *stream);
+
+/* Fused UnifiedEmbedding.call for one feature (unified_embedding.py:198-215): for value v and
+ * chunk c, bucket = SipHash-2-4_{(salt0[c], salt1[c])}(value) mod num_bins and
+ *   out[v, c*d:(c+1)*d] = tables[c][bucket, :]
+ * i.e. Hashing -> lookup -> concat of the feature's n_chunks components in one pass.  Values are
+ * ids[n_values] (int32/int64) or, when `bytes` != NULL, strings packed as in
+ * tfrs_hash_bucket_strong_bytes.  `tables`, `salt0`, `salt1` are HOST arrays of n_chunks
+ * entries (device table pointers, each [num_bins, d]); d must be 4 * 2^k <= 256, otherwise
+ * TFRS_ENOTIMPL.  out[n_values, n_chunks * d]; buckets[n_values, n_chunks] (optional, may be
+ * NULL) keeps the bucket of every lookup for the backward (the IndexedSlices indices). */
+int tfrs_unified_embedding_fwd(const void *ids, int ids_are_i64, const unsigned char *bytes,
+                               const int64_t *offsets, int64_t n_values, int n_chunks,
+                               const float *const *tables, const uint64_t *salt0,
+                               const uint64_t *salt1, int64_t num_bins, int d, float *out,
+                               int64_t *buckets, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Retrieval.call loss (tasks/retrieval.py:172-210, layers/loss.py:114-158):

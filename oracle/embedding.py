@@ -59,6 +59,61 @@ def lookup_sparse(table: np.ndarray, ids: np.ndarray, row_splits: np.ndarray,
   return out
 
 
+def lookup_sparse_grad_rows(grad_out: np.ndarray, row_splits: np.ndarray,
+                            weights: Optional[np.ndarray] = None, combiner: str = "mean"
+                            ) -> np.ndarray:
+  """Backward of ``lookup_sparse`` wrt the looked-up rows (the values of the IndexedSlices
+  gradient TensorFlow's tape produces for the table, ``models/base.py:77``): following the
+  autodiff of ``sum_j w_j e_j / den`` -- divide the incoming gradient by ``den`` first, then
+  scale by ``w_p`` -- ``grad_rows[p] = (grad_out[b] / den_b) * w_p`` in float32."""
+  grad_out = np.asarray(grad_out, dtype=np.float32)
+  row_splits = np.asarray(row_splits)
+  nnz = int(row_splits[-1])
+  rows = np.zeros((nnz, grad_out.shape[1]), dtype=np.float32)
+  for b in range(row_splits.shape[0] - 1):
+    lo, hi = int(row_splits[b]), int(row_splits[b + 1])
+    if hi == lo:
+      continue
+    w = (np.ones(hi - lo, dtype=np.float32) if weights is None
+         else np.asarray(weights[lo:hi], dtype=np.float32))
+    if combiner == "sum":
+      den = np.float32(1.0)
+    elif combiner == "mean":
+      den = np.float32(0.0)
+      for x in w:
+        den = np.float32(den + x)
+    elif combiner == "sqrtn":
+      sq = np.float32(0.0)
+      for x in w:
+        sq = np.float32(sq + x * x)
+      den = np.float32(np.sqrt(sq))
+    else:
+      raise ValueError(f"unknown combiner {combiner}")
+    g = (grad_out[b] / den).astype(np.float32)
+    for j in range(hi - lo):
+      rows[lo + j] = g * w[j]
+  return rows
+
+
+def sequence_lookup(table: np.ndarray, ids: np.ndarray, row_splits: np.ndarray,
+                    max_sequence_length: int, positions: Optional[np.ndarray] = None
+                    ) -> np.ndarray:
+  """Sequence feature (``FeatureConfig.max_sequence_length > 0``) on the TPUEmbedding CPU
+  branch (``tpu_embedding_layer.py:913-919``): no combiner; entry j of
+  row b goes to ``out[b, j]`` (or ``out[b, positions[p]]`` for sparse inputs), entries at
+  positions >= L are dropped, the rest of ``[B, L, D]`` is zero."""
+  table = np.asarray(table, dtype=np.float32)
+  row_splits = np.asarray(row_splits)
+  nrows = row_splits.shape[0] - 1
+  out = np.zeros((nrows, max_sequence_length, table.shape[1]), dtype=np.float32)
+  for b in range(nrows):
+    for p in range(int(row_splits[b]), int(row_splits[b + 1])):
+      pos = p - int(row_splits[b]) if positions is None else int(positions[p])
+      if pos < max_sequence_length:
+        out[b, pos] = table[ids[p]]
+  return out
+
+
 def scatter_add_grad(grad_out: np.ndarray, ids: np.ndarray, vocab: int) -> np.ndarray:
   """Backward of ``gather``: dense ``[V, D]`` gradient, duplicates summed in
   occurrence order (float32), i.e. ``UnsortedSegmentSum``."""

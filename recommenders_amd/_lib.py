@@ -16,6 +16,7 @@ TFRS_OK, TFRS_EINVAL, TFRS_ENOTIMPL, TFRS_EHIP, TFRS_ENOMEM, TFRS_ESTATE = 0, -1
 c_void_p, c_int, c_i64, c_size_t, c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                              ctypes.c_size_t, ctypes.c_float)
 P = c_void_p
+c_u64 = ctypes.c_uint64
 
 # name -> (restype, argtypes); mirrors include/tfrs_hip.h one to one.
 SIGNATURES = {
@@ -48,6 +49,11 @@ SIGNATURES = {
     "tfrs_embedding_gather_fwd": (c_int, [P, c_i64, c_int, P, c_int, c_i64, P, P, P]),
     "tfrs_embedding_segment_reduce_fwd": (c_int, [P, c_i64, c_int, P, P, c_int, P, c_i64,
                                                   c_int, P, P, P]),
+    "tfrs_embedding_segment_reduce_bwd": (c_int, [P, c_int, P, c_int, P, c_i64, c_int, P, P]),
+    "tfrs_hash_bucket_strong_ids": (c_int, [P, c_int, c_i64, c_i64, c_u64, c_u64, P, P]),
+    "tfrs_hash_bucket_strong_bytes": (c_int, [P, P, c_i64, c_i64, c_u64, c_u64, P, P]),
+    "tfrs_unified_embedding_fwd": (c_int, [P, c_int, P, P, c_i64, c_int, P, P, P, c_i64, c_int, P,
+                                           P, P]),
     "tfrs_embedding_scatter_add_bwd": (c_int, [P, P, P, c_i64, c_int, P, P, c_float, c_float,
                                                c_int, P]),
     "tfrs_embedding_scatter_add_rowscan": (c_int, [P, P, c_int, c_i64, c_int, c_i64, P, P, c_float,

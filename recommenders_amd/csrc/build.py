@@ -28,6 +28,7 @@ SOURCES = [
     "topk_select16.hip",
     "topk_api.hip",
     "embedding.hip",
+    "hashing.hip",
     "softmax.hip",
     "interaction.hip",
 ]

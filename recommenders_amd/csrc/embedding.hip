@@ -168,6 +168,57 @@ __global__ void __launch_bounds__(256) segment_reduce_kernel(
   }
 }
 
+// ---- segment (combiner) reduce backward ---------------------------------------------------
+// d out[b] / d e_p = w_p / den_b for every entry p of segment b (den as in the forward), so the
+// gradient rows of the nnz looked-up entries are grad_rows[p] = (grad_out[b] / den_b) * w_p:
+// the IndexedSlices form (ids, grad_rows) the scatter-add / sparse Adagrad kernels consume.
+// Same lane mapping as the forward (D/4 lanes per segment): grad_out read once per segment,
+// nnz*D*4 bytes written.
+template <typename IdT, int VEC>
+__global__ void __launch_bounds__(256) segment_reduce_bwd_kernel(
+    const float *__restrict__ grad_out, int d, const void *__restrict__ row_splits,
+    const float *__restrict__ weights, int64_t nrows, int combiner,
+    float *__restrict__ grad_rows) {
+  const int per_row = d / VEC;
+  const int64_t total = nrows * per_row;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = t / per_row;
+    const int c = (int)(t - row * per_row);
+    const int64_t lo = load_id<IdT>(row_splits, row), hi = load_id<IdT>(row_splits, row + 1);
+    if (hi <= lo) continue;
+    float den = 1.0f;
+    if (combiner != 0) {
+      float wsum = 0.f, wsq = 0.f;
+      for (int64_t p = lo; p < hi; ++p) {
+        const float w = weights ? weights[p] : 1.0f;
+        wsum += w;
+        wsq = __builtin_fmaf(w, w, wsq);
+      }
+      den = combiner == 1 ? wsum : sqrtf(wsq);
+    }
+    float g[VEC];
+    if (VEC == 4) {
+      const float4 gv = reinterpret_cast<const float4 *>(grad_out)[t];
+      g[0] = gv.x / den;
+      g[1 % VEC] = gv.y / den;
+      g[2 % VEC] = gv.z / den;
+      g[3 % VEC] = gv.w / den;
+    } else {
+      g[0] = grad_out[t] / den;
+    }
+    for (int64_t p = lo; p < hi; ++p) {
+      const float w = weights ? weights[p] : 1.0f;
+      if (VEC == 4) {
+        reinterpret_cast<float4 *>(grad_rows)[p * per_row + c] =
+            make_float4(g[0] * w, g[1 % VEC] * w, g[2 % VEC] * w, g[3 % VEC] * w);
+      } else {
+        grad_rows[p * per_row + c] = g[0] * w;
+      }
+    }
+  }
+}
+
 // ---- scatter-add backward (+ fused Adagrad) --------------------------------------------
 // Input: ids sorted ascending (stable) with perm[i] = original position.  A lane group
 // owns every position that starts a run of equal ids and sums the run's gradient rows in
@@ -185,6 +236,7 @@ __global__ void __launch_bounds__(256) scatter_add_kernel(
     const int64_t i = t / per_row;
     const int c = (int)(t - i * per_row);
     const int64_t id = sorted_ids[i];
+    if (id < 0) continue;                            // padding slot of a sequence feature
     if (i > 0 && sorted_ids[i - 1] == id) continue;  // not the start of a run
     float g[VEC];
 #pragma unroll
@@ -337,6 +389,34 @@ extern "C" int tfrs_embedding_segment_reduce_fwd(const float *table, int64_t voc
       hipLaunchKernelGGL((segment_reduce_kernel<int32_t, 4>), grid, block, 0, s, table, vocab, d, ids, row_splits, weights, nrows, combiner, out, err_flag);
     else
       hipLaunchKernelGGL((segment_reduce_kernel<int32_t, 1>), grid, block, 0, s, table, vocab, d, ids, row_splits, weights, nrows, combiner, out, err_flag);
+  }
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+extern "C" int tfrs_embedding_segment_reduce_bwd(const float *grad_out, int d,
+                                                 const void *row_splits, int splits_are_i64,
+                                                 const float *weights, int64_t nrows,
+                                                 int combiner, float *grad_rows, void *stream) {
+  TFRS_CHECK_ARG(d >= 1 && nrows >= 0, "embedding_segment_reduce_bwd: bad shape");
+  TFRS_CHECK_ARG(combiner >= 0 && combiner <= 2,
+                 "embedding_segment_reduce_bwd: combiner must be 0 (sum), 1 (mean) or 2 (sqrtn)");
+  if (nrows == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(grad_out && row_splits && grad_rows, "embedding_segment_reduce_bwd: NULL pointer");
+  const bool vec = (d % 4 == 0) && (((uintptr_t)grad_out | (uintptr_t)grad_rows) % 16 == 0);
+  const int64_t total = nrows * (vec ? d / 4 : d);
+  const dim3 grid(grid_for(total, 256 * 64)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (splits_are_i64) {
+    if (vec)
+      hipLaunchKernelGGL((segment_reduce_bwd_kernel<int64_t, 4>), grid, block, 0, s, grad_out, d, row_splits, weights, nrows, combiner, grad_rows);
+    else
+      hipLaunchKernelGGL((segment_reduce_bwd_kernel<int64_t, 1>), grid, block, 0, s, grad_out, d, row_splits, weights, nrows, combiner, grad_rows);
+  } else {
+    if (vec)
+      hipLaunchKernelGGL((segment_reduce_bwd_kernel<int32_t, 4>), grid, block, 0, s, grad_out, d, row_splits, weights, nrows, combiner, grad_rows);
+    else
+      hipLaunchKernelGGL((segment_reduce_bwd_kernel<int32_t, 1>), grid, block, 0, s, grad_out, d, row_splits, weights, nrows, combiner, grad_rows);
   }
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;

@@ -1,3 +1,3 @@
 """Experimental components (mirrors tensorflow_recommenders/experimental)."""
 
-from recommenders_amd.experimental import models  # noqa: F401
+from recommenders_amd.experimental import layers, models  # noqa: F401

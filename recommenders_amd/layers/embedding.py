@@ -181,3 +181,9 @@ class _ValidatedGather(_GatherFn):
     ctx.vocab = table.shape[0]
     ctx.table_ref = table
     return gather_rows(table, ids, validate=True)
+
+
+# the feature/table-configured front-end lives beside the raw lookups, as in the reference's
+# layers/embedding package (layers/embedding/__init__.py:17)
+from recommenders_amd.layers.tpu_embedding_layer import (  # noqa: E402,F401
+    FeatureConfig, RaggedIds, SparseIds, TableConfig, TPUEmbedding)

@@ -1,0 +1,411 @@
+"""Feature/table-configured embedding front-end over the HIP lookup kernels.
+
+Mirrors ``tfrs.layers.embedding.TPUEmbedding`` on the branch the reference takes off-TPU
+(``layers/embedding/tpu_embedding_layer.py:596-667`` constructor, ``:702-706`` mid-level
+API = ``TPUEmbeddingForServing``, ``:862-925`` call): a nested structure of
+``FeatureConfig`` objects, each pointing at a (possibly shared) ``TableConfig``; ``call``
+takes ids in the same structure and returns activations in the same structure:
+
+* dense integer tensor -> plain row lookup, rank preserved (``[n, 4]`` ids -> ``[n, 4, D]``);
+* ``RaggedIds`` / ``SparseIds`` -> per-row combine with the table's ``combiner``
+  (``sum`` / ``mean`` / ``sqrtn``) and optional weights; empty rows give zeros;
+* ``max_sequence_length > 0`` -> no combining: ``[B, L, D]`` padded with zeros, rows longer
+  than ``L`` truncated.
+
+``TableConfig`` / ``FeatureConfig`` restate ``tf.tpu.experimental.embedding.{TableConfig,
+FeatureConfig}`` (TensorFlow, not vendored under the reference tree).  Off-TPU the tables
+are ordinary trainable variables updated by the model's optimizer, so here they are
+``torch.nn.Parameter`` s tagged for sliced gradients: with
+``recommenders_amd.optimizers.Adagrad`` the backward emits ``(ids, grad_rows)`` and the fused
+sparse-Adagrad kernel updates the touched rows; with any other optimizer the deterministic
+scatter-add builds the dense table gradient.  The ``optimizer`` constructor argument only
+creates slot variables on TPU in the reference and is kept for signature parity.
+"""
+
+import math
+from typing import Any, Callable, Dict, Iterable, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from recommenders_amd import _lib
+import recommenders_amd.layers.embedding as emb
+
+_COMBINERS = ("sum", "mean", "sqrtn")
+
+
+# ------------------------------------------------------------------------------ configs
+class TableConfig:
+  """``tf.tpu.experimental.embedding.TableConfig``: one embedding table
+  ``[vocabulary_size, dim]``; ``initializer(shape) -> array`` (default: truncated normal,
+  stddev ``1/sqrt(dim)``); ``combiner`` used by every sparse/ragged feature on the table."""
+
+  def __init__(self, vocabulary_size: int, dim: int,
+               initializer: Optional[Callable[[Tuple[int, int]], Any]] = None,
+               optimizer: Any = None, combiner: str = "mean", name: Optional[str] = None):
+    if not isinstance(vocabulary_size, int) or vocabulary_size < 1:
+      raise ValueError(f"vocabulary_size must be an int >= 1; got {vocabulary_size!r}")
+    if not isinstance(dim, int) or dim < 1:
+      raise ValueError(f"dim must be an int >= 1; got {dim!r}")
+    if initializer is not None and not callable(initializer):
+      raise ValueError("initializer must be callable if specified")
+    if combiner not in _COMBINERS:
+      raise ValueError(f"combiner must be one of {list(_COMBINERS)}; got {combiner!r}")
+    self.vocabulary_size = vocabulary_size
+    self.dim = dim
+    self.initializer = initializer
+    self.optimizer = optimizer
+    self.combiner = combiner
+    self.name = name
+
+  def __repr__(self):
+    return (f"TableConfig(vocabulary_size={self.vocabulary_size}, dim={self.dim}, "
+            f"combiner={self.combiner!r}, name={self.name!r})")
+
+
+class FeatureConfig:
+  """``tf.tpu.experimental.embedding.FeatureConfig``: one input feature looked up in
+  ``table``; ``max_sequence_length > 0`` makes it a sequence feature (no combiner)."""
+
+  def __init__(self, table: TableConfig, max_sequence_length: int = 0,
+               validate_weights_and_indices: bool = True,
+               output_shape: Optional[Sequence[int]] = None, name: Optional[str] = None):
+    if not isinstance(table, TableConfig):
+      raise ValueError(f"table must be a TableConfig; got {type(table)}")
+    if not isinstance(max_sequence_length, int) or max_sequence_length < 0:
+      raise ValueError(f"max_sequence_length must be an int >= 0; got {max_sequence_length!r}")
+    if output_shape is not None:
+      raise NotImplementedError("FeatureConfig.output_shape (rank > 2 sparse inputs) is not "
+                                "on the hot path")
+    self.table = table
+    self.max_sequence_length = max_sequence_length
+    self.validate_weights_and_indices = validate_weights_and_indices
+    self.output_shape = output_shape
+    self.name = name
+
+  def __repr__(self):
+    return (f"FeatureConfig(table={self.table!r}, "
+            f"max_sequence_length={self.max_sequence_length}, name={self.name!r})")
+
+
+# ------------------------------------------------------------------- ragged / sparse ids
+class RaggedIds:
+  """Rank-2 ragged ids (the ``tf.RaggedTensor`` inputs of ``TPUEmbedding.call``): row ``b``
+  owns ``values[row_splits[b]:row_splits[b+1]]``.  ``values`` is an integer (or, for
+  weights, float) tensor -- or a NumPy array of strings on its way into ``Hashing``."""
+
+  def __init__(self, values, row_splits):
+    self.values = values if isinstance(values, (torch.Tensor, np.ndarray)) else (
+        torch.as_tensor(values))
+    self.row_splits = torch.as_tensor(row_splits).long()
+    if self.row_splits.ndim != 1 or self.row_splits.numel() < 1:
+      raise ValueError("row_splits must be a vector of length nrows + 1")
+    if int(self.row_splits[0]) != 0 or int(self.row_splits[-1]) != len(self.values):
+      raise ValueError("row_splits must start at 0 and end at len(values)")
+
+  @classmethod
+  def from_row_splits(cls, values, row_splits) -> "RaggedIds":
+    return cls(values, row_splits)
+
+  @classmethod
+  def from_row_lengths(cls, values, row_lengths) -> "RaggedIds":
+    lens = torch.as_tensor(row_lengths).long()
+    return cls(values, torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(lens, 0)]))
+
+  @classmethod
+  def from_nested(cls, rows: Iterable[Iterable]) -> "RaggedIds":
+    rows = [list(r) for r in rows]
+    flat = [x for r in rows for x in r]
+    if flat and isinstance(flat[0], (str, bytes, np.str_, np.bytes_)):
+      values = np.asarray(flat)
+    else:
+      values = torch.as_tensor(flat if flat else [], dtype=torch.long)
+    return cls.from_row_lengths(values, [len(r) for r in rows])
+
+  @property
+  def nrows(self) -> int:
+    return self.row_splits.numel() - 1
+
+  def with_values(self, values) -> "RaggedIds":
+    return RaggedIds(values, self.row_splits)
+
+
+class SparseIds:
+  """Rank-2 sparse ids (``tf.SparseTensor``): ``indices[nnz, 2]`` in row-major order,
+  ``values[nnz]``, ``dense_shape = (batch, width)``."""
+
+  def __init__(self, indices, values, dense_shape):
+    self.indices = torch.as_tensor(indices).long().reshape(-1, 2)
+    self.values = values if isinstance(values, torch.Tensor) else torch.as_tensor(values)
+    self.dense_shape = tuple(int(x) for x in dense_shape)
+    if len(self.dense_shape) != 2:
+      raise ValueError("only rank-2 SparseIds are supported")
+    if self.indices.shape[0] != self.values.shape[0]:
+      raise ValueError("indices and values disagree on nnz")
+
+  def _csr(self) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(row_splits[batch + 1], position-in-row[nnz]); indices must be row-major sorted."""
+    rows = self.indices[:, 0]
+    if rows.numel() and bool((rows[1:] < rows[:-1]).any()):
+      raise ValueError("SparseIds.indices must be sorted in row-major order")
+    counts = torch.bincount(rows, minlength=self.dense_shape[0])
+    splits = torch.cat([torch.zeros(1, dtype=torch.long, device=counts.device),
+                        torch.cumsum(counts, 0)])
+    return splits, self.indices[:, 1]
+
+
+# ----------------------------------------------------------------- nested-structure glue
+def _flatten(structure) -> List[Any]:
+  """tf.nest order: dicts by sorted key, sequences in order, anything else is a leaf."""
+  if isinstance(structure, dict):
+    return [leaf for k in sorted(structure) for leaf in _flatten(structure[k])]
+  if isinstance(structure, (list, tuple)):
+    return [leaf for s in structure for leaf in _flatten(s)]
+  return [structure]
+
+
+def _flatten_with_paths(structure, prefix="") -> List[Tuple[str, Any]]:
+  if isinstance(structure, dict):
+    return [x for k in sorted(structure)
+            for x in _flatten_with_paths(structure[k], f"{prefix}/{k}" if prefix else str(k))]
+  if isinstance(structure, (list, tuple)):
+    return [x for i, s in enumerate(structure)
+            for x in _flatten_with_paths(s, f"{prefix}/{i}" if prefix else str(i))]
+  return [(prefix, structure)]
+
+
+def _pack_as(structure, flat: List[Any]):
+  it = iter(flat)
+
+  def build(s):
+    if isinstance(s, dict):
+      filled = {k: build(s[k]) for k in sorted(s)}
+      return {k: filled[k] for k in s}        # keep the structure's own key order
+    if isinstance(s, (list, tuple)):
+      return type(s)(build(x) for x in s)
+    return next(it)
+
+  return build(structure)
+
+
+def _same_structure(a, b) -> bool:
+  if isinstance(a, dict):
+    return isinstance(b, dict) and sorted(a) == sorted(b) and all(
+        _same_structure(a[k], b[k]) for k in a)
+  if isinstance(a, (list, tuple)):
+    return isinstance(b, (list, tuple)) and len(a) == len(b) and all(
+        _same_structure(x, y) for x, y in zip(a, b))
+  return not isinstance(b, (dict, list, tuple))
+
+
+# --------------------------------------------------------------------------- autograd ops
+class _SegmentReduceFn(torch.autograd.Function):
+  """Combiner lookup with the IndexedSlices-style backward."""
+
+  @staticmethod
+  def forward(ctx, table, ids, row_splits, weights, combiner):
+    ctx.save_for_backward(ids, row_splits, weights if weights is not None else ids.new_empty(0))
+    ctx.has_weights = weights is not None
+    ctx.combiner = combiner
+    ctx.vocab = table.shape[0]
+    ctx.table_ref = table
+    return emb.embedding_lookup_sparse(table, ids, row_splits, weights, combiner)
+
+  @staticmethod
+  def backward(ctx, grad_out):
+    ids, row_splits, weights = ctx.saved_tensors
+    weights = weights if ctx.has_weights else None
+    rows = segment_reduce_grad_rows(grad_out, row_splits, weights, ctx.combiner, ids.numel())
+    table = ctx.table_ref
+    if getattr(table, "_tfrs_sparse_grad", False):
+      table._tfrs_slices.append((ids, rows))
+      return None, None, None, None, None
+    return emb.scatter_add_rows(rows, ids, ctx.vocab), None, None, None, None
+
+
+def segment_reduce_grad_rows(grad_out: torch.Tensor, row_splits: torch.Tensor,
+                             weights: Optional[torch.Tensor], combiner: str,
+                             nnz: int) -> torch.Tensor:
+  """``grad_rows[p] = (grad_out[b] / den_b) * w_p`` for every looked-up entry ``p`` of row
+  ``b`` through ``tfrs_embedding_segment_reduce_bwd``."""
+  g = grad_out.contiguous()
+  d = g.shape[-1]
+  rows = torch.empty((nnz, d), dtype=torch.float32, device=g.device)
+  splits = row_splits.to(g.device).long().contiguous()
+  w = None if weights is None else weights.to(g.device, torch.float32).contiguous()
+  _lib.check(_lib.load().tfrs_embedding_segment_reduce_bwd(
+      _lib.ptr(g), d, _lib.ptr(splits), 1, _lib.ptr(w), splits.numel() - 1,
+      emb._COMBINERS[combiner], _lib.ptr(rows), _lib.current_stream()))
+  return rows
+
+
+class _PaddedGatherFn(torch.autograd.Function):
+  """Sequence lookup: ids padded with -1 gather zero rows; the backward skips them."""
+
+  @staticmethod
+  def forward(ctx, table, padded_ids):
+    ctx.save_for_backward(padded_ids)
+    ctx.vocab = table.shape[0]
+    ctx.table_ref = table
+    return emb.gather_rows(table, padded_ids)
+
+  @staticmethod
+  def backward(ctx, grad_out):
+    (padded_ids,) = ctx.saved_tensors
+    table = ctx.table_ref
+    g = grad_out.contiguous()
+    if getattr(table, "_tfrs_sparse_grad", False):
+      table._tfrs_slices.append((padded_ids, g))
+      return None, None
+    return _scatter_skip_padding(g, padded_ids, ctx.vocab), None
+
+
+def _scatter_skip_padding(grad_out: torch.Tensor, padded_ids: torch.Tensor, vocab: int):
+  """Dense table gradient of a padded lookup: the -1 slots never match a table row in the
+  row-scan kernel and are skipped by the sorted kernel."""
+  return emb.scatter_add_rows(grad_out, padded_ids, vocab)
+
+
+# --------------------------------------------------------------------------------- layer
+def _default_initializer(shape: Tuple[int, int], device) -> torch.Tensor:
+  w = torch.empty(shape, dtype=torch.float32, device=device)
+  std = 1.0 / math.sqrt(shape[1])
+  torch.nn.init.trunc_normal_(w, mean=0.0, std=std, a=-2 * std, b=2 * std)
+  return w
+
+
+class TPUEmbedding(torch.nn.Module):
+  """``tfrs.layers.embedding.TPUEmbedding(feature_config, optimizer, ...)`` off-TPU.
+
+  ``embedding_tables`` maps every distinct ``TableConfig`` to its ``[vocab, dim]`` parameter;
+  features that share a ``TableConfig`` share the parameter (``tpu_embedding_layer_test.py:
+  51-80``: ``watched`` and ``favorited`` both read ``video_table``)."""
+
+  def __init__(self, feature_config, optimizer=None,
+               pipeline_execution_with_tensor_core: bool = False,
+               batch_size: Optional[int] = None, embedding_feature=None,
+               sparse_core_embedding_config=None, device: Optional[torch.device] = None):
+    super().__init__()
+    flat = _flatten_with_paths(feature_config)
+    if not flat:
+      raise ValueError("feature_config holds no FeatureConfig")
+    for path, f in flat:
+      if not isinstance(f, FeatureConfig):
+        raise ValueError(f"feature_config leaf {path!r} is {type(f)}; FeatureConfig expected")
+    self._feature_config = feature_config
+    self._optimizer = optimizer
+    self.batch_size = batch_size
+    dev = device if device is not None else (
+        torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu"))
+    self._tables: Dict[TableConfig, torch.nn.Parameter] = {}
+    params = []
+    for path, f in flat:
+      if f.name is None:
+        f.name = path
+      t = f.table
+      if t in self._tables:
+        continue
+      if t.name is None:
+        t.name = f"table_{len(self._tables)}"
+      shape = (t.vocabulary_size, t.dim)
+      if t.initializer is None:
+        w = _default_initializer(shape, dev)
+      else:
+        w = torch.as_tensor(np.asarray(t.initializer(shape), dtype=np.float32)).reshape(shape)
+        w = w.to(dev).contiguous()
+      p = torch.nn.Parameter(w)
+      p._tfrs_embedding = True
+      self._tables[t] = p
+      params.append(p)
+    names = [t.name for t in self._tables]
+    if len(set(names)) != len(names):
+      raise ValueError(f"TableConfig names must be unique; got {names}")
+    self._params = torch.nn.ParameterList(params)
+
+  @property
+  def embedding_tables(self) -> Dict[TableConfig, torch.nn.Parameter]:
+    return dict(self._tables)
+
+  def update_embedding_table(self, table: TableConfig, embedding_table: torch.Tensor) -> None:
+    """Replace a table's values (``tpu_embedding_layer.py:927-945``)."""
+    if table in self._tables:
+      with torch.no_grad():
+        self._tables[table].copy_(torch.as_tensor(embedding_table, dtype=torch.float32))
+
+  # -- one feature ------------------------------------------------------------------------
+  @staticmethod
+  def _validate(path: str, f: FeatureConfig, inp, weight) -> None:
+    """The argument checks of the CPU lookup, for every feature before any kernel runs."""
+    if weight is not None:
+      if not isinstance(inp, (RaggedIds, SparseIds)):
+        raise ValueError(f"Weight specified for {path}, but input is dense.")
+      if type(weight) is not type(inp):
+        raise ValueError(f"Weight for {path} is of type {type(weight)} but it does not match "
+                         f"type of the input which is {type(inp)}.")
+      if f.max_sequence_length > 0:
+        raise ValueError(f"Weight specified for {path}, but this is a sequence feature.")
+    if isinstance(inp, (RaggedIds, SparseIds)):
+      if not isinstance(inp.values, torch.Tensor):
+        raise ValueError(f"Input {path} holds non-integer values; hash or index them first.")
+    elif isinstance(inp, (torch.Tensor, int, np.integer, np.ndarray)):
+      if f.max_sequence_length > 0:
+        raise ValueError(f"Feature {path} is a sequence feature but a dense tensor was passed.")
+    else:
+      raise ValueError(f"Input {path} is type {type(inp)}. Tensor, SparseIds or RaggedIds "
+                       "expected.")
+
+  def _lookup(self, path: str, f: FeatureConfig, inp, weight) -> torch.Tensor:
+    table = self._tables[f.table]
+    dev = table.device
+    if isinstance(inp, (RaggedIds, SparseIds)):
+      if isinstance(inp, RaggedIds):
+        splits, pos = inp.row_splits, None
+        nrows = inp.nrows
+      else:
+        splits, pos = inp._csr()
+        nrows = inp.dense_shape[0]
+      ids = inp.values.to(dev).long()
+      splits = splits.to(dev)
+      if f.max_sequence_length > 0:
+        return self._sequence_lookup(table, ids, splits, pos, nrows, f.max_sequence_length)
+      w = None if weight is None else weight.values.to(dev, torch.float32)
+      return _SegmentReduceFn.apply(table, ids, splits, w, f.table.combiner)
+    if not isinstance(inp, torch.Tensor):
+      inp = torch.as_tensor(inp)
+    return emb._GatherFn.apply(table, inp.to(dev))
+
+  @staticmethod
+  def _sequence_lookup(table, ids, splits, pos, nrows, max_len) -> torch.Tensor:
+    """``[B, L, D]``: entry ``p`` of row ``b`` lands at ``[b, pos_p]`` if ``pos_p < L``;
+    everything else stays zero (TPU embedding truncates sequences to ``max_sequence_length``)."""
+    dev = table.device
+    lens = splits[1:] - splits[:-1]
+    rows = torch.repeat_interleave(torch.arange(nrows, device=dev), lens)
+    if pos is None:
+      pos = torch.arange(ids.numel(), device=dev) - splits[:-1][rows]
+    else:
+      pos = pos.to(dev)
+    keep = pos < max_len
+    padded = torch.full((nrows, max_len), -1, dtype=torch.long, device=dev)
+    padded[rows[keep], pos[keep]] = ids[keep]
+    return _PaddedGatherFn.apply(table, padded)
+
+  # -- call -------------------------------------------------------------------------------
+  def forward(self, features, weights=None, serving_config=None):
+    config = self._feature_config if serving_config is None else serving_config
+    if not _same_structure(config, features):
+      raise ValueError("features must have the same nested structure as feature_config")
+    flat_cfg = _flatten_with_paths(config)
+    flat_in = _flatten(features)
+    if weights is not None:
+      if not _same_structure(features, weights):
+        raise ValueError("weights must have the same nested structure as features")
+      flat_w = _flatten(weights)
+    else:
+      flat_w = [None] * len(flat_in)
+    for (path, f), inp, w in zip(flat_cfg, flat_in, flat_w):
+      if f.table not in self._tables:
+        raise ValueError(f"feature {path!r} refers to a table this layer does not own")
+      self._validate(path, f, inp, w)
+    out = [self._lookup(path, f, inp, w) for (path, f), inp, w in zip(flat_cfg, flat_in, flat_w)]
+    return _pack_as(config, out)

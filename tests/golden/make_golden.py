@@ -203,7 +203,24 @@ def embedding():
                    expected=[[6, 7], [2, 3], [6, 7], [2, 3]])))
 
 
+def hashing():
+  """SipHash-2-4 known answers (Aumasson & Bernstein, "SipHash: a fast short-input PRF",
+  Appendix A and the 64-entry vector table of the public reference implementation):
+  key = bytes 00..0f, message = bytes 00..len-1, output as a little-endian 64-bit word.
+  These pin the hash under ``Hashing(salt=...)`` of unified_embedding.py:155-159; the
+  TensorFlow glue around it (decimal strings, modulo) is not asserted by the reference's
+  tests (unified_embedding_test.py:73-150 check shapes only) and stays unpinned."""
+  dump("hashing.json", dict(
+      source="SipHash-2-4 reference vectors; key 000102..0f, message 00..len-1",
+      key=[0x0706050403020100, 0x0F0E0D0C0B0A0908],
+      vectors=[dict(len=n, hash=h) for n, h in (
+          (0, "726fdb47dd0e0e31"), (1, "74f839c593dc67fd"), (2, "0d6c8009d9a94f5a"),
+          (3, "85676696d7fb7e2d"), (4, "cf2794e0277187b7"), (5, "18765564cd99a68d"),
+          (15, "a129ca6149be45e5"), (63, "958a324ceb064572"))]))
+
+
 if __name__ == "__main__":
+  hashing()
   topk_grid()
   metric()
   retrieval()
