@@ -259,13 +259,17 @@ int tfrs_inbatch_softmax_ce_fwd(const float *q, const float *c, int64_t nq, int6
                                 const uint8_t *score_mask, float *out_loss,
                                 float *out_lse, float *out_pos, void *workspace,
                                 size_t workspace_bytes, void *stream);
-/* dq[nq, d], dc[nc, d] for upstream scalar gradient `gloss` (device float, NULL = 1). */
+/* dq[nq, d], dc[nc, d] for upstream scalar gradient `gloss` (device float, NULL = 1).
+ * reuse_forward_workspace != 0 promises that `workspace` is the buffer the forward call was
+ * given for the same q, c, sample_weight and has not been written since: the backward then
+ * reuses the operand images the forward left there instead of rebuilding them. */
 int tfrs_inbatch_softmax_ce_bwd(const float *q, const float *c, int64_t nq, int64_t nc,
                                 int d, const float *sample_weight, float inv_temperature,
                                 const float *log_q_correction, const int64_t *cand_ids,
                                 const uint8_t *score_mask, const float *lse,
                                 const float *gloss, float *dq, float *dc, void *workspace,
-                                size_t workspace_bytes, void *stream);
+                                size_t workspace_bytes, int reuse_forward_workspace,
+                                void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Cross.call (layers/feature_interaction/dcn.py:151-186), full rank, linear

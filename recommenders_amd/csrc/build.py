@@ -30,6 +30,7 @@ SOURCES = [
     "embedding.hip",
     "hashing.hip",
     "softmax.hip",
+    "softmax16.hip",
     "interaction.hip",
 ]
 

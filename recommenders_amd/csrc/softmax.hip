@@ -51,6 +51,7 @@ struct SoftmaxArgs {
   const float *lse;     // [nq]
   const float *gloss;   // device scalar or NULL (= 1)
   float *partial;       // [nsplit, rows, d] partial gradients
+  uint32_t *ticket;     // finalize kernel's arrival counter (re-armed by the forward kernel)
 };
 
 __device__ __forceinline__ float make_logit(float dot, int64_t query, int64_t cand,
@@ -77,6 +78,9 @@ __global__ void __launch_bounds__(256) softmax_fwd_kernel(const SoftmaxArgs a_in
     a.ids = nullptr;
     a.mask = nullptr;
   }
+  // re-arms the finalize kernel's ticket: it runs strictly after this kernel (a hipMemsetAsync
+  // node is not reliably ordered against kernel nodes when the step replays from a HIP graph)
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.ticket = 0u;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
@@ -375,6 +379,23 @@ static void launch_bwd(const SoftmaxArgs &a, hipStream_t s) {
     hipLaunchKernelGGL((softmax_bwd_kernel<DP, RQ, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, s, a);
 }
 
+// softmax16.hip: the split-fp16 path
+size_t softmax16_workspace_bytes(int64_t nq, int64_t nc, int d);
+int softmax16_forward(const float *q, const float *c, int64_t nq, int64_t nc, int d, const float *w,
+                      float inv_t, float *out_loss, float *out_lse, float *out_pos, void *ws,
+                      hipStream_t s);
+int softmax16_backward(const float *q, const float *c, int64_t nq, int64_t nc, int d, const float *w,
+                       float inv_t, const float *lse, const float *gloss, float *dq, float *dc,
+                       void *ws, int reuse, hipStream_t s);
+
+// TFRS_SOFTMAX_MODE=f32 keeps everything on the f32-MFMA kernels; default: the split-fp16 path
+// whenever no logit option that needs per-element side inputs is set.
+static bool use_f16_path(const float *corr, const int64_t *ids, const uint8_t *mask) {
+  const char *v = getenv("TFRS_SOFTMAX_MODE");   // read per call: tests switch it
+  const bool f32_only = v && v[0] == 'f' && v[1] == '3';
+  return !f32_only && !corr && !ids && !mask;
+}
+
 }  // namespace tfrs
 
 using namespace tfrs;
@@ -401,7 +422,9 @@ extern "C" size_t tfrs_inbatch_softmax_workspace_bytes(int64_t nq, int64_t nc, i
   const size_t fwd = 2 * al((size_t)nsf * nq * 4) + al((size_t)nq * 4) +
                      al((size_t)((nq + 255) / 256) * 8) + al(4);  // + finalize partials, ticket
   const size_t bwd = al((size_t)nsq * nq * d * 4) + al((size_t)nsc * nc * d * 4);
-  return fwd > bwd ? fwd : bwd;
+  const size_t f32 = fwd > bwd ? fwd : bwd;
+  const size_t f16 = d <= 128 ? softmax16_workspace_bytes(nq, nc, d) : 0;
+  return f32 > f16 ? f32 : f16;
 }
 
 extern "C" int tfrs_inbatch_softmax_ce_fwd(const float *q, const float *c, int64_t nq, int64_t nc,
@@ -417,6 +440,9 @@ extern "C" int tfrs_inbatch_softmax_ce_fwd(const float *q, const float *c, int64
     set_error("inbatch_softmax_ce_fwd: workspace too small");
     return TFRS_ENOMEM;
   }
+  if (use_f16_path(log_q_correction, cand_ids, score_mask))
+    return softmax16_forward(q, c, nq, nc, d, sample_weight, inv_temperature, out_loss, out_lse,
+                             out_pos, workspace, (hipStream_t)stream);
   SoftmaxArgs a = {};
   a.q = q; a.c = c; a.nq = nq; a.nc = nc; a.d = d;
   a.w = sample_weight; a.inv_t = inv_temperature; a.corr = log_q_correction;
@@ -429,8 +455,8 @@ extern "C" int tfrs_inbatch_softmax_ce_fwd(const float *q, const float *c, int64
   const unsigned fin_blocks = (unsigned)((nq + 255) / 256);
   double *block_part = reinterpret_cast<double *>(p); p += al((size_t)fin_blocks * 8);
   uint32_t *ticket = reinterpret_cast<uint32_t *>(p);
+  a.ticket = ticket;
   hipStream_t s = (hipStream_t)stream;
-  TFRS_HIP(hipMemsetAsync(ticket, 0, 4, s));
   switch (softmax_padded_dim(d)) {
     case 8: launch_fwd<8>(a, s); break;
     case 16: launch_fwd<16>(a, s); break;
@@ -451,7 +477,7 @@ extern "C" int tfrs_inbatch_softmax_ce_bwd(const float *q, const float *c, int64
                                            const int64_t *cand_ids, const uint8_t *score_mask,
                                            const float *lse, const float *gloss, float *dq,
                                            float *dc, void *workspace, size_t workspace_bytes,
-                                           void *stream) {
+                                           int reuse_forward_workspace, void *stream) {
   int rc = check_common(q, c, nq, nc, d, "inbatch_softmax_ce_bwd");
   if (rc != TFRS_OK) return rc;
   TFRS_CHECK_ARG(lse && dq && dc && workspace, "inbatch_softmax_ce_bwd: NULL pointer");
@@ -460,6 +486,9 @@ extern "C" int tfrs_inbatch_softmax_ce_bwd(const float *q, const float *c, int64
     return TFRS_ENOMEM;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (use_f16_path(log_q_correction, cand_ids, score_mask))
+    return softmax16_backward(q, c, nq, nc, d, sample_weight, inv_temperature, lse, gloss, dq, dc,
+                              workspace, reuse_forward_workspace, s);
   SoftmaxArgs a = {};
   a.q = q; a.c = c; a.nq = nq; a.nc = nc; a.d = d;
   a.w = sample_weight; a.inv_t = inv_temperature; a.corr = log_q_correction;

@@ -1,0 +1,763 @@
+// softmax16.hip -- the default in-batch sampled-softmax path: split-fp16 MFMA GEMMs.
+//
+// Same contract as softmax.hip (tasks/retrieval.py:172-210 and its gradient, models/base.py:77)
+// for the default Retrieval configuration (optional sample weights and temperature; the
+// sampling-probability correction, accidental-hit removal and score mask stay on the f32
+// kernels).  The f32-input MFMA runs at 157 TFLOP/s, the fp16 one at 2.5 PFLOP/s: every f32
+// operand x is therefore split once per step into two fp16 numbers, x * 2^a = hi + lo with
+// |x * 2^a - hi - lo| <= 2^-22 |x * 2^a| (a = per-row power of two that puts the row's largest
+// magnitude in [2^9, 2^10), so nothing under- or overflows in fp16), and every product of the
+// three GEMMs of a step is formed as  hi*hi + hi*lo + lo*hi  on the fp16 matrix cores with f32
+// accumulation: f32-level accuracy (the dropped lo*lo term is 2^-22 relative) at a third of
+// the fp16 rate, about 5x the f32 MFMA rate.  Power-of-two scales are undone exactly.
+//
+// Kernels of one step:
+//   prep      q, c (f32)  ->  row-major hi/lo images (GEMM1 operands), transposed + permuted
+//             hi/lo images (GEMM2 operand: lane = feature, 8 contiguous halves = the 8 streamed
+//             rows of one MFMA k-group), per-row inverse scales, the largest scale exponent
+//   fwd       workgroup = 4 waves x 32 owned query rows, streams 32-candidate tiles through a
+//             double-buffered LDS stage shared by the 4 waves; S tile = 3*D/16 MFMAs; online
+//             base-2 max / sum-exp per row in registers; partial (max, sum) per split
+//   finalize  combines splits, writes lse / pos / the weighted loss (deterministic)
+//   bwd x2    (rows = queries -> dq, rows = candidates -> dc): recomputes the S tile, forms
+//             T = (softmax - onehot) * streamed-row factor in the accumulator layout, splits it
+//             to fp16 and feeds it straight back as the B operand of the second GEMM
+//             out^T[feature][row] += X^T T  (3*D/16 more MFMAs); no transposes, no atomics
+//   reduce    sums the per-split partial gradients in split order
+//
+// Roofline: MFMA-bound in the large-batch limit, 3 * (2 nq nc d) MFMA flop forward and
+// 3 * (4 nq nc d) per backward kernel, priced against the dense fp16 peak; the ALGORITHMIC
+// flop are 2 nq nc d and 8 nq nc d as before.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "mfma_tile.h"
+
+namespace tfrs {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+struct Side16 {
+  const _Float16 *hi, *lo;        // [np, DP] scaled rows
+  const _Float16 *xt_hi, *xt_lo;  // [np / 32][DP][32] transposed, streamed rows permuted
+  const float *inv;               // [np] 2^-a (undoes the row scale)
+  const uint32_t *bmax;           // [np / 32] per 32-row block: max biased exponent of (|w_r| *) inv_r
+  int64_t n, np;
+};
+
+struct Sm16Args {
+  Side16 q, c;
+  int d;
+  const float *w;
+  float inv_t;
+  int nsplit;
+  int64_t split_len;
+  float *pm, *pl, *ppos;
+  const float *lse;
+  const float *gloss;
+  float *partial;
+};
+
+__device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// streamed-row position p = kk*16 + h*8 + e of the transposed image <-> row of the 32-row tile
+// held by accumulator register r = 8*kk + e of lane half h (tile_row_of_reg)
+__host__ __device__ inline int xt_row_of_pos(int p) {
+  const int kk = p >> 4, hh = (p >> 3) & 1, e = p & 7;
+  return (e & 3) + 8 * ((e >> 2) + 2 * kk) + 4 * hh;
+}
+
+// ---- prep ------------------------------------------------------------------------------
+struct PrepSide {
+  const float *x;
+  int64_t n;
+  const float *w;
+  _Float16 *hi, *lo, *xt_hi, *xt_lo;
+  float *inv;
+  uint32_t *bmax;
+};
+
+// One launch converts both matrices: blocks [0, q_blocks) take 32-row blocks of q, the rest of c.
+template <int DP>
+__global__ void __launch_bounds__(256) sm16_prep_kernel(const PrepSide sq, const PrepSide sc,
+                                                        int q_blocks, int d,
+                                                        uint32_t *__restrict__ ticket) {
+  __shared__ float tile[32][DP + 1];
+  __shared__ float s_scale[32];
+  __shared__ uint32_t s_exp[32];
+  // first kernel of the chain: re-arms the multi-block finalize kernel's ticket (a
+  // hipMemsetAsync node is not reliably ordered against kernel nodes when the step is replayed
+  // from a HIP graph)
+  if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0u;
+  const bool is_q = (int)blockIdx.x < q_blocks;
+  const PrepSide &sd = is_q ? sq : sc;
+  const int blk = is_q ? (int)blockIdx.x : (int)blockIdx.x - q_blocks;
+  const float *__restrict__ x = sd.x;
+  const float *__restrict__ w = sd.w;
+  const int64_t n = sd.n;
+  _Float16 *__restrict__ hi = sd.hi, *__restrict__ lo = sd.lo;
+  _Float16 *__restrict__ xt_hi = sd.xt_hi, *__restrict__ xt_lo = sd.xt_lo;
+  float *__restrict__ inv = sd.inv;
+  uint32_t *__restrict__ bmax = sd.bmax;
+  const int64_t r0 = (int64_t)blk * 32;
+  for (int idx = threadIdx.x; idx < 32 * DP; idx += 256) {
+    const int row = idx / DP, f = idx - row * DP;
+    const int64_t rg = r0 + row;
+    tile[row][f] = (rg < n && f < d) ? x[rg * d + f] : 0.0f;
+  }
+  __syncthreads();
+  {
+    const int row = threadIdx.x >> 3, part = threadIdx.x & 7;
+    float m = 0.0f;
+    for (int f = part; f < DP; f += 8) m = fmaxf(m, fabsf(tile[row][f]));
+    m = fmaxf(m, __shfl_xor(m, 1));
+    m = fmaxf(m, __shfl_xor(m, 2));
+    m = fmaxf(m, __shfl_xor(m, 4));
+    const uint32_t e = (f2u(m) >> 23) & 0xffu;
+    float s = 1.0f, iv = 1.0f;   // rows below 2^-100 flush to zero in fp16: treated as zero rows
+    if (e >= 27u && e < 255u) {
+      s = u2f((263u - e) << 23);   // largest magnitude of the row -> [2^9, 2^10)
+      iv = u2f((e - 9u) << 23);
+    }
+    if (part == 0) {
+      s_scale[row] = s;
+      inv[r0 + row] = iv;
+      uint32_t ev = 0u;
+      if (r0 + row < n) {
+        const float val = iv * (w ? fabsf(w[r0 + row]) : 1.0f);
+        ev = (f2u(val) >> 23) & 0xffu;
+      }
+      s_exp[row] = ev;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t ev = 0u;
+    for (int r = 0; r < 32; ++r) ev = s_exp[r] > ev ? s_exp[r] : ev;
+    bmax[blk] = ev;
+  }
+  for (int idx = threadIdx.x; idx < 32 * DP; idx += 256) {
+    const int row = idx / DP, f = idx - row * DP;
+    const float v = tile[row][f] * s_scale[row];
+    const _Float16 vh = (_Float16)v;
+    hi[(r0 + row) * DP + f] = vh;
+    lo[(r0 + row) * DP + f] = (_Float16)(v - (float)vh);
+  }
+  for (int idx = threadIdx.x; idx < 32 * DP; idx += 256) {
+    const int f = idx >> 5, p = idx & 31;
+    const int srow = xt_row_of_pos(p);
+    const float v = tile[srow][f] * s_scale[srow];
+    const _Float16 vh = (_Float16)v;
+    const int64_t o = ((int64_t)blk * DP + f) * 32 + p;
+    xt_hi[o] = vh;
+    xt_lo[o] = (_Float16)(v - (float)vh);
+  }
+}
+
+// ---- shared pieces of the streaming kernels -------------------------------------------------
+template <int DP>
+struct Stage16 {
+  static constexpr int kRowB = DP * 2 + 16;    // LDS bytes per image row: odd number of 16-B slots
+  static constexpr int kXtB = 64 + 16;         // LDS bytes per transposed row (32 halves + pad)
+  static constexpr int kChunks = 4 * DP;       // 16-byte pieces per image per tile
+  static constexpr int kPer = (kChunks + 255) / 256;
+  static constexpr int kImg = 32 * kRowB;
+  static constexpr int kXt = DP * kXtB;
+  static constexpr int kFwdBuf = 2 * kImg + 128;
+  static constexpr int kBwdBuf = 2 * kImg + 2 * kXt + 3 * 128;
+};
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// S tile (32 streamed rows x 32 owned rows) from the LDS image of the streamed rows.
+template <int DP>
+__device__ __forceinline__ f32x16 tile_dot16(const char *img_hi, const char *img_lo,
+                                             const h8 (&bh)[DP / 16], const h8 (&bl)[DP / 16],
+                                             int j, int h) {
+  constexpr int kRowB = Stage16<DP>::kRowB;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < DP / 16; ++i) {
+    const h8 ah = *reinterpret_cast<const h8 *>(img_hi + j * kRowB + (2 * i + h) * 16);
+    const h8 al = *reinterpret_cast<const h8 *>(img_lo + j * kRowB + (2 * i + h) * 16);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[i], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[i], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[i], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+template <int DP>
+__device__ __forceinline__ void load_owned(h8 (&bh)[DP / 16], h8 (&bl)[DP / 16], const Side16 &R,
+                                           int64_t row, int h) {
+#pragma unroll
+  for (int i = 0; i < DP / 16; ++i) {
+    bh[i] = *reinterpret_cast<const h8 *>(R.hi + row * DP + 16 * i + 8 * h);
+    bl[i] = *reinterpret_cast<const h8 *>(R.lo + row * DP + 16 * i + 8 * h);
+  }
+}
+
+// ---- forward ------------------------------------------------------------------------------
+template <int DP>
+__global__ void __launch_bounds__(256) sm16_fwd_kernel(const Sm16Args a) {
+  typedef Stage16<DP> St;
+  extern __shared__ __attribute__((aligned(16))) char smem16[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t rb = blockIdx.x / a.nsplit;
+  const int sp = (int)(blockIdx.x - rb * a.nsplit);
+  const int64_t base32 = rb * 128 + wave * 32;
+  const int64_t row = base32 + j;
+  const bool rvalid = row < a.q.n;
+
+  h8 bh[DP / 16], bl[DP / 16];
+  load_owned<DP>(bh, bl, a.q, row, h);
+  const float rowfac2 = a.q.inv[row] * a.inv_t * kLog2e;
+
+  const int64_t c_lo = (int64_t)sp * a.split_len;
+  int64_t c_hi = c_lo + a.split_len;
+  if (c_hi > a.c.n) c_hi = a.c.n;
+  const int nt = (int)((c_hi - c_lo + 31) / 32);
+
+  u32x4 st_hi[St::kPer], st_lo[St::kPer];
+  float st_inv = 0.0f;
+  auto stage_load = [&](int64_t s0) {
+#pragma unroll
+    for (int u = 0; u < St::kPer; ++u) {
+      const int ch = tid + u * 256;
+      if (ch < St::kChunks) {
+        const int srow = ch / (DP / 8), slot = ch - srow * (DP / 8);
+        st_hi[u] = *reinterpret_cast<const u32x4 *>(a.c.hi + (s0 + srow) * DP + slot * 8);
+        st_lo[u] = *reinterpret_cast<const u32x4 *>(a.c.lo + (s0 + srow) * DP + slot * 8);
+      }
+    }
+    if (tid < 32) st_inv = a.c.inv[s0 + tid];
+  };
+  auto stage_store = [&](char *buf) {
+#pragma unroll
+    for (int u = 0; u < St::kPer; ++u) {
+      const int ch = tid + u * 256;
+      if (ch < St::kChunks) {
+        const int srow = ch / (DP / 8), slot = ch - srow * (DP / 8);
+        *reinterpret_cast<u32x4 *>(buf + srow * St::kRowB + slot * 16) = st_hi[u];
+        *reinterpret_cast<u32x4 *>(buf + St::kImg + srow * St::kRowB + slot * 16) = st_lo[u];
+      }
+    }
+    if (tid < 32) reinterpret_cast<float *>(buf + 2 * St::kImg)[tid] = st_inv;
+  };
+
+  float m = -__builtin_inff(), l = 0.0f, pos2 = 0.0f;
+  bool haspos = false;
+  if (nt > 0) {
+    stage_load(c_lo);
+    stage_store(smem16);
+  }
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int64_t s0 = c_lo + (int64_t)t * 32;
+    char *buf = smem16 + (t & 1) * St::kFwdBuf;
+    if (t + 1 < nt) stage_load(s0 + 32);
+    const f32x16 acc = tile_dot16<DP>(buf, buf + St::kImg, bh, bl, j, h);
+    const float *sinv = reinterpret_cast<const float *>(buf + 2 * St::kImg);
+    float v2[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 sv = *reinterpret_cast<const f32x4 *>(sinv + 8 * g + 4 * h);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v2[4 * g + k] = acc[4 * g + k] * sv[k] * rowfac2;
+    }
+    if (s0 + 32 > c_hi) {   // ragged last tile
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (s0 + tile_row_of_reg(r, h) >= c_hi) v2[r] = -__builtin_inff();
+    }
+    if (s0 == base32) {     // the tile that holds the positives of this wave's rows
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (tile_row_of_reg(r, h) == j) {
+          pos2 = v2[r];
+          haspos = true;
+        }
+    }
+    float tmax = v2[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, v2[r]);
+    if (tmax > m) {
+      l *= fast_exp2(m - tmax);   // m = -inf on the first tile: exp2(-inf) = 0 and l = 0
+      m = tmax;
+    }
+    if (m > -__builtin_inff()) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) l += fast_exp2(v2[r] - m);
+    }
+    if (t + 1 < nt) stage_store(smem16 + ((t + 1) & 1) * St::kFwdBuf);
+    __syncthreads();
+  }
+  const float m2 = __shfl_xor(m, 32), l2 = __shfl_xor(l, 32);
+  const float mm = fmaxf(m, m2);
+  float ll = 0.0f;
+  if (m > -__builtin_inff()) ll += l * fast_exp2(m - mm);
+  if (m2 > -__builtin_inff()) ll += l2 * fast_exp2(m2 - mm);
+  if (h == 0 && rvalid) {
+    a.pm[(int64_t)sp * a.q.n + row] = mm;     // base-2 domain
+    a.pl[(int64_t)sp * a.q.n + row] = ll;
+  }
+  if (haspos && rvalid) a.ppos[row] = pos2 * kLn2;
+}
+
+// Combines the per-split base-2 (max, sum) pairs, writes lse / pos and the weighted loss.
+// One wave per 64 rows; the splits' partials are fetched in batches of 16 independent loads
+// (one memory latency per batch instead of one per split).  Every block leaves a partial loss
+// in block_part[] and the LAST block to arrive (ticket, re-armed by the prep kernel) adds the
+// partials in block order: the loss does not depend on scheduling.
+__global__ void __launch_bounds__(64) sm16_finalize_kernel(const Sm16Args a, float *out_loss,
+                                                           float *out_lse, float *out_pos,
+                                                           double *block_part, uint32_t *ticket) {
+  const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const bool valid = row < a.q.n;
+  const int64_t r = valid ? row : 0;
+  float mm = -__builtin_inff(), ll = 0.0f;
+  for (int s0 = 0; s0 < a.nsplit; s0 += 16) {
+    float pm[16], pl[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const bool ok = s0 + k < a.nsplit;
+      pm[k] = ok ? a.pm[(int64_t)(s0 + k) * a.q.n + r] : -__builtin_inff();
+      pl[k] = ok ? a.pl[(int64_t)(s0 + k) * a.q.n + r] : 0.0f;
+    }
+    float bm = pm[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) bm = fmaxf(bm, pm[k]);
+    if (bm > mm) {
+      ll *= fast_exp2(mm - bm);
+      mm = bm;
+    }
+    if (mm > -__builtin_inff()) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) ll += pl[k] * fast_exp2(pm[k] - mm);   // pm = -inf: + 0
+    }
+  }
+  double local = 0.0;
+  if (valid) {
+    const float lse = (mm + log2f(ll)) * kLn2;
+    const float pos = a.ppos[row];
+    out_lse[row] = lse;
+    out_pos[row] = pos;
+    const float w = a.w ? a.w[row] : 1.0f;
+    local = (double)w * ((double)lse - (double)pos);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);   // fixed tree: reproducible
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&block_part[blockIdx.x], local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      double total = 0.0;
+      for (unsigned b = 0; b < gridDim.x; ++b)
+        total += __hip_atomic_load(&block_part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *out_loss = (float)total;
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// ---- backward -----------------------------------------------------------------------------
+// RQ = true : workgroup owns 128 queries, streams candidates, emits partial dq.
+// RQ = false: workgroup owns 128 candidates, streams queries, emits partial dc.
+template <int DP, bool RQ>
+__global__ void __launch_bounds__(256) sm16_bwd_kernel(const Sm16Args a) {
+  typedef Stage16<DP> St;
+  constexpr int NFB = DP / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem16[];
+  const Side16 &R = RQ ? a.q : a.c;
+  const Side16 &S = RQ ? a.c : a.q;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t rb = blockIdx.x / a.nsplit;
+  const int sp = (int)(blockIdx.x - rb * a.nsplit);
+  const int64_t base32 = rb * 128 + wave * 32;
+  const int64_t row = base32 + j;
+  const bool rvalid = row < R.n;
+
+  h8 bh[DP / 16], bl[DP / 16];
+  load_owned<DP>(bh, bl, R, row, h);
+  const float rowfac2 = R.inv[row] * a.inv_t * kLog2e;
+
+  // T = (softmax - onehot) * (streamed-row factor) is scaled by 2^G so that its largest
+  // possible magnitude is below 2^14: G from the streamed side's largest factor exponent.
+  uint32_t E = 0u;
+  {
+    __shared__ uint32_t s_e[4];
+    const int64_t nblk = S.np >> 5;
+    for (int64_t b = tid; b < nblk; b += 256) E = S.bmax[b] > E ? S.bmax[b] : E;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)E, off);
+      E = o > E ? o : E;
+    }
+    if (lane == 0) s_e[wave] = E;
+    __syncthreads();
+    E = s_e[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) E = s_e[k] > E ? s_e[k] : E;
+  }
+  int G = E ? 14 - ((int)E - 126) : 0;
+  G = G > 120 ? 120 : (G < -120 ? -120 : G);
+  const float tscale = u2f((uint32_t)(G + 127) << 23), tunscale = u2f((uint32_t)(127 - G) << 23);
+  const float gl = (a.gloss ? *a.gloss : 1.0f) * a.inv_t;
+  float lse2_r = 0.0f, coef_r = gl * tunscale;
+  if (RQ && rvalid) {
+    lse2_r = a.lse[row] * kLog2e;
+    if (a.w) coef_r *= a.w[row];
+  }
+
+  const int64_t s_lo = (int64_t)sp * a.split_len;
+  int64_t s_hi = s_lo + a.split_len;
+  if (s_hi > S.n) s_hi = S.n;
+  const int nt = (int)((s_hi - s_lo + 31) / 32);
+
+  u32x4 st_hi[St::kPer], st_lo[St::kPer], st_xh[St::kPer], st_xl[St::kPer];
+  float st_inv = 0.0f, st_lse = 0.0f, st_tf = 0.0f;
+  auto stage_load = [&](int64_t s0) {
+    const int64_t blk = s0 >> 5;
+#pragma unroll
+    for (int u = 0; u < St::kPer; ++u) {
+      const int ch = tid + u * 256;
+      if (ch < St::kChunks) {
+        const int srow = ch / (DP / 8), slot = ch - srow * (DP / 8);
+        st_hi[u] = *reinterpret_cast<const u32x4 *>(S.hi + (s0 + srow) * DP + slot * 8);
+        st_lo[u] = *reinterpret_cast<const u32x4 *>(S.lo + (s0 + srow) * DP + slot * 8);
+        const int f = ch >> 2, xs = ch & 3;
+        st_xh[u] = *reinterpret_cast<const u32x4 *>(S.xt_hi + (blk * DP + f) * 32 + xs * 8);
+        st_xl[u] = *reinterpret_cast<const u32x4 *>(S.xt_lo + (blk * DP + f) * 32 + xs * 8);
+      }
+    }
+    if (tid < 32) {
+      const int64_t sr = s0 + tid;
+      st_inv = S.inv[sr];
+      if (RQ) {
+        st_tf = st_inv * tscale;
+      } else {
+        const bool ok = sr < S.n;
+        st_lse = ok ? a.lse[sr] * kLog2e : 0.0f;
+        st_tf = (ok && a.w ? a.w[sr] : 1.0f) * st_inv * tscale;
+      }
+    }
+  };
+  auto stage_store = [&](char *buf) {
+#pragma unroll
+    for (int u = 0; u < St::kPer; ++u) {
+      const int ch = tid + u * 256;
+      if (ch < St::kChunks) {
+        const int srow = ch / (DP / 8), slot = ch - srow * (DP / 8);
+        *reinterpret_cast<u32x4 *>(buf + srow * St::kRowB + slot * 16) = st_hi[u];
+        *reinterpret_cast<u32x4 *>(buf + St::kImg + srow * St::kRowB + slot * 16) = st_lo[u];
+        const int f = ch >> 2, xs = ch & 3;
+        *reinterpret_cast<u32x4 *>(buf + 2 * St::kImg + f * St::kXtB + xs * 16) = st_xh[u];
+        *reinterpret_cast<u32x4 *>(buf + 2 * St::kImg + St::kXt + f * St::kXtB + xs * 16) = st_xl[u];
+      }
+    }
+    if (tid < 32) {
+      float *fl = reinterpret_cast<float *>(buf + 2 * St::kImg + 2 * St::kXt);
+      fl[tid] = st_inv;
+      fl[32 + tid] = st_lse;
+      fl[64 + tid] = st_tf;
+    }
+  };
+
+  f32x16 outacc[NFB];
+#pragma unroll
+  for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) outacc[fb][r] = 0.0f;
+
+  if (nt > 0) {
+    stage_load(s_lo);
+    stage_store(smem16);
+  }
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int64_t s0 = s_lo + (int64_t)t * 32;
+    char *buf = smem16 + (t & 1) * St::kBwdBuf;
+    if (t + 1 < nt) stage_load(s0 + 32);
+    const f32x16 acc = tile_dot16<DP>(buf, buf + St::kImg, bh, bl, j, h);
+    const float *fl = reinterpret_cast<const float *>(buf + 2 * St::kImg + 2 * St::kXt);
+    float tp[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 sv = *reinterpret_cast<const f32x4 *>(fl + 8 * g + 4 * h);
+      f32x4 ls = {lse2_r, lse2_r, lse2_r, lse2_r};
+      if (!RQ) ls = *reinterpret_cast<const f32x4 *>(fl + 32 + 8 * g + 4 * h);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v2 = acc[4 * g + k] * sv[k] * rowfac2;
+        tp[4 * g + k] = fast_exp2(v2 - ls[k]);
+      }
+    }
+    if (s0 == base32) {     // the tile that holds the positives: softmax - onehot
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (tile_row_of_reg(r, h) == j) tp[r] -= 1.0f;
+    }
+    if (s0 + 32 > s_hi) {   // ragged last tile: rows past the end contribute nothing
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (s0 + tile_row_of_reg(r, h) >= s_hi) tp[r] = 0.0f;
+    }
+    h8 th[2], tl[2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 tf = *reinterpret_cast<const f32x4 *>(fl + 64 + 8 * g + 4 * h);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = 4 * g + k;
+        const float v = tp[r] * tf[k];
+        const _Float16 vh = (_Float16)v;
+        th[r >> 3][r & 7] = vh;
+        tl[r >> 3][r & 7] = (_Float16)(v - (float)vh);
+      }
+    }
+    // out^T[feature][owned row] += sum over the tile's streamed rows X'[srow][feature] T[srow][row]
+    const char *xh = buf + 2 * St::kImg, *xl = xh + St::kXt;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int off = (fb * 32 + j) * St::kXtB + (kk * 16 + h * 8) * 2;
+        const h8 ah = *reinterpret_cast<const h8 *>(xh + off);
+        const h8 al = *reinterpret_cast<const h8 *>(xl + off);
+        outacc[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, th[kk], outacc[fb], 0, 0, 0);
+        outacc[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, tl[kk], outacc[fb], 0, 0, 0);
+        outacc[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, th[kk], outacc[fb], 0, 0, 0);
+      }
+    if (t + 1 < nt) stage_store(smem16 + ((t + 1) & 1) * St::kBwdBuf);
+    __syncthreads();
+  }
+
+  if (rvalid) {
+    float *dst = a.partial + ((int64_t)sp * R.n + row) * a.d;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int feat = fb * 32 + tile_row_of_reg(r, h);
+        if (feat < a.d) dst[feat] = outacc[fb][r] * coef_r;
+      }
+  }
+}
+
+// Both gradients' partials in one launch (elements [0, count_a) of a, then b).
+__global__ void __launch_bounds__(256) sm16_reduce2_kernel(const float *pa, int na, int64_t count_a,
+                                                           float *out_a, const float *pb, int nb,
+                                                           int64_t count_b, float *out_b) {
+  const int64_t total = count_a + count_b;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const bool first = t < count_a;
+    const float *p = first ? pa : pb;
+    const int64_t i = first ? t : t - count_a, cnt = first ? count_a : count_b;
+    const int ns = first ? na : nb;
+    float acc = 0.0f;
+    for (int sp = 0; sp < ns; ++sp) acc += p[(int64_t)sp * cnt + i];
+    (first ? out_a : out_b)[i] = acc;
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------
+static inline size_t al16(size_t x) { return (x + 255) / 256 * 256; }
+static inline int64_t pad128(int64_t n) { return (n + 127) / 128 * 128; }
+static inline int dp_of(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : 128); }
+
+static void plan16(int64_t n_rows, int64_t n_stream, int *nsplit, int64_t *split_len) {
+  const int64_t row_blocks = (n_rows + 127) / 128;
+  const int64_t tiles = (n_stream + 31) / 32;
+  static const int64_t target = [] {
+    const char *v = getenv("TFRS_SOFTMAX_WGS");
+    return (v && *v) ? (int64_t)atoll(v) : (int64_t)512;   // 2 workgroups per CU
+  }();
+  int64_t want = (target + row_blocks - 1) / row_blocks;
+  if (want > tiles) want = tiles;
+  if (want < 1) want = 1;
+  const int64_t per = (tiles + want - 1) / want;
+  *split_len = per * 32;
+  *nsplit = (int)((tiles + per - 1) / per);
+}
+
+struct Layout16 {
+  size_t header, q_hi, q_lo, q_xh, q_xl, q_inv, q_bmax, c_hi, c_lo, c_xh, c_xl, c_inv, c_bmax, scratch, total;
+};
+
+static Layout16 layout16(int64_t nq, int64_t nc, int d) {
+  const int dp = dp_of(d);
+  const int64_t nqp = pad128(nq), ncp = pad128(nc);
+  Layout16 L;
+  size_t o = 0;
+  L.header = o; o += 256;                                    // finalize ticket
+  const size_t iq = al16((size_t)nqp * dp * 2), ic = al16((size_t)ncp * dp * 2);
+  L.q_hi = o; o += iq; L.q_lo = o; o += iq; L.q_xh = o; o += iq; L.q_xl = o; o += iq;
+  L.q_inv = o; o += al16((size_t)nqp * 4);
+  L.q_bmax = o; o += al16((size_t)(nqp / 32) * 4);
+  L.c_hi = o; o += ic; L.c_lo = o; o += ic; L.c_xh = o; o += ic; L.c_xl = o; o += ic;
+  L.c_inv = o; o += al16((size_t)ncp * 4);
+  L.c_bmax = o; o += al16((size_t)(ncp / 32) * 4);
+  L.scratch = o;
+  int nsf, nsq, nsc;
+  int64_t len;
+  plan16(nq, nc, &nsf, &len);
+  plan16(nq, nc, &nsq, &len);
+  plan16(nc, nq, &nsc, &len);
+  const size_t fwd = 2 * al16((size_t)nsf * nq * 4) + al16((size_t)nq * 4) +
+                     al16((size_t)((nq + 63) / 64) * 8);
+  const size_t bwd = al16((size_t)nsq * nq * d * 4) + al16((size_t)nsc * nc * d * 4);
+  L.total = o + (fwd > bwd ? fwd : bwd);
+  return L;
+}
+
+size_t softmax16_workspace_bytes(int64_t nq, int64_t nc, int d) { return layout16(nq, nc, d).total; }
+
+static void fill_sides(Sm16Args *a, char *ws, const Layout16 &L, int64_t nq, int64_t nc) {
+  a->q = {reinterpret_cast<const _Float16 *>(ws + L.q_hi), reinterpret_cast<const _Float16 *>(ws + L.q_lo),
+          reinterpret_cast<const _Float16 *>(ws + L.q_xh), reinterpret_cast<const _Float16 *>(ws + L.q_xl),
+          reinterpret_cast<const float *>(ws + L.q_inv), reinterpret_cast<const uint32_t *>(ws + L.q_bmax),
+          nq, pad128(nq)};
+  a->c = {reinterpret_cast<const _Float16 *>(ws + L.c_hi), reinterpret_cast<const _Float16 *>(ws + L.c_lo),
+          reinterpret_cast<const _Float16 *>(ws + L.c_xh), reinterpret_cast<const _Float16 *>(ws + L.c_xl),
+          reinterpret_cast<const float *>(ws + L.c_inv), reinterpret_cast<const uint32_t *>(ws + L.c_bmax),
+          nc, pad128(nc)};
+}
+
+template <int DP>
+static int prep16(const float *q, const float *c, int64_t nq, int64_t nc, int d, const float *w,
+                  char *ws, const Layout16 &L, hipStream_t s) {
+  const PrepSide sq = {q, nq, w, reinterpret_cast<_Float16 *>(ws + L.q_hi),
+                       reinterpret_cast<_Float16 *>(ws + L.q_lo), reinterpret_cast<_Float16 *>(ws + L.q_xh),
+                       reinterpret_cast<_Float16 *>(ws + L.q_xl), reinterpret_cast<float *>(ws + L.q_inv),
+                       reinterpret_cast<uint32_t *>(ws + L.q_bmax)};
+  const PrepSide sc = {c, nc, nullptr, reinterpret_cast<_Float16 *>(ws + L.c_hi),
+                       reinterpret_cast<_Float16 *>(ws + L.c_lo), reinterpret_cast<_Float16 *>(ws + L.c_xh),
+                       reinterpret_cast<_Float16 *>(ws + L.c_xl), reinterpret_cast<float *>(ws + L.c_inv),
+                       reinterpret_cast<uint32_t *>(ws + L.c_bmax)};
+  const int qb = (int)(pad128(nq) / 32), cb = (int)(pad128(nc) / 32);
+  hipLaunchKernelGGL((sm16_prep_kernel<DP>), dim3((unsigned)(qb + cb)), dim3(256), 0, s, sq, sc, qb, d,
+                     reinterpret_cast<uint32_t *>(ws + L.header));
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+template <typename K>
+static int allow_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024)
+    TFRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return TFRS_OK;
+}
+
+template <int DP>
+static int fwd16(const float *q, const float *c, int64_t nq, int64_t nc, int d, const float *w,
+                 float inv_t, float *out_loss, float *out_lse, float *out_pos, char *ws,
+                 hipStream_t s) {
+  const Layout16 L = layout16(nq, nc, d);
+  int rc = prep16<DP>(q, c, nq, nc, d, w, ws, L, s);
+  if (rc != TFRS_OK) return rc;
+  Sm16Args a = {};
+  fill_sides(&a, ws, L, nq, nc);
+  a.d = d; a.w = w; a.inv_t = inv_t;
+  plan16(nq, nc, &a.nsplit, &a.split_len);
+  char *p = ws + L.scratch;
+  a.pm = reinterpret_cast<float *>(p); p += al16((size_t)a.nsplit * nq * 4);
+  a.pl = reinterpret_cast<float *>(p); p += al16((size_t)a.nsplit * nq * 4);
+  a.ppos = reinterpret_cast<float *>(p); p += al16((size_t)nq * 4);
+  double *block_part = reinterpret_cast<double *>(p);
+  uint32_t *ticket = reinterpret_cast<uint32_t *>(ws + L.header);
+  const size_t lds = 2 * Stage16<DP>::kFwdBuf;
+  rc = allow_lds(sm16_fwd_kernel<DP>, lds);
+  if (rc != TFRS_OK) return rc;
+  const int64_t wgs = ((nq + 127) / 128) * a.nsplit;
+  hipLaunchKernelGGL((sm16_fwd_kernel<DP>), dim3((unsigned)wgs), dim3(256), lds, s, a);
+  TFRS_LAUNCH_CHECK();
+  const unsigned fin_blocks = (unsigned)((nq + 63) / 64);
+  hipLaunchKernelGGL(sm16_finalize_kernel, dim3(fin_blocks), dim3(64), 0, s, a, out_loss, out_lse,
+                     out_pos, block_part, ticket);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+template <int DP>
+static int bwd16(const float *q, const float *c, int64_t nq, int64_t nc, int d, const float *w,
+                 float inv_t, const float *lse, const float *gloss, float *dq, float *dc, char *ws,
+                 int reuse, hipStream_t s) {
+  const Layout16 L = layout16(nq, nc, d);
+  if (!reuse) {
+    int rc = prep16<DP>(q, c, nq, nc, d, w, ws, L, s);
+    if (rc != TFRS_OK) return rc;
+  }
+  Sm16Args a = {};
+  fill_sides(&a, ws, L, nq, nc);
+  a.d = d; a.w = w; a.inv_t = inv_t; a.lse = lse; a.gloss = gloss;
+  const size_t lds = 2 * Stage16<DP>::kBwdBuf;
+  int rc = allow_lds(sm16_bwd_kernel<DP, true>, lds);
+  if (rc != TFRS_OK) return rc;
+  rc = allow_lds(sm16_bwd_kernel<DP, false>, lds);
+  if (rc != TFRS_OK) return rc;
+  char *p = ws + L.scratch;
+
+  plan16(nq, nc, &a.nsplit, &a.split_len);
+  const int nsq = a.nsplit;
+  float *part_q = nsq == 1 ? dq : reinterpret_cast<float *>(p);
+  a.partial = part_q;
+  hipLaunchKernelGGL((sm16_bwd_kernel<DP, true>), dim3((unsigned)(((nq + 127) / 128) * nsq)), dim3(256),
+                     lds, s, a);
+  TFRS_LAUNCH_CHECK();
+  p += al16((size_t)nsq * nq * d * 4);
+  plan16(nc, nq, &a.nsplit, &a.split_len);
+  const int nsc = a.nsplit;
+  float *part_c = nsc == 1 ? dc : reinterpret_cast<float *>(p);
+  a.partial = part_c;
+  hipLaunchKernelGGL((sm16_bwd_kernel<DP, false>), dim3((unsigned)(((nc + 127) / 128) * nsc)),
+                     dim3(256), lds, s, a);
+  TFRS_LAUNCH_CHECK();
+  // per-split partial gradients -> dq, dc (a side with a single split wrote its output directly)
+  const int64_t cq = nsq > 1 ? nq * d : 0, cc = nsc > 1 ? nc * d : 0;
+  if (cq + cc > 0) {
+    hipLaunchKernelGGL(sm16_reduce2_kernel, dim3((unsigned)std::min<int64_t>((cq + cc + 255) / 256, 4096)),
+                       dim3(256), 0, s, part_q, nsq, cq, dq, part_c, nsc, cc, dc);
+    TFRS_LAUNCH_CHECK();
+  }
+  return TFRS_OK;
+}
+
+int softmax16_forward(const float *q, const float *c, int64_t nq, int64_t nc, int d, const float *w,
+                      float inv_t, float *out_loss, float *out_lse, float *out_pos, void *ws,
+                      hipStream_t s) {
+  char *p = static_cast<char *>(ws);
+  switch (dp_of(d)) {
+    case 32: return fwd16<32>(q, c, nq, nc, d, w, inv_t, out_loss, out_lse, out_pos, p, s);
+    case 64: return fwd16<64>(q, c, nq, nc, d, w, inv_t, out_loss, out_lse, out_pos, p, s);
+    default: return fwd16<128>(q, c, nq, nc, d, w, inv_t, out_loss, out_lse, out_pos, p, s);
+  }
+}
+
+int softmax16_backward(const float *q, const float *c, int64_t nq, int64_t nc, int d, const float *w,
+                       float inv_t, const float *lse, const float *gloss, float *dq, float *dc,
+                       void *ws, int reuse, hipStream_t s) {
+  char *p = static_cast<char *>(ws);
+  switch (dp_of(d)) {
+    case 32: return bwd16<32>(q, c, nq, nc, d, w, inv_t, lse, gloss, dq, dc, p, reuse, s);
+    case 64: return bwd16<64>(q, c, nq, nc, d, w, inv_t, lse, gloss, dq, dc, p, reuse, s);
+    default: return bwd16<128>(q, c, nq, nc, d, w, inv_t, lse, gloss, dq, dc, p, reuse, s);
+  }
+}
+
+}  // namespace tfrs

@@ -49,6 +49,15 @@ class Adagrad(torch.optim.Optimizer):
       state["accumulator"] = torch.full_like(p, init)
     return state["accumulator"]
 
+  @torch.no_grad()
+  def reset_state_(self) -> None:
+    """Accumulators back to ``initial_accumulator_value`` in place (same storage)."""
+    for group in self.param_groups:
+      for p in group["params"]:
+        acc = self.state[p].get("accumulator") if p in self.state else None
+        if acc is not None:
+          acc.fill_(group["initial_accumulator_value"])
+
   def zero_grad(self, set_to_none: bool = True) -> None:
     super().zero_grad(set_to_none=set_to_none)
     for group in self.param_groups:

@@ -14,6 +14,7 @@ user-supplied ``loss``, ``num_hard_negatives`` (:205-208) and multi-head (3-D) q
 sequence on that tensor.
 """
 
+import os
 from typing import Callable, List, Optional, Sequence, Union
 
 import numpy as np
@@ -47,18 +48,17 @@ class _InBatchSoftmaxFn(torch.autograd.Function):
         _lib.ptr(q), _lib.ptr(c), nq, nc, d, _lib.ptr(sample_weight), float(inv_t),
         _lib.ptr(log_corr), _lib.ptr(cand_ids), _lib.ptr(score_mask), _lib.ptr(loss),
         _lib.ptr(lse), _lib.ptr(pos), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
-    ctx.save_for_backward(q, c, sample_weight, log_corr, cand_ids, score_mask, lse)
+    # the workspace keeps the forward's operand images for the backward (split-fp16 path)
+    ctx.save_for_backward(q, c, sample_weight, log_corr, cand_ids, score_mask, lse, ws)
     ctx.inv_t = float(inv_t)
     return loss
 
   @staticmethod
   def backward(ctx, gloss):
-    q, c, sample_weight, log_corr, cand_ids, score_mask, lse = ctx.saved_tensors
+    q, c, sample_weight, log_corr, cand_ids, score_mask, lse, ws = ctx.saved_tensors
     lib = _lib.load()
     nq, d = q.shape
     nc = c.shape[0]
-    ws = torch.empty((lib.tfrs_inbatch_softmax_workspace_bytes(nq, nc, d),),
-                     dtype=torch.uint8, device=q.device)
     dq = torch.empty_like(q)
     dc = torch.empty_like(c)
     g = gloss.to(torch.float32).contiguous()
@@ -66,6 +66,7 @@ class _InBatchSoftmaxFn(torch.autograd.Function):
         _lib.ptr(q), _lib.ptr(c), nq, nc, d, _lib.ptr(sample_weight), ctx.inv_t,
         _lib.ptr(log_corr), _lib.ptr(cand_ids), _lib.ptr(score_mask), _lib.ptr(lse),
         _lib.ptr(g), _lib.ptr(dq), _lib.ptr(dc), _lib.ptr(ws), ws.numel(),
+        0 if os.environ.get("TFRS_SOFTMAX_NO_REUSE") else 1,
         _lib.current_stream()))
     return dq, dc, None, None, None, None, None
 

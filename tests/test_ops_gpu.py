@@ -101,7 +101,19 @@ def test_embedding_combiners():
 
 
 # ---------------------------------------------------------------------------- retrieval
-def test_retrieval_golden_cases():
+@pytest.fixture(params=["f16", "f32"])
+def softmax_mode(request, monkeypatch):
+  """The in-batch softmax has two arithmetic paths that must both meet the tolerances: the
+  default split-fp16 MFMA kernels (hi*hi + hi*lo + lo*hi, f32 accumulate) and the f32-MFMA
+  kernels (also used whenever a per-element logit option is set)."""
+  if request.param == "f32":
+    monkeypatch.setenv("TFRS_SOFTMAX_MODE", "f32")
+  else:
+    monkeypatch.delenv("TFRS_SOFTMAX_MODE", raising=False)
+  return request.param
+
+
+def test_retrieval_golden_cases(softmax_mode):
   """tasks/retrieval_test.py:33-71,112-137,181-213,257-298 on the HIP path."""
   import recommenders_amd as tfrs
   g = load_golden("retrieval.json")
@@ -133,7 +145,7 @@ def test_retrieval_golden_cases():
 
 @pytest.mark.parametrize("nq,nc,d", [(2, 2, 3), (64, 64, 64), (100, 333, 20), (257, 300, 128),
                                      (512, 512, 32), (1000, 1024, 64)])
-def test_inbatch_softmax_options_vs_oracle(nq, nc, d):
+def test_inbatch_softmax_options_vs_oracle(nq, nc, d, softmax_mode):
   """loss within 1e-5 relative, gradients within 1e-4 relative (+1e-6 abs) of the
   float64 oracle, for every fused logit option."""
   from recommenders_amd.tasks.retrieval import in_batch_softmax_loss
@@ -177,6 +189,33 @@ def test_inbatch_softmax_options_vs_oracle(nq, nc, d):
     scale = max(np.abs(dc_ref).max(), 1e-6)
     np.testing.assert_allclose(_np(tc.grad) / 2.0, dc_ref, rtol=1e-4, atol=1e-5 * scale,
                                err_msg=str(sorted(kw)))
+
+
+@pytest.mark.parametrize("nq,nc,d,scale", [(4096, 4096, 64, 0.05), (300, 4500, 100, 1.0),
+                                           (1024, 1024, 128, 30.0), (130, 130, 7, 1e-3)])
+def test_inbatch_softmax_f16_path_sizes(nq, nc, d, scale):
+  """The split-fp16 path at the MovieLens batch (several splits, 32 row blocks), with ragged
+  tiles, D up to 128, tiny and large embedding magnitudes, uneven row norms, sample weights
+  spanning 4 decades and a temperature: same tolerances as the f32 path."""
+  from recommenders_amd.tasks.retrieval import in_batch_softmax_loss
+  rng = np.random.default_rng(nq + d)
+  # query magnitude `scale`, candidate magnitude chosen so that logits stay O(1): the softmax is
+  # not saturated and gradients are well conditioned, while the operands sit decades apart
+  cscale = 2.0 / (scale * np.sqrt(d))
+  q = (rng.normal(size=(nq, d)) * scale * np.exp(0.5 * rng.normal(size=(nq, 1)))).astype(np.float32)
+  c = (rng.normal(size=(nc, d)) * cscale * np.exp(0.5 * rng.normal(size=(nc, 1)))).astype(np.float32)
+  q[5] = 0.0                                        # a zero row
+  w = (10.0 ** rng.uniform(-2, 2, size=nq)).astype(np.float32)
+  for kw in (dict(), dict(sample_weight=w, temperature=0.5)):
+    ref = o_ret.loss(q, c, **kw)
+    dq_ref, dc_ref = o_ret.loss_grads(q, c, **kw)
+    tq, tc = _t(q).requires_grad_(True), _t(c).requires_grad_(True)
+    loss = in_batch_softmax_loss(tq, tc, sample_weight=None if not kw else _t(w),
+                                 temperature=kw.get("temperature"))
+    np.testing.assert_allclose(float(loss), float(ref), rtol=1e-5)
+    (loss * 0.5).backward()
+    for got, want in ((_np(tq.grad) * 2.0, dq_ref), (_np(tc.grad) * 2.0, dc_ref)):
+      np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5 * max(np.abs(want).max(), 1e-6))
 
 
 def test_retrieval_hard_negatives_and_custom_paths():
@@ -353,6 +392,48 @@ def test_model_train_step_contract():
   ev = model.test_step(batch)
   assert "factorized_top_k/top_10_categorical_accuracy" in ev
   assert 0.0 <= float(ev["factorized_top_k/top_10_categorical_accuracy"]) <= 1.0
+
+
+def test_graphed_train_step_matches_eager():
+  """Model.make_graphed_train_step: the HIP-graph replay of train_step walks exactly the
+  eager trajectory (same kernels, same order) and leaves no trace of its warm-up."""
+  import recommenders_amd as tfrs
+  rng = np.random.default_rng(3)
+
+  class TwoTower(tfrs.Model):
+    def __init__(self):
+      super().__init__()
+      self.user_model = tfrs.layers.embedding.Embedding(943, 64)
+      self.item_model = tfrs.layers.embedding.Embedding(1682, 64)
+      self.task = tfrs.tasks.Retrieval()
+
+    def compute_loss(self, features, training=False):
+      return self.task(self.user_model(features["user_id"]), self.item_model(features["movie_id"]),
+                       compute_metrics=False)
+
+  def make():
+    torch.manual_seed(5)
+    m = TwoTower()
+    m.compile(optimizer=tfrs.optimizers.Adagrad(m.parameters(), learning_rate=0.5))
+    return m
+
+  batches = [{"user_id": _t(rng.integers(0, 943, size=4096)),
+              "movie_id": _t(rng.integers(0, 1682, size=4096))} for _ in range(4)]
+  eager, graphed = make(), make()
+  for a, b in zip(eager.parameters(), graphed.parameters()):
+    np.testing.assert_array_equal(_np(a), _np(b))
+  step = graphed.make_graphed_train_step(batches[0])
+  for a, b in zip(eager.parameters(), graphed.parameters()):      # warm-up rolled back
+    np.testing.assert_array_equal(_np(a), _np(b))
+  for batch in batches + batches:
+    le = eager.train_step(batch)
+    lg = step(batch)
+    assert float(le["loss"]) == float(lg["loss"])
+    assert set(lg) == set(le)
+  for a, b in zip(eager.parameters(), graphed.parameters()):
+    np.testing.assert_array_equal(_np(a), _np(b))
+  with pytest.raises(ValueError, match="captured for"):
+    step({"user_id": batches[0]["user_id"][:10], "movie_id": batches[0]["movie_id"][:10]})
 
 
 def test_adagrad_optimizer_sparse_slices_match_dense_formula():
