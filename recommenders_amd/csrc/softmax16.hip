@@ -11,19 +11,26 @@
 // accumulation: f32-level accuracy (the dropped lo*lo term is 2^-22 relative) at a third of
 // the fp16 rate, about 5x the f32 MFMA rate.  Power-of-two scales are undone exactly.
 //
+// Data layout: each matrix becomes an array of 32-row RECORDS that already have the LDS layout
+// of one streamed tile,
+//   [hi rows | lo rows | inv scale | lse2 | w*inv | transposed hi | transposed lo]
+// (row-major rows padded to an odd number of 16-byte slots -> conflict-free ds_read_b128; the
+// transposed part is the second GEMM's operand: lane = feature, 8 contiguous halves = the 8
+// streamed rows of one MFMA k-group, in accumulator-register order), so a tile is staged with
+// straight direct-to-LDS copies (global_load_lds, no registers) into a ring of LDS buffers that
+// runs up to 2 tiles ahead of the MFMAs.
+//
 // Kernels of one step:
-//   prep      q, c (f32)  ->  row-major hi/lo images (GEMM1 operands), transposed + permuted
-//             hi/lo images (GEMM2 operand: lane = feature, 8 contiguous halves = the 8 streamed
-//             rows of one MFMA k-group), per-row inverse scales, the largest scale exponent
-//   fwd       workgroup = 4 waves x 32 owned query rows, streams 32-candidate tiles through a
-//             double-buffered LDS stage shared by the 4 waves; S tile = 3*D/16 MFMAs; online
-//             base-2 max / sum-exp per row in registers; partial (max, sum) per split
-//   finalize  combines splits, writes lse / pos / the weighted loss (deterministic)
+//   prep      q, c (f32) -> records, per-block largest scale exponent        (1 launch)
+//   fwd       workgroup = 4 waves x 32 owned query rows, streams candidate tiles; S tile =
+//             3*D/16 MFMAs; online base-2 max / sum-exp per row in registers
+//   finalize  combines splits, writes lse / pos / the weighted loss (deterministic) and the
+//             per-query lse2 the backward needs into the query records
 //   bwd x2    (rows = queries -> dq, rows = candidates -> dc): recomputes the S tile, forms
 //             T = (softmax - onehot) * streamed-row factor in the accumulator layout, splits it
 //             to fp16 and feeds it straight back as the B operand of the second GEMM
 //             out^T[feature][row] += X^T T  (3*D/16 more MFMAs); no transposes, no atomics
-//   reduce    sums the per-split partial gradients in split order
+//   reduce    sums the per-split partial gradients in split order             (1 launch)
 //
 // Roofline: MFMA-bound in the large-batch limit, 3 * (2 nq nc d) MFMA flop forward and
 // 3 * (4 nq nc d) per backward kernel, priced against the dense fp16 peak; the ALGORITHMIC
@@ -37,15 +44,32 @@
 namespace tfrs {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
+// Byte layout of one 32-row record (= one LDS ring buffer).
+template <int DP>
+struct Rec16 {
+  static constexpr int kRowB = DP * 2 + 16;   // row-major row: odd number of 16-B slots
+  static constexpr int kXtB = 64 + 16;        // transposed row: 32 halves + pad
+  static constexpr int kHi = 0;
+  static constexpr int kLo = 32 * kRowB;
+  static constexpr int kInv = 64 * kRowB;     // float[32]  2^-a (undoes the row scale)
+  static constexpr int kLse = kInv + 128;     // float[32]  lse * log2(e)      (query records)
+  static constexpr int kWq = kLse + 128;      // float[32]  w * 2^-a           (query records)
+  static constexpr int kXh = kWq + 128;
+  static constexpr int kXl = kXh + DP * kXtB;
+  static constexpr int kBytes = kXl + DP * kXtB;
+  static constexpr int kFwdBytes = kLse;      // the forward streams [hi | lo | inv] only
+  static_assert(kBytes % 64 == 0 && kFwdBytes % 64 == 0, "records split evenly over 4 waves");
+};
+
 struct Side16 {
-  const _Float16 *hi, *lo;        // [np, DP] scaled rows
-  const _Float16 *xt_hi, *xt_lo;  // [np / 32][DP][32] transposed, streamed rows permuted
-  const float *inv;               // [np] 2^-a (undoes the row scale)
-  const uint32_t *bmax;           // [np / 32] per 32-row block: max biased exponent of (|w_r| *) inv_r
+  const char *rec;        // [np / 32] records
+  const uint32_t *bmax;   // [np / 32] per record: max biased exponent of (|w_r| *) inv_r
   int64_t n, np;
 };
 
@@ -60,6 +84,7 @@ struct Sm16Args {
   const float *lse;
   const float *gloss;
   float *partial;
+  char *q_rec_w;          // writable view of the query records (finalize fills lse2)
 };
 
 __device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
@@ -78,8 +103,7 @@ struct PrepSide {
   const float *x;
   int64_t n;
   const float *w;
-  _Float16 *hi, *lo, *xt_hi, *xt_lo;
-  float *inv;
+  char *rec;
   uint32_t *bmax;
 };
 
@@ -88,12 +112,12 @@ template <int DP>
 __global__ void __launch_bounds__(256) sm16_prep_kernel(const PrepSide sq, const PrepSide sc,
                                                         int q_blocks, int d,
                                                         uint32_t *__restrict__ ticket) {
+  typedef Rec16<DP> RL;
   __shared__ float tile[32][DP + 1];
   __shared__ float s_scale[32];
   __shared__ uint32_t s_exp[32];
-  // first kernel of the chain: re-arms the multi-block finalize kernel's ticket (a
-  // hipMemsetAsync node is not reliably ordered against kernel nodes when the step is replayed
-  // from a HIP graph)
+  // first kernel of the chain: re-arms the finalize kernel's ticket (a hipMemsetAsync node is
+  // not reliably ordered against kernel nodes when the step is replayed from a HIP graph)
   if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0u;
   const bool is_q = (int)blockIdx.x < q_blocks;
   const PrepSide &sd = is_q ? sq : sc;
@@ -101,10 +125,7 @@ __global__ void __launch_bounds__(256) sm16_prep_kernel(const PrepSide sq, const
   const float *__restrict__ x = sd.x;
   const float *__restrict__ w = sd.w;
   const int64_t n = sd.n;
-  _Float16 *__restrict__ hi = sd.hi, *__restrict__ lo = sd.lo;
-  _Float16 *__restrict__ xt_hi = sd.xt_hi, *__restrict__ xt_lo = sd.xt_lo;
-  float *__restrict__ inv = sd.inv;
-  uint32_t *__restrict__ bmax = sd.bmax;
+  char *__restrict__ rec = sd.rec + (int64_t)blk * RL::kBytes;
   const int64_t r0 = (int64_t)blk * 32;
   for (int idx = threadIdx.x; idx < 32 * DP; idx += 256) {
     const int row = idx / DP, f = idx - row * DP;
@@ -127,12 +148,12 @@ __global__ void __launch_bounds__(256) sm16_prep_kernel(const PrepSide sq, const
     }
     if (part == 0) {
       s_scale[row] = s;
-      inv[r0 + row] = iv;
+      const float wr = (w && r0 + row < n) ? w[r0 + row] : 1.0f;
+      reinterpret_cast<float *>(rec + RL::kInv)[row] = iv;
+      reinterpret_cast<float *>(rec + RL::kLse)[row] = 0.0f;      // finalize overwrites (queries)
+      reinterpret_cast<float *>(rec + RL::kWq)[row] = wr * iv;
       uint32_t ev = 0u;
-      if (r0 + row < n) {
-        const float val = iv * (w ? fabsf(w[r0 + row]) : 1.0f);
-        ev = (f2u(val) >> 23) & 0xffu;
-      }
+      if (r0 + row < n) ev = (f2u(fabsf(wr) * iv) >> 23) & 0xffu;
       s_exp[row] = ev;
     }
   }
@@ -140,54 +161,94 @@ __global__ void __launch_bounds__(256) sm16_prep_kernel(const PrepSide sq, const
   if (threadIdx.x == 0) {
     uint32_t ev = 0u;
     for (int r = 0; r < 32; ++r) ev = s_exp[r] > ev ? s_exp[r] : ev;
-    bmax[blk] = ev;
+    sd.bmax[blk] = ev;
   }
   for (int idx = threadIdx.x; idx < 32 * DP; idx += 256) {
     const int row = idx / DP, f = idx - row * DP;
     const float v = tile[row][f] * s_scale[row];
     const _Float16 vh = (_Float16)v;
-    hi[(r0 + row) * DP + f] = vh;
-    lo[(r0 + row) * DP + f] = (_Float16)(v - (float)vh);
+    reinterpret_cast<_Float16 *>(rec + RL::kHi + row * RL::kRowB)[f] = vh;
+    reinterpret_cast<_Float16 *>(rec + RL::kLo + row * RL::kRowB)[f] = (_Float16)(v - (float)vh);
   }
   for (int idx = threadIdx.x; idx < 32 * DP; idx += 256) {
     const int f = idx >> 5, p = idx & 31;
     const int srow = xt_row_of_pos(p);
     const float v = tile[srow][f] * s_scale[srow];
     const _Float16 vh = (_Float16)v;
-    const int64_t o = ((int64_t)blk * DP + f) * 32 + p;
-    xt_hi[o] = vh;
-    xt_lo[o] = (_Float16)(v - (float)vh);
+    reinterpret_cast<_Float16 *>(rec + RL::kXh + f * RL::kXtB)[p] = vh;
+    reinterpret_cast<_Float16 *>(rec + RL::kXl + f * RL::kXtB)[p] = (_Float16)(v - (float)vh);
   }
 }
 
 // ---- shared pieces of the streaming kernels -------------------------------------------------
-template <int DP>
-struct Stage16 {
-  static constexpr int kRowB = DP * 2 + 16;    // LDS bytes per image row: odd number of 16-B slots
-  static constexpr int kXtB = 64 + 16;         // LDS bytes per transposed row (32 halves + pad)
-  static constexpr int kChunks = 4 * DP;       // 16-byte pieces per image per tile
-  static constexpr int kPer = (kChunks + 255) / 256;
-  static constexpr int kImg = 32 * kRowB;
-  static constexpr int kXt = DP * kXtB;
-  static constexpr int kFwdBuf = 2 * kImg + 128;
-  static constexpr int kBwdBuf = 2 * kImg + 2 * kXt + 3 * 128;
+// Direct-to-LDS copy of the first BYTES of a record; every wave moves one quarter with the same
+// number of wave-instructions (1 KiB each, the last one partially masked), so a fixed vmcnt
+// tells every wave how many of its copies are still in flight.
+template <int BYTES>
+struct Copy16 {
+  static constexpr int kQuarter = BYTES / 4;
+  static constexpr int kInstr = (kQuarter + 1023) / 1024;
+  static_assert(kQuarter % 16 == 0, "quarter must be whole 16-byte pieces");
+  static_assert(kQuarter % 1024 != 0, "the masked tail keeps every instruction non-empty");
 };
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// The copy is issued through inline assembly on purpose: for the builtin the compiler cannot
+// prove that the copy into one ring buffer is independent of the ds_reads of another (same
+// loop, rotating roles) and serialises them with s_waitcnt vmcnt(0), which would expose the
+// full memory latency the ring is there to hide.  Completion is tracked by hand instead
+// (wait_tile below): copies of one wave complete in issue order, and every wave issues the
+// same number per tile.
+__device__ __forceinline__ void glds_copy16(const char *gsrc_lane, const char *lds_wave_base) {
+  const uint32_t m0v = (uint32_t)(uintptr_t)(
+      __attribute__((address_space(3))) const char *)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               :
+               : "v"(gsrc_lane), "s"(m0v)
+               : "memory", "m0");
+}
+
+template <int BYTES>
+__device__ __forceinline__ void stage_glds(const char *src, char *dst, int wave, int lane) {
+  typedef Copy16<BYTES> C;
+#pragma unroll
+  for (int i = 0; i < C::kInstr; ++i) {
+    const int off = wave * C::kQuarter + i * 1024;
+    if (i * 1024 + lane * 16 < C::kQuarter) glds_copy16(src + off + lane * 16, dst + off);
+  }
+}
+
+// s_waitcnt vmcnt(n) alone (expcnt / lgkmcnt untouched); n < 64
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  static_assert(N >= 0 && N < 64, "vmcnt range");
+  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+
+// waits until at most `newer` later tiles' copies of this wave are in flight, then meets the
+// other waves: after the barrier the tile is complete in LDS and the buffer that the next
+// prefetch overwrites is no longer being read by anyone
+template <int INSTR, int MAXNEWER>
+__device__ __forceinline__ void wait_tile(int newer) {
+  if (MAXNEWER >= 1 && newer >= 1) {
+    wait_vm<INSTR>();
+  } else {
+    wait_vm<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+}
 
 // S tile (32 streamed rows x 32 owned rows) from the LDS image of the streamed rows.
 template <int DP>
-__device__ __forceinline__ f32x16 tile_dot16(const char *img_hi, const char *img_lo,
-                                             const h8 (&bh)[DP / 16], const h8 (&bl)[DP / 16],
-                                             int j, int h) {
-  constexpr int kRowB = Stage16<DP>::kRowB;
+__device__ __forceinline__ f32x16 tile_dot16(const char *buf, const h8 (&bh)[DP / 16],
+                                             const h8 (&bl)[DP / 16], int j, int h) {
+  typedef Rec16<DP> RL;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
   for (int i = 0; i < DP / 16; ++i) {
-    const h8 ah = *reinterpret_cast<const h8 *>(img_hi + j * kRowB + (2 * i + h) * 16);
-    const h8 al = *reinterpret_cast<const h8 *>(img_lo + j * kRowB + (2 * i + h) * 16);
+    const h8 ah = *reinterpret_cast<const h8 *>(buf + RL::kHi + j * RL::kRowB + (2 * i + h) * 16);
+    const h8 al = *reinterpret_cast<const h8 *>(buf + RL::kLo + j * RL::kRowB + (2 * i + h) * 16);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[i], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[i], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[i], acc, 0, 0, 0);
@@ -195,21 +256,32 @@ __device__ __forceinline__ f32x16 tile_dot16(const char *img_hi, const char *img
   return acc;
 }
 
+// owned rows' B operands from their record; returns the row's inverse scale
 template <int DP>
-__device__ __forceinline__ void load_owned(h8 (&bh)[DP / 16], h8 (&bl)[DP / 16], const Side16 &R,
-                                           int64_t row, int h) {
+__device__ __forceinline__ float load_owned(h8 (&bh)[DP / 16], h8 (&bl)[DP / 16], const Side16 &R,
+                                            int64_t row, int h) {
+  typedef Rec16<DP> RL;
+  const char *rec = R.rec + (row >> 5) * RL::kBytes;
+  const int rr = (int)(row & 31);
 #pragma unroll
   for (int i = 0; i < DP / 16; ++i) {
-    bh[i] = *reinterpret_cast<const h8 *>(R.hi + row * DP + 16 * i + 8 * h);
-    bl[i] = *reinterpret_cast<const h8 *>(R.lo + row * DP + 16 * i + 8 * h);
+    bh[i] = *reinterpret_cast<const h8 *>(rec + RL::kHi + rr * RL::kRowB + (2 * i + h) * 16);
+    bl[i] = *reinterpret_cast<const h8 *>(rec + RL::kLo + rr * RL::kRowB + (2 * i + h) * 16);
   }
+  return reinterpret_cast<const float *>(rec + RL::kInv)[rr];
 }
 
 // ---- forward ------------------------------------------------------------------------------
 template <int DP>
 __global__ void __launch_bounds__(256) sm16_fwd_kernel(const Sm16Args a) {
-  typedef Stage16<DP> St;
-  extern __shared__ __attribute__((aligned(16))) char smem16[];
+  typedef Rec16<DP> RL;
+  constexpr int NB = 3;                               // ring depth: copies run 2 tiles ahead
+  constexpr int kInstr = Copy16<RL::kFwdBytes>::kInstr;
+  // separate LDS objects: the compiler can then tell that the copy into one buffer does not
+  // alias the reads of another and does not serialise them with s_waitcnt vmcnt(0)
+  __shared__ __attribute__((aligned(16))) char ring0[RL::kFwdBytes];
+  __shared__ __attribute__((aligned(16))) char ring1[RL::kFwdBytes];
+  __shared__ __attribute__((aligned(16))) char ring2[RL::kFwdBytes];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
@@ -219,61 +291,38 @@ __global__ void __launch_bounds__(256) sm16_fwd_kernel(const Sm16Args a) {
   const int64_t row = base32 + j;
   const bool rvalid = row < a.q.n;
 
-  h8 bh[DP / 16], bl[DP / 16];
-  load_owned<DP>(bh, bl, a.q, row, h);
-  const float rowfac2 = a.q.inv[row] * a.inv_t * kLog2e;
-
   const int64_t c_lo = (int64_t)sp * a.split_len;
   int64_t c_hi = c_lo + a.split_len;
   if (c_hi > a.c.n) c_hi = a.c.n;
   const int nt = (int)((c_hi - c_lo + 31) / 32);
+  const char *src = a.c.rec + (c_lo >> 5) * RL::kBytes;
 
-  u32x4 st_hi[St::kPer], st_lo[St::kPer];
-  float st_inv = 0.0f;
-  auto stage_load = [&](int64_t s0) {
-#pragma unroll
-    for (int u = 0; u < St::kPer; ++u) {
-      const int ch = tid + u * 256;
-      if (ch < St::kChunks) {
-        const int srow = ch / (DP / 8), slot = ch - srow * (DP / 8);
-        st_hi[u] = *reinterpret_cast<const u32x4 *>(a.c.hi + (s0 + srow) * DP + slot * 8);
-        st_lo[u] = *reinterpret_cast<const u32x4 *>(a.c.lo + (s0 + srow) * DP + slot * 8);
-      }
-    }
-    if (tid < 32) st_inv = a.c.inv[s0 + tid];
-  };
-  auto stage_store = [&](char *buf) {
-#pragma unroll
-    for (int u = 0; u < St::kPer; ++u) {
-      const int ch = tid + u * 256;
-      if (ch < St::kChunks) {
-        const int srow = ch / (DP / 8), slot = ch - srow * (DP / 8);
-        *reinterpret_cast<u32x4 *>(buf + srow * St::kRowB + slot * 16) = st_hi[u];
-        *reinterpret_cast<u32x4 *>(buf + St::kImg + srow * St::kRowB + slot * 16) = st_lo[u];
-      }
-    }
-    if (tid < 32) reinterpret_cast<float *>(buf + 2 * St::kImg)[tid] = st_inv;
-  };
+  if (nt > 0) stage_glds<RL::kFwdBytes>(src, ring0, wave, lane);
+  if (nt > 1) stage_glds<RL::kFwdBytes>(src + RL::kBytes, ring1, wave, lane);
+
+  h8 bh[DP / 16], bl[DP / 16];
+  const float rowfac2 = load_owned<DP>(bh, bl, a.q, row, h) * a.inv_t * kLog2e;
 
   float m = -__builtin_inff(), l = 0.0f, pos2 = 0.0f;
   bool haspos = false;
-  if (nt > 0) {
-    stage_load(c_lo);
-    stage_store(smem16);
-  }
-  __syncthreads();
-  for (int t = 0; t < nt; ++t) {
+  // every ordinary load of the prologue lands here, OUTSIDE the loop: a compiler-placed
+  // vmcnt(0) at their first use inside the loop body would also drain the ring's copies on
+  // every iteration
+  wait_vm<0>();
+
+  auto step = [&](const char *cur, char *pre, int t) __attribute__((always_inline)) {
+    wait_tile<kInstr, NB - 2>(nt - 1 - t);
+    if (t + NB - 1 < nt)
+      stage_glds<RL::kFwdBytes>(src + (int64_t)(t + NB - 1) * RL::kBytes, pre, wave, lane);
     const int64_t s0 = c_lo + (int64_t)t * 32;
-    char *buf = smem16 + (t & 1) * St::kFwdBuf;
-    if (t + 1 < nt) stage_load(s0 + 32);
-    const f32x16 acc = tile_dot16<DP>(buf, buf + St::kImg, bh, bl, j, h);
-    const float *sinv = reinterpret_cast<const float *>(buf + 2 * St::kImg);
+    const f32x16 acc = tile_dot16<DP>(cur, bh, bl, j, h);
+    const float *sinv = reinterpret_cast<const float *>(cur + RL::kInv);
     float v2[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const f32x4 sv = *reinterpret_cast<const f32x4 *>(sinv + 8 * g + 4 * h);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v2[4 * g + k] = acc[4 * g + k] * sv[k] * rowfac2;
+      for (int k = 0; k < 4; ++k) v2[4 * g + k] = acc[4 * g + k] * (sv[k] * rowfac2);
     }
     if (s0 + 32 > c_hi) {   // ragged last tile
 #pragma unroll
@@ -296,12 +345,21 @@ __global__ void __launch_bounds__(256) sm16_fwd_kernel(const Sm16Args a) {
       m = tmax;
     }
     if (m > -__builtin_inff()) {
+      float l0 = 0.0f, l1 = 0.0f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) l += fast_exp2(v2[r] - m);
+      for (int r = 0; r < 16; r += 2) {
+        l0 += fast_exp2(v2[r] - m);
+        l1 += fast_exp2(v2[r + 1] - m);
+      }
+      l += l0 + l1;
     }
-    if (t + 1 < nt) stage_store(smem16 + ((t + 1) & 1) * St::kFwdBuf);
-    __syncthreads();
+  };
+  for (int t = 0; t < nt; t += NB) {
+    step(ring0, ring2, t);
+    if (t + 1 < nt) step(ring1, ring0, t + 1);
+    if (t + 2 < nt) step(ring2, ring1, t + 2);
   }
+
   const float m2 = __shfl_xor(m, 32), l2 = __shfl_xor(l, 32);
   const float mm = fmaxf(m, m2);
   float ll = 0.0f;
@@ -314,14 +372,17 @@ __global__ void __launch_bounds__(256) sm16_fwd_kernel(const Sm16Args a) {
   if (haspos && rvalid) a.ppos[row] = pos2 * kLn2;
 }
 
-// Combines the per-split base-2 (max, sum) pairs, writes lse / pos and the weighted loss.
-// One wave per 64 rows; the splits' partials are fetched in batches of 16 independent loads
-// (one memory latency per batch instead of one per split).  Every block leaves a partial loss
-// in block_part[] and the LAST block to arrive (ticket, re-armed by the prep kernel) adds the
-// partials in block order: the loss does not depend on scheduling.
+// Combines the per-split base-2 (max, sum) pairs, writes lse / pos and the weighted loss, and
+// leaves lse * log2(e) in the query records for the backward.  One wave per 64 rows; the
+// splits' partials are fetched in batches of 16 independent loads (one memory latency per
+// batch instead of one per split).  Every block leaves a partial loss in block_part[] and the
+// LAST block to arrive (ticket, re-armed by the prep kernel) adds the partials in block order:
+// the loss does not depend on scheduling.
+template <int DP>
 __global__ void __launch_bounds__(64) sm16_finalize_kernel(const Sm16Args a, float *out_loss,
                                                            float *out_lse, float *out_pos,
                                                            double *block_part, uint32_t *ticket) {
+  typedef Rec16<DP> RL;
   const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const bool valid = row < a.q.n;
   const int64_t r = valid ? row : 0;
@@ -348,10 +409,12 @@ __global__ void __launch_bounds__(64) sm16_finalize_kernel(const Sm16Args a, flo
   }
   double local = 0.0;
   if (valid) {
-    const float lse = (mm + log2f(ll)) * kLn2;
+    const float lse2 = mm + log2f(ll);
+    const float lse = lse2 * kLn2;
     const float pos = a.ppos[row];
     out_lse[row] = lse;
     out_pos[row] = pos;
+    reinterpret_cast<float *>(a.q_rec_w + (row >> 5) * RL::kBytes + RL::kLse)[row & 31] = lse * kLog2e;
     const float w = a.w ? a.w[row] : 1.0f;
     local = (double)w * ((double)lse - (double)pos);
   }
@@ -372,14 +435,29 @@ __global__ void __launch_bounds__(64) sm16_finalize_kernel(const Sm16Args a, flo
   }
 }
 
+// The backward alone (no forward in this workspace): lse comes from the caller; this fills the
+// lse2 slots of the query records that the finalize kernel would have written.
+template <int DP>
+__global__ void __launch_bounds__(256) sm16_fill_lse_kernel(const float *lse, int64_t nq, char *q_rec) {
+  typedef Rec16<DP> RL;
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row < nq)
+    reinterpret_cast<float *>(q_rec + (row >> 5) * RL::kBytes + RL::kLse)[row & 31] = lse[row] * kLog2e;
+}
+
 // ---- backward -----------------------------------------------------------------------------
 // RQ = true : workgroup owns 128 queries, streams candidates, emits partial dq.
 // RQ = false: workgroup owns 128 candidates, streams queries, emits partial dc.
 template <int DP, bool RQ>
 __global__ void __launch_bounds__(256) sm16_bwd_kernel(const Sm16Args a) {
-  typedef Stage16<DP> St;
+  typedef Rec16<DP> RL;
   constexpr int NFB = DP / 32;
-  extern __shared__ __attribute__((aligned(16))) char smem16[];
+  constexpr int NB = DP <= 64 ? 3 : 2;
+  constexpr int kInstr = Copy16<RL::kBytes>::kInstr;
+  __shared__ __attribute__((aligned(16))) char ring0[RL::kBytes];
+  __shared__ __attribute__((aligned(16))) char ring1[RL::kBytes];
+  __shared__ __attribute__((aligned(16))) char ring2[NB > 2 ? RL::kBytes : 16];
+  __shared__ uint32_t s_e[4];
   const Side16 &R = RQ ? a.q : a.c;
   const Side16 &S = RQ ? a.c : a.q;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -391,15 +469,22 @@ __global__ void __launch_bounds__(256) sm16_bwd_kernel(const Sm16Args a) {
   const int64_t row = base32 + j;
   const bool rvalid = row < R.n;
 
+  const int64_t s_lo = (int64_t)sp * a.split_len;
+  int64_t s_hi = s_lo + a.split_len;
+  if (s_hi > S.n) s_hi = S.n;
+  const int nt = (int)((s_hi - s_lo + 31) / 32);
+  const char *src = S.rec + (s_lo >> 5) * RL::kBytes;
+
+  if (nt > 0) stage_glds<RL::kBytes>(src, ring0, wave, lane);
+  if (NB > 2 && nt > 1) stage_glds<RL::kBytes>(src + RL::kBytes, ring1, wave, lane);
+
   h8 bh[DP / 16], bl[DP / 16];
-  load_owned<DP>(bh, bl, R, row, h);
-  const float rowfac2 = R.inv[row] * a.inv_t * kLog2e;
+  const float rowfac2 = load_owned<DP>(bh, bl, R, row, h) * a.inv_t * kLog2e;
 
   // T = (softmax - onehot) * (streamed-row factor) is scaled by 2^G so that its largest
   // possible magnitude is below 2^14: G from the streamed side's largest factor exponent.
-  uint32_t E = 0u;
   {
-    __shared__ uint32_t s_e[4];
+    uint32_t E = 0u;
     const int64_t nblk = S.np >> 5;
     for (int64_t b = tid; b < nblk; b += 256) E = S.bmax[b] > E ? S.bmax[b] : E;
 #pragma unroll
@@ -408,74 +493,15 @@ __global__ void __launch_bounds__(256) sm16_bwd_kernel(const Sm16Args a) {
       E = o > E ? o : E;
     }
     if (lane == 0) s_e[wave] = E;
-    __syncthreads();
-    E = s_e[0];
-#pragma unroll
-    for (int k = 1; k < 4; ++k) E = s_e[k] > E ? s_e[k] : E;
   }
-  int G = E ? 14 - ((int)E - 126) : 0;
-  G = G > 120 ? 120 : (G < -120 ? -120 : G);
-  const float tscale = u2f((uint32_t)(G + 127) << 23), tunscale = u2f((uint32_t)(127 - G) << 23);
-  const float gl = (a.gloss ? *a.gloss : 1.0f) * a.inv_t;
-  float lse2_r = 0.0f, coef_r = gl * tunscale;
+  float lse2_r = 0.0f, w_r = 1.0f;
   if (RQ && rvalid) {
     lse2_r = a.lse[row] * kLog2e;
-    if (a.w) coef_r *= a.w[row];
+    if (a.w) w_r = a.w[row];
   }
-
-  const int64_t s_lo = (int64_t)sp * a.split_len;
-  int64_t s_hi = s_lo + a.split_len;
-  if (s_hi > S.n) s_hi = S.n;
-  const int nt = (int)((s_hi - s_lo + 31) / 32);
-
-  u32x4 st_hi[St::kPer], st_lo[St::kPer], st_xh[St::kPer], st_xl[St::kPer];
-  float st_inv = 0.0f, st_lse = 0.0f, st_tf = 0.0f;
-  auto stage_load = [&](int64_t s0) {
-    const int64_t blk = s0 >> 5;
-#pragma unroll
-    for (int u = 0; u < St::kPer; ++u) {
-      const int ch = tid + u * 256;
-      if (ch < St::kChunks) {
-        const int srow = ch / (DP / 8), slot = ch - srow * (DP / 8);
-        st_hi[u] = *reinterpret_cast<const u32x4 *>(S.hi + (s0 + srow) * DP + slot * 8);
-        st_lo[u] = *reinterpret_cast<const u32x4 *>(S.lo + (s0 + srow) * DP + slot * 8);
-        const int f = ch >> 2, xs = ch & 3;
-        st_xh[u] = *reinterpret_cast<const u32x4 *>(S.xt_hi + (blk * DP + f) * 32 + xs * 8);
-        st_xl[u] = *reinterpret_cast<const u32x4 *>(S.xt_lo + (blk * DP + f) * 32 + xs * 8);
-      }
-    }
-    if (tid < 32) {
-      const int64_t sr = s0 + tid;
-      st_inv = S.inv[sr];
-      if (RQ) {
-        st_tf = st_inv * tscale;
-      } else {
-        const bool ok = sr < S.n;
-        st_lse = ok ? a.lse[sr] * kLog2e : 0.0f;
-        st_tf = (ok && a.w ? a.w[sr] : 1.0f) * st_inv * tscale;
-      }
-    }
-  };
-  auto stage_store = [&](char *buf) {
-#pragma unroll
-    for (int u = 0; u < St::kPer; ++u) {
-      const int ch = tid + u * 256;
-      if (ch < St::kChunks) {
-        const int srow = ch / (DP / 8), slot = ch - srow * (DP / 8);
-        *reinterpret_cast<u32x4 *>(buf + srow * St::kRowB + slot * 16) = st_hi[u];
-        *reinterpret_cast<u32x4 *>(buf + St::kImg + srow * St::kRowB + slot * 16) = st_lo[u];
-        const int f = ch >> 2, xs = ch & 3;
-        *reinterpret_cast<u32x4 *>(buf + 2 * St::kImg + f * St::kXtB + xs * 16) = st_xh[u];
-        *reinterpret_cast<u32x4 *>(buf + 2 * St::kImg + St::kXt + f * St::kXtB + xs * 16) = st_xl[u];
-      }
-    }
-    if (tid < 32) {
-      float *fl = reinterpret_cast<float *>(buf + 2 * St::kImg + 2 * St::kXt);
-      fl[tid] = st_inv;
-      fl[32 + tid] = st_lse;
-      fl[64 + tid] = st_tf;
-    }
-  };
+  const float gl = (a.gloss ? *a.gloss : 1.0f) * a.inv_t;
+  float tscale = 1.0f, coef_r = 0.0f;
+  wait_vm<0>();   // prologue loads land outside the loop (see the forward kernel)
 
   f32x16 outacc[NFB];
 #pragma unroll
@@ -483,17 +509,22 @@ __global__ void __launch_bounds__(256) sm16_bwd_kernel(const Sm16Args a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) outacc[fb][r] = 0.0f;
 
-  if (nt > 0) {
-    stage_load(s_lo);
-    stage_store(smem16);
-  }
-  __syncthreads();
-  for (int t = 0; t < nt; ++t) {
+  auto step = [&](const char *cur, char *pre, int t) __attribute__((always_inline)) {
+    wait_tile<kInstr, NB - 2>(nt - 1 - t);
+    if (t + NB - 1 < nt)
+      stage_glds<RL::kBytes>(src + (int64_t)(t + NB - 1) * RL::kBytes, pre, wave, lane);
+    if (t == 0) {           // the first barrier also published s_e
+      uint32_t Em = s_e[0];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) Em = s_e[k] > Em ? s_e[k] : Em;
+      int G = Em ? 14 - ((int)Em - 126) : 0;
+      G = G > 120 ? 120 : (G < -120 ? -120 : G);
+      tscale = u2f((uint32_t)(G + 127) << 23);
+      coef_r = gl * u2f((uint32_t)(127 - G) << 23) * w_r;
+    }
     const int64_t s0 = s_lo + (int64_t)t * 32;
-    char *buf = smem16 + (t & 1) * St::kBwdBuf;
-    if (t + 1 < nt) stage_load(s0 + 32);
-    const f32x16 acc = tile_dot16<DP>(buf, buf + St::kImg, bh, bl, j, h);
-    const float *fl = reinterpret_cast<const float *>(buf + 2 * St::kImg + 2 * St::kXt);
+    const f32x16 acc = tile_dot16<DP>(cur, bh, bl, j, h);
+    const float *fl = reinterpret_cast<const float *>(cur + RL::kInv);
     float tp[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -501,10 +532,8 @@ __global__ void __launch_bounds__(256) sm16_bwd_kernel(const Sm16Args a) {
       f32x4 ls = {lse2_r, lse2_r, lse2_r, lse2_r};
       if (!RQ) ls = *reinterpret_cast<const f32x4 *>(fl + 32 + 8 * g + 4 * h);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float v2 = acc[4 * g + k] * sv[k] * rowfac2;
-        tp[4 * g + k] = fast_exp2(v2 - ls[k]);
-      }
+      for (int k = 0; k < 4; ++k)
+        tp[4 * g + k] = fast_exp2(acc[4 * g + k] * (sv[k] * rowfac2) - ls[k]);
     }
     if (s0 == base32) {     // the tile that holds the positives: softmax - onehot
 #pragma unroll
@@ -519,34 +548,72 @@ __global__ void __launch_bounds__(256) sm16_bwd_kernel(const Sm16Args a) {
     h8 th[2], tl[2];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 tf = *reinterpret_cast<const f32x4 *>(fl + 64 + 8 * g + 4 * h);
+      // streamed-row factor: 2^-a (RQ) or w * 2^-a (rows = candidates: the weight belongs to
+      // the streamed query), times the common 2^G
+      const f32x4 tf = *reinterpret_cast<const f32x4 *>(fl + (RQ ? 0 : 64) + 8 * g + 4 * h);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int r = 4 * g + k;
-        const float v = tp[r] * tf[k];
+        const float v = tp[r] * (tf[k] * tscale);
         const _Float16 vh = (_Float16)v;
         th[r >> 3][r & 7] = vh;
         tl[r >> 3][r & 7] = (_Float16)(v - (float)vh);
       }
     }
     // out^T[feature][owned row] += sum over the tile's streamed rows X'[srow][feature] T[srow][row]
-    const char *xh = buf + 2 * St::kImg, *xl = xh + St::kXt;
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        const int off = (fb * 32 + j) * St::kXtB + (kk * 16 + h * 8) * 2;
-        const h8 ah = *reinterpret_cast<const h8 *>(xh + off);
-        const h8 al = *reinterpret_cast<const h8 *>(xl + off);
+        const int off = (fb * 32 + j) * RL::kXtB + (kk * 16 + h * 8) * 2;
+        const h8 ah = *reinterpret_cast<const h8 *>(cur + RL::kXh + off);
+        const h8 al = *reinterpret_cast<const h8 *>(cur + RL::kXl + off);
         outacc[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, th[kk], outacc[fb], 0, 0, 0);
         outacc[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, tl[kk], outacc[fb], 0, 0, 0);
         outacc[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, th[kk], outacc[fb], 0, 0, 0);
       }
-    if (t + 1 < nt) stage_store(smem16 + ((t + 1) & 1) * St::kBwdBuf);
-    __syncthreads();
+  };
+  if (NB > 2) {
+    for (int t = 0; t < nt; t += 3) {
+      step(ring0, ring2, t);
+      if (t + 1 < nt) step(ring1, ring0, t + 1);
+      if (t + 2 < nt) step(ring2, ring1, t + 2);
+    }
+  } else {
+    for (int t = 0; t < nt; t += 2) {
+      step(ring0, ring1, t);
+      if (t + 1 < nt) step(ring1, ring0, t + 1);
+    }
   }
 
-  if (rvalid) {
+  // Epilogue.  The accumulators hold out^T (lane = owned row, register = feature): written
+  // directly that is one 4-byte store per lane with a row stride between lanes.  Each wave
+  // instead transposes 32 features at a time through its own LDS scratch and stores whole
+  // 128-byte row segments as float4.
+  if ((a.d & 3) == 0) {
+    constexpr int kLd = 36;                      // floats per LDS row: 32 + 4 (bank spread)
+    __shared__ __attribute__((aligned(16))) float scr_all[4 * 32 * kLd];
+    float *scr = scr_all + wave * 32 * kLd;
+    const int pr = lane >> 3, pc = lane & 7;     // 8 lanes x float4 = one 32-feature row segment
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) scr[j * kLd + tile_row_of_reg(r, h)] = outacc[fb][r] * coef_r;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int rr = it * 8 + pr;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(scr + rr * kLd + pc * 4);
+        const int64_t grow = base32 + rr;
+        const int feat = fb * 32 + pc * 4;
+        if (grow < R.n && feat < a.d)
+          *reinterpret_cast<f32x4 *>(a.partial + ((int64_t)sp * R.n + grow) * a.d + feat) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();           // scr is rewritten by the next feature block
+    }
+  } else if (rvalid) {
     float *dst = a.partial + ((int64_t)sp * R.n + row) * a.d;
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb)
@@ -579,6 +646,9 @@ __global__ void __launch_bounds__(256) sm16_reduce2_kernel(const float *pa, int 
 static inline size_t al16(size_t x) { return (x + 255) / 256 * 256; }
 static inline int64_t pad128(int64_t n) { return (n + 127) / 128 * 128; }
 static inline int dp_of(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : 128); }
+static inline size_t rec_bytes(int dp) {
+  return dp == 32 ? Rec16<32>::kBytes : (dp == 64 ? Rec16<64>::kBytes : Rec16<128>::kBytes);
+}
 
 static void plan16(int64_t n_rows, int64_t n_stream, int *nsplit, int64_t *split_len) {
   const int64_t row_blocks = (n_rows + 127) / 128;
@@ -596,7 +666,7 @@ static void plan16(int64_t n_rows, int64_t n_stream, int *nsplit, int64_t *split
 }
 
 struct Layout16 {
-  size_t header, q_hi, q_lo, q_xh, q_xl, q_inv, q_bmax, c_hi, c_lo, c_xh, c_xl, c_inv, c_bmax, scratch, total;
+  size_t header, q_rec, q_bmax, c_rec, c_bmax, scratch, total;
 };
 
 static Layout16 layout16(int64_t nq, int64_t nc, int d) {
@@ -605,12 +675,9 @@ static Layout16 layout16(int64_t nq, int64_t nc, int d) {
   Layout16 L;
   size_t o = 0;
   L.header = o; o += 256;                                    // finalize ticket
-  const size_t iq = al16((size_t)nqp * dp * 2), ic = al16((size_t)ncp * dp * 2);
-  L.q_hi = o; o += iq; L.q_lo = o; o += iq; L.q_xh = o; o += iq; L.q_xl = o; o += iq;
-  L.q_inv = o; o += al16((size_t)nqp * 4);
+  L.q_rec = o; o += al16((size_t)(nqp / 32) * rec_bytes(dp));
   L.q_bmax = o; o += al16((size_t)(nqp / 32) * 4);
-  L.c_hi = o; o += ic; L.c_lo = o; o += ic; L.c_xh = o; o += ic; L.c_xl = o; o += ic;
-  L.c_inv = o; o += al16((size_t)ncp * 4);
+  L.c_rec = o; o += al16((size_t)(ncp / 32) * rec_bytes(dp));
   L.c_bmax = o; o += al16((size_t)(ncp / 32) * 4);
   L.scratch = o;
   int nsf, nsq, nsc;
@@ -628,39 +695,20 @@ static Layout16 layout16(int64_t nq, int64_t nc, int d) {
 size_t softmax16_workspace_bytes(int64_t nq, int64_t nc, int d) { return layout16(nq, nc, d).total; }
 
 static void fill_sides(Sm16Args *a, char *ws, const Layout16 &L, int64_t nq, int64_t nc) {
-  a->q = {reinterpret_cast<const _Float16 *>(ws + L.q_hi), reinterpret_cast<const _Float16 *>(ws + L.q_lo),
-          reinterpret_cast<const _Float16 *>(ws + L.q_xh), reinterpret_cast<const _Float16 *>(ws + L.q_xl),
-          reinterpret_cast<const float *>(ws + L.q_inv), reinterpret_cast<const uint32_t *>(ws + L.q_bmax),
-          nq, pad128(nq)};
-  a->c = {reinterpret_cast<const _Float16 *>(ws + L.c_hi), reinterpret_cast<const _Float16 *>(ws + L.c_lo),
-          reinterpret_cast<const _Float16 *>(ws + L.c_xh), reinterpret_cast<const _Float16 *>(ws + L.c_xl),
-          reinterpret_cast<const float *>(ws + L.c_inv), reinterpret_cast<const uint32_t *>(ws + L.c_bmax),
-          nc, pad128(nc)};
+  a->q = {ws + L.q_rec, reinterpret_cast<const uint32_t *>(ws + L.q_bmax), nq, pad128(nq)};
+  a->c = {ws + L.c_rec, reinterpret_cast<const uint32_t *>(ws + L.c_bmax), nc, pad128(nc)};
+  a->q_rec_w = ws + L.q_rec;
 }
 
 template <int DP>
 static int prep16(const float *q, const float *c, int64_t nq, int64_t nc, int d, const float *w,
                   char *ws, const Layout16 &L, hipStream_t s) {
-  const PrepSide sq = {q, nq, w, reinterpret_cast<_Float16 *>(ws + L.q_hi),
-                       reinterpret_cast<_Float16 *>(ws + L.q_lo), reinterpret_cast<_Float16 *>(ws + L.q_xh),
-                       reinterpret_cast<_Float16 *>(ws + L.q_xl), reinterpret_cast<float *>(ws + L.q_inv),
-                       reinterpret_cast<uint32_t *>(ws + L.q_bmax)};
-  const PrepSide sc = {c, nc, nullptr, reinterpret_cast<_Float16 *>(ws + L.c_hi),
-                       reinterpret_cast<_Float16 *>(ws + L.c_lo), reinterpret_cast<_Float16 *>(ws + L.c_xh),
-                       reinterpret_cast<_Float16 *>(ws + L.c_xl), reinterpret_cast<float *>(ws + L.c_inv),
-                       reinterpret_cast<uint32_t *>(ws + L.c_bmax)};
+  const PrepSide sq = {q, nq, w, ws + L.q_rec, reinterpret_cast<uint32_t *>(ws + L.q_bmax)};
+  const PrepSide sc = {c, nc, nullptr, ws + L.c_rec, reinterpret_cast<uint32_t *>(ws + L.c_bmax)};
   const int qb = (int)(pad128(nq) / 32), cb = (int)(pad128(nc) / 32);
   hipLaunchKernelGGL((sm16_prep_kernel<DP>), dim3((unsigned)(qb + cb)), dim3(256), 0, s, sq, sc, qb, d,
                      reinterpret_cast<uint32_t *>(ws + L.header));
   TFRS_LAUNCH_CHECK();
-  return TFRS_OK;
-}
-
-template <typename K>
-static int allow_lds(K kernel, size_t bytes) {
-  if (bytes > 64 * 1024)
-    TFRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   return TFRS_OK;
 }
 
@@ -681,14 +729,11 @@ static int fwd16(const float *q, const float *c, int64_t nq, int64_t nc, int d, 
   a.ppos = reinterpret_cast<float *>(p); p += al16((size_t)nq * 4);
   double *block_part = reinterpret_cast<double *>(p);
   uint32_t *ticket = reinterpret_cast<uint32_t *>(ws + L.header);
-  const size_t lds = 2 * Stage16<DP>::kFwdBuf;
-  rc = allow_lds(sm16_fwd_kernel<DP>, lds);
-  if (rc != TFRS_OK) return rc;
   const int64_t wgs = ((nq + 127) / 128) * a.nsplit;
-  hipLaunchKernelGGL((sm16_fwd_kernel<DP>), dim3((unsigned)wgs), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((sm16_fwd_kernel<DP>), dim3((unsigned)wgs), dim3(256), 0, s, a);
   TFRS_LAUNCH_CHECK();
   const unsigned fin_blocks = (unsigned)((nq + 63) / 64);
-  hipLaunchKernelGGL(sm16_finalize_kernel, dim3(fin_blocks), dim3(64), 0, s, a, out_loss, out_lse,
+  hipLaunchKernelGGL((sm16_finalize_kernel<DP>), dim3(fin_blocks), dim3(64), 0, s, a, out_loss, out_lse,
                      out_pos, block_part, ticket);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
@@ -702,15 +747,13 @@ static int bwd16(const float *q, const float *c, int64_t nq, int64_t nc, int d, 
   if (!reuse) {
     int rc = prep16<DP>(q, c, nq, nc, d, w, ws, L, s);
     if (rc != TFRS_OK) return rc;
+    hipLaunchKernelGGL((sm16_fill_lse_kernel<DP>), dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s,
+                       lse, nq, ws + L.q_rec);
+    TFRS_LAUNCH_CHECK();
   }
   Sm16Args a = {};
   fill_sides(&a, ws, L, nq, nc);
   a.d = d; a.w = w; a.inv_t = inv_t; a.lse = lse; a.gloss = gloss;
-  const size_t lds = 2 * Stage16<DP>::kBwdBuf;
-  int rc = allow_lds(sm16_bwd_kernel<DP, true>, lds);
-  if (rc != TFRS_OK) return rc;
-  rc = allow_lds(sm16_bwd_kernel<DP, false>, lds);
-  if (rc != TFRS_OK) return rc;
   char *p = ws + L.scratch;
 
   plan16(nq, nc, &a.nsplit, &a.split_len);
@@ -718,7 +761,7 @@ static int bwd16(const float *q, const float *c, int64_t nq, int64_t nc, int d, 
   float *part_q = nsq == 1 ? dq : reinterpret_cast<float *>(p);
   a.partial = part_q;
   hipLaunchKernelGGL((sm16_bwd_kernel<DP, true>), dim3((unsigned)(((nq + 127) / 128) * nsq)), dim3(256),
-                     lds, s, a);
+                     0, s, a);
   TFRS_LAUNCH_CHECK();
   p += al16((size_t)nsq * nq * d * 4);
   plan16(nc, nq, &a.nsplit, &a.split_len);
@@ -726,7 +769,7 @@ static int bwd16(const float *q, const float *c, int64_t nq, int64_t nc, int d, 
   float *part_c = nsc == 1 ? dc : reinterpret_cast<float *>(p);
   a.partial = part_c;
   hipLaunchKernelGGL((sm16_bwd_kernel<DP, false>), dim3((unsigned)(((nc + 127) / 128) * nsc)),
-                     dim3(256), lds, s, a);
+                     dim3(256), 0, s, a);
   TFRS_LAUNCH_CHECK();
   // per-split partial gradients -> dq, dc (a side with a single split wrote its output directly)
   const int64_t cq = nsq > 1 ? nq * d : 0, cc = nsc > 1 ? nc * d : 0;
