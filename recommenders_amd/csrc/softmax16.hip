@@ -181,15 +181,15 @@ __global__ void __launch_bounds__(256) sm16_prep_kernel(const PrepSide sq, const
 }
 
 // ---- shared pieces of the streaming kernels -------------------------------------------------
-// Direct-to-LDS copy of the first BYTES of a record; every wave moves one quarter with the same
+// Direct-to-LDS copy of the first BYTES of a record; every wave moves one NW-th with the same
 // number of wave-instructions (1 KiB each, the last one partially masked), so a fixed vmcnt
 // tells every wave how many of its copies are still in flight.
-template <int BYTES>
+template <int BYTES, int NW>
 struct Copy16 {
-  static constexpr int kQuarter = BYTES / 4;
-  static constexpr int kInstr = (kQuarter + 1023) / 1024;
-  static_assert(kQuarter % 16 == 0, "quarter must be whole 16-byte pieces");
-  static_assert(kQuarter % 1024 != 0, "the masked tail keeps every instruction non-empty");
+  static constexpr int kPart = BYTES / NW;    // bytes copied by one wave
+  static constexpr int kInstr = (kPart + 1023) / 1024;
+  static_assert(BYTES % NW == 0 && kPart % 16 == 0, "each wave copies whole 16-byte pieces");
+  static_assert(kPart % 1024 != 0, "the masked tail keeps every instruction non-empty");
 };
 
 // The copy is issued through inline assembly on purpose: for the builtin the compiler cannot
@@ -207,13 +207,13 @@ __device__ __forceinline__ void glds_copy16(const char *gsrc_lane, const char *l
                : "memory", "m0");
 }
 
-template <int BYTES>
+template <int BYTES, int NW>
 __device__ __forceinline__ void stage_glds(const char *src, char *dst, int wave, int lane) {
-  typedef Copy16<BYTES> C;
+  typedef Copy16<BYTES, NW> C;
 #pragma unroll
   for (int i = 0; i < C::kInstr; ++i) {
-    const int off = wave * C::kQuarter + i * 1024;
-    if (i * 1024 + lane * 16 < C::kQuarter) glds_copy16(src + off + lane * 16, dst + off);
+    const int off = wave * C::kPart + i * 1024;
+    if (i * 1024 + lane * 16 < C::kPart) glds_copy16(src + off + lane * 16, dst + off);
   }
 }
 
@@ -242,16 +242,23 @@ template <int DP>
 __device__ __forceinline__ f32x16 tile_dot16(const char *buf, const h8 (&bh)[DP / 16],
                                              const h8 (&bl)[DP / 16], int j, int h) {
   typedef Rec16<DP> RL;
+  // all A fragments of the tile are fetched before the first MFMA: the chain then never waits
+  // on LDS latency between k-steps
+  h8 ah[DP / 16], al[DP / 16];
+#pragma unroll
+  for (int i = 0; i < DP / 16; ++i) {
+    ah[i] = *reinterpret_cast<const h8 *>(buf + RL::kHi + j * RL::kRowB + (2 * i + h) * 16);
+    al[i] = *reinterpret_cast<const h8 *>(buf + RL::kLo + j * RL::kRowB + (2 * i + h) * 16);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
   for (int i = 0; i < DP / 16; ++i) {
-    const h8 ah = *reinterpret_cast<const h8 *>(buf + RL::kHi + j * RL::kRowB + (2 * i + h) * 16);
-    const h8 al = *reinterpret_cast<const h8 *>(buf + RL::kLo + j * RL::kRowB + (2 * i + h) * 16);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[i], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[i], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[i], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[i], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[i], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[i], acc, 0, 0, 0);
   }
   return acc;
 }
@@ -272,11 +279,13 @@ __device__ __forceinline__ float load_owned(h8 (&bh)[DP / 16], h8 (&bl)[DP / 16]
 }
 
 // ---- forward ------------------------------------------------------------------------------
-template <int DP>
-__global__ void __launch_bounds__(256) sm16_fwd_kernel(const Sm16Args a) {
+// NW waves x 32 owned rows per workgroup: 4 for small batches (more workgroups), 8 for large ones
+// (every staged tile then serves twice the rows: the streaming traffic per flop halves).
+template <int DP, int NW>
+__global__ void __launch_bounds__(NW * 64) sm16_fwd_kernel(const Sm16Args a) {
   typedef Rec16<DP> RL;
   constexpr int NB = 3;                               // ring depth: copies run 2 tiles ahead
-  constexpr int kInstr = Copy16<RL::kFwdBytes>::kInstr;
+  constexpr int kInstr = Copy16<RL::kFwdBytes, NW>::kInstr;
   // separate LDS objects: the compiler can then tell that the copy into one buffer does not
   // alias the reads of another and does not serialise them with s_waitcnt vmcnt(0)
   __shared__ __attribute__((aligned(16))) char ring0[RL::kFwdBytes];
@@ -287,7 +296,7 @@ __global__ void __launch_bounds__(256) sm16_fwd_kernel(const Sm16Args a) {
   const int j = lane & 31, h = lane >> 5;
   const int64_t rb = blockIdx.x / a.nsplit;
   const int sp = (int)(blockIdx.x - rb * a.nsplit);
-  const int64_t base32 = rb * 128 + wave * 32;
+  const int64_t base32 = rb * (NW * 32) + wave * 32;
   const int64_t row = base32 + j;
   const bool rvalid = row < a.q.n;
 
@@ -297,8 +306,8 @@ __global__ void __launch_bounds__(256) sm16_fwd_kernel(const Sm16Args a) {
   const int nt = (int)((c_hi - c_lo + 31) / 32);
   const char *src = a.c.rec + (c_lo >> 5) * RL::kBytes;
 
-  if (nt > 0) stage_glds<RL::kFwdBytes>(src, ring0, wave, lane);
-  if (nt > 1) stage_glds<RL::kFwdBytes>(src + RL::kBytes, ring1, wave, lane);
+  if (nt > 0) stage_glds<RL::kFwdBytes, NW>(src, ring0, wave, lane);
+  if (nt > 1) stage_glds<RL::kFwdBytes, NW>(src + RL::kBytes, ring1, wave, lane);
 
   h8 bh[DP / 16], bl[DP / 16];
   const float rowfac2 = load_owned<DP>(bh, bl, a.q, row, h) * a.inv_t * kLog2e;
@@ -313,7 +322,7 @@ __global__ void __launch_bounds__(256) sm16_fwd_kernel(const Sm16Args a) {
   auto step = [&](const char *cur, char *pre, int t) __attribute__((always_inline)) {
     wait_tile<kInstr, NB - 2>(nt - 1 - t);
     if (t + NB - 1 < nt)
-      stage_glds<RL::kFwdBytes>(src + (int64_t)(t + NB - 1) * RL::kBytes, pre, wave, lane);
+      stage_glds<RL::kFwdBytes, NW>(src + (int64_t)(t + NB - 1) * RL::kBytes, pre, wave, lane);
     const int64_t s0 = c_lo + (int64_t)t * 32;
     const f32x16 acc = tile_dot16<DP>(cur, bh, bl, j, h);
     const float *sinv = reinterpret_cast<const float *>(cur + RL::kInv);
@@ -324,12 +333,14 @@ __global__ void __launch_bounds__(256) sm16_fwd_kernel(const Sm16Args a) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) v2[4 * g + k] = acc[4 * g + k] * (sv[k] * rowfac2);
     }
-    if (s0 + 32 > c_hi) {   // ragged last tile
+    if (s0 + 32 > c_hi) {   // ragged last tile (wave-uniform and rare: kept a real branch)
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         if (s0 + tile_row_of_reg(r, h) >= c_hi) v2[r] = -__builtin_inff();
     }
     if (s0 == base32) {     // the tile that holds the positives of this wave's rows
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         if (tile_row_of_reg(r, h) == j) {
@@ -448,16 +459,16 @@ __global__ void __launch_bounds__(256) sm16_fill_lse_kernel(const float *lse, in
 // ---- backward -----------------------------------------------------------------------------
 // RQ = true : workgroup owns 128 queries, streams candidates, emits partial dq.
 // RQ = false: workgroup owns 128 candidates, streams queries, emits partial dc.
-template <int DP, bool RQ>
-__global__ void __launch_bounds__(256) sm16_bwd_kernel(const Sm16Args a) {
+template <int DP, bool RQ, int NW>
+__global__ void __launch_bounds__(NW * 64) sm16_bwd_kernel(const Sm16Args a) {
   typedef Rec16<DP> RL;
   constexpr int NFB = DP / 32;
   constexpr int NB = DP <= 64 ? 3 : 2;
-  constexpr int kInstr = Copy16<RL::kBytes>::kInstr;
+  constexpr int kInstr = Copy16<RL::kBytes, NW>::kInstr;
   __shared__ __attribute__((aligned(16))) char ring0[RL::kBytes];
   __shared__ __attribute__((aligned(16))) char ring1[RL::kBytes];
   __shared__ __attribute__((aligned(16))) char ring2[NB > 2 ? RL::kBytes : 16];
-  __shared__ uint32_t s_e[4];
+  __shared__ uint32_t s_e[NW];
   const Side16 &R = RQ ? a.q : a.c;
   const Side16 &S = RQ ? a.c : a.q;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -465,7 +476,7 @@ __global__ void __launch_bounds__(256) sm16_bwd_kernel(const Sm16Args a) {
   const int j = lane & 31, h = lane >> 5;
   const int64_t rb = blockIdx.x / a.nsplit;
   const int sp = (int)(blockIdx.x - rb * a.nsplit);
-  const int64_t base32 = rb * 128 + wave * 32;
+  const int64_t base32 = rb * (NW * 32) + wave * 32;
   const int64_t row = base32 + j;
   const bool rvalid = row < R.n;
 
@@ -475,8 +486,8 @@ __global__ void __launch_bounds__(256) sm16_bwd_kernel(const Sm16Args a) {
   const int nt = (int)((s_hi - s_lo + 31) / 32);
   const char *src = S.rec + (s_lo >> 5) * RL::kBytes;
 
-  if (nt > 0) stage_glds<RL::kBytes>(src, ring0, wave, lane);
-  if (NB > 2 && nt > 1) stage_glds<RL::kBytes>(src + RL::kBytes, ring1, wave, lane);
+  if (nt > 0) stage_glds<RL::kBytes, NW>(src, ring0, wave, lane);
+  if (NB > 2 && nt > 1) stage_glds<RL::kBytes, NW>(src + RL::kBytes, ring1, wave, lane);
 
   h8 bh[DP / 16], bl[DP / 16];
   const float rowfac2 = load_owned<DP>(bh, bl, R, row, h) * a.inv_t * kLog2e;
@@ -486,7 +497,7 @@ __global__ void __launch_bounds__(256) sm16_bwd_kernel(const Sm16Args a) {
   {
     uint32_t E = 0u;
     const int64_t nblk = S.np >> 5;
-    for (int64_t b = tid; b < nblk; b += 256) E = S.bmax[b] > E ? S.bmax[b] : E;
+    for (int64_t b = tid; b < nblk; b += NW * 64) E = S.bmax[b] > E ? S.bmax[b] : E;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       const uint32_t o = (uint32_t)__shfl_xor((int)E, off);
@@ -512,11 +523,11 @@ __global__ void __launch_bounds__(256) sm16_bwd_kernel(const Sm16Args a) {
   auto step = [&](const char *cur, char *pre, int t) __attribute__((always_inline)) {
     wait_tile<kInstr, NB - 2>(nt - 1 - t);
     if (t + NB - 1 < nt)
-      stage_glds<RL::kBytes>(src + (int64_t)(t + NB - 1) * RL::kBytes, pre, wave, lane);
+      stage_glds<RL::kBytes, NW>(src + (int64_t)(t + NB - 1) * RL::kBytes, pre, wave, lane);
     if (t == 0) {           // the first barrier also published s_e
       uint32_t Em = s_e[0];
 #pragma unroll
-      for (int k = 1; k < 4; ++k) Em = s_e[k] > Em ? s_e[k] : Em;
+      for (int k = 1; k < NW; ++k) Em = s_e[k] > Em ? s_e[k] : Em;
       int G = Em ? 14 - ((int)Em - 126) : 0;
       G = G > 120 ? 120 : (G < -120 ? -120 : G);
       tscale = u2f((uint32_t)(G + 127) << 23);
@@ -536,11 +547,13 @@ __global__ void __launch_bounds__(256) sm16_bwd_kernel(const Sm16Args a) {
         tp[4 * g + k] = fast_exp2(acc[4 * g + k] * (sv[k] * rowfac2) - ls[k]);
     }
     if (s0 == base32) {     // the tile that holds the positives: softmax - onehot
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         if (tile_row_of_reg(r, h) == j) tp[r] -= 1.0f;
     }
     if (s0 + 32 > s_hi) {   // ragged last tile: rows past the end contribute nothing
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         if (s0 + tile_row_of_reg(r, h) >= s_hi) tp[r] = 0.0f;
@@ -592,7 +605,7 @@ __global__ void __launch_bounds__(256) sm16_bwd_kernel(const Sm16Args a) {
   // 128-byte row segments as float4.
   if ((a.d & 3) == 0) {
     constexpr int kLd = 36;                      // floats per LDS row: 32 + 4 (bank spread)
-    __shared__ __attribute__((aligned(16))) float scr_all[4 * 32 * kLd];
+    __shared__ __attribute__((aligned(16))) float scr_all[NW * 32 * kLd];
     float *scr = scr_all + wave * 32 * kLd;
     const int pr = lane >> 3, pc = lane & 7;     // 8 lanes x float4 = one 32-feature row segment
 #pragma unroll
@@ -644,14 +657,24 @@ __global__ void __launch_bounds__(256) sm16_reduce2_kernel(const float *pa, int 
 
 // ---- host side ----------------------------------------------------------------------------
 static inline size_t al16(size_t x) { return (x + 255) / 256 * 256; }
-static inline int64_t pad128(int64_t n) { return (n + 127) / 128 * 128; }
+static inline int64_t pad128(int64_t n) { return (n + 255) / 256 * 256; }   // records cover whole 256-row blocks
+// waves per workgroup for a side with n_rows owned rows
+static inline int nw_of(int64_t n_rows) {
+  static const int forced = [] {
+    const char *v = getenv("TFRS_SOFTMAX_NW");
+    return (v && *v) ? atoi(v) : 0;
+  }();
+  if (forced == 4 || forced == 8) return forced;
+  return n_rows >= 16384 ? 8 : 4;
+}
 static inline int dp_of(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : 128); }
 static inline size_t rec_bytes(int dp) {
   return dp == 32 ? Rec16<32>::kBytes : (dp == 64 ? Rec16<64>::kBytes : Rec16<128>::kBytes);
 }
 
 static void plan16(int64_t n_rows, int64_t n_stream, int *nsplit, int64_t *split_len) {
-  const int64_t row_blocks = (n_rows + 127) / 128;
+  const int64_t per_wg = nw_of(n_rows) * 32;
+  const int64_t row_blocks = (n_rows + per_wg - 1) / per_wg;
   const int64_t tiles = (n_stream + 31) / 32;
   static const int64_t target = [] {
     const char *v = getenv("TFRS_SOFTMAX_WGS");
@@ -729,8 +752,13 @@ static int fwd16(const float *q, const float *c, int64_t nq, int64_t nc, int d, 
   a.ppos = reinterpret_cast<float *>(p); p += al16((size_t)nq * 4);
   double *block_part = reinterpret_cast<double *>(p);
   uint32_t *ticket = reinterpret_cast<uint32_t *>(ws + L.header);
-  const int64_t wgs = ((nq + 127) / 128) * a.nsplit;
-  hipLaunchKernelGGL((sm16_fwd_kernel<DP>), dim3((unsigned)wgs), dim3(256), 0, s, a);
+  if (nw_of(nq) == 8) {
+    hipLaunchKernelGGL((sm16_fwd_kernel<DP, 8>), dim3((unsigned)(((nq + 255) / 256) * a.nsplit)),
+                       dim3(512), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((sm16_fwd_kernel<DP, 4>), dim3((unsigned)(((nq + 127) / 128) * a.nsplit)),
+                       dim3(256), 0, s, a);
+  }
   TFRS_LAUNCH_CHECK();
   const unsigned fin_blocks = (unsigned)((nq + 63) / 64);
   hipLaunchKernelGGL((sm16_finalize_kernel<DP>), dim3(fin_blocks), dim3(64), 0, s, a, out_loss, out_lse,
@@ -760,16 +788,26 @@ static int bwd16(const float *q, const float *c, int64_t nq, int64_t nc, int d, 
   const int nsq = a.nsplit;
   float *part_q = nsq == 1 ? dq : reinterpret_cast<float *>(p);
   a.partial = part_q;
-  hipLaunchKernelGGL((sm16_bwd_kernel<DP, true>), dim3((unsigned)(((nq + 127) / 128) * nsq)), dim3(256),
-                     0, s, a);
+  if (nw_of(nq) == 8) {
+    hipLaunchKernelGGL((sm16_bwd_kernel<DP, true, 8>), dim3((unsigned)(((nq + 255) / 256) * nsq)),
+                       dim3(512), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((sm16_bwd_kernel<DP, true, 4>), dim3((unsigned)(((nq + 127) / 128) * nsq)),
+                       dim3(256), 0, s, a);
+  }
   TFRS_LAUNCH_CHECK();
   p += al16((size_t)nsq * nq * d * 4);
   plan16(nc, nq, &a.nsplit, &a.split_len);
   const int nsc = a.nsplit;
   float *part_c = nsc == 1 ? dc : reinterpret_cast<float *>(p);
   a.partial = part_c;
-  hipLaunchKernelGGL((sm16_bwd_kernel<DP, false>), dim3((unsigned)(((nc + 127) / 128) * nsc)),
-                     dim3(256), 0, s, a);
+  if (nw_of(nc) == 8) {
+    hipLaunchKernelGGL((sm16_bwd_kernel<DP, false, 8>), dim3((unsigned)(((nc + 255) / 256) * nsc)),
+                       dim3(512), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((sm16_bwd_kernel<DP, false, 4>), dim3((unsigned)(((nc + 127) / 128) * nsc)),
+                       dim3(256), 0, s, a);
+  }
   TFRS_LAUNCH_CHECK();
   // per-split partial gradients -> dq, dc (a side with a single split wrote its output directly)
   const int64_t cq = nsq > 1 ? nq * d : 0, cc = nsc > 1 ? nc * d : 0;

@@ -55,24 +55,43 @@ struct Scan16Geom {
   static constexpr int kStageB = kTileN * kRowB;
   static constexpr int kChunks = kStageB / 16;
   static constexpr int kLoads = (kChunks + kThreads16 - 1) / kThreads16;
-  static constexpr int kLdsBytes = 2 * kStageB;
+  static constexpr int kMetaOff = 2 * kStageB;      // two 16-byte StageMeta slots after the tiles
+  static constexpr int kLdsBytes = 2 * kStageB + 32;
 };
 
 typedef __attribute__((address_space(3))) void lds_void16_t;
 typedef __attribute__((address_space(1))) const void gbl_void16_t;
 
-// Linear stage copy HBM/L2 -> LDS with the direct-to-LDS load (the fp16 image already has
-// its LDS layout): every wave-instruction moves 1 KiB.
+// Direct-to-LDS copy of 16 bytes per lane (LDS address = wave base + lane * 16).  Issued from
+// inline assembly on purpose: for the builtin the compiler cannot prove that the copy into one
+// stage buffer is independent of the ds_reads of the other and of neighbouring loads, and
+// drains it with s_waitcnt vmcnt(0) right after issue -- the prefetch then never overlaps the
+// MFMAs of the current stage.  Completion is tracked by hand: `wait_dma()` before the barrier
+// that ends a stage.
+__device__ __forceinline__ void glds_copy16(const char *gsrc_lane, const char *lds_wave_base) {
+  const uint32_t m0v = (uint32_t)(uintptr_t)(
+      __attribute__((address_space(3))) const char *)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               :
+               : "v"(gsrc_lane), "s"(m0v)
+               : "memory", "m0");
+}
+__device__ __forceinline__ void wait_dma() {   // s_waitcnt vmcnt(0), other counters untouched
+  __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8) | (0 << 14));
+}
+
+// Linear stage copy HBM/L2 -> LDS (the fp16 image already has its LDS layout): every
+// wave-instruction moves 1 KiB; the stage's 16-byte StageMeta rides along into its LDS slot.
 template <int CHUNKS, int LOADS>
-__device__ __forceinline__ void stage16_glds(const char *gsrc, char *lds_dst, int tid, int wave) {
+__device__ __forceinline__ void stage16_glds(const char *gsrc, char *lds_dst, const StageMeta *meta,
+                                             char *lds_meta, int tid, int wave) {
 #pragma unroll
   for (int i = 0; i < LOADS; ++i) {
     const int ch0 = i * kThreads16 + wave * 64;
-    if (ch0 < CHUNKS) {  // wave-uniform (CHUNKS is a multiple of 64)
-      __builtin_amdgcn_global_load_lds((gbl_void16_t *)(gsrc + (size_t)(i * kThreads16 + tid) * 16),
-                                       (lds_void16_t *)(lds_dst + ch0 * 16), 16, 0, 0);
-    }
+    if (ch0 < CHUNKS)  // wave-uniform (CHUNKS is a multiple of 64)
+      glds_copy16(gsrc + (size_t)(i * kThreads16 + tid) * 16, lds_dst + ch0 * 16);
   }
+  if (tid == 0) glds_copy16(reinterpret_cast<const char *>(meta), lds_meta);
 }
 
 __device__ __forceinline__ f16x8 as_f16x8(u32x4 v) {
@@ -182,21 +201,22 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
   static_assert(G::kChunks % 64 == 0, "stage size must be a whole number of wave copies");
   const char *gsrc = a.packed16 + first_stage * (int64_t)G::kStageB;
   const int64_t gstep = stride * (int64_t)G::kStageB;
-  stage16_glds<G::kChunks, G::kLoads>(gsrc, smem, tid, wave);
   const StageMeta *mp = a.meta + first_stage;
-  StageMeta sm = mp[0];
+  stage16_glds<G::kChunks, G::kLoads>(gsrc, smem, mp, smem + G::kMetaOff, tid, wave);
+  wait_dma();
   __syncthreads();
 
   float binmax[kQG] = {-__builtin_inff(), -__builtin_inff()};
   for (int st = 0; st < nst; ++st) {
     const char *tile = smem + (st & 1) * G::kStageB;
     const bool more = (st + 1 < nst);
-    StageMeta sm_next = sm;
     if (more) {  // prefetch the next stage into the other buffer (its readers passed the barrier)
       stage16_glds<G::kChunks, G::kLoads>(gsrc + (int64_t)(st + 1) * gstep,
-                                          smem + ((st + 1) & 1) * G::kStageB, tid, wave);
-      sm_next = mp[(int64_t)(st + 1) * stride];
+                                          smem + ((st + 1) & 1) * G::kStageB,
+                                          mp + (int64_t)(st + 1) * stride,
+                                          smem + G::kMetaOff + ((st + 1) & 1) * 16, tid, wave);
     }
+    const StageMeta sm = *reinterpret_cast<const StageMeta *>(smem + G::kMetaOff + (st & 1) * 16);
     // MFMA result = true prefilter score / (qscale * stage scale): compare against the
     // threshold divided by the same powers of two; `unscale` restores survivors' scores.
     float thr[kQG], unscale[kQG];
@@ -300,8 +320,8 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
             a.binmax[qrow[g] * a.ld_binmax + 2 * ((i0 + st) / a.bin_stages) + h] = binmax[g];
       }
     }
-    sm = sm_next;
-    __syncthreads();
+    wait_dma();      // this wave's share of the next stage has landed ...
+    __syncthreads();  // ... and so has everybody else's; the current buffer is free again
   }
 
   if (MODE == kModeFilter) {
