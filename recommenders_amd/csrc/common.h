@@ -192,6 +192,10 @@ struct Scan16Args {
   float *binmax;
   int64_t ld_binmax;
   int bin_stages;        // stages per bin (stages_per_split must be a multiple of it)
+  uint32_t *zero_word;   // FILTER: word re-armed (= 0) for the kernel that follows (the
+                         // flagged-query counter); NULL otherwise.  In-kernel instead of a
+                         // hipMemsetAsync because memset nodes are not reliably ordered against
+                         // kernel nodes when a captured call is replayed from a HIP graph.
 };
 int launch_scan16(const Scan16Args &a, hipStream_t stream);
 constexpr int kScan16QueriesPerWg = 512;

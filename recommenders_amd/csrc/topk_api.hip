@@ -392,11 +392,11 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
     set_error("topk: survivor workspace too small (%d segments x %u)", s16.nseg, s16.cap_l);
     return TFRS_ENOMEM;
   }
+  s16.zero_word = reinterpret_cast<uint32_t *>(w.redo);   // the flagged-query counter, re-armed
   if ((rc = timed_scan16(s16, 2.0 * (double)nq * (double)n * d, stream)) != TFRS_OK) return rc;
 
   // prefilter top-K + exact re-scoring; flagged queries (list overflow, retained set too
   // large) are answered by the exact recompute path of the generic select kernel
-  TFRS_HIP(hipMemsetAsync(w.redo, 0, 4, stream));  // the flagged-query counter
   if ((rc = launch_list_topk16(q, nq, d, packed, w.buf, w.cnt, s16.cap_l, s16.nseg, k, w.qk,
                                img.norm_max, out_scores, out_idx, w.redo, idx_base, stream)) != TFRS_OK)
     return rc;

@@ -128,6 +128,7 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (MODE == kModeFilter && a.zero_word && blockIdx.x == 0 && tid == 0) *a.zero_word = 0u;
   const int j = lane & 31;  // query column of this lane
   const int h = lane >> 5;  // k half of the MFMA step / upper candidate half of the C layout
 

@@ -313,10 +313,10 @@ class BruteForce(TopK):
   def _identifier_table(self) -> _Identifiers:
     return self._ids
 
-  def _query_rows(self, queries, k: int) -> Tuple[Tensor, Tensor]:
+  def _query_rows(self, queries, k: int, embedded: bool = False) -> Tuple[Tensor, Tensor]:
     if self._index is None:                                             # :594-598
       raise ValueError(NOT_INDEXED_MESSAGE)
-    q = self._embed(queries)                                            # :600-601
+    q = queries if embedded else self._embed(queries)                   # :600-601
     if q.shape[1] != self._d:
       raise ValueError(f"Query dimension {q.shape[1]} does not match the index ({self._d}).")
     lib = _lib.load()
@@ -333,6 +333,41 @@ class BruteForce(TopK):
     k = k if k is not None else self._k
     scores, rows = self._query_rows(queries, k)
     return scores, self._ids.gather(rows)                               # :607
+
+  def make_graphed_call(self, example_queries, k: Optional[int] = None):
+    """``call`` for a fixed batch shape, captured once in a HIP graph and replayed.
+
+    A small-batch query is a chain of ~8 short kernels (query norms, threshold pass, filter
+    pass, exact re-scoring); replaying them from a graph removes the per-launch host cost that
+    dominates the latency of single queries.  ``query_model`` (if any) and the identifier
+    lookup stay outside the graph; the search itself -- same kernels, same results -- is
+    inside.  Returns ``f(queries) -> (scores, identifiers)``; the returned score tensor is
+    overwritten by the next call.  The index must not be re-indexed afterwards."""
+    k = k if k is not None else self._k
+    if self._index is None:
+      raise ValueError(NOT_INDEXED_MESSAGE)
+    static_q = self._embed(example_queries).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      for _ in range(2):
+        self._query_rows(static_q, k, embedded=True)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+      scores, rows = self._query_rows(static_q, k, embedded=True)
+
+    def graphed(queries):
+      q = self._embed(queries)
+      if q.shape != static_q.shape:
+        raise ValueError(f"graphed call was captured for queries of shape {tuple(static_q.shape)}; "
+                         f"got {tuple(q.shape)}")
+      static_q.copy_(q, non_blocking=True)
+      graph.replay()
+      return scores, self._ids.gather(rows)
+
+    graphed.graph = graph
+    return graphed
 
   def candidates(self) -> Tensor:
     """The indexed candidate matrix (unpacked copy), for checkpointing."""

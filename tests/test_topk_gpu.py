@@ -463,3 +463,26 @@ def test_bruteforce_save_load_roundtrip(tmp_path, id_kind, filter_mode):
   fresh = ftk.BruteForce().load_state_dict(layer.state_dict())
   s2, i2 = fresh(q)
   np.testing.assert_array_equal(_np(s0), _np(s2))
+
+
+@pytest.mark.parametrize("nq", [1, 64, 1024])
+def test_bruteforce_graphed_call_matches_eager(nq, filter_mode):
+  """BruteForce.make_graphed_call: the HIP-graph replay of the search returns exactly what the
+  eager call returns, for fresh query batches (no stale counters / thresholds between replays)."""
+  import torch
+  ftk = _layers()
+  rng = np.random.default_rng(77 + nq)
+  n, d, k = 150000, 64, 100
+  corpus = (rng.normal(size=(n, d)) / np.sqrt(d)).astype(np.float32)
+  layer = ftk.BruteForce(k=k).index(torch.as_tensor(corpus).cuda())
+  graphed = layer.make_graphed_call(torch.as_tensor(np.zeros((nq, d), np.float32)).cuda())
+  for it in range(3):
+    q = (rng.normal(size=(nq, d)) / np.sqrt(d)).astype(np.float32)
+    if it == 2:
+      q[0] = corpus[123] * 3.0                     # a query with one dominant match
+    s_e, i_e = layer(torch.as_tensor(q).cuda())
+    s_g, i_g = graphed(torch.as_tensor(q).cuda())
+    np.testing.assert_array_equal(_np(i_g), _np(i_e))
+    np.testing.assert_array_equal(_np(s_g), _np(s_e))
+  with pytest.raises(ValueError, match="captured for"):
+    graphed(torch.as_tensor(np.zeros((nq + 1, d), np.float32)).cuda())
