@@ -197,6 +197,8 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
     mycnt[g] = 0;
   }
   const uint32_t row_limit = (uint32_t)a.row_limit;
+  const bool wave_active =
+      (int64_t)qt * kScan16QueriesPerWg + wave * (kQG * 32) < a.nq;   // wave-uniform
 
   // ---- stage 0 -> LDS ------------------------------------------------------------
   static_assert(G::kChunks % 64 == 0, "stage size must be a whole number of wave copies");
@@ -238,6 +240,11 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
     const uint32_t stage_row = (uint32_t)((first_stage + (int64_t)st * stride) * kTileN);
     const char *ap = tile + j * G::kRowB + h * 16;
 
+    // Small batches: a wave whose 64 query slots are all padding only helps to stage the tiles
+    // (it still issues its copies and meets the barriers) and skips the scoring, so the stage
+    // rate of a B <= 64 call is set by the HBM stream, not by MFMAs on padding.
+    if (!wave_active) goto stage_done;
+    {
     // A fragments are double-buffered in registers: the ds_reads of sub-tile t+1 are issued
     // before the MFMAs of sub-tile t, so no MFMA waits on LDS latency inside a stage.
     u32x4 af[2][G::kSteps];
@@ -310,7 +317,9 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
         }
       }
     }
-    if (MODE == kModeBinMax) {
+    }
+  stage_done:
+    if (MODE == kModeBinMax && wave_active) {
       // scores of different stages are compared in true units
 #pragma unroll
       for (int g = 0; g < kQG; ++g) binmax[g] = __builtin_fmaxf(binmax[g], stagemax[g] * unscale[g]);

@@ -181,30 +181,59 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
   for (int i = lane; i < dp; i += 64) qs[i] = (i < a.d) ? a.q[row * a.d + i] : 0.0f;
 
   // ---- gather the segmented list into LDS (lanes <-> segments, entry-major rows) ----------
+  // Small batches split the corpus over many workgroups, i.e. many short segments per query
+  // (1024 at B = 1): the counts of 16 x 64 segments are fetched as one batch of independent
+  // loads, then the first two entries of all of them as a second batch, so the gather costs
+  // two memory latencies instead of two per 64 segments.
   const uint2 *qbuf = a.buf + (row * (int64_t)a.cap_l) * a.nseg;
   int total = 0;       // wave-uniform
   bool bad = false;    // overflowed segment or list longer than kCap
-  for (int sb = 0; sb < a.nseg; sb += 64) {
-    const int sg = sb + lane;
-    const uint32_t c = (sg < a.nseg) ? a.cnt[row * a.nseg + sg] : 0u;
-    bad = bad || (c > a.cap_l);
-    uint32_t cmax = c;
-    for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, off));
-    if (cmax > a.cap_l) break;  // (uniform) the query is redone anyway
-    for (uint32_t e0 = 0; e0 < cmax; e0 += 4) {
-      uint2 v[4];
+  auto push = [&](bool p, uint2 v) __attribute__((always_inline)) {
+    const uint64_t mask = __ballot(p);
+    const int pos = total + (int)sel16_mbcnt(mask);
+    if (p && pos < kCap) ent[pos] = v;
+    total += (int)__popcll(mask);
+  };
+  constexpr int kCntBatch = 16;
+  for (int sb0 = 0; sb0 < a.nseg && !bad; sb0 += 64 * kCntBatch) {
+    uint32_t cnts[kCntBatch];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        v[u] = make_uint2(0u, 0u);
-        if (e0 + u < c) v[u] = qbuf[(int64_t)(e0 + u) * a.nseg + sg];
+    for (int b = 0; b < kCntBatch; ++b) {
+      const int sg = sb0 + b * 64 + lane;
+      cnts[b] = (sg < a.nseg) ? a.cnt[row * a.nseg + sg] : 0u;
+    }
+#pragma unroll
+    for (int b = 0; b < kCntBatch; ++b) bad = bad || (cnts[b] > a.cap_l);
+    if (__ballot(bad) != 0ull) {   // (uniform) the query is redone anyway
+      bad = true;
+      break;
+    }
+    // first two entries of every segment of the batch: one wave of independent loads
+    uint2 v[kCntBatch][2];
+#pragma unroll
+    for (int b = 0; b < kCntBatch; ++b)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        v[b][e] = make_uint2(0u, 0u);
+        if ((uint32_t)e < cnts[b]) v[b][e] = qbuf[(int64_t)e * a.nseg + sb0 + b * 64 + lane];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool p = e0 + u < c;
-        const uint64_t mask = __ballot(p);
-        const int pos = total + (int)sel16_mbcnt(mask);
-        if (p && pos < kCap) ent[pos] = v[u];
-        total += (int)__popcll(mask);
+    for (int b = 0; b < kCntBatch; ++b) {
+      if (sb0 + b * 64 >= a.nseg) break;   // uniform
+#pragma unroll
+      for (int e = 0; e < 2; ++e) push((uint32_t)e < cnts[b], v[b][e]);
+      // longer segments (large batches: few splits, ~7 entries each): 4 entries per round
+      uint32_t cmax = cnts[b];
+      for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, off));
+      for (uint32_t e0 = 2; e0 < cmax; e0 += 4) {
+        uint2 w[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          w[x] = make_uint2(0u, 0u);
+          if (e0 + x < cnts[b]) w[x] = qbuf[(int64_t)(e0 + x) * a.nseg + sb0 + b * 64 + lane];
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) push(e0 + x < cnts[b], w[x]);
       }
     }
   }
