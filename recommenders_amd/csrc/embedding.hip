@@ -281,7 +281,10 @@ __global__ void __launch_bounds__(256) scatter_rowscan_kernel(
   // the id list goes through LDS in chunks shared by the workgroup's 4 rows, so a wave's scan
   // is 64 LDS reads per 4096 ids instead of 64 dependent global loads
   constexpr int kChunk = 4096;
+  constexpr int kHitCap = 128;
   __shared__ int64_t s_ids[kChunk];
+  __shared__ int s_hits[4][kHitCap];
+  int *my_hits = s_hits[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63;
   const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const bool row_ok = v < vocab;
@@ -293,20 +296,44 @@ __global__ void __launch_bounds__(256) scatter_rowscan_kernel(
     for (int e = threadIdx.x; e < m; e += 256) s_ids[e] = load_id<IdT>(ids, c0 + e);
     __syncthreads();
     if (!row_ok) continue;
+    // Two phases per chunk: the scan only records where this row's id occurs (in order); the
+    // gradient rows are then fetched eight at a time as independent loads and added in
+    // occurrence order -- one memory latency per eight duplicates instead of one per duplicate.
+    int nh = 0;   // wave-uniform
+    auto flush = [&]() __attribute__((always_inline)) {
+      for (int i0 = 0; i0 < nh; i0 += 8) {
+        float r[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int hp = (i0 + u < nh) ? my_hits[i0 + u] : my_hits[i0];
+          const float *row = grad_out + (c0 + hp) * d;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) r[u][s] = (lane + 64 * s < d) ? row[lane + 64 * s] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (i0 + u < nh) {   // uniform
+#pragma unroll
+            for (int s = 0; s < 4; ++s) g[s] += r[u][s];
+          }
+      }
+      nh = 0;
+    };
     for (int base = 0; base < m; base += 64) {
       const int p = base + lane;
       const bool hit = (p < m) && (s_ids[p] == v);
-      uint64_t mask = __ballot(hit);
-      touched = touched || (mask != 0ull);
-      while (mask != 0ull) {
-        const int64_t pos = c0 + base + __builtin_ctzll(mask);
-        mask &= mask - 1ull;
-        const float *row = grad_out + pos * d;
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-          if (lane + 64 * s < d) g[s] += row[lane + 64 * s];
-      }
+      const uint64_t mask = __ballot(hit);
+      if (mask == 0ull) continue;
+      touched = true;
+      if (nh + 64 > kHitCap) flush();
+      const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+      if (hit) my_hits[nh + (int)below] = p;
+      nh += (int)__popcll(mask);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
+    flush();
   }
   if (!row_ok) return;
 #pragma unroll

@@ -460,22 +460,20 @@ __global__ void __launch_bounds__(256) sm16_fill_lse_kernel(const float *lse, in
 // RQ = true : workgroup owns 128 queries, streams candidates, emits partial dq.
 // RQ = false: workgroup owns 128 candidates, streams queries, emits partial dc.
 template <int DP, bool RQ, int NW>
-__global__ void __launch_bounds__(NW * 64) sm16_bwd_kernel(const Sm16Args a) {
+__device__ __forceinline__ void sm16_bwd_body(const Sm16Args &a, const int block, char *ring0,
+                                              char *ring1, char *ring2, uint32_t *s_e,
+                                              float *scr_all) {
   typedef Rec16<DP> RL;
   constexpr int NFB = DP / 32;
   constexpr int NB = DP <= 64 ? 3 : 2;
   constexpr int kInstr = Copy16<RL::kBytes, NW>::kInstr;
-  __shared__ __attribute__((aligned(16))) char ring0[RL::kBytes];
-  __shared__ __attribute__((aligned(16))) char ring1[RL::kBytes];
-  __shared__ __attribute__((aligned(16))) char ring2[NB > 2 ? RL::kBytes : 16];
-  __shared__ uint32_t s_e[NW];
   const Side16 &R = RQ ? a.q : a.c;
   const Side16 &S = RQ ? a.c : a.q;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
-  const int64_t rb = blockIdx.x / a.nsplit;
-  const int sp = (int)(blockIdx.x - rb * a.nsplit);
+  const int64_t rb = block / a.nsplit;
+  const int sp = (int)(block - rb * a.nsplit);
   const int64_t base32 = rb * (NW * 32) + wave * 32;
   const int64_t row = base32 + j;
   const bool rvalid = row < R.n;
@@ -605,7 +603,6 @@ __global__ void __launch_bounds__(NW * 64) sm16_bwd_kernel(const Sm16Args a) {
   // 128-byte row segments as float4.
   if ((a.d & 3) == 0) {
     constexpr int kLd = 36;                      // floats per LDS row: 32 + 4 (bank spread)
-    __shared__ __attribute__((aligned(16))) float scr_all[NW * 32 * kLd];
     float *scr = scr_all + wave * 32 * kLd;
     const int pr = lane >> 3, pc = lane & 7;     // 8 lanes x float4 = one 32-feature row segment
 #pragma unroll
@@ -636,6 +633,24 @@ __global__ void __launch_bounds__(NW * 64) sm16_bwd_kernel(const Sm16Args a) {
         if (feat < a.d) dst[feat] = outacc[fb][r] * coef_r;
       }
   }
+}
+
+// One launch for both directions: blocks [0, q_blocks) own queries (-> dq partials), the rest own
+// candidates (-> dc partials).  The LDS objects are declared once and shared by the two bodies.
+template <int DP, int NW>
+__global__ void __launch_bounds__(NW * 64) sm16_bwd_kernel(const Sm16Args aq, const Sm16Args ac,
+                                                           const int q_blocks) {
+  typedef Rec16<DP> RL;
+  constexpr int NB = DP <= 64 ? 3 : 2;
+  __shared__ __attribute__((aligned(16))) char ring0[RL::kBytes];
+  __shared__ __attribute__((aligned(16))) char ring1[RL::kBytes];
+  __shared__ __attribute__((aligned(16))) char ring2[NB > 2 ? RL::kBytes : 16];
+  __shared__ __attribute__((aligned(16))) float scr_all[NW * 32 * 36];
+  __shared__ uint32_t s_e[NW];
+  if ((int)blockIdx.x < q_blocks)
+    sm16_bwd_body<DP, true, NW>(aq, (int)blockIdx.x, ring0, ring1, ring2, s_e, scr_all);
+  else
+    sm16_bwd_body<DP, false, NW>(ac, (int)blockIdx.x - q_blocks, ring0, ring1, ring2, s_e, scr_all);
 }
 
 // Both gradients' partials in one launch (elements [0, count_a) of a, then b).
@@ -784,29 +799,34 @@ static int bwd16(const float *q, const float *c, int64_t nq, int64_t nc, int d, 
   a.d = d; a.w = w; a.inv_t = inv_t; a.lse = lse; a.gloss = gloss;
   char *p = ws + L.scratch;
 
-  plan16(nq, nc, &a.nsplit, &a.split_len);
-  const int nsq = a.nsplit;
+  Sm16Args aq = a, ac = a;
+  plan16(nq, nc, &aq.nsplit, &aq.split_len);
+  const int nsq = aq.nsplit;
   float *part_q = nsq == 1 ? dq : reinterpret_cast<float *>(p);
-  a.partial = part_q;
-  if (nw_of(nq) == 8) {
-    hipLaunchKernelGGL((sm16_bwd_kernel<DP, true, 8>), dim3((unsigned)(((nq + 255) / 256) * nsq)),
-                       dim3(512), 0, s, a);
-  } else {
-    hipLaunchKernelGGL((sm16_bwd_kernel<DP, true, 4>), dim3((unsigned)(((nq + 127) / 128) * nsq)),
-                       dim3(256), 0, s, a);
-  }
-  TFRS_LAUNCH_CHECK();
+  aq.partial = part_q;
   p += al16((size_t)nsq * nq * d * 4);
-  plan16(nc, nq, &a.nsplit, &a.split_len);
-  const int nsc = a.nsplit;
+  plan16(nc, nq, &ac.nsplit, &ac.split_len);
+  const int nsc = ac.nsplit;
   float *part_c = nsc == 1 ? dc : reinterpret_cast<float *>(p);
-  a.partial = part_c;
-  if (nw_of(nc) == 8) {
-    hipLaunchKernelGGL((sm16_bwd_kernel<DP, false, 8>), dim3((unsigned)(((nc + 255) / 256) * nsc)),
-                       dim3(512), 0, s, a);
+  ac.partial = part_c;
+  // both directions in one launch (a second launch only if the two sides differ in workgroup size)
+  const int nwq = nw_of(nq), nwc = nw_of(nc);
+  const int qb = (int)(((nq + nwq * 32 - 1) / (nwq * 32)) * nsq);
+  const int cb = (int)(((nc + nwc * 32 - 1) / (nwc * 32)) * nsc);
+  if (nwq == nwc) {
+    if (nwq == 8)
+      hipLaunchKernelGGL((sm16_bwd_kernel<DP, 8>), dim3((unsigned)(qb + cb)), dim3(512), 0, s, aq, ac, qb);
+    else
+      hipLaunchKernelGGL((sm16_bwd_kernel<DP, 4>), dim3((unsigned)(qb + cb)), dim3(256), 0, s, aq, ac, qb);
   } else {
-    hipLaunchKernelGGL((sm16_bwd_kernel<DP, false, 4>), dim3((unsigned)(((nc + 127) / 128) * nsc)),
-                       dim3(256), 0, s, a);
+    if (nwq == 8)
+      hipLaunchKernelGGL((sm16_bwd_kernel<DP, 8>), dim3((unsigned)qb), dim3(512), 0, s, aq, ac, qb);
+    else
+      hipLaunchKernelGGL((sm16_bwd_kernel<DP, 4>), dim3((unsigned)qb), dim3(256), 0, s, aq, ac, qb);
+    if (nwc == 8)
+      hipLaunchKernelGGL((sm16_bwd_kernel<DP, 8>), dim3((unsigned)cb), dim3(512), 0, s, aq, ac, 0);
+    else
+      hipLaunchKernelGGL((sm16_bwd_kernel<DP, 4>), dim3((unsigned)cb), dim3(256), 0, s, aq, ac, 0);
   }
   TFRS_LAUNCH_CHECK();
   // per-split partial gradients -> dq, dc (a side with a single split wrote its output directly)

@@ -153,8 +153,28 @@ class Model(torch.nn.Module):
         else:
           self.optimizer.reset_state_()
 
+    def flat_tensors(x, out):
+      if isinstance(x, torch.Tensor):
+        out.append(x)
+      elif isinstance(x, dict):
+        for k in sorted(x, key=str):     # pair tensors by key, not by insertion order
+          flat_tensors(x[k], out)
+      elif isinstance(x, (list, tuple)):
+        for v in x:
+          flat_tensors(v, out)
+      return out
+
+    static_flat = flat_tensors(static_inputs, [])
+
     def step(inputs):
-      copy_into(static_inputs, inputs)
+      src_flat = flat_tensors(inputs, [])
+      same_layout = len(src_flat) == len(static_flat) and all(
+          s_.shape == d.shape and s_.dtype == d.dtype and s_.device == d.device
+          for s_, d in zip(src_flat, static_flat))
+      if same_layout and len(static_flat) > 1:
+        torch._foreach_copy_(static_flat, src_flat)      # one fused copy kernel for the batch
+      else:
+        copy_into(static_inputs, inputs)                 # (also raises on a shape mismatch)
       graph.replay()
       return logs
 
