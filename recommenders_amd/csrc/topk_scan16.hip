@@ -251,6 +251,71 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
 #pragma unroll
     for (int m = 0; m < G::kSteps; ++m) af[0][m] = *reinterpret_cast<const u32x4 *>(ap + m * 32);
 
+    // The two query groups of a wave are skewed by half a step: while the MFMA chain of one
+    // group's tile runs, the VALU work on the OTHER group's finished tile (max tree, threshold
+    // compare) is issued under it -- chain(g1, s) || check(g0, s), chain(g0, s+1) || check(g1, s).
+    // In straight order (both chains, then both checks) a wave issues nothing to the matrix
+    // pipe while it reduces its tiles, and the waves of a SIMD fall into that rhythm together.
+    f32x16 acc[kQG];
+    // acc[g][r] = s~(query g*32 + j, candidate stage_row + sub*32 + (r&3) + 8*(r>>2) + 4*h)
+    auto chain = [&](int g, int sub) __attribute__((always_inline)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][r] = 0.0f;
+#pragma unroll
+      for (int m = 0; m < G::kSteps; ++m)
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(af[sub & 1][m]), bq[g][m], acc[g], 0, 0, 0);
+    };
+    auto check = [&](int g, int sub) __attribute__((always_inline)) {
+      const f32x16 &c = acc[g];
+      if (MODE == kModeMaterialize) {
+        if (qvalid[g]) {
+          float *drow = a.dense + qrow[g] * a.ld_dense +
+                        ((int64_t)(i0 + st) * kTileN + sub * 32 + 4 * h);
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4)
+            *reinterpret_cast<float4 *>(drow + 8 * g4) =
+                make_float4(c[4 * g4 + 0] * unscale[g], c[4 * g4 + 1] * unscale[g],
+                            c[4 * g4 + 2] * unscale[g], c[4 * g4 + 3] * unscale[g]);
+        }
+        return;
+      }
+      const float m0 = max16(c);
+      if (MODE == kModeBinMax) {
+        stagemax[g] = __builtin_fmaxf(stagemax[g], m0);
+        // reduce NOW (the optimiser would otherwise sink the max trees to the end of the
+        // stage and keep all accumulator tiles alive -> scratch spills)
+        asm volatile("" : "+v"(stagemax[g]));
+        return;
+      }
+      if (__ballot(m0 > thr[g]) != 0ull) {  // some lane of the wave has a survivor in this tile
+        const uint32_t rbase = stage_row + sub * 32 + 4u * h;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const float gm = __builtin_fmaxf(mx3(c[4 * g4], c[4 * g4 + 1], c[4 * g4 + 2]), c[4 * g4 + 3]);
+          if (__ballot(gm > thr[g]) == 0ull) continue;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const float v = c[4 * g4 + rr];
+            const uint32_t row = rbase + rr + 8 * g4;
+            if (v > thr[g] && row < row_limit) {
+              if (mycnt[g] < a.cap_l) *wp[g] = make_uint2(__float_as_uint(v * unscale[g]), row);
+              wp[g] += a.nseg;
+              ++mycnt[g];
+            }
+          }
+        }
+      }
+    };
+    // one MFMA, then a few VALU instructions under it (the max tree is 8, the compare 2)
+    auto interleave = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < G::kSteps; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      }
+    };
+
+    chain(0, 0);
 #pragma unroll
     for (int sub = 0; sub < kTileN / 32; ++sub) {
       if (sub + 1 < kTileN / 32) {
@@ -260,61 +325,15 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
               *reinterpret_cast<const u32x4 *>(ap + (sub + 1) * 32 * G::kRowB + m * 32);
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this sub-tile's MFMAs
-      f32x16 acc[kQG];
-#pragma unroll
-      for (int g = 0; g < kQG; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][r] = 0.0f;
-      // chain-major order: the DP/16 MFMAs of one accumulator tile issue back to back
-#pragma unroll
-      for (int g = 0; g < kQG; ++g) {
-#pragma unroll
-        for (int m = 0; m < G::kSteps; ++m)
-          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(af[sub & 1][m]), bq[g][m], acc[g], 0, 0, 0);
-      }
-      // acc[g][r] = s~(query g*32 + j, candidate stage_row + sub*32 + (r&3) + 8*(r>>2) + 4*h)
-
-#pragma unroll
-      for (int g = 0; g < kQG; ++g) {
-        const f32x16 &c = acc[g];
-        if (MODE == kModeMaterialize) {
-          if (qvalid[g]) {
-            float *drow = a.dense + qrow[g] * a.ld_dense +
-                          ((int64_t)(i0 + st) * kTileN + sub * 32 + 4 * h);
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-              *reinterpret_cast<float4 *>(drow + 8 * g4) =
-                  make_float4(c[4 * g4 + 0] * unscale[g], c[4 * g4 + 1] * unscale[g],
-                              c[4 * g4 + 2] * unscale[g], c[4 * g4 + 3] * unscale[g]);
-          }
-          continue;
-        }
-        const float m0 = max16(c);
-        if (MODE == kModeBinMax) {
-          stagemax[g] = __builtin_fmaxf(stagemax[g], m0);
-          // reduce NOW (the optimiser would otherwise sink the max trees to the end of the
-          // stage and keep all 8 accumulator tiles alive -> scratch spills)
-          asm volatile("" : "+v"(stagemax[g]));
-          continue;
-        }
-        if (__ballot(m0 > thr[g]) != 0ull) {  // some lane of the wave has a survivor in this tile
-          const uint32_t rbase = stage_row + sub * 32 + 4u * h;
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const float gm = __builtin_fmaxf(mx3(c[4 * g4], c[4 * g4 + 1], c[4 * g4 + 2]), c[4 * g4 + 3]);
-            if (__ballot(gm > thr[g]) == 0ull) continue;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-              const float v = c[4 * g4 + rr];
-              const uint32_t row = rbase + rr + 8 * g4;
-              if (v > thr[g] && row < row_limit) {
-                if (mycnt[g] < a.cap_l) *wp[g] = make_uint2(__float_as_uint(v * unscale[g]), row);
-                wp[g] += a.nseg;
-                ++mycnt[g];
-              }
-            }
-          }
-        }
+      chain(1, sub);
+      check(0, sub);
+      if (MODE != kModeMaterialize) interleave();
+      if (sub + 1 < kTileN / 32) {
+        chain(0, sub + 1);
+        check(1, sub);
+        if (MODE != kModeMaterialize) interleave();
+      } else {
+        check(1, sub);
       }
     }
     }
