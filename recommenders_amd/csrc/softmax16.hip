@@ -675,10 +675,8 @@ static inline size_t al16(size_t x) { return (x + 255) / 256 * 256; }
 static inline int64_t pad128(int64_t n) { return (n + 255) / 256 * 256; }   // records cover whole 256-row blocks
 // waves per workgroup for a side with n_rows owned rows
 static inline int nw_of(int64_t n_rows) {
-  static const int forced = [] {
-    const char *v = getenv("TFRS_SOFTMAX_NW");
-    return (v && *v) ? atoi(v) : 0;
-  }();
+  const char *v = getenv("TFRS_SOFTMAX_NW");   // read per call: tests switch it
+  const int forced = (v && *v) ? atoi(v) : 0;
   if (forced == 4 || forced == 8) return forced;
   return n_rows >= 16384 ? 8 : 4;
 }

@@ -191,13 +191,23 @@ def test_inbatch_softmax_options_vs_oracle(nq, nc, d, softmax_mode):
                                err_msg=str(sorted(kw)))
 
 
+@pytest.mark.parametrize("waves", ["auto", "4", "8"])
 @pytest.mark.parametrize("nq,nc,d,scale", [(4096, 4096, 64, 0.05), (300, 4500, 100, 1.0),
-                                           (1024, 1024, 128, 30.0), (130, 130, 7, 1e-3)])
-def test_inbatch_softmax_f16_path_sizes(nq, nc, d, scale):
+                                           (1024, 1024, 128, 30.0), (130, 130, 7, 1e-3),
+                                           (200, 16500, 32, 0.3)])
+def test_inbatch_softmax_f16_path_sizes(nq, nc, d, scale, waves, monkeypatch):
   """The split-fp16 path at the MovieLens batch (several splits, 32 row blocks), with ragged
   tiles, D up to 128, tiny and large embedding magnitudes, uneven row norms, sample weights
   spanning 4 decades and a temperature: same tolerances as the f32 path."""
   from recommenders_amd.tasks.retrieval import in_batch_softmax_loss
+  # workgroup shape: 4 or 8 waves (x 32 owned rows); "auto" = 8 from 16384 owned rows on, so the
+  # last case runs its two backward directions with different shapes (two launches)
+  if waves == "auto":
+    monkeypatch.delenv("TFRS_SOFTMAX_NW", raising=False)
+  else:
+    monkeypatch.setenv("TFRS_SOFTMAX_NW", waves)
+  if (nq, waves) == (130, "8"):
+    monkeypatch.setenv("TFRS_SOFTMAX_NO_REUSE", "1")   # backward rebuilds the operand records
   rng = np.random.default_rng(nq + d)
   # query magnitude `scale`, candidate magnitude chosen so that logits stay O(1): the softmax is
   # not saturated and gradients are well conditioned, while the operands sit decades apart
