@@ -71,10 +71,14 @@ typedef __attribute__((address_space(1))) const void gbl_void16_t;
 __device__ __forceinline__ void glds_copy16(const char *gsrc_lane, const char *lds_wave_base) {
   const uint32_t m0v = (uint32_t)(uintptr_t)(
       __attribute__((address_space(3))) const char *)lds_wave_base;
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-               :
+  // M0 (the LDS base of the copy) is a reserved register the compiler does not track through
+  // inline assembly: it is saved and restored around the instruction.
+  uint32_t m0_saved;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(m0_saved)
                : "v"(gsrc_lane), "s"(m0v)
-               : "memory", "m0");
+               : "memory");
 }
 __device__ __forceinline__ void wait_dma() {   // s_waitcnt vmcnt(0), other counters untouched
   __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8) | (0 << 14));
