@@ -289,6 +289,18 @@ int tfrs_cross_fwd_ex(const float *x0, const float *x, const float *a, int ka,
 int tfrs_dense_fwd(const float *x, const float *kernel, const float *bias, int64_t batch,
                    int din, int dout, float *out, void *stream);
 
+/* The same two products on the fp16 matrix cores with split operands (x = hi + lo per
+ * power-of-two-scaled row / column; hi*hi + hi*lo + lo*hi with f32 accumulation): f32-grade
+ * results at ~3x the rate for large shapes.  The caller provides the workspace that holds the
+ * operand images (tfrs_gemm_f16_workspace_bytes(batch, dout, din)). */
+size_t tfrs_gemm_f16_workspace_bytes(int64_t m, int n, int k);
+int tfrs_dense_fwd_f16(const float *x, const float *kernel, const float *bias, int64_t batch,
+                       int din, int dout, float *out, void *workspace, size_t workspace_bytes,
+                       void *stream);
+int tfrs_cross_fwd_f16(const float *x0, const float *x, const float *kernel, const float *bias,
+                       float diag_scale, int64_t batch, int d, float *y, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * DotInteraction.call (layers/feature_interaction/dot_interaction.py:53-104):
  * x[batch, f, d] -> lower-triangle pairwise dots, row-major; self_interaction adds the

@@ -32,6 +32,7 @@ SOURCES = [
     "softmax.hip",
     "softmax16.hip",
     "interaction.hip",
+    "gemm16.hip",
 ]
 
 

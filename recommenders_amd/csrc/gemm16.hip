@@ -1,0 +1,369 @@
+// gemm16.hip -- f32-grade GEMM on the fp16 matrix cores (split operands), for the large dense
+// products of the ranking models: Cross (layers/feature_interaction/dcn.py:151-186: x @ kernel
+// with the cross formula fused in the epilogue), its gradients, and MLP / low-rank projections
+// (layers/blocks.py:46-61).  At BASELINE configs[3] (B = 65536, d = 3456) one Cross layer is a
+// 1.57 TFLOP product; the f32-input MFMA tops out at 157 TFLOP/s.
+//
+// C[M, N] = A[M, K] @ B[K, N] (row-major f32 in and out).  Every operand value x is split into two
+// fp16 numbers, x * 2^a = hi + lo (a = power of two per A row / per B column that puts the largest
+// magnitude of that row / column in [2^9, 2^10): no fp16 under- or overflow;
+// |x * 2^a - hi - lo| <= 2^-22 |x * 2^a|), and the product is accumulated in f32 as
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16: three MFMA products per f32 product, 16x the
+// f32 MFMA rate each.  The scales are powers of two and are undone exactly in the epilogue.
+//
+//   prep_rows   A  -> Ah, Al [Mp, Kp] (row-major, K padded to 32), inv_a[Mp]
+//   colmax +
+//   prep_cols   B  -> Bh, Bl [Np, Kp] (one row per OUTPUT column: K contiguous), inv_b[Np]
+//   gemm16      128 x 128 tile per workgroup (4 waves, 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles),
+//               K step 32; both operand tiles are staged by direct-to-LDS copies (16 B per lane,
+//               XOR-swizzled 16-byte slots instead of row padding, so an unpadded 64-byte tile
+//               row is conflict-free for ds_read_b128) into a double buffer; completion tracked
+//               by hand (s_waitcnt vmcnt + s_barrier), copies issued from inline assembly (see
+//               softmax16.hip for why); epilogue: * inv_a[row] * inv_b[col] + bias [cross formula].
+//
+// Roofline: MFMA-bound; ALGORITHMIC flop 2 M N K, the pipe executes 3x that, priced against the
+// dense fp16 peak.  Operand images cost M K + K N extra 4-byte writes per call (prep).
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "mfma_tile.h"
+
+namespace tfrs {
+
+typedef _Float16 g16h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 g16h4 __attribute__((ext_vector_type(4)));
+
+constexpr int kG16M = 128, kG16N = 128, kG16K = 32;
+constexpr int kG16Img = 128 * 64;   // bytes of one 128-row x 32-half tile image in LDS
+
+__device__ __forceinline__ uint32_t g16_f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ float g16_u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
+
+// power-of-two scale that puts `maxabs` in [2^9, 2^10), and its inverse (1, 1 for ~zero rows)
+__device__ __forceinline__ void g16_scale_of(float maxabs, float *s, float *inv) {
+  const uint32_t e = (g16_f2u(maxabs) >> 23) & 0xffu;
+  *s = 1.0f;
+  *inv = 1.0f;
+  if (e >= 27u && e < 255u) {
+    *s = g16_u2f((263u - e) << 23);
+    *inv = g16_u2f((e - 9u) << 23);
+  }
+}
+
+// ---- prep: rows of A ------------------------------------------------------------------------
+// one wave per row; rows in [m, mp) and columns in [k, kp) are zero
+__global__ void __launch_bounds__(256) g16_prep_rows_kernel(const float *__restrict__ x, int64_t m,
+                                                            int k, int kp, _Float16 *__restrict__ hi,
+                                                            _Float16 *__restrict__ lo,
+                                                            float *__restrict__ inv,
+                                                            uint32_t *__restrict__ colmax, int np) {
+  // first kernel of the chain: re-arms the column maxima the next kernel combines with atomicMax
+  // (no hipMemsetAsync: memset nodes are not reliably ordered under HIP-graph replay)
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < np; i += (int64_t)gridDim.x * 256)
+    colmax[i] = 0u;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool valid = row < m;
+  const float *xr = x + row * (int64_t)k;
+  const bool vec = (k % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  float mx = 0.0f;
+  if (valid) {
+    if (vec) {
+      for (int c = lane * 4; c < k; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(xr + c);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      }
+    } else {
+      for (int c = lane; c < k; c += 64) mx = fmaxf(mx, fabsf(xr[c]));
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  float s, iv;
+  g16_scale_of(mx, &s, &iv);
+  if (lane == 0) inv[row] = iv;
+  _Float16 *hr = hi + row * (int64_t)kp, *lr = lo + row * (int64_t)kp;
+  for (int c = lane * 4; c < kp; c += 256) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+      if (vec && c + 3 < k) {
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(xr + c);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (c + u < k) v[u] = xr[c + u];
+      }
+    }
+    g16h4 h4, l4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float sv = v[u] * s;
+      h4[u] = (_Float16)sv;
+      l4[u] = (_Float16)(sv - (float)h4[u]);
+    }
+    *reinterpret_cast<g16h4 *>(hr + c) = h4;
+    *reinterpret_cast<g16h4 *>(lr + c) = l4;
+  }
+}
+
+// ---- prep: columns of B (transposed images) ------------------------------------------------
+// B can be as large as A (dW = x^T dz: both operands are [batch, d] activations), so both passes
+// are parallel over K as well: (1) column maxima of 64-column x 1024-row slabs, combined with
+// atomicMax on the bit patterns of the non-negative maxima (order-independent, hence
+// reproducible; colmax is zeroed by the row-prep kernel that runs first), (2) 64 x 64 tiles
+// scaled, split and transposed through LDS.
+constexpr int kG16Slab = 1024;
+
+__global__ void __launch_bounds__(256) g16_colmax_kernel(const float *__restrict__ b, int k, int n,
+                                                         uint32_t *__restrict__ colmax) {
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x;
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * kG16Slab;
+  const int c = tid & 63, rg = tid >> 6;
+  float mx = 0.0f;
+  if (n0 + c < n) {
+    const int k1 = k0 + kG16Slab < k ? k0 + kG16Slab : k;
+    for (int r = k0 + rg; r < k1; r += 4) mx = fmaxf(mx, fabsf(b[(int64_t)r * n + n0 + c]));
+  }
+  red[rg][c] = mx;
+  __syncthreads();
+  if (tid < 64 && n0 + tid < n) {
+    const float m4 = fmaxf(fmaxf(red[0][tid], red[1][tid]), fmaxf(red[2][tid], red[3][tid]));
+    atomicMax(&colmax[n0 + tid], g16_f2u(m4));
+  }
+}
+
+__global__ void __launch_bounds__(256) g16_prep_cols_kernel(const float *__restrict__ b, int k, int n,
+                                                            int kp, const uint32_t *__restrict__ colmax,
+                                                            _Float16 *__restrict__ hi,
+                                                            _Float16 *__restrict__ lo,
+                                                            float *__restrict__ inv) {
+  __shared__ float tile[64][65];
+  __shared__ float s_scale[64];
+  const int tid = threadIdx.x;
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  if (tid < 64) {
+    float s, iv;
+    g16_scale_of(g16_u2f(colmax[n0 + tid]), &s, &iv);
+    s_scale[tid] = s;
+    if (blockIdx.y == 0) inv[n0 + tid] = iv;
+  }
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int r = e >> 6, cc = e & 63;
+    tile[r][cc] = (k0 + r < k && n0 + cc < n) ? b[(int64_t)(k0 + r) * n + n0 + cc] : 0.0f;
+  }
+  __syncthreads();
+  const int col = tid >> 2, seg = (tid & 3) * 16;   // 16 consecutive k of one output column
+  const float s = s_scale[col];
+  _Float16 *hr = hi + (int64_t)(n0 + col) * kp + k0 + seg;
+  _Float16 *lr = lo + (int64_t)(n0 + col) * kp + k0 + seg;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    g16h8 h8, l8;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float sv = tile[seg + q * 8 + u][col] * s;
+      h8[u] = (_Float16)sv;
+      l8[u] = (_Float16)(sv - (float)h8[u]);
+    }
+    *reinterpret_cast<g16h8 *>(hr + q * 8) = h8;
+    *reinterpret_cast<g16h8 *>(lr + q * 8) = l8;
+  }
+}
+
+// ---- the GEMM -------------------------------------------------------------------------------
+enum { kG16EpiBias = 0, kG16EpiCross = 1 };
+
+struct Gemm16Args {
+  const _Float16 *ah, *al, *bh, *bl;   // [mp, kp], [np, kp]
+  const float *inva, *invb;            // [mp], [np]
+  int64_t m;
+  int n, kp;
+  const float *bias;                   // [n] or NULL
+  const float *x0, *x;                 // cross epilogue: [m, n]
+  float diag;
+  float *out;                          // [m, n]
+};
+
+__device__ __forceinline__ void g16_dma16(const char *gsrc_lane, const char *lds_wave_base) {
+  const uint32_t m0v = (uint32_t)(uintptr_t)(
+      __attribute__((address_space(3))) const char *)lds_wave_base;
+  uint32_t m0_saved;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(m0_saved)
+               : "v"(gsrc_lane), "s"(m0v)
+               : "memory");
+}
+__device__ __forceinline__ void g16_wait_dma() {
+  __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8) | (0 << 14));
+}
+
+// LDS tile image: 128 rows x 4 slots of 16 bytes (32 halves), no padding; slot s of row r holds
+// the k-slot s ^ ((r >> 2) & 3): the 16 lanes a ds_read_b128 serves together then hit 16
+// different 16-byte bank groups.
+__device__ __forceinline__ int g16_slot(int row, int kslot) { return kslot ^ ((row >> 2) & 3); }
+
+template <int EPI>
+__global__ void __launch_bounds__(256, 2) gemm16_kernel(const Gemm16Args g) {
+  // [buffer][Ah | Al | Bh | Bl]
+  __shared__ __attribute__((aligned(16))) char lds[2][4 * kG16Img];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int j = lane & 31, h = lane >> 5;
+
+  // consecutive workgroups walk the N tiles of one M tile: the (large) A rows stay in L2
+  const int nbn = (g.n + kG16N - 1) / kG16N;
+  const int64_t bm = (int64_t)(blockIdx.x / nbn) * kG16M;
+  const int bn = (int)(blockIdx.x % nbn) * kG16N;
+  const int nk = g.kp / kG16K;
+
+  // staging: wave w copies tile rows [32w, 32w + 32) of each of the 4 images, 16 rows per
+  // instruction; lane i -> row 16u + (i >> 2), LDS slot i & 3 (the copy writes LDS linearly)
+  const int sr = lane >> 2, ss = lane & 3;
+  const char *src[4][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int r = wave * 32 + u * 16 + sr;
+    const int ks = g16_slot(r, ss);
+    src[0][u] = reinterpret_cast<const char *>(g.ah + (bm + r) * g.kp) + ks * 16;
+    src[1][u] = reinterpret_cast<const char *>(g.al + (bm + r) * g.kp) + ks * 16;
+    src[2][u] = reinterpret_cast<const char *>(g.bh + (int64_t)(bn + r) * g.kp) + ks * 16;
+    src[3][u] = reinterpret_cast<const char *>(g.bl + (int64_t)(bn + r) * g.kp) + ks * 16;
+  }
+  auto stage = [&](int kt, char *buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int im = 0; im < 4; ++im)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        g16_dma16(src[im][u] + (int64_t)kt * (kG16K * 2), buf + im * kG16Img + (wave * 32 + u * 16) * 64);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
+
+  stage(0, lds[0]);
+  g16_wait_dma();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const char *cur = lds[kt & 1];
+    if (kt + 1 < nk) stage(kt + 1, lds[(kt + 1) & 1]);
+    // fragments of this K step: k-slot q = 2 * kk + h
+    g16h8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ra = wm * 64 + i * 32 + j, rb = wn * 64 + i * 32 + j;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int oa = ra * 64 + g16_slot(ra, 2 * kk + h) * 16;
+        const int ob = rb * 64 + g16_slot(rb, 2 * kk + h) * 16;
+        ah[i][kk] = *reinterpret_cast<const g16h8 *>(cur + oa);
+        al[i][kk] = *reinterpret_cast<const g16h8 *>(cur + kG16Img + oa);
+        bh[i][kk] = *reinterpret_cast<const g16h8 *>(cur + 2 * kG16Img + ob);
+        bl[i][kk] = *reinterpret_cast<const g16h8 *>(cur + 3 * kG16Img + ob);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i][kk], bh[jn][kk], acc[i][jn], 0, 0, 0);
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i][kk], bl[jn][kk], acc[i][jn], 0, 0, 0);
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i][kk], bh[jn][kk], acc[i][jn], 0, 0, 0);
+        }
+    g16_wait_dma();     // this wave's share of the next K step has landed ...
+    __syncthreads();    // ... and everybody else's; the current buffer is free again
+  }
+
+  // epilogue: acc[i][jn][r] = C'[row = bm + wm*64 + i*32 + tile_row_of_reg(r, h)][col = bn + wn*64 + jn*32 + j]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+      const int col = bn + wn * 64 + jn * 32 + j;
+      if (col >= g.n) continue;
+      const float cs = g.invb[col];
+      const float bias = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = bm + wm * 64 + i * 32 + tile_row_of_reg(r, h);
+        if (row >= g.m) continue;
+        float v = acc[i][jn][r] * (g.inva[row] * cs) + bias;
+        const int64_t o = row * g.n + col;
+        if (EPI == kG16EpiCross) {
+          const float xv = g.x[o];
+          v = g.x0[o] * (v + g.diag * xv) + xv;
+        }
+        g.out[o] = v;
+      }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------
+static inline size_t g16_al(size_t x) { return (x + 255) / 256 * 256; }
+static inline int64_t g16_pad(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
+
+struct G16Layout {
+  int64_t mp, np;
+  int kp;
+  size_t ah, al, bh, bl, inva, invb, colmax, total;
+};
+
+static G16Layout g16_layout(int64_t m, int n, int k) {
+  G16Layout L;
+  L.mp = g16_pad(m, kG16M);
+  L.np = g16_pad(n, kG16N);
+  L.kp = (int)g16_pad(k, 64);   // 64: the column prep writes whole 64-k tiles
+  size_t o = 0;
+  const size_t ia = g16_al((size_t)L.mp * L.kp * 2), ib = g16_al((size_t)L.np * L.kp * 2);
+  L.ah = o; o += ia; L.al = o; o += ia;
+  L.bh = o; o += ib; L.bl = o; o += ib;
+  L.inva = o; o += g16_al((size_t)L.mp * 4);
+  L.invb = o; o += g16_al((size_t)L.np * 4);
+  L.colmax = o; o += g16_al((size_t)L.np * 4);
+  L.total = o;
+  return L;
+}
+
+size_t gemm16_workspace_bytes(int64_t m, int n, int k) { return g16_layout(m, n, k).total; }
+
+// C = A @ B (+ bias) [cross epilogue when x0 != NULL]; ws from gemm16_workspace_bytes
+int gemm16_run(const float *a, const float *b, int64_t m, int n, int k, const float *bias,
+               const float *x0, const float *x, float diag, float *out, void *ws, hipStream_t s) {
+  const G16Layout L = g16_layout(m, n, k);
+  char *w = static_cast<char *>(ws);
+  _Float16 *ah = reinterpret_cast<_Float16 *>(w + L.ah), *al = reinterpret_cast<_Float16 *>(w + L.al);
+  _Float16 *bh = reinterpret_cast<_Float16 *>(w + L.bh), *bl = reinterpret_cast<_Float16 *>(w + L.bl);
+  float *inva = reinterpret_cast<float *>(w + L.inva), *invb = reinterpret_cast<float *>(w + L.invb);
+  uint32_t *colmax = reinterpret_cast<uint32_t *>(w + L.colmax);
+  hipLaunchKernelGGL(g16_prep_rows_kernel, dim3((unsigned)(L.mp / 4)), dim3(256), 0, s, a, m, k, L.kp, ah,
+                     al, inva, colmax, (int)L.np);
+  hipLaunchKernelGGL(g16_colmax_kernel, dim3((unsigned)(L.np / 64), (unsigned)((k + kG16Slab - 1) / kG16Slab)),
+                     dim3(256), 0, s, b, k, n, colmax);
+  hipLaunchKernelGGL(g16_prep_cols_kernel, dim3((unsigned)(L.np / 64), (unsigned)(L.kp / 64)), dim3(256), 0,
+                     s, b, k, n, L.kp, colmax, bh, bl, invb);
+  TFRS_LAUNCH_CHECK();
+  Gemm16Args g = {};
+  g.ah = ah; g.al = al; g.bh = bh; g.bl = bl; g.inva = inva; g.invb = invb;
+  g.m = m; g.n = n; g.kp = L.kp;
+  g.bias = bias; g.x0 = x0; g.x = x; g.diag = diag; g.out = out;
+  const dim3 grid((unsigned)((L.mp / kG16M) * (L.np / kG16N)));
+  if (x0)
+    hipLaunchKernelGGL((gemm16_kernel<kG16EpiCross>), grid, dim3(256), 0, s, g);
+  else
+    hipLaunchKernelGGL((gemm16_kernel<kG16EpiBias>), grid, dim3(256), 0, s, g);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+}  // namespace tfrs

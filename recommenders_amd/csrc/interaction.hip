@@ -633,6 +633,49 @@ extern "C" int tfrs_dense_fwd(const float *x, const float *kernel, const float *
   return launch_gemm(g, kEpiBias, (hipStream_t)stream);
 }
 
+// ---- split-fp16 variants (gemm16.hip): same results to f32 accuracy, ~3x the rate on large
+// products; the caller provides the workspace for the operand images --------------------------
+namespace tfrs {
+size_t gemm16_workspace_bytes(int64_t m, int n, int k);
+int gemm16_run(const float *a, const float *b, int64_t m, int n, int k, const float *bias,
+               const float *x0, const float *x, float diag, float *out, void *ws, hipStream_t s);
+}  // namespace tfrs
+
+extern "C" size_t tfrs_gemm_f16_workspace_bytes(int64_t m, int n, int k) {
+  if (m < 1 || n < 1 || k < 1) return 256;
+  return gemm16_workspace_bytes(m, n, k);
+}
+
+extern "C" int tfrs_dense_fwd_f16(const float *x, const float *kernel, const float *bias,
+                                  int64_t batch, int din, int dout, float *out, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+  TFRS_CHECK_ARG(batch >= 0 && din >= 1 && dout >= 1, "dense_fwd_f16: bad shape");
+  if (batch == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(x && kernel && out && workspace, "dense_fwd_f16: NULL pointer");
+  if (workspace_bytes < gemm16_workspace_bytes(batch, dout, din)) {
+    set_error("dense_fwd_f16: workspace too small");
+    return TFRS_ENOMEM;
+  }
+  return gemm16_run(x, kernel, batch, dout, din, bias, nullptr, nullptr, 0.0f, out, workspace,
+                    (hipStream_t)stream);
+}
+
+extern "C" int tfrs_cross_fwd_f16(const float *x0, const float *x, const float *kernel,
+                                  const float *bias, float diag_scale, int64_t batch, int d,
+                                  float *y, void *workspace, size_t workspace_bytes, void *stream) {
+  TFRS_CHECK_ARG(batch >= 0 && d >= 1, "cross_fwd_f16: bad shape");
+  TFRS_CHECK_ARG(diag_scale >= 0.0f, "`diag_scale` should be non-negative. Got `diag_scale` = %g",
+                 (double)diag_scale);
+  if (batch == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(x0 && x && kernel && y && workspace, "cross_fwd_f16: NULL pointer");
+  if (workspace_bytes < gemm16_workspace_bytes(batch, d, d)) {
+    set_error("cross_fwd_f16: workspace too small");
+    return TFRS_ENOMEM;
+  }
+  return gemm16_run(x, kernel, batch, d, d, bias, x0, x, diag_scale, y, workspace,
+                    (hipStream_t)stream);
+}
+
 extern "C" int tfrs_dot_interaction_fwd(const float *x, int64_t batch, int f, int d,
                                         int self_interaction, int skip_gather, float *out,
                                         void *stream) {

@@ -9,6 +9,7 @@ projection through the same fused epilogue (``tfrs_cross_fwd_ex``).
 """
 
 import math
+import os
 from typing import Callable, Optional, Union
 
 import torch
@@ -49,12 +50,36 @@ def _initialize(spec: Union[str, Callable], shape, device) -> torch.Tensor:
   raise ValueError(f"Unknown initializer: {spec!r}")
 
 
+# Products of at least this many multiply-adds run on the split-fp16 GEMM (f32-grade results on
+# the fp16 matrix cores, csrc/gemm16.hip); smaller ones, where the operand conversion and the
+# 128 x 128 tiling do not pay, on the f32-MFMA kernel.  TFRS_GEMM_MODE=f32 forces the latter.
+_F16_GEMM_MIN_MACS = 1 << 28
+
+
+def _use_f16_gemm(m: int, n: int, k: int) -> bool:
+  if os.environ.get("TFRS_GEMM_MODE", "") == "f32":
+    return False
+  if os.environ.get("TFRS_GEMM_MODE", "") == "f16":
+    return True
+  return m * n * k >= _F16_GEMM_MIN_MACS and min(m, n, k) >= 128
+
+
 def dense(x: torch.Tensor, kernel: torch.Tensor, bias: Optional[torch.Tensor] = None
           ) -> torch.Tensor:
-  """``x @ kernel + bias`` (Keras Dense layout ``[in, out]``) via ``tfrs_dense_fwd``."""
+  """``x @ kernel + bias`` (Keras Dense layout ``[in, out]``) via ``tfrs_dense_fwd`` /
+  ``tfrs_dense_fwd_f16``."""
   x = x.contiguous()
   kernel = kernel.contiguous()
   out = torch.empty((x.shape[0], kernel.shape[1]), dtype=torch.float32, device=x.device)
+  m, k, n = x.shape[0], kernel.shape[0], kernel.shape[1]
+  if _use_f16_gemm(m, n, k):
+    lib = _lib.load()
+    ws = torch.empty((lib.tfrs_gemm_f16_workspace_bytes(m, n, k),), dtype=torch.uint8,
+                     device=x.device)
+    _lib.check(lib.tfrs_dense_fwd_f16(
+        _lib.ptr(x), _lib.ptr(kernel), _lib.ptr(bias), m, k, n, _lib.ptr(out), _lib.ptr(ws),
+        ws.numel(), _lib.current_stream()))
+    return out
   _lib.check(_lib.load().tfrs_dense_fwd(
       _lib.ptr(x), _lib.ptr(kernel), _lib.ptr(bias), x.shape[0], kernel.shape[0],
       kernel.shape[1], _lib.ptr(out), _lib.current_stream()))
@@ -87,9 +112,18 @@ class _CrossFn(torch.autograd.Function):
   def forward(ctx, x0, x, kernel, bias, diag):
     x0, x, kernel = x0.contiguous(), x.contiguous(), kernel.contiguous()
     y = torch.empty_like(x0)
-    _lib.check(_lib.load().tfrs_cross_fwd(
-        _lib.ptr(x0), _lib.ptr(x), _lib.ptr(kernel), _lib.ptr(bias), float(diag),
-        x0.shape[0], x0.shape[1], _lib.ptr(y), _lib.current_stream()))
+    b, d = x0.shape
+    if _use_f16_gemm(b, d, d):
+      lib = _lib.load()
+      ws = torch.empty((lib.tfrs_gemm_f16_workspace_bytes(b, d, d),), dtype=torch.uint8,
+                       device=x0.device)
+      _lib.check(lib.tfrs_cross_fwd_f16(
+          _lib.ptr(x0), _lib.ptr(x), _lib.ptr(kernel), _lib.ptr(bias), float(diag), b, d,
+          _lib.ptr(y), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+    else:
+      _lib.check(_lib.load().tfrs_cross_fwd(
+          _lib.ptr(x0), _lib.ptr(x), _lib.ptr(kernel), _lib.ptr(bias), float(diag),
+          b, d, _lib.ptr(y), _lib.current_stream()))
     ctx.save_for_backward(x0, x, kernel, bias)
     ctx.diag = float(diag)
     return y

@@ -306,10 +306,19 @@ def test_cross_golden():
   assert Cross.from_config(layer.get_config()).get_config() == layer.get_config()
 
 
+@pytest.fixture(params=["f32", "f16"])
+def gemm_mode(request, monkeypatch):
+  """Dense / Cross products run on the f32-MFMA GEMM or on the split-fp16 GEMM (the default for
+  large shapes); both must meet the same tolerances against the float64 oracle."""
+  monkeypatch.setenv("TFRS_GEMM_MODE", request.param)
+  return request.param
+
+
 @pytest.mark.parametrize("b,d,p", [(5, 3, None), (300, 96, None), (1000, 257, None),
                                    (4096, 512, None), (300, 96, 24), (513, 130, 7)])
-def test_cross_random_fwd_bwd(b, d, p):
-  """y and all gradients within 2e-5 relative of the float64 oracle (f32 MFMA GEMM)."""
+def test_cross_random_fwd_bwd(b, d, p, gemm_mode):
+  """y and all gradients within 2e-5 relative of the float64 oracle, on both GEMM paths (the
+  backward runs dx = dz W^T and dW = x^T dz through the same kernels)."""
   from recommenders_amd.layers.feature_interaction import Cross
   rng = np.random.default_rng(b + d)
   x0 = rng.normal(size=(b, d)).astype(np.float32)
@@ -331,6 +340,28 @@ def test_cross_random_fwd_bwd(b, d, p):
     dx0, dx, dw, db = o_fi.cross_grads(x0, x, kern, bias, dy, diag_scale=0.3)
     for got, want in ((tx0.grad, dx0), (tx.grad, dx), (layer.kernel.grad, dw), (layer.bias.grad, db)):
       np.testing.assert_allclose(_np(got), want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("m,k,n,sa,sb", [(1000, 300, 200, 1.0, 1.0), (257, 1030, 130, 1e-3, 50.0),
+                                         (2048, 2048, 512, 1.0, 0.02), (129, 64, 129, 7.0, 1.0)])
+def test_split_fp16_gemm_vs_float64(m, k, n, sa, sb, monkeypatch):
+  """tfrs_dense_fwd_f16 (hi*hi + hi*lo + lo*hi on the fp16 matrix cores): f32-grade result for
+  operands decades apart in magnitude, rows / columns of uneven norm, ragged M / N / K."""
+  from recommenders_amd.layers.feature_interaction import dcn
+  monkeypatch.setenv("TFRS_GEMM_MODE", "f16")
+  rng = np.random.default_rng(m + n)
+  a = (rng.normal(size=(m, k)) * sa * np.exp(rng.normal(size=(m, 1)))).astype(np.float32)
+  b = (rng.normal(size=(k, n)) * sb * np.exp(rng.normal(size=(1, n)))).astype(np.float32)
+  a[3] = 0.0
+  bias = rng.normal(size=(n,)).astype(np.float32)
+  got = _np(dcn.dense(_t(a), _t(b), _t(bias)))
+  ref = a.astype(np.float64) @ b.astype(np.float64) + bias
+  # error model of an f32 GEMM: relative to the row/column magnitudes, not to each entry
+  scale = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64) + np.abs(bias)
+  assert np.max(np.abs(got - ref) / scale) < 2e-6
+  monkeypatch.setenv("TFRS_GEMM_MODE", "f32")
+  f32 = _np(dcn.dense(_t(a), _t(b), _t(bias)))
+  assert np.max(np.abs(f32 - ref) / scale) < 2e-6           # the f32-MFMA kernel, same yardstick
 
 
 # ---------------------------------------------------------------------------- dot interaction
