@@ -271,16 +271,18 @@ __global__ void __launch_bounds__(256, 2) gemm16_kernel(const Gemm16Args g) {
         bl[i][kk] = *reinterpret_cast<const g16h8 *>(cur + 3 * kG16Img + ob);
       }
     }
+    // term-major: the products of one accumulator are 4 MFMAs apart, never back to back
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int term = 0; term < 3; ++term)
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn) {
-          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i][kk], bh[jn][kk], acc[i][jn], 0, 0, 0);
-          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i][kk], bl[jn][kk], acc[i][jn], 0, 0, 0);
-          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i][kk], bh[jn][kk], acc[i][jn], 0, 0, 0);
-        }
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int jn = 0; jn < 2; ++jn)
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? al[i][kk] : ah[i][kk],
+                                                                term == 1 ? bl[jn][kk] : bh[jn][kk],
+                                                                acc[i][jn], 0, 0, 0);
     g16_wait_dma();     // this wave's share of the next K step has landed ...
     __syncthreads();    // ... and everybody else's; the current buffer is free again
   }
@@ -309,6 +311,152 @@ __global__ void __launch_bounds__(256, 2) gemm16_kernel(const Gemm16Args g) {
     }
 }
 
+// ---- the large-shape GEMM: 256 x 256 tiles, 4-deep ring ---------------------------------------
+// The 128 x 128 kernel above loads 32 KB per 24 MFMAs per wave and keeps one K step in flight:
+// measured 1.9 us per step against 0.64 us of MFMA work -- it waits for memory.  This variant
+// quarters the bytes per flop (256 x 256 tile, 8 waves as 4 x 2, each 64 x 128 = 2 x 4 MFMA tiles)
+// and keeps three K steps of 16 in flight in a 4-buffer ring (128 KB of LDS, one workgroup per
+// CU, two waves per SIMD).  LDS rows are 32 bytes (16 halves): slot s of row r holds k-slot
+// s ^ ((r >> 3) & 1), which again gives the 16 lanes of a ds_read_b128 16 distinct bank groups.
+constexpr int kB16M = 256, kB16N = 256, kB16K = 16, kB16Ring = 4;
+constexpr int kB16Img = 256 * 32;          // bytes of one 256-row x 16-half image
+constexpr int kB16Stage = 4 * kB16Img;     // Ah | Al | Bh | Bl
+
+// s_waitcnt vmcnt(N) lgkmcnt(0): at most N copies of this wave in flight, and all of its own LDS
+// reads returned (so that the barrier that follows really hands the oldest buffer over)
+template <int N>
+__device__ __forceinline__ void g16_wait_vm() {
+  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(512) gemm16_big_kernel(const Gemm16Args g) {
+  __shared__ __attribute__((aligned(16))) char lds[kB16Ring * kB16Stage];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;     // 4 x 2 waves; wave tile 64 (M) x 128 (N)
+  const int j = lane & 31, h = lane >> 5;
+
+  const int nbn = (g.n + kB16N - 1) / kB16N;
+  const int64_t bm = (int64_t)(blockIdx.x / nbn) * kB16M;
+  const int bn = (int)(blockIdx.x % nbn) * kB16N;
+  const int nk = g.kp / kB16K;
+
+  // staging: one instruction = 32 rows x 2 slots; wave w copies rows [32w, 32w + 32) of each image
+  const int sr = lane >> 1, ss = lane & 1;
+  const int r = wave * 32 + sr;
+  const int ks = ss ^ ((r >> 3) & 1);
+  const char *src[4];
+  src[0] = reinterpret_cast<const char *>(g.ah + (bm + r) * g.kp) + ks * 16;
+  src[1] = reinterpret_cast<const char *>(g.al + (bm + r) * g.kp) + ks * 16;
+  src[2] = reinterpret_cast<const char *>(g.bh + (int64_t)(bn + r) * g.kp) + ks * 16;
+  src[3] = reinterpret_cast<const char *>(g.bl + (int64_t)(bn + r) * g.kp) + ks * 16;
+  auto stage = [&](int kt) __attribute__((always_inline)) {
+    char *buf = lds + (kt & (kB16Ring - 1)) * kB16Stage;
+#pragma unroll
+    for (int im = 0; im < 4; ++im)
+      g16_dma16(src[im] + (int64_t)kt * (kB16K * 2), buf + im * kB16Img + wave * 32 * 32);
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][jn][q] = 0.0f;
+
+  // every wave issues exactly 4 copies per K step, so "at most 4 * s copies in flight" means
+  // "all but the newest s steps have landed"
+  auto wait_step = [&](int kt) __attribute__((always_inline)) {
+    const int newer = nk - 1 - kt;             // steps issued after kt (at most 2 matter)
+    if (newer >= 2) g16_wait_vm<8>(); else if (newer == 1) g16_wait_vm<4>(); else g16_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();              // step kt is complete for everybody, and nobody
+                                               // reads the buffer of step kt - 1 any more
+  };
+  struct Frags {
+    g16h8 ah[2], al[2], bh[4], bl[4];
+  };
+  auto read_frags = [&](int kt, Frags &f) __attribute__((always_inline)) {
+    const char *cur = lds + (kt & (kB16Ring - 1)) * kB16Stage;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ra = wm * 64 + i * 32 + j;
+      const int oa = ra * 32 + (h ^ ((ra >> 3) & 1)) * 16;
+      f.ah[i] = *reinterpret_cast<const g16h8 *>(cur + oa);
+      f.al[i] = *reinterpret_cast<const g16h8 *>(cur + kB16Img + oa);
+    }
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn) {
+      const int rb = wn * 128 + jn * 32 + j;
+      const int ob = rb * 32 + (h ^ ((rb >> 3) & 1)) * 16;
+      f.bh[jn] = *reinterpret_cast<const g16h8 *>(cur + 2 * kB16Img + ob);
+      f.bl[jn] = *reinterpret_cast<const g16h8 *>(cur + 3 * kB16Img + ob);
+    }
+  };
+  // term-major: the three products of one accumulator are 8 MFMAs apart, never back to back
+  auto mfmas = [&](const Frags &f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int term = 0; term < 3; ++term)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? f.al[i] : f.ah[i],
+                                                              term == 1 ? f.bl[jn] : f.bh[jn],
+                                                              acc[i][jn], 0, 0, 0);
+  };
+  // Register double buffer: the fragments of step kt + 1 are read from LDS BEFORE the MFMAs of
+  // step kt are issued, so the LDS latency and the barrier skew of a step hide under a full
+  // step of matrix work (reading them at the top of their own step left the two waves of a
+  // SIMD waiting together after every barrier: MFMA busy 47 %).
+  auto half = [&](int kt, Frags &cur, Frags &nxt) __attribute__((always_inline)) {
+    if (kt + 1 < nk) {
+      wait_step(kt + 1);
+      if (kt + kB16Ring < nk) stage(kt + kB16Ring);   // into the buffer of step kt (already in registers)
+      read_frags(kt + 1, nxt);
+    }
+    mfmas(cur);
+  };
+#pragma unroll
+  for (int p = 0; p < kB16Ring; ++p)
+    if (p < nk) stage(p);
+  Frags fa, fb;
+  {
+    const int newer = nk - 1;                  // steps 1..3 may still be in flight
+    if (newer >= 3) g16_wait_vm<12>(); else if (newer == 2) g16_wait_vm<8>();
+    else if (newer == 1) g16_wait_vm<4>(); else g16_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+  }
+  read_frags(0, fa);
+  for (int kt = 0; kt < nk; kt += 2) {
+    half(kt, fa, fb);
+    if (kt + 1 < nk) half(kt + 1, fb, fa);
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn) {
+      const int col = bn + wn * 128 + jn * 32 + j;
+      if (col >= g.n) continue;
+      const float cs = g.invb[col];
+      const float bias = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int64_t row = bm + wm * 64 + i * 32 + tile_row_of_reg(q, h);
+        if (row >= g.m) continue;
+        float v = acc[i][jn][q] * (g.inva[row] * cs) + bias;
+        const int64_t o = row * g.n + col;
+        if (EPI == kG16EpiCross) {
+          const float xv = g.x[o];
+          v = g.x0[o] * (v + g.diag * xv) + xv;
+        }
+        g.out[o] = v;
+      }
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------
 static inline size_t g16_al(size_t x) { return (x + 255) / 256 * 256; }
 static inline int64_t g16_pad(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
@@ -321,8 +469,8 @@ struct G16Layout {
 
 static G16Layout g16_layout(int64_t m, int n, int k) {
   G16Layout L;
-  L.mp = g16_pad(m, kG16M);
-  L.np = g16_pad(n, kG16N);
+  L.mp = g16_pad(m, kB16M);   // both kernels' tiles divide 256
+  L.np = g16_pad(n, kB16N);
   L.kp = (int)g16_pad(k, 64);   // 64: the column prep writes whole 64-k tiles
   size_t o = 0;
   const size_t ia = g16_al((size_t)L.mp * L.kp * 2), ib = g16_al((size_t)L.np * L.kp * 2);
@@ -357,11 +505,27 @@ int gemm16_run(const float *a, const float *b, int64_t m, int n, int k, const fl
   g.ah = ah; g.al = al; g.bh = bh; g.bl = bl; g.inva = inva; g.invb = invb;
   g.m = m; g.n = n; g.kp = L.kp;
   g.bias = bias; g.x0 = x0; g.x = x; g.diag = diag; g.out = out;
-  const dim3 grid((unsigned)((L.mp / kG16M) * (L.np / kG16N)));
-  if (x0)
-    hipLaunchKernelGGL((gemm16_kernel<kG16EpiCross>), grid, dim3(256), 0, s, g);
-  else
-    hipLaunchKernelGGL((gemm16_kernel<kG16EpiBias>), grid, dim3(256), 0, s, g);
+  // large shapes: 256 x 256 tiles with the 4-deep ring; otherwise (few tiles: fill the chip)
+  // the 128 x 128 kernel.  TFRS_GEMM16_TILE = 128 | 256 forces one.
+  const char *tv = getenv("TFRS_GEMM16_TILE");
+  const int forced = (tv && *tv) ? atoi(tv) : 0;
+  const int64_t big_tiles = (L.mp / kB16M) * (L.np / kB16N);
+  const bool big = forced == 256 || (forced != 128 && big_tiles >= 512);
+  if (big) {
+    const dim3 grid((unsigned)(((m + kB16M - 1) / kB16M) * ((n + kB16N - 1) / kB16N)));
+    if (x0)
+      hipLaunchKernelGGL((gemm16_big_kernel<kG16EpiCross>), grid, dim3(512), 0, s, g);
+    else
+      hipLaunchKernelGGL((gemm16_big_kernel<kG16EpiBias>), grid, dim3(512), 0, s, g);
+  } else {
+    // tiles that hold at least one real row and column (the kernel derives its tile
+    // coordinates from ceil(n / 128), not from the 256-padded image sizes)
+    const dim3 grid((unsigned)(((m + kG16M - 1) / kG16M) * ((n + kG16N - 1) / kG16N)));
+    if (x0)
+      hipLaunchKernelGGL((gemm16_kernel<kG16EpiCross>), grid, dim3(256), 0, s, g);
+    else
+      hipLaunchKernelGGL((gemm16_kernel<kG16EpiBias>), grid, dim3(256), 0, s, g);
+  }
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
 }

@@ -342,17 +342,21 @@ def test_cross_random_fwd_bwd(b, d, p, gemm_mode):
       np.testing.assert_allclose(_np(got), want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
 
 
+@pytest.mark.parametrize("tile", ["128", "256"])
 @pytest.mark.parametrize("m,k,n,sa,sb", [(1000, 300, 200, 1.0, 1.0), (257, 1030, 130, 1e-3, 50.0),
-                                         (2048, 2048, 512, 1.0, 0.02), (129, 64, 129, 7.0, 1.0)])
-def test_split_fp16_gemm_vs_float64(m, k, n, sa, sb, monkeypatch):
+                                         (2048, 2048, 512, 1.0, 0.02), (129, 64, 129, 7.0, 1.0),
+                                         (4096, 13, 512, 1.0, 1.0), (4096, 512, 1, 1.0, 1.0),
+                                         (13, 4096, 128, 1.0, 1.0), (300, 1, 100, 1.0, 1.0)])
+def test_split_fp16_gemm_vs_float64(m, k, n, sa, sb, tile, monkeypatch):
   """tfrs_dense_fwd_f16 (hi*hi + hi*lo + lo*hi on the fp16 matrix cores): f32-grade result for
   operands decades apart in magnitude, rows / columns of uneven norm, ragged M / N / K."""
   from recommenders_amd.layers.feature_interaction import dcn
   monkeypatch.setenv("TFRS_GEMM_MODE", "f16")
+  monkeypatch.setenv("TFRS_GEMM16_TILE", tile)   # both kernels, incl. degenerate M / N / K
   rng = np.random.default_rng(m + n)
   a = (rng.normal(size=(m, k)) * sa * np.exp(rng.normal(size=(m, 1)))).astype(np.float32)
   b = (rng.normal(size=(k, n)) * sb * np.exp(rng.normal(size=(1, n)))).astype(np.float32)
-  a[3] = 0.0
+  a[min(3, m - 1)] = 0.0
   bias = rng.normal(size=(n,)).astype(np.float32)
   got = _np(dcn.dense(_t(a), _t(b), _t(bias)))
   ref = a.astype(np.float64) @ b.astype(np.float64) + bias
