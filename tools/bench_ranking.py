@@ -74,5 +74,8 @@ if __name__ == "__main__":
     run("dcn-v2 (small)", 4, 10000, 32, 4096, "cross")
     run("dlrm (small)", 8, 10000, 16, 4096, "dot")
   else:
-    run("configs[3] DCN-v2", 26, 1_000_000, 128, 65536, "cross")
-    run("configs[4] DLRM, one GPU's row shard", 100, 1_250_000, 32, 131072, "dot")
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    if only in ("", "c3"):
+      run("configs[3] DCN-v2", 26, 1_000_000, 128, 65536, "cross")
+    if only in ("", "c4"):
+      run("configs[4] DLRM, one GPU's row shard", 100, 1_250_000, 32, 131072, "dot")
