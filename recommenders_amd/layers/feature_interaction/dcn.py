@@ -53,7 +53,26 @@ def _initialize(spec: Union[str, Callable], shape, device) -> torch.Tensor:
 # Products of at least this many multiply-adds run on the split-fp16 GEMM (f32-grade results on
 # the fp16 matrix cores, csrc/gemm16.hip); smaller ones, where the operand conversion and the
 # 128 x 128 tiling do not pay, on the f32-MFMA kernel.  TFRS_GEMM_MODE=f32 forces the latter.
-_F16_GEMM_MIN_MACS = 1 << 28
+_F16_GEMM_MIN_MACS = 1 << 32
+
+
+# The split-fp16 GEMM keeps its operand images in a caller-provided workspace (gigabytes at the
+# ranking-model shapes).  One grow-only buffer per (device, stream) is reused: a fresh
+# torch.empty per call made the caching allocator go back to hipMalloc whenever a forward pass
+# followed a training step with a different allocation pattern (+16 ms per DLRM forward).
+# Reuse is safe because every user of the buffer is enqueued on that same stream.
+_GEMM_WS = {}
+
+
+def _gemm_workspace(nbytes: int, device: torch.device) -> torch.Tensor:
+  key = (device, torch.cuda.current_stream(device).cuda_stream)
+  ws = _GEMM_WS.get(key)
+  if ws is None or ws.numel() < nbytes:
+    _GEMM_WS.pop(key, None)
+    ws = None                      # release the old buffer before growing
+    ws = torch.empty((int(nbytes * 1.25),), dtype=torch.uint8, device=device)
+    _GEMM_WS[key] = ws
+  return ws
 
 
 def _use_f16_gemm(m: int, n: int, k: int) -> bool:
@@ -61,7 +80,12 @@ def _use_f16_gemm(m: int, n: int, k: int) -> bool:
     return False
   if os.environ.get("TFRS_GEMM_MODE", "") == "f16":
     return True
-  return m * n * k >= _F16_GEMM_MIN_MACS and min(m, n, k) >= 128
+  if min(m, n, k) < 128:
+    return False
+  macs = m * n * k
+  # measured (tools/exp_dense_shapes.py): 2x at >= 2^36, break-even near 2^32, but 3.6x already at
+  # 2^31 for the long-K products of weight gradients (m, n small; k = batch)
+  return macs >= _F16_GEMM_MIN_MACS or (macs >= (1 << 28) and k >= 4096)
 
 
 def dense(x: torch.Tensor, kernel: torch.Tensor, bias: Optional[torch.Tensor] = None
@@ -74,8 +98,7 @@ def dense(x: torch.Tensor, kernel: torch.Tensor, bias: Optional[torch.Tensor] = 
   m, k, n = x.shape[0], kernel.shape[0], kernel.shape[1]
   if _use_f16_gemm(m, n, k):
     lib = _lib.load()
-    ws = torch.empty((lib.tfrs_gemm_f16_workspace_bytes(m, n, k),), dtype=torch.uint8,
-                     device=x.device)
+    ws = _gemm_workspace(lib.tfrs_gemm_f16_workspace_bytes(m, n, k), x.device)
     _lib.check(lib.tfrs_dense_fwd_f16(
         _lib.ptr(x), _lib.ptr(kernel), _lib.ptr(bias), m, k, n, _lib.ptr(out), _lib.ptr(ws),
         ws.numel(), _lib.current_stream()))
@@ -115,8 +138,7 @@ class _CrossFn(torch.autograd.Function):
     b, d = x0.shape
     if _use_f16_gemm(b, d, d):
       lib = _lib.load()
-      ws = torch.empty((lib.tfrs_gemm_f16_workspace_bytes(b, d, d),), dtype=torch.uint8,
-                       device=x0.device)
+      ws = _gemm_workspace(lib.tfrs_gemm_f16_workspace_bytes(b, d, d), x0.device)
       _lib.check(lib.tfrs_cross_fwd_f16(
           _lib.ptr(x0), _lib.ptr(x), _lib.ptr(kernel), _lib.ptr(bias), float(diag), b, d,
           _lib.ptr(y), _lib.ptr(ws), ws.numel(), _lib.current_stream()))

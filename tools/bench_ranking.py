@@ -45,15 +45,20 @@ def run(name, n_tables, vocab, dim, batch, interaction, steps=3):
   labels = torch.randint(0, 2, (batch,), generator=g, device=dev)
   model(feats)                                            # builds the lazily-shaped Dense layers
   model.compile(optimizer=tfrs.optimizers.Adagrad(model.parameters(), learning_rate=0.01))
-  for _ in range(2):
-    model.train_step((feats, labels))
-  torch.cuda.synchronize()
-  t0 = time.perf_counter()
-  for _ in range(steps):
-    logs = model.train_step((feats, labels))
-  torch.cuda.synchronize()
-  dt = (time.perf_counter() - t0) / steps
+  fwd_only = os.environ.get("TFRS_BENCH_FWD_ONLY") == "1"     # profiling aid: forward passes only
+  logs, dt = {"loss": float("nan")}, float("nan")
+  if not fwd_only:
+    for _ in range(2):
+      model.train_step((feats, labels))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+      logs = model.train_step((feats, labels))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
   with torch.no_grad():
+    for _ in range(2):      # warm-up: the allocator re-shapes its cache after the training steps
+      model(feats)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
