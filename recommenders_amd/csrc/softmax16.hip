@@ -44,8 +44,6 @@
 namespace tfrs {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;

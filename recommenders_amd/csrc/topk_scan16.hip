@@ -59,8 +59,6 @@ struct Scan16Geom {
   static constexpr int kLdsBytes = 2 * kStageB + 32;
 };
 
-typedef __attribute__((address_space(3))) void lds_void16_t;
-typedef __attribute__((address_space(1))) const void gbl_void16_t;
 
 // Direct-to-LDS copy of 16 bytes per lane (LDS address = wave base + lane * 16).  Issued from
 // inline assembly on purpose: for the builtin the compiler cannot prove that the copy into one

@@ -23,7 +23,7 @@ creates slot variables on TPU in the reference and is kept for signature parity.
 """
 
 import math
-from typing import Any, Callable, Dict, Iterable, List, Optional, Sequence, Tuple, Union
+from typing import Any, Callable, Dict, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -257,13 +257,8 @@ class _PaddedGatherFn(torch.autograd.Function):
     if getattr(table, "_tfrs_sparse_grad", False):
       table._tfrs_slices.append((padded_ids, g))
       return None, None
-    return _scatter_skip_padding(g, padded_ids, ctx.vocab), None
-
-
-def _scatter_skip_padding(grad_out: torch.Tensor, padded_ids: torch.Tensor, vocab: int):
-  """Dense table gradient of a padded lookup: the -1 slots never match a table row in the
-  row-scan kernel and are skipped by the sorted kernel."""
-  return emb.scatter_add_rows(grad_out, padded_ids, vocab)
+    # the -1 slots never match a table row in the row-scan kernel and are skipped by the sorted one
+    return emb.scatter_add_rows(g, padded_ids, ctx.vocab), None
 
 
 # --------------------------------------------------------------------------------- layer
