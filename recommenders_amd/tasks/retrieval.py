@@ -91,6 +91,51 @@ def in_batch_softmax_loss(query_embeddings: torch.Tensor, candidate_embeddings: 
                                  candidate_embeddings.to(torch.float32), w, inv_t, corr, ids, mask)
 
 
+class _CrossReplicaConcatFn(torch.autograd.Function):
+  """all-gather along dim 0 with the caller's block first; backward = sum over ranks of the
+  gradients of the caller's block (a reduce-scatter)."""
+
+  @staticmethod
+  def forward(ctx, values, group):
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    values = values.contiguous()
+    n = values.shape[0]
+    gathered = torch.empty((world * n,) + tuple(values.shape[1:]), dtype=values.dtype,
+                           device=values.device)
+    dist.all_gather_into_tensor(gathered, values, group=group)   # blocks in rank order
+    ctx.group, ctx.world, ctx.rank = group, world, rank
+    return torch.roll(gathered, -rank * n, dims=0)
+
+  @staticmethod
+  def backward(ctx, grad):
+    import torch.distributed as dist
+    world, rank = ctx.world, ctx.rank
+    g = torch.roll(grad.reshape((world, -1) + tuple(grad.shape[1:])), rank, dims=0).contiguous()
+    out = torch.empty_like(g[0])
+    if dist.get_backend(ctx.group) == "gloo":          # gloo has no reduce_scatter
+      dist.all_reduce(g, group=ctx.group)
+      out.copy_(g[rank])
+    else:
+      dist.reduce_scatter_tensor(out, g, group=ctx.group)
+    return out, None
+
+
+def cross_replica_concat(values: torch.Tensor, group=None) -> torch.Tensor:
+  """``_cross_replica_concat`` of the reference (``tasks/retrieval.py:238-321``) on
+  ``torch.distributed``: every rank contributes ``values`` ``[n, ...]`` and receives the
+  concatenation of all ranks' blocks ``[world * n, ...]``, rotated so that ITS OWN block comes
+  first (rank i sees blocks i, i+1, ..., world-1, 0, ..., i-1) -- so ``labels = eye(n, world*n)``
+  still pairs query ``b`` with candidate ``b``.  One RCCL all-gather over xGMI forward; the
+  gradient of the caller's block is the sum of every rank's gradient for it (one
+  reduce-scatter), i.e. the gradient of the sum of the per-rank losses.  Without an initialised
+  process group (or with a single rank) it returns ``values`` unchanged."""
+  import torch.distributed as dist
+  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    return values
+  return _CrossReplicaConcatFn.apply(values, group)
+
+
 class TopKCategoricalAccuracy:
   """``tf.keras.metrics.TopKCategoricalAccuracy(k)`` for ``batch_metrics``: weighted
   mean of ``in_top_k(argmax(labels), logits, k)`` (ties count for the target)."""
@@ -121,8 +166,17 @@ class Retrieval(torch.nn.Module, base.Task):
                                        tfrs_metrics.Factorized]] = None,
                batch_metrics: Optional[List] = None, loss_metrics: Optional[List] = None,
                temperature: Optional[float] = None, num_hard_negatives: Optional[int] = None,
-               remove_accidental_hits: bool = False, name: Optional[str] = None) -> None:
+               remove_accidental_hits: bool = False, name: Optional[str] = None,
+               cross_replica_negatives: bool = False, process_group=None) -> None:
+    """``cross_replica_negatives`` (not in the reference's signature, which defines
+    ``_cross_replica_concat`` :238-321 but never calls it): under ``torch.distributed`` every
+    rank scores its queries against the candidates of ALL ranks -- ``world`` times more
+    in-batch negatives for one all-gather of ``[B, D]`` per rank.  Candidate ids and
+    sampling probabilities are gathered the same way; a ``score_mask`` must already have the
+    gathered width."""
     super().__init__()
+    self._cross_replica_negatives = cross_replica_negatives
+    self._process_group = process_group
     self.name = name or "retrieval"
     self._loss = loss            # None -> fused in-batch softmax (:86-87)
     if metrics is None:
@@ -191,6 +245,14 @@ class Retrieval(torch.nn.Module, base.Task):
       raise ValueError("When accidental hit removal is enabled, candidate ids "
                        "must be supplied.")
     q, c = query_embeddings, candidate_embeddings
+    if self._cross_replica_negatives:
+      c = cross_replica_concat(c, self._process_group)
+      if candidate_ids is not None:
+        candidate_ids = cross_replica_concat(torch.as_tensor(candidate_ids).to(c.device),
+                                             self._process_group)
+      if candidate_sampling_probability is not None:
+        candidate_sampling_probability = cross_replica_concat(
+            torch.as_tensor(candidate_sampling_probability).to(c.device), self._process_group)
     if sample_weight is not None and not isinstance(sample_weight, torch.Tensor):
       sample_weight = torch.as_tensor(np.asarray(sample_weight, dtype=np.float32))
     if sample_weight is not None:

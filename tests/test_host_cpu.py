@@ -243,3 +243,68 @@ def test_sharded_embedding_two_ranks_gloo(tmp_path):
   for r, (p, o) in enumerate(zip(procs, outs)):
     assert p.returncode == 0, f"rank {r} failed:\n{o}"
     assert f"rank {r} ok" in o
+
+
+_XREP_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from recommenders_amd.tasks.retrieval import cross_replica_concat
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+n, d = 5, 3
+rng = np.random.default_rng(11)
+blocks = [torch.tensor(rng.normal(size=(n, d)), dtype=torch.float32) for _ in range(world)]
+coef = [torch.tensor(rng.normal(size=(world * n, d)), dtype=torch.float32) for _ in range(world)]
+
+mine = blocks[rank].clone().requires_grad_(True)
+cat = cross_replica_concat(mine)
+# own block first, then the following ranks' blocks (reference docstring :239-292)
+want = torch.cat([blocks[(rank + s) % world] for s in range(world)], dim=0)
+assert torch.equal(cat.detach(), want), "wrong concatenation order"
+loss = (cat * coef[rank]).sum() + (cat ** 2).sum()        # this rank's loss
+loss.backward()
+
+# single-process reference: total loss = sum of the ranks' losses, as a function of all blocks
+ref = [b.clone().requires_grad_(True) for b in blocks]
+total = 0.0
+for r in range(world):
+  cat_r = torch.cat([ref[(r + s) % world] for s in range(world)], dim=0)
+  total = total + (cat_r * coef[r]).sum() + (cat_r ** 2).sum()
+total.backward()
+assert torch.allclose(mine.grad, ref[rank].grad, rtol=1e-6, atol=1e-6), "wrong gradient"
+
+ids = cross_replica_concat(torch.arange(n) + 100 * rank)   # integer side inputs ride along
+assert ids.tolist() == [100 * ((rank + s) % world) + i for s in range(world) for i in range(n)]
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_cross_replica_concat_two_ranks_gloo(tmp_path):
+  """world_size-2 gloo run of the cross-replica negatives exchange (tasks/retrieval.py:238-321):
+  own block first, and the gradient of a rank's block is the sum of all ranks' gradients for it."""
+  script = tmp_path / "xrep_worker.py"
+  script.write_text(_XREP_WORKER.format(root=ROOT))
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  port = s.getsockname()[1]
+  s.close()
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2",
+             OMP_NUM_THREADS="2")
+  procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+           for r in range(2)]
+  outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+  for r, (p, o) in enumerate(zip(procs, outs)):
+    assert p.returncode == 0, f"rank {r} failed:\n{o}"
+    assert f"rank {r} ok" in o
+
+
+def test_cross_replica_concat_is_identity_without_process_group():
+  from recommenders_amd.tasks.retrieval import cross_replica_concat
+  x = torch.arange(6.0).reshape(3, 2)
+  assert cross_replica_concat(x) is x
+
