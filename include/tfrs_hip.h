@@ -98,6 +98,14 @@ int tfrs_bruteforce_topk(const tfrs_index_t *index, const float *queries, int64_
                          int k, float *out_scores, int32_t *out_idx, void *workspace,
                          size_t workspace_bytes, void *stream);
 
+/* Measurement hook (bench.py, tests): after a tfrs_bruteforce_topk call with the same
+ * (workspace, nq, n, k) has completed on `stream`, returns how many of its queries took the
+ * exact-recompute ("redo") path of the fp16-prefiltered search (survivor list overflow or
+ * retained set too large; 0 on well-behaved data, and always 0 on the all-f32 path).
+ * Synchronises `stream`. */
+int tfrs_bruteforce_topk_redo_count(const void *workspace, int64_t nq, int64_t n, int k,
+                                    int32_t *redo_count_h, void *stream);
+
 /* Test hook: raw scores of the fp16 PREFILTER (never returned by the product path) for rows
  * [row_begin, row_end) of the index, row_begin a multiple of 128: out[nq, ld] with
  * ld = (row_end - row_begin) rounded up to 128; scratch: 2 * nq floats.  tests/ check

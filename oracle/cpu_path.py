@@ -49,3 +49,43 @@ def time_brute_force(candidates: np.ndarray, queries: np.ndarray, k: int,
         break
   return {"value": done / dt, "seconds": dt, "queries": done,
           "threads": torch.get_num_threads()}
+
+
+def time_train_step(batch: int = 4096, dim: int = 64, vocab: int = 2000, users: int = 943,
+                    items: int = 1682, lr: float = 0.5, budget_s: float = 5.0, seed: int = 0) -> dict:
+  """CPU restatement of the quickstart two-tower train step (reference ``README.md:58-97``,
+  ``models/base.py:64-85``): two ``Embedding`` lookups -> ``Retrieval`` loss
+  (``tasks/retrieval.py:172-210``: scores = q @ c^T, labels = eye, Keras
+  ``CategoricalCrossentropy(from_logits=True, reduction=SUM)``) -> backward -> Keras Adagrad
+  (``acc += g*g ; var -= lr * g / sqrt(acc + eps)``, dense here: at 2k-row tables TF-CPU's
+  sparse apply and the dense apply touch the same order of bytes).  torch-CPU autograd =
+  oneDNN sgemm + vectorised elementwise, all host threads; "CPU reference restatement (not
+  TensorFlow)"."""
+  g = torch.Generator().manual_seed(seed)
+  tables = [torch.empty(vocab, dim).uniform_(-0.05, 0.05, generator=g).requires_grad_(True)
+            for _ in range(2)]
+  accs = [torch.full((vocab, dim), 0.1) for _ in range(2)]
+  uid = torch.randint(0, users, (batch,), generator=g)
+  iid = torch.randint(0, items, (batch,), generator=g)
+  labels = torch.arange(batch)
+
+  def step():
+    q = torch.nn.functional.embedding(uid, tables[0])
+    c = torch.nn.functional.embedding(iid, tables[1])
+    loss = torch.nn.functional.cross_entropy(q @ c.t(), labels, reduction="sum")
+    grads = torch.autograd.grad(loss, tables)
+    with torch.no_grad():
+      for t, a, gr in zip(tables, accs, grads):
+        a.addcmul_(gr, gr)
+        t.addcdiv_(gr, torch.sqrt(a + 1e-7), value=-lr)
+    return float(loss.detach())
+
+  step()
+  n, t0 = 0, time.perf_counter()
+  while True:
+    step()
+    n += 1
+    dt = time.perf_counter() - t0
+    if dt >= budget_s or n >= 200:
+      break
+  return {"value": n / dt, "seconds": dt, "steps": n, "threads": torch.get_num_threads()}

@@ -192,6 +192,8 @@ struct Scan16Args {
   float *binmax;
   int64_t ld_binmax;
   int bin_stages;        // stages per bin (stages_per_split must be a multiple of it)
+  int drain_min;         // FILTER (second-generation kernel): queue entries that trigger a
+                         // drain at a stage end (0 -> 1)
   uint32_t *zero_word;   // FILTER: word re-armed (= 0) for the kernel that follows (the
                          // flagged-query counter); NULL otherwise.  In-kernel instead of a
                          // hipMemsetAsync because memset nodes are not reliably ordered against

@@ -32,6 +32,7 @@ struct TopkTuning {
   bool f16_filter;  // TFRS_TOPK_FILTER=f16 (default) | f32
   int64_t sample;   // fp16 path: the threshold pass scans every `sample`-th stage
   int64_t min_bins; // fp16 path: sampled bins required per query, in units of K
+  int64_t drain_min; // fp16 filter kernel: queue entries that trigger a drain at a stage end
 };
 
 static TopkTuning tuning() {
@@ -44,6 +45,7 @@ static TopkTuning tuning() {
   t.f16_filter = !(f && (f[0] == 'f' || f[0] == 'F') && f[1] == '3');
   t.sample = std::max<int64_t>(1, env_i64("TFRS_TOPK_SAMPLE", 4));
   t.min_bins = std::max<int64_t>(1, env_i64("TFRS_TOPK_MINBINS", 8));  // in 64-candidate bins
+  t.drain_min = std::max<int64_t>(1, env_i64("TFRS_SCAN16_DRAIN", 1));
   return t;
 }
 
@@ -392,6 +394,7 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
     set_error("topk: survivor workspace too small (%d segments x %u)", s16.nseg, s16.cap_l);
     return TFRS_ENOMEM;
   }
+  s16.drain_min = (int)t.drain_min;
   s16.zero_word = reinterpret_cast<uint32_t *>(w.redo);   // the flagged-query counter, re-armed
   if ((rc = timed_scan16(s16, 2.0 * (double)nq * (double)n * d, stream)) != TFRS_OK) return rc;
 
@@ -605,6 +608,21 @@ extern "C" int tfrs_bruteforce_topk(const tfrs_index_t *index, const float *quer
   return run_rounds(queries, nq, index->d, index->packed, index->n, /*idx_base=*/0,
                     /*seen=*/0, k, out_scores, out_idx, /*state_len=*/0, w, t,
                     (hipStream_t)stream, &new_len);
+}
+
+extern "C" int tfrs_bruteforce_topk_redo_count(const void *workspace, int64_t nq, int64_t n, int k,
+                                               int32_t *redo_count_h, void *stream) {
+  TFRS_CHECK_ARG(workspace && redo_count_h && nq > 0 && n > 0 && k > 0,
+                 "bruteforce_topk_redo_count: bad argument");
+  const TopkTuning t = tuning();
+  *redo_count_h = 0;
+  if (!(t.f16_filter && k <= kMaxKF16) || plan_sample(n, k, t).n_stages <= 0) return TFRS_OK;
+  const RoundWs w = carve_round_ws(static_cast<char *>(const_cast<void *>(workspace)), nq, n, k, t);
+  uint32_t v = 0;
+  TFRS_HIP(hipMemcpyAsync(&v, w.redo, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  TFRS_HIP(hipStreamSynchronize((hipStream_t)stream));
+  *redo_count_h = (int32_t)v;
+  return TFRS_OK;
 }
 
 // Test hook: the raw fp16 prefilter scores of rows [row_begin, row_end) (multiples of 128

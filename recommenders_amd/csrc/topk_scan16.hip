@@ -362,6 +362,292 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// FILTER pass, second generation (default; TFRS_SCAN16_V=1 selects the kernel above).
+//
+// Same decomposition, operand layout, skewed two-group schedule and filter rule as
+// scan16_kernel<DP, FILTER>; what changed is everything AROUND the matrix stream:
+//   * survivors leave the scoring loop through a per-wave LDS queue ("dump & drain"): a lane
+//     whose 16-score column holds a survivor appends its 16 accumulators + {threshold, unscale,
+//     row base, source lane} (80 bytes, five ds_write_b128, no search, no global store) and
+//     the wave goes straight back to its MFMAs.  At the end of the stage the queue is drained
+//     with all 64 lanes working: lane L tests score L%16 of entry L/16, survivors take a slot
+//     from the per-(query, lane half) counter (LDS atomic) and are stored 4 entries per pass.
+//     The first-generation kernel searched the 32x32 tile with one lane active (ballot ladder
+//     + element loop, ~54 instructions and 6 taken branches per survivor) and issued one
+//     8-byte store per survivor: measured +147 us (search) and +118 us (stores) per batch.
+//   * no global store, scratch access or pointer bookkeeping is left in the scoring loop, so the
+//     only VMEM operations in flight there are the stage copies: the per-stage
+//     `s_waitcnt vmcnt(0)` waits for copies issued a whole stage earlier (the first-generation
+//     kernel spilled 7 VGPRs, and every scratch reload forced a vmcnt(0) right behind the
+//     prefetch it had just issued).  Per-query write offsets / counts live in LDS.
+// A tile that does not fit into the queue any more (adversarial data: near-duplicate clusters)
+// takes a direct per-element path with the same counters; nothing is ever dropped silently (counts
+// beyond cap_l flag the query for the exact redo exactly as before).
+template <int DP>
+struct Scan16FGeom : Scan16Geom<DP> {
+  using B = Scan16Geom<DP>;
+  static constexpr int kQCap = 32;                       // queue entries per wave
+  static constexpr int kEntB = 80;                       // 16 scores + 16-byte header
+  // queue + 128 segment counters + 128 x {flo, fqk, qscale, pad} per-query filter constants
+  static constexpr int kWaveB = kQCap * kEntB + 128 * 4 + 128 * 16;
+  static constexpr int kQueueOff = (B::kLdsBytes + 15) / 16 * 16;
+  static constexpr int kLdsBytesF = kQueueOff + kWaves16 * kWaveB;
+};
+
+__device__ __forceinline__ uint32_t lds_atomic_inc(uint32_t *p) {
+  return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+
+template <int DP>
+__global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16f_kernel(const Scan16Args a) {
+  using G = Scan16FGeom<DP>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (a.zero_word && blockIdx.x == 0 && tid == 0) *a.zero_word = 0u;
+  const int j = lane & 31;
+  const int h = lane >> 5;
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int xcd = bid & 7, pos = bid >> 3;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + pos;
+  const int split = logical / a.n_qtiles;
+  const int qt = logical - split * a.n_qtiles;
+
+  const int i0 = split * a.stages_per_split;
+  int i1 = i0 + a.stages_per_split;
+  if (i1 > a.n_stages) i1 = a.n_stages;
+  if (i0 >= i1) return;
+  const int nst = i1 - i0;
+  const int64_t first_stage = a.stage0 + (int64_t)i0 * a.stage_stride;
+
+  // per-wave LDS: survivor queue + the 128 (group, lane) segment counters
+  char *const qbase = smem + G::kQueueOff + wave * G::kWaveB;
+  uint32_t *const wcnt = reinterpret_cast<uint32_t *>(qbase + G::kQCap * G::kEntB);
+  wcnt[lane] = 0u;
+  wcnt[64 + lane] = 0u;
+  const int64_t q0 = (int64_t)qt * kScan16QueriesPerWg + wave * (kQG * 32);   // wave's first query
+
+  // ---- this wave's 2 x 32 queries -> fp16 MFMA B operands (resident) -------------
+  f16x8 bq[kQG][G::kSteps];
+  // per (group, lane): {(lower - tiny) / qscale, qk / qscale, qscale} parked in LDS (re-read
+  // once per stage: three more resident VGPR pairs do not fit under 128)
+  float4 *const qconst = reinterpret_cast<float4 *>(qbase + G::kQCap * G::kEntB + 128 * 4);
+#pragma unroll
+  for (int g = 0; g < kQG; ++g) {
+    const int64_t qrow = q0 + g * 32 + j;
+    const bool qvalid = qrow < a.nq;
+    const float *qp = a.q + qrow * a.d;
+    const float qsc = qvalid ? a.qscale[qrow] : 1.0f;
+    const float qinv = 1.0f / qsc;  // exact: power of two
+    const bool vec_ok = (a.d == DP) && ((reinterpret_cast<uintptr_t>(a.q) & 15) == 0);  // uniform
+#pragma unroll
+    for (int m = 0; m < G::kSteps; ++m) {
+      float x[8];
+      if (vec_ok) {
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+        if (qvalid) {
+          lo = *reinterpret_cast<const float4 *>(qp + 16 * m + 8 * h);
+          hi = *reinterpret_cast<const float4 *>(qp + 16 * m + 8 * h + 4);
+        }
+        x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w;
+        x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int k = 16 * m + 8 * h + i;
+          x[i] = (qvalid && k < a.d) ? qp[k] : 0.0f;
+        }
+      }
+      u32x4 w;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[i] = cvt_f16x2(x[2 * i] * qinv, x[2 * i + 1] * qinv);
+      bq[g][m] = as_f16x8(w);
+    }
+    // thr = ((lower - qk * norm) - tiny) / (qscale * stage scale); divisions by powers of two
+    // commute with the roundings, so this is the first-generation threshold up to the order of
+    // the two subtractions (tiny is far below one ulp of lower unless lower is ~0)
+    qconst[g * 64 + lane] = make_float4(qvalid ? (a.lower[qrow] - kF16Tiny) * qinv : __builtin_inff(),
+                                        qvalid ? a.qk[qrow] * qinv : 0.0f, qsc, 0.0f);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t row_limit = (uint32_t)a.row_limit;
+  const bool wave_active = q0 < a.nq;   // wave-uniform
+  int qtail = 0;                        // wave-uniform: entries in the queue
+
+  // drain: lane L tests score L % 16 of entry p0 + L / 16
+  auto drain = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int r = lane & 15;
+    const uint32_t rofs = (uint32_t)((r & 3) + 8 * (r >> 2));
+    for (int p0 = 0; p0 < qtail; p0 += 4) {
+      const int e = p0 + (lane >> 4);
+      if (e < qtail) {
+        const char *ep = qbase + e * G::kEntB;
+        const float v = *reinterpret_cast<const float *>(ep + 4 * r);
+        const uint4 hd = *reinterpret_cast<const uint4 *>(ep + 64);
+        const uint32_t row = hd.z + rofs;
+        if (v > __uint_as_float(hd.x) && row < row_limit) {
+          const uint32_t src = hd.w;   // g * 64 + source lane
+          const uint32_t slot = lds_atomic_inc(&wcnt[src]);
+          if (slot < a.cap_l) {
+            const int64_t qrow = q0 + (src >> 6) * 32 + (src & 31);
+            const int seg = 2 * split + (int)((src >> 5) & 1);
+            const float un = qconst[src].z * __uint_as_float(hd.y);   // qscale * stage scale
+            a.buf[(qrow * (int64_t)a.cap_l + slot) * a.nseg + seg] =
+                make_uint2(__float_as_uint(v * un), row);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    qtail = 0;
+  };
+
+  // ---- stage 0 -> LDS ------------------------------------------------------------
+  static_assert(G::kChunks % 64 == 0, "stage size must be a whole number of wave copies");
+  const char *gsrc = a.packed16 + first_stage * (int64_t)G::kStageB;
+  const int64_t gstep = (int64_t)a.stage_stride * (int64_t)G::kStageB;
+  const StageMeta *mp = a.meta + first_stage;
+  stage16_glds<G::kChunks, G::kLoads>(gsrc, smem, mp, smem + G::kMetaOff, tid, wave);
+  wait_dma();
+  __syncthreads();
+
+  for (int st = 0; st < nst; ++st) {
+    const char *tile = smem + (st & 1) * G::kStageB;
+    if (st + 1 < nst) {  // prefetch the next stage into the other buffer (its readers passed the barrier)
+      stage16_glds<G::kChunks, G::kLoads>(gsrc + (int64_t)(st + 1) * gstep,
+                                          smem + ((st + 1) & 1) * G::kStageB,
+                                          mp + (int64_t)(st + 1) * a.stage_stride,
+                                          smem + G::kMetaOff + ((st + 1) & 1) * 16, tid, wave);
+    }
+    if (wave_active) {
+    const StageMeta sm = *reinterpret_cast<const StageMeta *>(smem + G::kMetaOff + (st & 1) * 16);
+    // wave-uniform stage constants -> SGPRs
+    const float s_norm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sm.norm)));
+    const uint32_t s_scale_bits = __builtin_amdgcn_readfirstlane(__float_as_uint(sm.scale));
+    const float s_inv = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sm.inv_scale)));
+    float thr[kQG];
+#pragma unroll
+    for (int g = 0; g < kQG; ++g) {
+      const float4 qc = qconst[g * 64 + lane];
+      thr[g] = __builtin_fmaf(-qc.y, s_norm, qc.x) * s_inv;
+    }
+    const uint32_t stage_row = (uint32_t)((first_stage + (int64_t)st * a.stage_stride) * kTileN);
+    const char *ap = tile + j * G::kRowB + h * 16;
+
+    u32x4 af[2][G::kSteps];
+#pragma unroll
+    for (int m = 0; m < G::kSteps; ++m) af[0][m] = *reinterpret_cast<const u32x4 *>(ap + m * 32);
+
+    f32x16 acc[kQG];
+    auto chain = [&](int g, int sub) __attribute__((always_inline)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][r] = 0.0f;
+#pragma unroll
+      for (int m = 0; m < G::kSteps; ++m)
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(af[sub & 1][m]), bq[g][m], acc[g], 0, 0, 0);
+    };
+    auto check = [&](int g, int sub) __attribute__((always_inline)) {
+      const f32x16 &c = acc[g];
+      const float m0 = max16(c);
+      const bool hot = m0 > thr[g];
+      const uint64_t hm = __ballot(hot);
+      if (__builtin_expect(hm != 0ull, 0)) {   // wave-uniform: some lane's 16-score column holds a survivor
+        const uint32_t rbase = stage_row + sub * 32 + 4u * h;
+        uint64_t rem = hm;
+        do {   // one round unless the queue is full (bursts of near-duplicates, identical queries)
+          const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(rem >> 32),
+                               __builtin_amdgcn_mbcnt_lo((uint32_t)rem, 0u));
+          const bool mine = ((rem >> lane) & 1ull) != 0ull && qtail + rank < G::kQCap;
+          if (mine) {
+            char *e = qbase + (qtail + rank) * G::kEntB;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+              *reinterpret_cast<float4 *>(e + 16 * g4) =
+                  make_float4(c[4 * g4], c[4 * g4 + 1], c[4 * g4 + 2], c[4 * g4 + 3]);
+            *reinterpret_cast<uint4 *>(e + 64) =
+                make_uint4(__float_as_uint(thr[g]), s_scale_bits, rbase, (uint32_t)(g * 64 + lane));
+          }
+          const uint64_t taken = __ballot(mine);
+          qtail += __builtin_popcountll(taken);
+          rem &= ~taken;
+          if (__builtin_expect(rem != 0ull, 0)) drain();
+        } while (__builtin_expect(rem != 0ull, 0));
+      }
+    };
+    auto interleave = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < G::kSteps; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      }
+    };
+
+    chain(0, 0);
+#pragma unroll
+    for (int sub = 0; sub < kTileN / 32; ++sub) {
+      if (sub + 1 < kTileN / 32) {
+#pragma unroll
+        for (int m = 0; m < G::kSteps; ++m)
+          af[(sub + 1) & 1][m] =
+              *reinterpret_cast<const u32x4 *>(ap + (sub + 1) * 32 * G::kRowB + m * 32);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      chain(1, sub);
+      check(0, sub);
+      interleave();
+      if (sub + 1 < kTileN / 32) {
+        chain(0, sub + 1);
+        check(1, sub);
+        interleave();
+      } else {
+        check(1, sub);
+      }
+    }
+    }
+    // The stage copies were issued a whole stage ago and the previous drain's stores before
+    // them: nothing recent is outstanding here.
+    wait_dma();
+    if (qtail >= a.drain_min || (st == nst - 1 && qtail > 0)) drain();
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // every segment's count is written (counts beyond cap_l flag the query for the exact redo)
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int g = 0; g < kQG; ++g) {
+    const int64_t qrow = q0 + g * 32 + j;
+    if (qrow < a.nq) a.cnt[qrow * a.nseg + 2 * split + h] = wcnt[g * 64 + lane];
+  }
+}
+
+template <int DP>
+static int launch_scan16f(const Scan16Args &a, hipStream_t stream) {
+  using G = Scan16FGeom<DP>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    TFRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan16f_kernel<DP>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytesF));
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)(a.n_qtiles * a.n_splits));
+  hipLaunchKernelGGL((scan16f_kernel<DP>), grid, dim3(kThreads16), G::kLdsBytesF, stream, a);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
 template <int DP, int MODE>
 static int launch_scan16_variant(const Scan16Args &a, hipStream_t stream) {
   using G = Scan16Geom<DP>;
@@ -384,14 +670,29 @@ static int launch_scan16_dp(const Scan16Args &a, hipStream_t stream) {
   return launch_scan16_variant<DP, kModeFilter>(a, stream);
 }
 
-int launch_scan16(const Scan16Args &a, hipStream_t stream) {
+static int scan16_generation() {
+  const char *e = getenv("TFRS_SCAN16_V");   // read per call: one process can compare both
+  return (e && e[0] == '1') ? 1 : 2;
+}
+
+int launch_scan16(const Scan16Args &a_in, hipStream_t stream) {
+  Scan16Args a = a_in;
   if (a.nq <= 0 || a.n_stages <= 0) return TFRS_OK;
+  if (a.drain_min < 1) a.drain_min = 1;
   TFRS_CHECK_ARG(a.stage_stride >= 1 && a.stages_per_split >= 1 &&
                      (int64_t)a.n_splits * a.stages_per_split >= a.n_stages,
                  "scan16: bad stage split");
   TFRS_CHECK_ARG(a.dense || a.binmax || a.nseg == 2 * a.n_splits, "scan16: nseg must be 2 * n_splits");
   TFRS_CHECK_ARG(!a.binmax || (a.bin_stages >= 1 && a.stages_per_split % a.bin_stages == 0),
                  "scan16: stages_per_split must be a multiple of bin_stages");
+  if (!a.dense && !a.binmax && scan16_generation() == 2) {
+    switch (padded_dim16(a.d)) {
+      case 16: return launch_scan16f<16>(a, stream);
+      case 32: return launch_scan16f<32>(a, stream);
+      case 64: return launch_scan16f<64>(a, stream);
+      case 128: return launch_scan16f<128>(a, stream);
+    }
+  }
   switch (padded_dim16(a.d)) {
     case 16: return launch_scan16_dp<16>(a, stream);
     case 32: return launch_scan16_dp<32>(a, stream);

@@ -310,6 +310,44 @@ class BruteForce(TopK):
     self._n, self._d = cand.shape
     return self
 
+  def index_from_dataset(self, candidates: Iterable, total_rows: Optional[int] = None) -> "BruteForce":
+    """``TopK.index_from_dataset`` (:179-215).  With ``total_rows`` (the dataset's cardinality)
+    the blocks are packed straight into a device index reserved once
+    (``tfrs_index_reserve`` / ``tfrs_index_append``): peak memory is the packed index plus ONE
+    block instead of the reference's ``tf.concat`` of every block (:196-215), which is what a
+    corpus of 100 M rows needs.  Without it the blocks are concatenated like the reference."""
+    if total_rows is None:
+      return super().index_from_dataset(candidates)
+    _check_candidates_with_identifiers(candidates)
+    handle, ids, has_ids, n, d = None, [], None, 0, 0
+    for element in candidates:
+      if isinstance(element, (tuple, list)):
+        i, c = element
+        has_ids = True
+        ids.append(i.cpu().numpy() if isinstance(i, torch.Tensor) else np.asarray(i))
+      else:
+        c, has_ids = element, False
+      block = _as_f32_matrix(c, "candidates")
+      if handle is None:
+        d = block.shape[1]
+        handle = _IndexHandle()
+        _lib.check(handle._lib.tfrs_index_reserve(handle.handle, int(total_rows), d,
+                                                  _lib.current_stream()))
+      elif block.shape[1] != d:
+        raise ValueError(f"Candidate blocks disagree on the embedding dimension ({block.shape[1]} vs {d}).")
+      if n + block.shape[0] > total_rows:
+        raise ValueError(f"The dataset holds more than total_rows={total_rows} candidates.")
+      _lib.check(handle._lib.tfrs_index_append(handle.handle, _lib.ptr(block), block.shape[0],
+                                               _lib.current_stream()))
+      torch.cuda.current_stream().synchronize()   # `block` may be a temporary upload
+      n += block.shape[0]
+    if handle is None:
+      raise ValueError("The candidate dataset is empty.")
+    self._index = handle
+    self._ids = _Identifiers(np.concatenate(ids, axis=0) if has_ids else None, n)
+    self._n, self._d = n, d
+    return self
+
   def _identifier_table(self) -> _Identifiers:
     return self._ids
 
@@ -327,7 +365,19 @@ class BruteForce(TopK):
     _lib.check(lib.tfrs_bruteforce_topk(
         self._index.handle, _lib.ptr(q), nq, k, _lib.ptr(scores), _lib.ptr(rows),
         _lib.ptr(ws), ws.numel(), _lib.current_stream()))               # :603-605
+    self._last_call = (ws, nq, k)
     return scores, rows
+
+  def last_redo_count(self) -> int:
+    """Queries of the most recent ``call`` that were answered by the exact-recompute path of
+    the fp16-prefiltered search (0 on well-behaved data).  Synchronises the stream."""
+    if getattr(self, "_last_call", None) is None:
+      return 0
+    ws, nq, k = self._last_call
+    out = ctypes.c_int32(0)
+    _lib.check(_lib.load().tfrs_bruteforce_topk_redo_count(
+        _lib.ptr(ws), nq, self._n, k, ctypes.byref(out), _lib.current_stream()))
+    return int(out.value)
 
   def call(self, queries, k: Optional[int] = None):
     k = k if k is not None else self._k
@@ -419,11 +469,22 @@ class Streaming(TopK):
   """Retrieves the K highest scoring items from a large candidate stream
   (reference :336-512).  Keeps only a reference to the candidate iterable and
   re-reads it on every call; the running state is ``[B, <=K]`` in HBM.
+
+  ``cache_packed_blocks`` (default on; not in the reference): when every element the iterable
+  yields is a GPU-resident tensor whose storage is unchanged since the previous call (the
+  common serving case: a list of device blocks), the packed f32 + fp16 images built from them
+  are kept between calls in ONE device index -- rows in stream order, so global row numbers
+  are the reference's counter (:477-488) -- and a call is then exactly ``BruteForce.call`` on
+  it: no re-upload, no re-pack, no per-block threshold pass.  Any change of a block (new
+  storage, in-place write, different shapes) rebuilds the images; iterables that produce fresh
+  tensors on every pass, or host arrays, take the block-by-block path, whose device footprint
+  is one block.  The cache holds 2.1x the candidate bytes (1.6x at dim 128).
   """
 
   def __init__(self, query_model: Optional[Callable] = None, k: int = 10,
                handle_incomplete_batches: bool = True,
-               num_parallel_calls: Optional[int] = None, sorted_order: bool = True) -> None:
+               num_parallel_calls: Optional[int] = None, sorted_order: bool = True,
+               cache_packed_blocks: bool = True) -> None:
     super().__init__(k=k)
     self.query_model = query_model
     self._candidates = None
@@ -431,10 +492,15 @@ class Streaming(TopK):
     self._num_parallel_calls = num_parallel_calls  # accepted for API parity; unused
     self._sorted = sorted_order                    # results are always sorted
     self._last_ids: Optional[_Identifiers] = None
+    self._cache_blocks = cache_packed_blocks
+    self._cache_key = None
+    self._cache: Optional[BruteForce] = None
+    self._base_row = 0
 
   def index_from_dataset(self, candidates: Iterable) -> "Streaming":
     _check_candidates_with_identifiers(candidates)                     # :386
     self._candidates = candidates                                      # :388
+    self._cache_key, self._cache = None, None
     return self
 
   def index(self, candidates, identifiers=None) -> "Streaming":
@@ -446,16 +512,70 @@ class Streaming(TopK):
   def _identifier_table(self) -> _Identifiers:
     return self._last_ids
 
+  # -- cached path ---------------------------------------------------------------------------
+  def _block_keys(self):
+    """(key, blocks, ids) when every block is a cacheable GPU tensor, else None.  Iterates the
+    dataset once without touching the device (shapes / pointers / version counters only)."""
+    keys, blocks, ids = [], [], []
+    for element in self._candidates:
+      block_ids = None
+      if isinstance(element, (tuple, list)):
+        block_ids, block = element
+      else:
+        block = element
+      if not (isinstance(block, torch.Tensor) and block.is_cuda and block.dim() == 2
+              and block.dtype == torch.float32 and block.is_contiguous()):
+        return None
+      if block_ids is not None:
+        if isinstance(block_ids, torch.Tensor):
+          keys.append((block_ids.data_ptr(), tuple(block_ids.shape), block_ids._version))
+        else:
+          return None     # host identifiers may change silently between calls
+      keys.append((block.data_ptr(), tuple(block.shape), block._version))
+      blocks.append(block)
+      ids.append(block_ids)
+    return (tuple(keys), blocks, ids) if blocks else None
+
+  def _cached_index(self, k: int) -> Optional["BruteForce"]:
+    if not self._cache_blocks:
+      return None
+    probe = self._block_keys()
+    if probe is None:
+      self._cache_key, self._cache = None, None
+      return None
+    key, blocks, ids = probe
+    if not self._handle_incomplete_batches and any(b.shape[0] < k for b in blocks):   # :431-436
+      raise ValueError(BATCH_TOO_SMALL_MESSAGE.format(k=k))
+    if key != self._cache_key:
+      total = sum(b.shape[0] for b in blocks)
+      if self._base_row + total > 0x7FFFFFFF:
+        raise ValueError("Streaming: global row numbers exceed int32 (base_row + rows = %d)"
+                         % (self._base_row + total))
+      has_ids = ids[0] is not None
+      bf = BruteForce(k=self._k)
+      bf.index_from_dataset([(i, b) for i, b in zip(ids, blocks)] if has_ids else blocks,
+                            total_rows=total)
+      self._cache_key, self._cache = key, bf
+    return self._cache
+
   def _query_rows(self, queries, k: int) -> Tuple[Tensor, Tensor]:
     if self._candidates is None:                                        # :412-416
       raise ValueError(NOT_INDEXED_MESSAGE)
     q = self._embed(queries)                                            # :418-419
+    cached = self._cached_index(k)
+    if cached is not None:
+      if q.shape[1] != cached._d:
+        raise ValueError(f"Candidate dimension {cached._d} does not match queries ({q.shape[1]}).")
+      kk = min(k, cached._n)     # handle_incomplete_batches semantics: fewer rows than k (:465-468)
+      scores, rows = cached._query_rows(q, kk, embedded=True)
+      self._last_ids = cached._ids
+      return scores, (rows + self._base_row if self._base_row else rows)
     lib = _lib.load()
     nq, d = q.shape
     state_scores = torch.zeros((nq, k), dtype=torch.float32, device=q.device)
     state_rows = torch.zeros((nq, k), dtype=torch.int32, device=q.device)
     state_len = 0
-    counter = 0                                                         # :421-422
+    counter = self._base_row                                            # :421-422
     ids = []
     has_ids = False
     new_len = ctypes.c_int32(0)
@@ -474,6 +594,8 @@ class Streaming(TopK):
         raise ValueError(f"Candidate dimension {block.shape[1]} does not match queries ({d}).")
       if not self._handle_incomplete_batches and nb < k:               # :431-436, :34-54
         raise ValueError(BATCH_TOO_SMALL_MESSAGE.format(k=k))
+      if counter + nb > 0x7FFFFFFF:
+        raise ValueError("Streaming: global row numbers exceed int32 (%d)" % (counter + nb))
       need = lib.tfrs_streaming_topk_workspace_bytes(nq, nb, d, k)
       if ws is None or ws.numel() < need:
         ws = _workspace(need)
@@ -483,16 +605,75 @@ class Streaming(TopK):
           ws.numel(), _lib.current_stream()))                          # :424-472
       state_len = int(new_len.value)
       counter += nb                                                     # :477-478
-    self._last_ids = _Identifiers(np.concatenate(ids, axis=0) if has_ids else None, counter)
+    self._last_ids = _Identifiers(np.concatenate(ids, axis=0) if has_ids else None,
+                                  counter - self._base_row)
     return state_scores[:, :state_len], state_rows[:, :state_len]
+
+  def _ids_of_rows(self, rows: Tensor):
+    return self._last_ids.gather(rows - self._base_row if self._base_row else rows)
 
   def call(self, queries, k: Optional[int] = None):
     k = k if k is not None else self._k
     scores, rows = self._query_rows(queries, k)
-    return scores, self._last_ids.gather(rows)                          # :438
+    return scores, self._ids_of_rows(rows)                              # :438
 
   def is_exact(self) -> bool:
     return True
+
+
+def _exchange_and_merge(scores: Tensor, rows: Tensor, k: int, group, merge: Optional[Callable]):
+  """The ONE exchange step of row-sharded top-K: this rank's (score bits, global row)[nq, k]
+  lists go back to back into one int32 buffer [2, nq, k]; a single all_gather delivers
+  [world, 2, nq, k] (2 * nq * k * 4 bytes per rank, one direct xGMI send per peer) and the merge
+  kernel reads the parts in place with the (score desc, row asc) rule, so every rank ends
+  with exactly the single-GPU result."""
+  import torch.distributed as dist
+  if not (dist.is_available() and dist.is_initialized()):
+    return scores, rows
+  world = dist.get_world_size(group)
+  if world == 1:
+    return scores, rows
+  nq = scores.shape[0]
+  if scores.shape[1] < k:      # a shard with fewer than k rows: pad with empty slots (row -1)
+    pad = k - scores.shape[1]
+    scores = torch.cat([scores, scores.new_full((nq, pad), float("-inf"))], dim=1)
+    rows = torch.cat([rows, rows.new_full((nq, pad), -1)], dim=1)
+  mine = torch.empty((2, nq, k), dtype=torch.int32, device=scores.device)
+  mine[0].copy_(scores.contiguous().view(torch.int32))
+  mine[1].copy_(rows)
+  gathered = torch.empty((world, 2, nq, k), dtype=torch.int32, device=scores.device)
+  dist.all_gather_into_tensor(gathered.view(world * 2 * nq, k), mine.view(2 * nq, k), group=group)
+  if merge is not None:
+    return merge(gathered[:, 0].contiguous().view(torch.float32), gathered[:, 1].contiguous(), k)
+  out_s = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
+  out_i = torch.empty((nq, k), dtype=torch.int32, device=scores.device)
+  base = gathered.view(-1)
+  _lib.check(_lib.load().tfrs_topk_merge_strided(
+      base.data_ptr(), base.data_ptr() + nq * k * 4, world, 2 * nq * k, nq, k, k,
+      _lib.ptr(out_s), _lib.ptr(out_i), _lib.current_stream()))
+  return out_s, out_i
+
+
+def _global_identifiers(rows: Tensor, local_ids: Optional[Tensor], base_row: int, n_local: int, group):
+  """identifiers[global row] when every rank only holds the identifiers of its own rows: the
+  owner fills its entries, one all_reduce(sum) of the [nq, k] int64 matrix completes it."""
+  import torch.distributed as dist
+  if local_ids is None:
+    return rows
+  local = rows.long() - base_row
+  mine = (local >= 0) & (local < n_local)
+  out = torch.zeros(rows.shape, dtype=torch.int64, device=rows.device)
+  out[mine] = local_ids.to(rows.device).long()[local[mine]]
+  if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    dist.all_reduce(out, group=group)
+  return out.to(local_ids.dtype)
+
+
+def _check_shard_rows(base_row: int, n_local: int) -> None:
+  if base_row < 0 or base_row + n_local > 0x7FFFFFFF:
+    raise ValueError(
+        f"sharded top-K returns int32 global row numbers (like the reference's int32 counter, "
+        f":380-382): base_row + rows = {base_row} + {n_local} does not fit")
 
 
 class ShardedBruteForce(TopK):
@@ -504,7 +685,8 @@ class ShardedBruteForce(TopK):
   per-shard ``(score, global row)[B, K]`` lists -- the only exchange step of the path,
   ``2 * B * K * 4`` bytes per rank -- and merges them with the same
   (score desc, row asc) rule, so every rank holds exactly the single-GPU result.
-  Not part of the reference (which has no multi-device top-K); see DESIGN.md.
+  ``identifiers`` (numeric, this shard's rows) are resolved by their owners and completed with
+  one small all_reduce.  Not part of the reference (which has no multi-device top-K).
   """
 
   def __init__(self, query_model: Optional[Callable] = None, k: int = 10,
@@ -515,61 +697,98 @@ class ShardedBruteForce(TopK):
     self._group = process_group
     self._local = BruteForce(k=k)
     self._base_row = 0
+    self._n_local = 0
+    self._local_ids: Optional[Tensor] = None
     self._ids = _Identifiers(None, 0)
     # injection points so the collective logic can be exercised on CPU (gloo) in tests
     self._local_search = local_search
     self._merge = merge
 
+  def _set_identifiers(self, identifiers, n_local: int) -> None:
+    self._local_ids = None
+    if identifiers is None:
+      return
+    if len(identifiers) != n_local:
+      raise ValueError("The candidates and identifiers tensors must have the same number of"
+                       f" rows (got {n_local} candidates rows and {len(identifiers)} identifier rows). ")
+    ids = identifiers if isinstance(identifiers, torch.Tensor) else np.asarray(identifiers)
+    if not isinstance(ids, torch.Tensor):
+      if ids.dtype.kind not in "iub":
+        raise NotImplementedError("ShardedBruteForce resolves integer identifiers only; map other "
+                                  "identifier types from the returned global row numbers on the host.")
+      ids = torch.as_tensor(ids)
+    self._local_ids = ids
+
   def index(self, candidates: ArrayLike, identifiers: Optional[ArrayLike] = None,
             base_row: int = 0) -> "ShardedBruteForce":
-    if identifiers is not None:
-      raise NotImplementedError("ShardedBruteForce returns global row numbers; map "
-                                "identifiers on the host.")
-    self._base_row = int(base_row)
+    n_local = len(candidates)
+    _check_shard_rows(int(base_row), n_local)
+    self._set_identifiers(identifiers, n_local)
+    self._base_row, self._n_local = int(base_row), n_local
     if self._local_search is None:
       self._local.index(candidates)
     else:
       self._cand = candidates
     return self
 
+  def index_from_dataset(self, candidates: Iterable, total_rows: Optional[int] = None,
+                         base_row: int = 0) -> "ShardedBruteForce":
+    """This rank's shard from an iterable of blocks (streamed into the device index when
+    ``total_rows`` -- the shard's row count -- is given, see ``BruteForce.index_from_dataset``)."""
+    self._local.index_from_dataset(candidates, total_rows=total_rows)
+    _check_shard_rows(int(base_row), self._local._n)
+    ids = self._local._ids
+    self._set_identifiers(ids.device if ids.device is not None else
+                          (None if ids.is_range else ids.host), self._local._n)
+    self._base_row, self._n_local = int(base_row), self._local._n
+    return self
+
   def _identifier_table(self) -> _Identifiers:
     return self._ids
 
   def _query_rows(self, queries, k: int) -> Tuple[Tensor, Tensor]:
-    import torch.distributed as dist
     if self._local_search is None:
-      scores, rows = self._local._query_rows(self._embed(queries), k)
+      kk = min(k, self._local._n)
+      scores, rows = self._local._query_rows(self._embed(queries), kk)
     else:
       scores, rows = self._local_search(queries, self._cand, k)
     rows = rows + self._base_row
-    if not (dist.is_available() and dist.is_initialized()):
-      return scores, rows
-    world = dist.get_world_size(self._group)
-    if world == 1:
-      return scores, rows
-    nq = scores.shape[0]
-    # ONE exchange: this rank's scores (bit pattern) and global rows back to back in one int32
-    # buffer [2, nq, k]; the all-gather delivers [world, 2, nq, k] and the merge kernel reads
-    # the parts in place (stride 2 * nq * k).  2 * nq * k * 4 bytes per rank.
-    mine = torch.empty((2, nq, k), dtype=torch.int32, device=scores.device)
-    mine[0].copy_(scores.contiguous().view(torch.int32))
-    mine[1].copy_(rows)
-    gathered = torch.empty((world, 2, nq, k), dtype=torch.int32, device=scores.device)
-    dist.all_gather_into_tensor(gathered.view(world * 2 * nq, k), mine.view(2 * nq, k),
-                                group=self._group)
-    if self._merge is not None:
-      return self._merge(gathered[:, 0].contiguous().view(torch.float32), gathered[:, 1].contiguous(), k)
-    out_s = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
-    out_i = torch.empty((nq, k), dtype=torch.int32, device=scores.device)
-    base = gathered.view(-1)
-    _lib.check(_lib.load().tfrs_topk_merge_strided(
-        base.data_ptr(), base.data_ptr() + nq * k * 4, world, 2 * nq * k, nq, k, k,
-        _lib.ptr(out_s), _lib.ptr(out_i), _lib.current_stream()))
-    return out_s, out_i
+    return _exchange_and_merge(scores, rows, k, self._group, self._merge)
 
   def call(self, queries, k: Optional[int] = None):
     k = k if k is not None else self._k
-    return self._query_rows(queries, k)
+    scores, rows = self._query_rows(queries, k)
+    return scores, _global_identifiers(rows, self._local_ids, self._base_row, self._n_local, self._group)
 
   def is_exact(self) -> bool:
     return True
+
+
+class ShardedStreaming(Streaming):
+  """``Streaming`` over a candidate stream that is row-sharded across ranks (BASELINE.json
+  configs[2]: "Streaming top-100 sharded over 8 MI355X"): rank r streams ITS blocks, whose rows
+  carry the global row numbers ``base_row, base_row + 1, ...``; the per-shard results are
+  exchanged and merged exactly like ``ShardedBruteForce``.  Returns global row numbers
+  (identifiers in the stream are resolved for the local rows only when every rank passes
+  them; otherwise map rows on the host)."""
+
+  def __init__(self, query_model: Optional[Callable] = None, k: int = 10,
+               handle_incomplete_batches: bool = True, process_group=None,
+               cache_packed_blocks: bool = True, merge: Optional[Callable] = None) -> None:
+    super().__init__(query_model=query_model, k=k,
+                     handle_incomplete_batches=handle_incomplete_batches,
+                     cache_packed_blocks=cache_packed_blocks)
+    self._group = process_group
+    self._merge = merge
+
+  def index_from_dataset(self, candidates: Iterable, base_row: int = 0) -> "ShardedStreaming":
+    super().index_from_dataset(candidates)
+    if base_row < 0:
+      raise ValueError("base_row must be non-negative")
+    self._base_row = int(base_row)
+    return self
+
+  def call(self, queries, k: Optional[int] = None):
+    k = k if k is not None else self._k
+    scores, rows = self._query_rows(queries, k)       # local shard, global row numbers
+    return _exchange_and_merge(scores, rows, k, self._group, self._merge)

@@ -64,12 +64,18 @@ class _ShardedLookup(torch.autograd.Function):
   def forward(ctx, shard, ids, layer):
     group, world = layer._group, _world(layer._group)
     flat = ids.reshape(-1).long()
+    # ids outside [0, input_dim) read as a zero row and receive no gradient, like the plain
+    # gather kernel; they are routed to rank 0 as row -1 so that every rank's split sizes stay
+    # consistent (an unchecked owner >= world would desynchronise the all_to_all and hang)
+    bad = (flat < 0) | (flat >= layer.input_dim)
     owner = torch.div(flat, layer.rows_per_rank, rounding_mode="floor")
+    owner = torch.where(bad, torch.zeros_like(owner), owner)
+    flat = torch.where(bad, torch.full_like(flat, -1), flat)
     order = torch.argsort(owner, stable=True)
     send_counts = torch.bincount(owner, minlength=world).tolist()
     counts_t = torch.tensor(send_counts, dtype=torch.int64, device=flat.device)
     recv_counts = all_to_all_v(counts_t, [1] * world, [1] * world, group).tolist()
-    send_ids = (flat - owner * layer.rows_per_rank)[order]            # shard-local row numbers
+    send_ids = torch.where(bad, flat, flat - owner * layer.rows_per_rank)[order]   # shard-local rows
     recv_ids = all_to_all_v(send_ids, send_counts, recv_counts, group)
     rows = layer._gather(shard, recv_ids)                             # HIP gather on the owner
     back = all_to_all_v(rows, recv_counts, send_counts, group)        # rows in `order` order
@@ -116,6 +122,7 @@ class ShardedEmbedding(torch.nn.Module):
     w.uniform_(-0.05, 0.05)
     self.embeddings = torch.nn.Parameter(w)
     self.embeddings._tfrs_embedding = True
+    self.embeddings._tfrs_row_sharded = True   # rank-local rows: excluded from the DP gradient sum
     # injection points so the exchange logic can be exercised on CPU (gloo) in tests
     self._gather = local_gather if local_gather is not None else emb.gather_rows
     self._scatter = local_scatter if local_scatter is not None else emb.scatter_add_rows

@@ -22,8 +22,103 @@ class Model(torch.nn.Module):
   def compute_loss(self, inputs, training: bool = False) -> torch.Tensor:   # :49-62
     raise NotImplementedError("Implementers must implement the `compute_loss` method.")
 
-  def compile(self, optimizer: Optional[torch.optim.Optimizer] = None, **kwargs) -> None:
+  def compile(self, optimizer: Optional[torch.optim.Optimizer] = None, process_group=None,
+              sync_gradients: Optional[bool] = None, bucket_bytes: int = 64 << 20,
+              **kwargs) -> None:
+    """``sync_gradients`` (default: on whenever ``torch.distributed`` is initialised with more
+    than one rank) makes ``train_step`` data-parallel the way the reference is under a
+    ``tf.distribute`` strategy (``experimental/models/ranking.py:199-201``: "the default
+    gradients allreduce performs sum"): after ``backward`` the gradients of all ranks are
+    SUMMED before the optimizer runs, so replicas stay identical.  Dense gradients travel in
+    flat buckets of ``bucket_bytes`` as reduce-scatter + all-gather (RCCL over xGMI; per-link
+    bound rings like few large messages); the ``(ids, rows)`` slices of embedding lookups are
+    all-gathered in rank order and handed to the fused sparse Adagrad as one IndexedSlices."""
     self.optimizer = optimizer
+    self._process_group = process_group
+    self._sync_gradients = sync_gradients
+    self._bucket_bytes = int(bucket_bytes)
+
+  # data-parallel gradient exchange ------------------------------------------------------
+  def _sync_world(self) -> int:
+    import torch.distributed as dist
+    if getattr(self, "_sync_gradients", None) is False:
+      return 1
+    if not (dist.is_available() and dist.is_initialized()):
+      return 1
+    return dist.get_world_size(getattr(self, "_process_group", None))
+
+  def _all_reduce_gradients(self) -> None:
+    """Sum of every rank's gradients, in place (see ``compile``)."""
+    import torch.distributed as dist
+    world = self._sync_world()
+    if world == 1:
+      return
+    group = getattr(self, "_process_group", None)
+    params = [p for p in self.parameters()
+              if p.requires_grad and not getattr(p, "_tfrs_row_sharded", False)]
+    # dense gradients: flat buckets in parameter order (identical on every rank)
+    dense = [p for p in params if p.grad is not None]
+    bucket: List[torch.Tensor] = []
+    size = 0
+
+    def flush():
+      nonlocal bucket, size
+      if not bucket:
+        return
+      grads = [p.grad for p in bucket]
+      n = sum(g.numel() for g in grads)
+      padded = -(-n // world) * world
+      flat = torch.zeros((padded,), dtype=torch.float32, device=grads[0].device)
+      torch._foreach_copy_(list(flat[:n].split([g.numel() for g in grads])),
+                           [g.reshape(-1).to(torch.float32) for g in grads])
+      shard = torch.empty((padded // world,), dtype=torch.float32, device=flat.device)
+      dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group)
+      dist.all_gather_into_tensor(flat, shard, group=group)
+      for g, piece in zip(grads, flat[:n].split([g.numel() for g in grads])):
+        g.copy_(piece.view_as(g))
+      bucket, size = [], 0
+
+    for p in dense:
+      bucket.append(p)
+      size += p.grad.numel() * 4
+      if size >= self._bucket_bytes:
+        flush()
+    flush()
+    # embedding slices: every rank contributes (ids, rows); concatenated in rank order so that
+    # all replicas apply the same IndexedSlices in the same order (bit-identical tables)
+    for p in params:
+      slices = getattr(p, "_tfrs_slices", None)
+      if slices is None or not getattr(p, "_tfrs_sparse_grad", False):
+        continue
+      d = p.shape[1]
+      if slices:
+        ids = torch.cat([s[0].reshape(-1).long() for s in slices])
+        rows = torch.cat([s[1].reshape(-1, d) for s in slices])
+      else:
+        ids = torch.empty((0,), dtype=torch.int64, device=p.device)
+        rows = torch.empty((0, d), dtype=torch.float32, device=p.device)
+      n = torch.tensor([ids.numel()], dtype=torch.int64, device=p.device)
+      counts = torch.empty((world,), dtype=torch.int64, device=p.device)
+      dist.all_gather_into_tensor(counts, n, group=group)
+      counts = [int(c) for c in counts.tolist()]
+      m = max(counts)
+      if m == 0:
+        continue
+      ids_pad = torch.full((m,), -1, dtype=torch.int64, device=p.device)
+      rows_pad = torch.zeros((m, d), dtype=torch.float32, device=p.device)
+      ids_pad[:ids.numel()] = ids
+      rows_pad[:ids.numel()] = rows
+      all_ids = torch.empty((world * m,), dtype=torch.int64, device=p.device)
+      all_rows = torch.empty((world * m, d), dtype=torch.float32, device=p.device)
+      dist.all_gather_into_tensor(all_ids, ids_pad, group=group)
+      dist.all_gather_into_tensor(all_rows, rows_pad, group=group)
+      if all(c == m for c in counts):
+        merged = (all_ids, all_rows)
+      else:
+        keep = torch.cat([torch.arange(r * m, r * m + c, device=p.device) for r, c in enumerate(counts)])
+        merged = (all_ids[keep], all_rows[keep])
+      slices.clear()
+      slices.append(merged)
 
   # Keras-like hooks -------------------------------------------------------------------
   @property
@@ -82,6 +177,7 @@ class Model(torch.nn.Module):
     reg = self._regularization_loss(loss)
     total = loss if reg is None else loss + reg
     total.backward(gradient=self._constant(1.0, total))               # :77
+    self._all_reduce_gradients()     # the strategy's gradient all-reduce (sum); no-op on 1 rank
     self.optimizer.step()                                              # :78
     return self._metrics_dict(loss, self._constant(0.0, loss) if reg is None else reg, total)
 
@@ -103,6 +199,9 @@ class Model(torch.nn.Module):
     iterations stay applied as ordinary training steps on ``example_inputs``."""
     if self.optimizer is None:
       raise RuntimeError("Call `compile(optimizer=...)` before training.")
+    if self._sync_world() > 1:
+      raise RuntimeError("make_graphed_train_step does not capture the gradient exchange; use "
+                         "train_step under data parallelism (or compile(sync_gradients=False)).")
 
     def map_tensors(x, fn):
       if isinstance(x, torch.Tensor):

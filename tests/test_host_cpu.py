@@ -308,3 +308,179 @@ def test_cross_replica_concat_is_identity_without_process_group():
   x = torch.arange(6.0).reshape(3, 2)
   assert cross_replica_concat(x) is x
 
+
+
+def _run_two_ranks(tmp_path, name, source):
+  script = tmp_path / name
+  script.write_text(source.format(root=ROOT))
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  port = s.getsockname()[1]
+  s.close()
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2",
+             OMP_NUM_THREADS="2")
+  procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+           for r in range(2)]
+  outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+  for r, (p, o) in enumerate(zip(procs, outs)):
+    assert p.returncode == 0, f"rank {r} failed:\n{o}"
+    assert f"rank {r} ok" in o
+
+
+_DP_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+import recommenders_amd as tfrs
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+torch.manual_seed(5)
+B, D, H = 64, 12, 7                               # global batch; every rank trains on B / world rows
+x = torch.randn(B, D); y = torch.randn(B)
+
+class Net(tfrs.Model):
+  def __init__(self):
+    super().__init__()
+    self.a = torch.nn.Linear(D, H); self.b = torch.nn.Linear(H, 1)
+  def compute_loss(self, inputs, training=False):
+    xb, yb = inputs
+    per_example = (self.b(torch.tanh(self.a(xb))).reshape(-1) - yb) ** 2
+    replicas = dist.get_world_size() if self._sync_world() > 1 else 1
+    return per_example.mean() / replicas          # experimental/models/ranking.py:198-201
+
+def make(sync):
+  torch.manual_seed(9)
+  m = Net()
+  m.compile(optimizer=tfrs.optimizers.Adagrad(m.parameters(), learning_rate=0.3),
+            sync_gradients=sync, bucket_bytes=128)   # tiny buckets: several reduce-scatter rounds
+  return m
+
+dp = make(None)                                   # default: synchronise (2 ranks are up)
+single = make(False)                              # one "rank" on the full batch, no exchange
+per = B // world
+for step in range(4):
+  dp.train_step((x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per]))
+  single.train_step((x, y))
+for (n1, p1), (n2, p2) in zip(dp.named_parameters(), single.named_parameters()):
+  assert torch.allclose(p1, p2, rtol=1e-6, atol=1e-6), (n1, float((p1 - p2).abs().max()))
+# replicas are bit-identical
+for p in dp.parameters():
+  both = [torch.empty_like(p) for _ in range(world)]
+  dist.all_gather(both, p.detach())
+  assert torch.equal(both[0], both[1])
+
+# embedding slices: every rank ends with the rank-ordered concatenation of all ranks' (ids, rows)
+class Slices(tfrs.Model):
+  def __init__(self):
+    super().__init__()
+    self.table = torch.nn.Parameter(torch.zeros(10, 3))
+m = Slices(); m.compile(optimizer=None)
+m.table._tfrs_sparse_grad = True
+n_mine = 3 + rank                                  # ragged counts across ranks
+m.table._tfrs_slices = [(torch.arange(n_mine) + 10 * rank, torch.full((n_mine, 3), float(rank + 1)))]
+m._all_reduce_gradients()
+ids, rows = m.table._tfrs_slices[0]
+assert ids.tolist() == [0, 1, 2, 10, 11, 12, 13], ids.tolist()
+assert rows[:, 0].tolist() == [1.0] * 3 + [2.0] * 4
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_data_parallel_train_step_two_ranks_gloo(tmp_path):
+  """world_size-2 gloo run of `Model.train_step` with the gradient exchange: two ranks on
+  half-batches reach the parameters of one rank on the full batch (1e-6), replicas stay
+  bit-identical, and embedding slices are all-gathered in rank order."""
+  _run_two_ranks(tmp_path, "dp_worker.py", _DP_WORKER)
+
+
+_SSTREAM_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from oracle import topk as o_topk
+from recommenders_amd.layers import factorized_top_k as ftk
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+rng = np.random.default_rng(321)
+n, nq, d, k = 1500, 19, 8, 40
+cand = rng.integers(-3, 4, size=(n, d)).astype(np.float32)
+qry = rng.integers(-3, 4, size=(nq, d)).astype(np.float32)
+lo, hi = (0, 700) if rank == 0 else (700, n)          # uneven shards
+
+class FakeStreaming(ftk.ShardedStreaming):            # oracle stands in for the GPU scan
+  def _query_rows(self, queries, kk):
+    blocks = list(self._candidates)
+    s, i = o_topk.brute_force(np.asarray(queries), np.concatenate(blocks), kk)
+    return torch.from_numpy(s), torch.from_numpy(i.astype(np.int32)) + self._base_row
+
+def merge(all_s, all_i, kk):
+  w, b, _ = all_s.shape
+  fs = all_s.permute(1, 0, 2).reshape(b, -1).numpy()
+  fi = all_i.permute(1, 0, 2).reshape(b, -1).numpy()
+  out_s, out_i = np.empty((b, kk), np.float32), np.empty((b, kk), np.int32)
+  for r in range(b):
+    order = np.lexsort((fi[r], -fs[r]))[:kk]
+    out_s[r], out_i[r] = fs[r][order], fi[r][order]
+  return torch.from_numpy(out_s), torch.from_numpy(out_i)
+
+layer = FakeStreaming(k=k, merge=merge).index_from_dataset(
+    [cand[lo:hi][j:j + 128] for j in range(0, hi - lo, 128)], base_row=lo)
+s, i = layer(qry)
+es, ei = o_topk.brute_force(qry, cand, k)
+assert np.array_equal(i.numpy(), ei) and np.array_equal(s.numpy(), es)
+
+# ShardedBruteForce: a shard whose rows would not fit int32 global row numbers is refused
+try:
+  ftk.ShardedBruteForce(k=5, local_search=lambda *a: None).index(cand[:10], base_row=2**31 - 5)
+  raise SystemExit("expected ValueError")
+except ValueError as e:
+  assert "int32" in str(e)
+# integer identifiers are resolved by their owners
+def local_search(q, c, kk):
+  s_, i_ = o_topk.brute_force(np.asarray(q), np.asarray(c), kk)
+  return torch.from_numpy(s_), torch.from_numpy(i_.astype(np.int32))
+ids_all = (np.arange(n) * 7 + 3).astype(np.int64)
+sb = ftk.ShardedBruteForce(k=k, local_search=local_search, merge=merge).index(
+    cand[lo:hi], identifiers=ids_all[lo:hi], base_row=lo)
+s2, id2 = sb(qry)
+assert np.array_equal(id2.numpy(), ids_all[ei])
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_streaming_and_identifiers_two_ranks_gloo(tmp_path):
+  """world_size-2 gloo run: ShardedStreaming (uneven shards, global row numbers from base_row)
+  and ShardedBruteForce with integer identifiers equal the single-shard oracle; a base_row
+  that would overflow int32 row numbers raises."""
+  _run_two_ranks(tmp_path, "sstream_worker.py", _SSTREAM_WORKER)
+
+
+def test_sharded_embedding_routes_out_of_range_ids_consistently():
+  """ids outside [0, input_dim) must not desynchronise the exchange: they become row -1 on
+  rank 0 (a zero row, no gradient)."""
+  from oracle import embedding as o_emb
+  from recommenders_amd.layers.sharded_embedding import ShardedEmbedding
+  def gather(shard, ids):
+    out = np.zeros((ids.numel(), shard.shape[1]), np.float32)
+    ok = (ids.numpy() >= 0) & (ids.numpy() < shard.shape[0])
+    out[ok] = shard.detach().numpy()[ids.numpy()[ok]]
+    return torch.from_numpy(out)
+  def scatter(g, ids, vocab):
+    ok = (ids.numpy() >= 0) & (ids.numpy() < vocab)
+    return torch.from_numpy(o_emb.scatter_add_grad(g.numpy()[ok], ids.numpy()[ok], vocab))
+  layer = ShardedEmbedding(10, 4, device=torch.device("cpu"), local_gather=gather, local_scatter=scatter)
+  ids = torch.tensor([3, -2, 10, 9, 123456])
+  out = layer(ids)
+  want = layer.embeddings.detach()[torch.tensor([3, 0, 0, 9, 0])].clone()
+  want[[1, 2, 4]] = 0.0
+  assert torch.equal(out.detach(), want)
+  out.sum().backward()
+  g = layer.embeddings.grad
+  assert g[3].eq(1).all() and g[9].eq(1).all() and g.sum() == 8.0

@@ -1,5 +1,6 @@
-"""Timing experiment: fp16 prefilter scan with and without survivors (TFRS_DEBUG_NO_SURVIVORS)."""
-import ctypes, os, sys, time
+"""Timing experiment: fp16 filter kernel generations / drain threshold / sample stride on the
+BASELINE configs[1] batch (per-launch HIP-event times from tfrs_profile_*)."""
+import ctypes, os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from recommenders_amd import _lib
@@ -11,24 +12,34 @@ corpus = torch.randn((1_000_000, 64), generator=g, device=dev) / 8.0
 queries = torch.randn((8192, 64), generator=g, device=dev) / 8.0
 index = ftk.BruteForce(k=100).index(corpus)
 lib = _lib.load()
-for env in [{}, {"TFRS_TOPK_WGS": "512"},
-            {"TFRS_TOPK_RHO": "4"}, {"TFRS_TOPK_RHO": "2"}, {"TFRS_TOPK_RHO": "16"}, {"TFRS_TOPK_PREFIX": "16384"}]:
-  for k in ("TFRS_TOPK_WGS", "TFRS_TOPK_RHO", "TFRS_TOPK_PREFIX"):
+KEYS = ("TFRS_SCAN16_V", "TFRS_SCAN16_DRAIN", "TFRS_TOPK_SAMPLE", "TFRS_TOPK_WGS")
+ref = None
+for env in [{"TFRS_SCAN16_V": "1"}, {}, {"TFRS_SCAN16_DRAIN": "4"}, {"TFRS_SCAN16_DRAIN": "8"},
+            {"TFRS_SCAN16_DRAIN": "16"}, {"TFRS_TOPK_SAMPLE": "8"}, {"TFRS_TOPK_SAMPLE": "6"},
+            {"TFRS_TOPK_SAMPLE": "3"}, {"TFRS_TOPK_WGS": "1024"}, {"TFRS_TOPK_WGS": "256"}]:
+  for k in KEYS:
     os.environ.pop(k, None)
   os.environ.update(env)
-  for _ in range(2):
-    index(queries)
+  for _ in range(3):
+    out = index(queries)
   torch.cuda.synchronize()
+  if ref is None:
+    ref = (out[0].clone(), out[1].clone())
+  same = bool(torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]))
   lib.tfrs_profile_enable(1)
   t0 = time.perf_counter()
-  steps = 10
+  steps = 20
   for _ in range(steps):
     index(queries)
   torch.cuda.synchronize()
   dt = (time.perf_counter() - t0) / steps
-  ms, n, fl = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
-  lib.tfrs_profile_read_kind(1, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
+  res = {}
+  for kind in (1, 2):
+    ms, n, fl = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
+    lib.tfrs_profile_read_kind(kind, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
+    res[kind] = (ms.value / steps, fl.value / max(ms.value, 1e-9) / 1e9)
   lib.tfrs_profile_read(None, None, None)
   lib.tfrs_profile_enable(0)
-  print(env, f"step={dt*1e3:.3f} ms scan16={ms.value/steps:.3f} ms launches/step={n.value//steps} "
-        f"scan16 TFLOP/s={fl.value/ms.value/1e9:.0f}", flush=True)
+  print(json.dumps({"env": env, "step_ms": round(dt * 1e3, 4), "filter_ms": round(res[1][0], 4),
+                    "filter_tflops": round(res[1][1], 1), "binmax_ms": round(res[2][0], 4),
+                    "same_as_v1": same}), flush=True)
