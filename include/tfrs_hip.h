@@ -287,6 +287,22 @@ int tfrs_inbatch_softmax_ce_bwd(const float *q, const float *c, int64_t nq, int6
 int tfrs_cross_fwd(const float *x0, const float *x, const float *kernel,
                    const float *bias, float diag_scale, int64_t batch, int d, float *y,
                    void *stream);
+/* Gradients of the same layer (its backward under tfrs.Model.train_step, models/base.py:77):
+ * with z = x @ kernel + bias + diag_scale * x and dz = dy * x0
+ *   dx0 = dy * z ;  dx = dz @ kernel^T + dy + diag_scale * dz ;
+ *   dkernel = x^T @ dz ;  dbias[d] = column sums of dz (NULL to skip).
+ * Three fused GEMM launches: z and dz never exist in HBM and nothing is transposed.
+ * tfrs_cross_bwd = f32 MFMA; tfrs_cross_bwd_f16 = split-fp16 MFMA (large products), same
+ * results to f32 accuracy.  workspace from tfrs_cross_bwd_workspace_bytes(batch, d, f16). */
+size_t tfrs_cross_bwd_workspace_bytes(int64_t batch, int d, int f16);
+int tfrs_cross_bwd(const float *x0, const float *x, const float *kernel, const float *bias,
+                   float diag_scale, const float *dy, int64_t batch, int d, float *dx0,
+                   float *dx, float *dkernel, float *dbias, void *workspace,
+                   size_t workspace_bytes, void *stream);
+int tfrs_cross_bwd_f16(const float *x0, const float *x, const float *kernel, const float *bias,
+                       float diag_scale, const float *dy, int64_t batch, int d, float *dx0,
+                       float *dx, float *dkernel, float *dbias, void *workspace,
+                       size_t workspace_bytes, void *stream);
 /* Low-rank form (dcn.py:131-148, multi_layer_dcn.py:147-153): a[batch, ka] = x @ U is
  * computed first (tfrs_dense_fwd); this call does  y = x0 * (a @ kernel[ka, d] + bias +
  * diag_scale * x) + x  with the same fused epilogue. */
@@ -296,6 +312,14 @@ int tfrs_cross_fwd_ex(const float *x0, const float *x, const float *a, int ka,
 /* z = x @ kernel (+bias) only (used for low-rank U/V and activations): out[batch, dout]. */
 int tfrs_dense_fwd(const float *x, const float *kernel, const float *bias, int64_t batch,
                    int din, int dout, float *out, void *stream);
+/* Gradients of the same Dense (layers/blocks.py:46-61 MLP layers, low-rank Cross projections
+ * dcn.py:176-180): dx[batch, din] = dy @ kernel^T, dkernel[din, dout] = x^T @ dy,
+ * dbias[dout] = column sums of dy; NULL outputs are skipped.  The transposed operands are read
+ * in place.  f16 != 0 selects the split-fp16 MFMA path (large products). */
+size_t tfrs_dense_bwd_workspace_bytes(int64_t batch, int din, int dout, int f16);
+int tfrs_dense_bwd(const float *x, const float *kernel, const float *dy, int64_t batch, int din,
+                   int dout, float *dx, float *dkernel, float *dbias, int f16, void *workspace,
+                   size_t workspace_bytes, void *stream);
 
 /* The same two products on the fp16 matrix cores with split operands (x = hi + lo per
  * power-of-two-scaled row / column; hi*hi + hi*lo + lo*hi with f32 accumulation): f32-grade

@@ -53,7 +53,10 @@ __device__ __forceinline__ void g16_scale_of(float maxabs, float *s, float *inv)
 
 // ---- prep: rows of A ------------------------------------------------------------------------
 // one wave per row; rows in [m, mp) and columns in [k, kp) are zero
-__global__ void __launch_bounds__(256) g16_prep_rows_kernel(const float *__restrict__ x, int64_t m,
+// `mul` (optional, same shape as x): the image is built from x * mul (dz = dy * x0 of the Cross
+// backward never exists in HBM).
+__global__ void __launch_bounds__(256) g16_prep_rows_kernel(const float *__restrict__ x,
+                                                            const float *__restrict__ mul, int64_t m,
                                                             int k, int kp, _Float16 *__restrict__ hi,
                                                             _Float16 *__restrict__ lo,
                                                             float *__restrict__ inv,
@@ -66,16 +69,19 @@ __global__ void __launch_bounds__(256) g16_prep_rows_kernel(const float *__restr
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const bool valid = row < m;
   const float *xr = x + row * (int64_t)k;
-  const bool vec = (k % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  const float *mr = mul ? mul + row * (int64_t)k : nullptr;
+  const bool vec = (k % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                   (!mul || (reinterpret_cast<uintptr_t>(mul) & 15) == 0);
   float mx = 0.0f;
   if (valid) {
     if (vec) {
       for (int c = lane * 4; c < k; c += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(xr + c);
+        f32x4 v = *reinterpret_cast<const f32x4 *>(xr + c);
+        if (mr) v = v * *reinterpret_cast<const f32x4 *>(mr + c);
         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
       }
     } else {
-      for (int c = lane; c < k; c += 64) mx = fmaxf(mx, fabsf(xr[c]));
+      for (int c = lane; c < k; c += 64) mx = fmaxf(mx, fabsf(mr ? xr[c] * mr[c] : xr[c]));
     }
   }
 #pragma unroll
@@ -88,12 +94,13 @@ __global__ void __launch_bounds__(256) g16_prep_rows_kernel(const float *__restr
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (valid) {
       if (vec && c + 3 < k) {
-        const f32x4 t = *reinterpret_cast<const f32x4 *>(xr + c);
+        f32x4 t = *reinterpret_cast<const f32x4 *>(xr + c);
+        if (mr) t = t * *reinterpret_cast<const f32x4 *>(mr + c);
         v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
       } else {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          if (c + u < k) v[u] = xr[c + u];
+          if (c + u < k) v[u] = mr ? xr[c + u] * mr[c + u] : xr[c + u];
       }
     }
     g16h4 h4, l4;
@@ -116,26 +123,53 @@ __global__ void __launch_bounds__(256) g16_prep_rows_kernel(const float *__restr
 // scaled, split and transposed through LDS.
 constexpr int kG16Slab = 1024;
 
-__global__ void __launch_bounds__(256) g16_colmax_kernel(const float *__restrict__ b, int k, int n,
-                                                         uint32_t *__restrict__ colmax) {
+// `psum` (optional): psum[slab, n] = column sums of the slab's rows (b * mul), combined
+// afterwards in slab order by g16_colsum_kernel -- a deterministic db = sum_rows dz.
+__global__ void __launch_bounds__(256) g16_colmax_kernel(const float *__restrict__ b,
+                                                         const float *__restrict__ mul, int k, int n,
+                                                         uint32_t *__restrict__ colmax,
+                                                         float *__restrict__ psum) {
   __shared__ float red[4][64];
+  __shared__ float reds[4][64];
   const int tid = threadIdx.x;
   const int n0 = blockIdx.x * 64, k0 = blockIdx.y * kG16Slab;
   const int c = tid & 63, rg = tid >> 6;
-  float mx = 0.0f;
+  float mx = 0.0f, sum = 0.0f;
   if (n0 + c < n) {
     const int k1 = k0 + kG16Slab < k ? k0 + kG16Slab : k;
-    for (int r = k0 + rg; r < k1; r += 4) mx = fmaxf(mx, fabsf(b[(int64_t)r * n + n0 + c]));
+    for (int r = k0 + rg; r < k1; r += 4) {
+      const int64_t o = (int64_t)r * n + n0 + c;
+      const float v = mul ? b[o] * mul[o] : b[o];
+      mx = fmaxf(mx, fabsf(v));
+      sum += v;
+    }
   }
   red[rg][c] = mx;
+  reds[rg][c] = sum;
   __syncthreads();
   if (tid < 64 && n0 + tid < n) {
     const float m4 = fmaxf(fmaxf(red[0][tid], red[1][tid]), fmaxf(red[2][tid], red[3][tid]));
     atomicMax(&colmax[n0 + tid], g16_f2u(m4));
+    if (psum) psum[(int64_t)blockIdx.y * n + n0 + tid] = (reds[0][tid] + reds[1][tid]) + (reds[2][tid] + reds[3][tid]);
   }
 }
 
-__global__ void __launch_bounds__(256) g16_prep_cols_kernel(const float *__restrict__ b, int k, int n,
+__global__ void __launch_bounds__(256) g16_colsum_kernel(const float *__restrict__ psum, int nslab, int n,
+                                                         float *__restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.0f;
+  for (int i = 0; i < nslab; ++i) s += psum[(int64_t)i * n + c];
+  out[c] = s;
+}
+
+__global__ void __launch_bounds__(256) g16_zero_kernel(uint32_t *__restrict__ p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
+__global__ void __launch_bounds__(256) g16_prep_cols_kernel(const float *__restrict__ b,
+                                                            const float *__restrict__ mul, int k, int n,
                                                             int kp, const uint32_t *__restrict__ colmax,
                                                             _Float16 *__restrict__ hi,
                                                             _Float16 *__restrict__ lo,
@@ -152,7 +186,12 @@ __global__ void __launch_bounds__(256) g16_prep_cols_kernel(const float *__restr
   }
   for (int e = tid; e < 64 * 64; e += 256) {
     const int r = e >> 6, cc = e & 63;
-    tile[r][cc] = (k0 + r < k && n0 + cc < n) ? b[(int64_t)(k0 + r) * n + n0 + cc] : 0.0f;
+    float v = 0.0f;
+    if (k0 + r < k && n0 + cc < n) {
+      const int64_t o = (int64_t)(k0 + r) * n + n0 + cc;
+      v = mul ? b[o] * mul[o] : b[o];
+    }
+    tile[r][cc] = v;
   }
   __syncthreads();
   const int col = tid >> 2, seg = (tid & 3) * 16;   // 16 consecutive k of one output column
@@ -174,7 +213,27 @@ __global__ void __launch_bounds__(256) g16_prep_cols_kernel(const float *__restr
 }
 
 // ---- the GEMM -------------------------------------------------------------------------------
-enum { kG16EpiBias = 0, kG16EpiCross = 1 };
+// epilogues (v = scaled accumulator + bias):
+//   Bias     out = v
+//   Cross    out = e0 * (v + diag * e1) + e1          e0 = x0, e1 = x   (Cross.call)
+//   CrossDx0 out = e0 * (v + diag * e1)               e0 = dy, e1 = x   (dx0 = dy * z)
+//   CrossDx  out = v + e0 + diag * e0 * e1            e0 = dy, e1 = x0  (dx = dz W^T + dy + diag dz)
+enum { kG16EpiBias = 0, kG16EpiCross = 1, kG16EpiCrossDx0 = 2, kG16EpiCrossDx = 3 };
+
+template <int EPI>
+__device__ __forceinline__ float g16_epilogue(float v, const float *e0, const float *e1, float diag,
+                                              int64_t o) {
+  if (EPI == kG16EpiCross) {
+    const float xv = e1[o];
+    return e0[o] * (v + diag * xv) + xv;
+  }
+  if (EPI == kG16EpiCrossDx0) return e0[o] * (v + diag * e1[o]);
+  if (EPI == kG16EpiCrossDx) {
+    const float dyv = e0[o];
+    return v + dyv + diag * dyv * e1[o];
+  }
+  return v;
+}
 
 struct Gemm16Args {
   const _Float16 *ah, *al, *bh, *bl;   // [mp, kp], [np, kp]
@@ -182,7 +241,7 @@ struct Gemm16Args {
   int64_t m;
   int n, kp;
   const float *bias;                   // [n] or NULL
-  const float *x0, *x;                 // cross epilogue: [m, n]
+  const float *x0, *x;                 // epilogue operands e0, e1: [m, n] (see the enum below)
   float diag;
   float *out;                          // [m, n]
 };
@@ -300,13 +359,9 @@ __global__ void __launch_bounds__(256, 2) gemm16_kernel(const Gemm16Args g) {
       for (int r = 0; r < 16; ++r) {
         const int64_t row = bm + wm * 64 + i * 32 + tile_row_of_reg(r, h);
         if (row >= g.m) continue;
-        float v = acc[i][jn][r] * (g.inva[row] * cs) + bias;
+        const float v = acc[i][jn][r] * (g.inva[row] * cs) + bias;
         const int64_t o = row * g.n + col;
-        if (EPI == kG16EpiCross) {
-          const float xv = g.x[o];
-          v = g.x0[o] * (v + g.diag * xv) + xv;
-        }
-        g.out[o] = v;
+        g.out[o] = g16_epilogue<EPI>(v, g.x0, g.x, g.diag, o);
       }
     }
 }
@@ -446,13 +501,9 @@ __global__ void __launch_bounds__(512) gemm16_big_kernel(const Gemm16Args g) {
       for (int q = 0; q < 16; ++q) {
         const int64_t row = bm + wm * 64 + i * 32 + tile_row_of_reg(q, h);
         if (row >= g.m) continue;
-        float v = acc[i][jn][q] * (g.inva[row] * cs) + bias;
+        const float v = acc[i][jn][q] * (g.inva[row] * cs) + bias;
         const int64_t o = row * g.n + col;
-        if (EPI == kG16EpiCross) {
-          const float xv = g.x[o];
-          v = g.x0[o] * (v + g.diag * xv) + xv;
-        }
-        g.out[o] = v;
+        g.out[o] = g16_epilogue<EPI>(v, g.x0, g.x, g.diag, o);
       }
     }
 }
@@ -464,7 +515,7 @@ static inline int64_t g16_pad(int64_t x, int64_t q) { return (x + q - 1) / q * q
 struct G16Layout {
   int64_t mp, np;
   int kp;
-  size_t ah, al, bh, bl, inva, invb, colmax, total;
+  size_t ah, al, bh, bl, inva, invb, colmax, colmax_a, psum, total;
 };
 
 static G16Layout g16_layout(int64_t m, int n, int k) {
@@ -479,54 +530,157 @@ static G16Layout g16_layout(int64_t m, int n, int k) {
   L.inva = o; o += g16_al((size_t)L.mp * 4);
   L.invb = o; o += g16_al((size_t)L.np * 4);
   L.colmax = o; o += g16_al((size_t)L.np * 4);
+  L.colmax_a = o; o += g16_al((size_t)L.mp * 4);
+  L.psum = o; o += g16_al((size_t)((k + kG16Slab - 1) / kG16Slab) * L.np * 4);
   L.total = o;
   return L;
 }
 
 size_t gemm16_workspace_bytes(int64_t m, int n, int k) { return g16_layout(m, n, k).total; }
 
-// C = A @ B (+ bias) [cross epilogue when x0 != NULL]; ws from gemm16_workspace_bytes
-int gemm16_run(const float *a, const float *b, int64_t m, int n, int k, const float *bias,
-               const float *x0, const float *x, float diag, float *out, void *ws, hipStream_t s) {
+// One operand of the product C[M, N] = A[M, K] @ B[K, N].  `t` = the array holds the TRANSPOSE
+// (A given as [K, M], B given as [N, K]); `mul` = optional elementwise multiplier of the same
+// shape/layout.  Either way the images end up K-contiguous per output row / column, so no
+// transposed copy of an activation is ever materialised (dW = x^T dz reads x and dz as they are).
+struct G16Operand {
+  const float *p;
+  const float *mul;
+  bool t;
+};
+
+template <int EPI>
+static void g16_launch(const Gemm16Args &g, bool big, hipStream_t s) {
+  if (big) {
+    const dim3 grid((unsigned)(((g.m + kB16M - 1) / kB16M) * ((g.n + kB16N - 1) / kB16N)));
+    hipLaunchKernelGGL((gemm16_big_kernel<EPI>), grid, dim3(512), 0, s, g);
+  } else {
+    // tiles that hold at least one real row and column (the kernel derives its tile
+    // coordinates from ceil(n / 128), not from the 256-padded image sizes)
+    const dim3 grid((unsigned)(((g.m + kG16M - 1) / kG16M) * ((g.n + kG16N - 1) / kG16N)));
+    hipLaunchKernelGGL((gemm16_kernel<EPI>), grid, dim3(256), 0, s, g);
+  }
+}
+
+// C = A @ B (+ bias) with epilogue `epi` on (e0, e1, diag); colsum (optional, B not transposed):
+// colsum[n] = sum_k (B * mul)[k, n].  ws from gemm16_workspace_bytes(m, n, k).
+int gemm16_run_ex(const G16Operand &a, const G16Operand &b, int64_t m, int n, int k,
+                  const float *bias, int epi, const float *e0, const float *e1, float diag,
+                  float *out, float *colsum, void *ws, hipStream_t s) {
   const G16Layout L = g16_layout(m, n, k);
   char *w = static_cast<char *>(ws);
   _Float16 *ah = reinterpret_cast<_Float16 *>(w + L.ah), *al = reinterpret_cast<_Float16 *>(w + L.al);
   _Float16 *bh = reinterpret_cast<_Float16 *>(w + L.bh), *bl = reinterpret_cast<_Float16 *>(w + L.bl);
   float *inva = reinterpret_cast<float *>(w + L.inva), *invb = reinterpret_cast<float *>(w + L.invb);
   uint32_t *colmax = reinterpret_cast<uint32_t *>(w + L.colmax);
-  hipLaunchKernelGGL(g16_prep_rows_kernel, dim3((unsigned)(L.mp / 4)), dim3(256), 0, s, a, m, k, L.kp, ah,
-                     al, inva, colmax, (int)L.np);
-  hipLaunchKernelGGL(g16_colmax_kernel, dim3((unsigned)(L.np / 64), (unsigned)((k + kG16Slab - 1) / kG16Slab)),
-                     dim3(256), 0, s, b, k, n, colmax);
-  hipLaunchKernelGGL(g16_prep_cols_kernel, dim3((unsigned)(L.np / 64), (unsigned)(L.kp / 64)), dim3(256), 0,
-                     s, b, k, n, L.kp, colmax, bh, bl, invb);
+  uint32_t *colmax_a = reinterpret_cast<uint32_t *>(w + L.colmax_a);
+  float *psum = reinterpret_cast<float *>(w + L.psum);
+  const unsigned nslab = (unsigned)((k + kG16Slab - 1) / kG16Slab);
+  // column maxima are combined with atomicMax: re-armed by a kernel, not a memset node
+  hipLaunchKernelGGL(g16_zero_kernel, dim3((unsigned)((L.np + L.mp + 255) / 256)), dim3(256), 0, s,
+                     colmax, (int)(L.np + L.mp));   // colmax and colmax_a are adjacent
+  if (!a.t) {
+    hipLaunchKernelGGL(g16_prep_rows_kernel, dim3((unsigned)(L.mp / 4)), dim3(256), 0, s, a.p, a.mul, m, k,
+                       L.kp, ah, al, inva, colmax, 0);
+  } else {   // a.p is [K, M]: image row i = column i of the array
+    hipLaunchKernelGGL(g16_colmax_kernel, dim3((unsigned)(L.mp / 64), nslab), dim3(256), 0, s, a.p, a.mul,
+                       k, (int)m, colmax_a, (float *)nullptr);
+    hipLaunchKernelGGL(g16_prep_cols_kernel, dim3((unsigned)(L.mp / 64), (unsigned)(L.kp / 64)), dim3(256),
+                       0, s, a.p, a.mul, k, (int)m, L.kp, colmax_a, ah, al, inva);
+  }
+  if (!b.t) {
+    hipLaunchKernelGGL(g16_colmax_kernel, dim3((unsigned)(L.np / 64), nslab), dim3(256), 0, s, b.p, b.mul,
+                       k, n, colmax, colsum ? psum : (float *)nullptr);
+    hipLaunchKernelGGL(g16_prep_cols_kernel, dim3((unsigned)(L.np / 64), (unsigned)(L.kp / 64)), dim3(256),
+                       0, s, b.p, b.mul, k, n, L.kp, colmax, bh, bl, invb);
+    if (colsum)
+      hipLaunchKernelGGL(g16_colsum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, psum,
+                         (int)nslab, n, colsum);
+  } else {   // b.p is [N, K]: already one row per output column
+    hipLaunchKernelGGL(g16_prep_rows_kernel, dim3((unsigned)(L.np / 4)), dim3(256), 0, s, b.p, b.mul,
+                       (int64_t)n, k, L.kp, bh, bl, invb, colmax, 0);
+  }
   TFRS_LAUNCH_CHECK();
   Gemm16Args g = {};
   g.ah = ah; g.al = al; g.bh = bh; g.bl = bl; g.inva = inva; g.invb = invb;
   g.m = m; g.n = n; g.kp = L.kp;
-  g.bias = bias; g.x0 = x0; g.x = x; g.diag = diag; g.out = out;
+  g.bias = bias; g.x0 = e0; g.x = e1; g.diag = diag; g.out = out;
   // large shapes: 256 x 256 tiles with the 4-deep ring; otherwise (few tiles: fill the chip)
   // the 128 x 128 kernel.  TFRS_GEMM16_TILE = 128 | 256 forces one.
   const char *tv = getenv("TFRS_GEMM16_TILE");
   const int forced = (tv && *tv) ? atoi(tv) : 0;
   const int64_t big_tiles = (L.mp / kB16M) * (L.np / kB16N);
   const bool big = forced == 256 || (forced != 128 && big_tiles >= 512);
-  if (big) {
-    const dim3 grid((unsigned)(((m + kB16M - 1) / kB16M) * ((n + kB16N - 1) / kB16N)));
-    if (x0)
-      hipLaunchKernelGGL((gemm16_big_kernel<kG16EpiCross>), grid, dim3(512), 0, s, g);
-    else
-      hipLaunchKernelGGL((gemm16_big_kernel<kG16EpiBias>), grid, dim3(512), 0, s, g);
-  } else {
-    // tiles that hold at least one real row and column (the kernel derives its tile
-    // coordinates from ceil(n / 128), not from the 256-padded image sizes)
-    const dim3 grid((unsigned)(((m + kG16M - 1) / kG16M) * ((n + kG16N - 1) / kG16N)));
-    if (x0)
-      hipLaunchKernelGGL((gemm16_kernel<kG16EpiCross>), grid, dim3(256), 0, s, g);
-    else
-      hipLaunchKernelGGL((gemm16_kernel<kG16EpiBias>), grid, dim3(256), 0, s, g);
+  switch (epi) {
+    case kG16EpiCross: g16_launch<kG16EpiCross>(g, big, s); break;
+    case kG16EpiCrossDx0: g16_launch<kG16EpiCrossDx0>(g, big, s); break;
+    case kG16EpiCrossDx: g16_launch<kG16EpiCrossDx>(g, big, s); break;
+    default: g16_launch<kG16EpiBias>(g, big, s); break;
   }
   TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+// C = A @ B (+ bias) [cross epilogue when x0 != NULL]; ws from gemm16_workspace_bytes
+int gemm16_run(const float *a, const float *b, int64_t m, int n, int k, const float *bias,
+               const float *x0, const float *x, float diag, float *out, void *ws, hipStream_t s) {
+  return gemm16_run_ex({a, nullptr, false}, {b, nullptr, false}, m, n, k, bias,
+                       x0 ? kG16EpiCross : kG16EpiBias, x0, x, diag, out, nullptr, ws, s);
+}
+
+// Cross backward (layers/feature_interaction/dcn.py:151-186 under models/base.py:77), full rank,
+// linear preactivation.  With z = x W + b + diag x and dz = dy * x0:
+//   dx0 = dy * z                     product 1: x @ W,     epilogue CrossDx0 (z never stored)
+//   dx  = dz W^T + dy + diag * dz    product 2: dz @ W^T,  B = W read as [N, K] (no transpose copy),
+//                                    A image built from dy * x0 on the fly, epilogue CrossDx
+//   dW  = x^T dz                     product 3: both operands read K-major as they lie in HBM
+//   db  = column sums of dz          by-product of product 3's column-maximum pass
+// One workspace serves the three products in turn.
+size_t gemm16_cross_bwd_workspace_bytes(int64_t batch, int d) {
+  return std::max(g16_layout(batch, d, d).total, g16_layout(d, d, (int)batch).total);
+}
+
+int gemm16_cross_bwd(const float *x0, const float *x, const float *kernel, const float *bias,
+                     float diag, const float *dy, int64_t batch, int d, float *dx0, float *dx,
+                     float *dkernel, float *dbias, void *ws, hipStream_t s) {
+  int rc = gemm16_run_ex({x, nullptr, false}, {kernel, nullptr, false}, batch, d, d, bias,
+                         kG16EpiCrossDx0, dy, x, diag, dx0, nullptr, ws, s);
+  if (rc != TFRS_OK) return rc;
+  rc = gemm16_run_ex({dy, x0, false}, {kernel, nullptr, true}, batch, d, d, nullptr, kG16EpiCrossDx, dy,
+                     x0, diag, dx, nullptr, ws, s);
+  if (rc != TFRS_OK) return rc;
+  return gemm16_run_ex({x, nullptr, true}, {dy, x0, false}, d, d, (int)batch, nullptr, kG16EpiBias, nullptr,
+                       nullptr, 0.0f, dkernel, dbias, ws, s);
+}
+
+
+size_t gemm16_dense_bwd_workspace_bytes(int64_t batch, int din, int dout) {
+  return std::max(g16_layout(batch, din, dout).total, g16_layout(din, dout, (int)batch).total);
+}
+
+// dx = dy W^T (W read as [N = din, K = dout]), dW = x^T dy, db = column sums of dy
+int gemm16_dense_bwd(const float *x, const float *kernel, const float *dy, int64_t batch, int din,
+                     int dout, float *dx, float *dkernel, float *dbias, void *ws, hipStream_t s) {
+  int rc = TFRS_OK;
+  if (dx)
+    rc = gemm16_run_ex({dy, nullptr, false}, {kernel, nullptr, true}, batch, din, dout, nullptr, kG16EpiBias,
+                       nullptr, nullptr, 0.0f, dx, nullptr, ws, s);
+  if (rc != TFRS_OK) return rc;
+  if (dkernel)
+    return gemm16_run_ex({x, nullptr, true}, {dy, nullptr, false}, din, dout, (int)batch, nullptr,
+                         kG16EpiBias, nullptr, nullptr, 0.0f, dkernel, dbias, ws, s);
+  if (dbias) {   // bias gradient alone: the column pass of the B operand, no product
+    const G16Layout L = g16_layout(din, dout, (int)batch);
+    char *w = static_cast<char *>(ws);
+    uint32_t *colmax = reinterpret_cast<uint32_t *>(w + L.colmax);
+    float *psum = reinterpret_cast<float *>(w + L.psum);
+    const unsigned nslab = (unsigned)((batch + kG16Slab - 1) / kG16Slab);
+    hipLaunchKernelGGL(g16_zero_kernel, dim3((unsigned)((L.np + 255) / 256)), dim3(256), 0, s, colmax, (int)L.np);
+    hipLaunchKernelGGL(g16_colmax_kernel, dim3((unsigned)(L.np / 64), nslab), dim3(256), 0, s, dy,
+                       (const float *)nullptr, (int)batch, dout, colmax, psum);
+    hipLaunchKernelGGL(g16_colsum_kernel, dim3((unsigned)((dout + 255) / 256)), dim3(256), 0, s, psum,
+                       (int)nslab, dout, dbias);
+    TFRS_LAUNCH_CHECK();
+  }
   return TFRS_OK;
 }
 

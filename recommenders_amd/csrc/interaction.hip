@@ -31,21 +31,30 @@ constexpr int kBM = 128, kBN = 128, kBK = 16;
 constexpr int kLdA = kBK + 4;   // 20 floats = 5 x 16 B: odd number of 16-B slots per row
 constexpr int kLdB = kBN + 4;   // row of B tile
 
-enum { kEpiBias = 0, kEpiCross = 1 };
+// epilogues on v = accumulator + bias (e0 = x0 field, e1 = x field), same set as gemm16.hip:
+//   Bias     out = v
+//   Cross    out = e0 * (v + diag * e1) + e1          e0 = x0, e1 = x   (Cross.call)
+//   CrossDx0 out = e0 * (v + diag * e1)               e0 = dy, e1 = x   (dx0 = dy * z)
+//   CrossDx  out = v + e0 + diag * e0 * e1            e0 = dy, e1 = x0  (dx = dz W^T + dy + diag dz)
+enum { kEpiBias = 0, kEpiCross = 1, kEpiCrossDx0 = 2, kEpiCrossDx = 3 };
 
 struct GemmArgs {
   const float *a, *b;
   int64_t m;
   int n, k;
   const float *bias;  // [n] or NULL
-  // cross epilogue
+  // epilogue operands
   const float *x0;    // [m, n]
-  const float *x;     // [m, n] (== a, n == k)
+  const float *x;     // [m, n]
   float diag;
   float *out;         // [m, n]
+  // optional elementwise multipliers, same shape/layout as a / b (dz = dy * x0 is never stored)
+  const float *amul, *bmul;
 };
 
-template <int EPI>
+// AT: `a` holds A^T ([K, M] row-major); BT: `b` holds B^T ([N, K] row-major).  The tiles are
+// transposed on their way into LDS, so dW = x^T dz and dx = dz W^T read x, dz and W as they lie.
+template <int EPI, bool AT, bool BT>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float as[2][kBM * kLdA];
   __shared__ __attribute__((aligned(16))) float bs[2][kBK * kLdB];
@@ -61,8 +70,26 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
   const int64_t bm = (int64_t)(blockIdx.x / nbn) * kBM;
   const int bn = (int)(blockIdx.x % nbn) * kBN;
 
-  const bool a_vec = (g.k % 4 == 0) && (((uintptr_t)g.a) % 16 == 0);
-  const bool b_vec = (g.n % 4 == 0) && (((uintptr_t)g.b) % 16 == 0);
+  const bool a_vec = ((AT ? g.m : (int64_t)g.k) % 4 == 0) && (((uintptr_t)g.a) % 16 == 0) &&
+                     (!g.amul || ((uintptr_t)g.amul) % 16 == 0);
+  const bool b_vec = ((BT ? g.k : g.n) % 4 == 0) && (((uintptr_t)g.b) % 16 == 0) &&
+                     (!g.bmul || ((uintptr_t)g.bmul) % 16 == 0);
+  // 4 consecutive elements of a row-major [rows, ld] array (zero outside), optional multiplier
+  auto load4 = [&](const float *p, const float *mul, int64_t r, int64_t c, int64_t rows, int64_t ld,
+                   bool vec) -> f32x4 {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows) {
+      if (vec && c + 3 < ld) {
+        v = *reinterpret_cast<const f32x4 *>(p + r * ld + c);
+        if (mul) v = v * *reinterpret_cast<const f32x4 *>(mul + r * ld + c);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (c + t < ld) v[t] = mul ? p[r * ld + c + t] * mul[r * ld + c + t] : p[r * ld + c + t];
+      }
+    }
+    return v;
+  };
 
   // staging: A tile 128 x 16 = 512 float4 -> 2 per thread; B tile 16 x 128 = 512 float4 -> 2
   f32x4 sa[2], sb[2];
@@ -70,44 +97,34 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int e = tid + i * 256;      // 0..511
-      const int ar = e >> 2, ac = (e & 3) * 4;          // A: row 0..127, col 0,4,8,12
-      const int64_t gr = bm + ar;
-      const int gk = k0 + ac;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gr < g.m) {
-        if (a_vec && gk + 3 < g.k) {
-          v = *reinterpret_cast<const f32x4 *>(g.a + gr * g.k + gk);
-        } else {
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            if (gk + t < g.k) v[t] = g.a[gr * g.k + gk + t];
-        }
+      if (!AT) {   // A tile 128 (m) x 16 (k): row e >> 2, k (e & 3) * 4 .. + 3
+        sa[i] = load4(g.a, g.amul, bm + (e >> 2), k0 + (e & 3) * 4, g.m, g.k, a_vec);
+      } else {     // A^T: k row e >> 5, m (e & 31) * 4 .. + 3
+        sa[i] = load4(g.a, g.amul, k0 + (e >> 5), bm + (e & 31) * 4, g.k, g.m, a_vec);
       }
-      sa[i] = v;
-      const int br = e >> 5, bc = (e & 31) * 4;         // B: row 0..15, col 0..124
-      const int gkb = k0 + br;
-      const int gn = bn + bc;
-      f32x4 u = {0.f, 0.f, 0.f, 0.f};
-      if (gkb < g.k) {
-        if (b_vec && gn + 3 < g.n) {
-          u = *reinterpret_cast<const f32x4 *>(g.b + (int64_t)gkb * g.n + gn);
-        } else {
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            if (gn + t < g.n) u[t] = g.b[(int64_t)gkb * g.n + gn + t];
-        }
+      if (!BT) {   // B tile 16 (k) x 128 (n): k row e >> 5, n (e & 31) * 4 .. + 3
+        sb[i] = load4(g.b, g.bmul, k0 + (e >> 5), bn + (e & 31) * 4, g.k, g.n, b_vec);
+      } else {     // B^T: n row e >> 2, k (e & 3) * 4 .. + 3
+        sb[i] = load4(g.b, g.bmul, bn + (e >> 2), k0 + (e & 3) * 4, g.n, g.k, b_vec);
       }
-      sb[i] = u;
     }
   };
   auto store_tiles = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int e = tid + i * 256;
-      const int ar = e >> 2, ac = (e & 3) * 4;
-      *reinterpret_cast<f32x4 *>(&as[buf][ar * kLdA + ac]) = sa[i];
-      const int br = e >> 5, bc = (e & 31) * 4;
-      *reinterpret_cast<f32x4 *>(&bs[buf][br * kLdB + bc]) = sb[i];
+      if (!AT) {
+        *reinterpret_cast<f32x4 *>(&as[buf][(e >> 2) * kLdA + (e & 3) * 4]) = sa[i];
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) as[buf][((e & 31) * 4 + t) * kLdA + (e >> 5)] = sa[i][t];
+      }
+      if (!BT) {
+        *reinterpret_cast<f32x4 *>(&bs[buf][(e >> 5) * kLdB + (e & 31) * 4]) = sb[i];
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bs[buf][((e & 3) * 4 + t) * kLdB + (e >> 2)] = sb[i][t];
+      }
     }
   };
 
@@ -172,6 +189,11 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
         if (EPI == kEpiCross) {
           const float xv = g.x[o];
           v = g.x0[o] * (v + g.diag * xv) + xv;
+        } else if (EPI == kEpiCrossDx0) {
+          v = g.x0[o] * (v + g.diag * g.x[o]);
+        } else if (EPI == kEpiCrossDx) {
+          const float dyv = g.x0[o];
+          v = v + dyv + g.diag * dyv * g.x[o];
         }
         g.out[o] = v;
       }
@@ -590,14 +612,20 @@ static bool launch_dot_mfma(const float *x, int64_t batch, int f, int d, int sel
 
 using namespace tfrs;
 
-static int launch_gemm(const GemmArgs &g, int epi, hipStream_t s) {
+static int launch_gemm(const GemmArgs &g, int epi, hipStream_t s, bool at = false, bool bt = false) {
   const int64_t nbm = (g.m + kBM - 1) / kBM;
   const int nbn = (g.n + kBN - 1) / kBN;
   const dim3 grid((unsigned)(nbm * nbn));
-  if (epi == kEpiCross)
-    hipLaunchKernelGGL((gemm_kernel<kEpiCross>), grid, dim3(256), 0, s, g);
+  if (at)            // dW = x^T dz
+    hipLaunchKernelGGL((gemm_kernel<kEpiBias, true, false>), grid, dim3(256), 0, s, g);
+  else if (bt)       // dx = dz W^T + dy + diag dz
+    hipLaunchKernelGGL((gemm_kernel<kEpiCrossDx, false, true>), grid, dim3(256), 0, s, g);
+  else if (epi == kEpiCross)
+    hipLaunchKernelGGL((gemm_kernel<kEpiCross, false, false>), grid, dim3(256), 0, s, g);
+  else if (epi == kEpiCrossDx0)
+    hipLaunchKernelGGL((gemm_kernel<kEpiCrossDx0, false, false>), grid, dim3(256), 0, s, g);
   else
-    hipLaunchKernelGGL((gemm_kernel<kEpiBias>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_kernel<kEpiBias, false, false>), grid, dim3(256), 0, s, g);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
 }
@@ -639,7 +667,165 @@ namespace tfrs {
 size_t gemm16_workspace_bytes(int64_t m, int n, int k);
 int gemm16_run(const float *a, const float *b, int64_t m, int n, int k, const float *bias,
                const float *x0, const float *x, float diag, float *out, void *ws, hipStream_t s);
+size_t gemm16_cross_bwd_workspace_bytes(int64_t batch, int d);
+size_t gemm16_dense_bwd_workspace_bytes(int64_t batch, int din, int dout);
+int gemm16_dense_bwd(const float *x, const float *kernel, const float *dy, int64_t batch, int din,
+                     int dout, float *dx, float *dkernel, float *dbias, void *ws, hipStream_t s);
+int gemm16_cross_bwd(const float *x0, const float *x, const float *kernel, const float *bias,
+                     float diag, const float *dy, int64_t batch, int d, float *dx0, float *dx,
+                     float *dkernel, float *dbias, void *ws, hipStream_t s);
+
+// db[j] = sum_b dy[b, j] * x0[b, j]: partial sums over slabs of 256 rows (one workgroup per
+// 64 columns x slab, coalesced rows), then a fixed-order reduction: deterministic, no atomics.
+constexpr int kDbSlab = 256;
+__global__ void __launch_bounds__(256) colsum_mul_partial_kernel(const float *__restrict__ a,
+                                                                 const float *__restrict__ b,
+                                                                 int64_t rows, int n,
+                                                                 float *__restrict__ part) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
+  const int64_t r0 = (int64_t)blockIdx.y * kDbSlab;
+  const int64_t r1 = r0 + kDbSlab < rows ? r0 + kDbSlab : rows;
+  float s = 0.0f;
+  if (col < n)
+    for (int64_t r = r0 + rg; r < r1; r += 4) s += b ? a[r * n + col] * b[r * n + col] : a[r * n + col];
+  red[rg][c] = s;
+  __syncthreads();
+  if (threadIdx.x < 64 && col < n)
+    part[(int64_t)blockIdx.y * n + col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+__global__ void __launch_bounds__(256) colsum_reduce_kernel(const float *__restrict__ part, int nslab,
+                                                            int n, float *__restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.0f;
+  for (int i = 0; i < nslab; ++i) s += part[(int64_t)i * n + c];
+  out[c] = s;
+}
 }  // namespace tfrs
+
+// ---- Cross backward (layers/feature_interaction/dcn.py:151-186 under models/base.py:77) ------
+// full rank, linear preactivation; z = x W + b + diag x, dz = dy * x0:
+//   dx0 = dy * z ; dx = dz W^T + dy + diag dz ; dW = x^T dz ; db = column sums of dz
+// Three GEMM launches (z lives only in the first one's epilogue, dz only in operand loads) plus
+// the db reduction; nothing is transposed or staged in HBM.
+extern "C" size_t tfrs_cross_bwd_workspace_bytes(int64_t batch, int d, int f16) {
+  if (batch < 1 || d < 1) return 256;
+  if (f16) return gemm16_cross_bwd_workspace_bytes(batch, d);
+  return (size_t)((batch + kDbSlab - 1) / kDbSlab) * d * 4 + 256;
+}
+
+static int cross_bwd_check(const char *who, const float *x0, const float *x, const float *kernel,
+                           float diag, const float *dy, int64_t batch, int d, float *dx0, float *dx,
+                           float *dkernel, void *ws) {
+  TFRS_CHECK_ARG(batch >= 0 && d >= 1, "%s: bad shape", who);
+  TFRS_CHECK_ARG(diag >= 0.0f, "`diag_scale` should be non-negative. Got `diag_scale` = %g", (double)diag);
+  if (batch == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(x0 && x && kernel && dy && dx0 && dx && dkernel && ws, "%s: NULL pointer", who);
+  return TFRS_OK;
+}
+
+extern "C" int tfrs_cross_bwd(const float *x0, const float *x, const float *kernel,
+                              const float *bias, float diag_scale, const float *dy, int64_t batch,
+                              int d, float *dx0, float *dx, float *dkernel, float *dbias,
+                              void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = cross_bwd_check("cross_bwd", x0, x, kernel, diag_scale, dy, batch, d, dx0, dx, dkernel, workspace);
+  if (rc != TFRS_OK || batch == 0) return rc;
+  if (workspace_bytes < tfrs_cross_bwd_workspace_bytes(batch, d, 0)) {
+    set_error("cross_bwd: workspace too small");
+    return TFRS_ENOMEM;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  GemmArgs g = {};
+  // dx0 = dy * (x W + b + diag x)
+  g.a = x; g.b = kernel; g.m = batch; g.n = d; g.k = d; g.bias = bias;
+  g.x0 = dy; g.x = x; g.diag = diag_scale; g.out = dx0;
+  if ((rc = launch_gemm(g, kEpiCrossDx0, s)) != TFRS_OK) return rc;
+  // dx = (dy * x0) W^T + dy + diag dy x0
+  g = {};
+  g.a = dy; g.amul = x0; g.b = kernel; g.m = batch; g.n = d; g.k = d;
+  g.x0 = dy; g.x = x0; g.diag = diag_scale; g.out = dx;
+  if ((rc = launch_gemm(g, kEpiCrossDx, s, false, true)) != TFRS_OK) return rc;
+  // dW = x^T (dy * x0)
+  g = {};
+  g.a = x; g.b = dy; g.bmul = x0; g.m = d; g.n = d; g.k = (int)batch; g.out = dkernel;
+  if ((rc = launch_gemm(g, kEpiBias, s, true, false)) != TFRS_OK) return rc;
+  if (dbias) {
+    const int nslab = (int)((batch + kDbSlab - 1) / kDbSlab);
+    float *part = static_cast<float *>(workspace);
+    hipLaunchKernelGGL(colsum_mul_partial_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)nslab),
+                       dim3(256), 0, s, dy, x0, batch, d, part);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, s, part,
+                       nslab, d, dbias);
+    TFRS_LAUNCH_CHECK();
+  }
+  return TFRS_OK;
+}
+
+// ---- Dense backward (Keras Dense [in, out] kernels of layers/blocks.py:46-61 and the low-rank
+// Cross projections dcn.py:176-180): dx = dy W^T, dW = x^T dy, db = column sums of dy, with the
+// transposed operands read in place (NULL outputs are skipped) ---------------------------------
+extern "C" size_t tfrs_dense_bwd_workspace_bytes(int64_t batch, int din, int dout, int f16) {
+  if (batch < 1 || din < 1 || dout < 1) return 256;
+  if (f16) return gemm16_dense_bwd_workspace_bytes(batch, din, dout);
+  return (size_t)((batch + kDbSlab - 1) / kDbSlab) * dout * 4 + 256;
+}
+
+extern "C" int tfrs_dense_bwd(const float *x, const float *kernel, const float *dy, int64_t batch,
+                              int din, int dout, float *dx, float *dkernel, float *dbias,
+                              int f16, void *workspace, size_t workspace_bytes, void *stream) {
+  TFRS_CHECK_ARG(batch >= 0 && din >= 1 && dout >= 1, "dense_bwd: bad shape");
+  if (batch == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(x && kernel && dy && workspace, "dense_bwd: NULL pointer");
+  TFRS_CHECK_ARG(batch <= 0x7FFFFFFFll, "dense_bwd: batch too large");
+  if (workspace_bytes < tfrs_dense_bwd_workspace_bytes(batch, din, dout, f16)) {
+    set_error("dense_bwd: workspace too small");
+    return TFRS_ENOMEM;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (f16) return gemm16_dense_bwd(x, kernel, dy, batch, din, dout, dx, dkernel, dbias, workspace, s);
+  int rc;
+  GemmArgs g = {};
+  if (dx) {        // dx[b, i] = sum_j dy[b, j] W[i, j]
+    g.a = dy; g.b = kernel; g.m = batch; g.n = din; g.k = dout; g.out = dx;
+    hipLaunchKernelGGL((gemm_kernel<kEpiBias, false, true>),
+                       dim3((unsigned)(((batch + kBM - 1) / kBM) * ((din + kBN - 1) / kBN))), dim3(256), 0, s, g);
+    TFRS_LAUNCH_CHECK();
+  }
+  if (dkernel) {   // dW[i, j] = sum_b x[b, i] dy[b, j]
+    g = {};
+    g.a = x; g.b = dy; g.m = din; g.n = dout; g.k = (int)batch; g.out = dkernel;
+    if ((rc = launch_gemm(g, kEpiBias, s, true, false)) != TFRS_OK) return rc;
+  }
+  if (dbias) {
+    const int nslab = (int)((batch + kDbSlab - 1) / kDbSlab);
+    float *part = static_cast<float *>(workspace);
+    hipLaunchKernelGGL(colsum_mul_partial_kernel, dim3((unsigned)((dout + 63) / 64), (unsigned)nslab),
+                       dim3(256), 0, s, dy, (const float *)nullptr, batch, dout, part);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((dout + 255) / 256)), dim3(256), 0, s, part,
+                       nslab, dout, dbias);
+    TFRS_LAUNCH_CHECK();
+  }
+  return TFRS_OK;
+}
+
+extern "C" int tfrs_cross_bwd_f16(const float *x0, const float *x, const float *kernel,
+                                  const float *bias, float diag_scale, const float *dy,
+                                  int64_t batch, int d, float *dx0, float *dx, float *dkernel,
+                                  float *dbias, void *workspace, size_t workspace_bytes,
+                                  void *stream) {
+  int rc = cross_bwd_check("cross_bwd_f16", x0, x, kernel, diag_scale, dy, batch, d, dx0, dx, dkernel,
+                           workspace);
+  if (rc != TFRS_OK || batch == 0) return rc;
+  TFRS_CHECK_ARG(batch <= 0x7FFFFFFFll, "cross_bwd_f16: batch too large");
+  if (workspace_bytes < gemm16_cross_bwd_workspace_bytes(batch, d)) {
+    set_error("cross_bwd_f16: workspace too small");
+    return TFRS_ENOMEM;
+  }
+  return gemm16_cross_bwd(x0, x, kernel, bias, diag_scale, dy, batch, d, dx0, dx, dkernel, dbias,
+                          workspace, (hipStream_t)stream);
+}
 
 extern "C" size_t tfrs_gemm_f16_workspace_bytes(int64_t m, int n, int k) {
   if (m < 1 || n < 1 || k < 1) return 256;

@@ -109,8 +109,27 @@ def dense(x: torch.Tensor, kernel: torch.Tensor, bias: Optional[torch.Tensor] = 
   return out
 
 
+def dense_backward(x: torch.Tensor, kernel: torch.Tensor, dy: torch.Tensor, need_dx: bool = True,
+                   need_dk: bool = True, need_db: bool = False):
+  """Gradients of ``x @ kernel + bias`` through ``tfrs_dense_bwd``: ``dx = dy @ kernel^T``,
+  ``dkernel = x^T @ dy``, ``dbias = sum_rows dy`` -- the transposed operands are read in place
+  (no ``.t().contiguous()`` copies of activations)."""
+  x, kernel, dy = x.contiguous(), kernel.contiguous(), dy.contiguous()
+  m, k, n = x.shape[0], kernel.shape[0], kernel.shape[1]
+  dx = torch.empty_like(x) if need_dx else None
+  dk = torch.empty_like(kernel) if need_dk else None
+  db = torch.empty((n,), dtype=torch.float32, device=x.device) if need_db else None
+  lib = _lib.load()
+  f16 = 1 if _use_f16_gemm(m, n, k) else 0
+  ws = _gemm_workspace(lib.tfrs_dense_bwd_workspace_bytes(m, k, n, f16), x.device)
+  _lib.check(lib.tfrs_dense_bwd(_lib.ptr(x), _lib.ptr(kernel), _lib.ptr(dy), m, k, n, _lib.ptr(dx),
+                                _lib.ptr(dk), _lib.ptr(db), f16, _lib.ptr(ws), ws.numel(),
+                                _lib.current_stream()))
+  return dx, dk, db
+
+
 class _DenseFn(torch.autograd.Function):
-  """Dense with gradients, every GEMM on the HIP kernel."""
+  """Dense with gradients, every GEMM on the HIP kernels."""
 
   @staticmethod
   def forward(ctx, x, kernel, bias):
@@ -121,11 +140,8 @@ class _DenseFn(torch.autograd.Function):
   @staticmethod
   def backward(ctx, dy):
     x, kernel = ctx.saved_tensors
-    dy = dy.contiguous()
-    dx = dense(dy, kernel.t().contiguous())
-    dk = dense(x.t().contiguous(), dy)
-    db = dy.sum(dim=0) if ctx.has_bias else None
-    return dx, dk, db
+    return dense_backward(x, kernel, dy, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                          ctx.has_bias and ctx.needs_input_grad[2])
 
 
 class _CrossFn(torch.autograd.Function):
@@ -152,18 +168,21 @@ class _CrossFn(torch.autograd.Function):
 
   @staticmethod
   def backward(ctx, dy):
+    """One ``tfrs_cross_bwd[_f16]`` call: dx0 = dy * z (z recomputed in the first GEMM's
+    epilogue), dx = dz W^T + dy + diag dz, dW = x^T dz, db = sum_rows dz with dz = dy * x0
+    formed in the operand loads -- no transposes, no elementwise passes, no z / dz in HBM."""
     x0, x, kernel, bias = ctx.saved_tensors
     dy = dy.contiguous()
-    z = dense(x, kernel, bias)                     # recomputed, not stored
-    if ctx.diag:
-      z = z + ctx.diag * x
-    dz = dy * x0
-    dx0 = dy * z
-    dx = dense(dz, kernel.t().contiguous()) + dy
-    if ctx.diag:
-      dx = dx + ctx.diag * dz
-    dk = dense(x.t().contiguous(), dz)
-    db = dz.sum(dim=0) if bias is not None else None
+    b, d = x0.shape
+    dx0, dx, dk = torch.empty_like(x0), torch.empty_like(x), torch.empty_like(kernel)
+    db = torch.empty_like(bias) if bias is not None else None
+    lib = _lib.load()
+    f16 = 1 if _use_f16_gemm(b, d, d) else 0
+    ws = _gemm_workspace(lib.tfrs_cross_bwd_workspace_bytes(b, d, f16), x0.device)
+    fn = lib.tfrs_cross_bwd_f16 if f16 else lib.tfrs_cross_bwd
+    _lib.check(fn(_lib.ptr(x0), _lib.ptr(x), _lib.ptr(kernel), _lib.ptr(bias), ctx.diag,
+                  _lib.ptr(dy), b, d, _lib.ptr(dx0), _lib.ptr(dx), _lib.ptr(dk), _lib.ptr(db),
+                  _lib.ptr(ws), ws.numel(), _lib.current_stream()))
     return dx0, dx, dk, db, None
 
 
@@ -288,7 +307,5 @@ class _LowRankCrossFn(torch.autograd.Function):
     dz = dy * x0
     dx0 = dy * z
     dx = dy + (ctx.diag * dz if ctx.diag else 0.0)
-    dh = dense(dz, kernel_v.t().contiguous())
-    dv = dense(h.t().contiguous(), dz)
-    db = dz.sum(dim=0) if bias is not None else None
+    dh, dv, db = dense_backward(h, kernel_v, dz, True, True, bias is not None)
     return dx0, dx, dh, dv, db, None

@@ -258,15 +258,18 @@ class Retrieval(torch.nn.Module, base.Task):
     if sample_weight is not None:
       sample_weight = sample_weight.to(q.device)
 
+    # the fused kernels hold an embedding row in registers: dims above 128 (outside their
+    # envelope; the reference accepts any dim) take the explicit-logits path below
+    wide = q.dim() == 2 and q.shape[-1] > 128
     need_matrix = (q.dim() == 3 or self._loss is not None
-                   or self._num_hard_negatives is not None
+                   or self._num_hard_negatives is not None or wide
                    or (compute_batch_metrics and len(self._batch_metrics) > 0))
     scores = labels = None
     if need_matrix:
       scores, labels = self._logits_and_labels(
           q, c, candidate_sampling_probability, candidate_ids, score_mask)
 
-    if self._loss is None and q.dim() == 2 and self._num_hard_negatives is None:
+    if self._loss is None and q.dim() == 2 and self._num_hard_negatives is None and not wide:
       loss = in_batch_softmax_loss(                                     # fused :172-210
           q, c, sample_weight, self._temperature, candidate_sampling_probability,
           candidate_ids if self._remove_accidental_hits else None, score_mask)
