@@ -51,6 +51,17 @@ __device__ __forceinline__ void g16_scale_of(float maxabs, float *s, float *inv)
   }
 }
 
+// Image addressing.  An image holds `rows_p` rows of kp halves.  With kb == kp a row is contiguous
+// (offset row * kp + k).  Long-K products (dW = x^T dz: K = batch) use K-BLOCKED images, kb < kp:
+// block q = k / kb holds all rows' k in [q * kb, (q + 1) * kb) back to back, offset
+// (q * rows_p + row) * kb + k % kb -- the 256-row operand tile of one K block is then ONE
+// contiguous 256 * kb * 2-byte range instead of 256 pieces 2 * kp bytes apart (at K = 65536 every
+// 32-byte piece of a K step sat in a different page: the product ran at 60 % of the rate of the
+// K = 3456 ones).
+__device__ __forceinline__ int64_t g16_img_off(int64_t row, int k, int kp, int kb, int64_t rows_p) {
+  return kb == kp ? row * (int64_t)kp + k : ((int64_t)(k / kb) * rows_p + row) * kb + (k % kb);
+}
+
 // ---- prep: rows of A ------------------------------------------------------------------------
 // one wave per row; rows in [m, mp) and columns in [k, kp) are zero
 // `mul` (optional, same shape as x): the image is built from x * mul (dz = dy * x0 of the Cross
@@ -60,7 +71,8 @@ __global__ void __launch_bounds__(256) g16_prep_rows_kernel(const float *__restr
                                                             int k, int kp, _Float16 *__restrict__ hi,
                                                             _Float16 *__restrict__ lo,
                                                             float *__restrict__ inv,
-                                                            uint32_t *__restrict__ colmax, int np) {
+                                                            uint32_t *__restrict__ colmax, int np,
+                                                            int kb, int64_t rows_p) {
   // first kernel of the chain: re-arms the column maxima the next kernel combines with atomicMax
   // (no hipMemsetAsync: memset nodes are not reliably ordered under HIP-graph replay)
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < np; i += (int64_t)gridDim.x * 256)
@@ -89,8 +101,8 @@ __global__ void __launch_bounds__(256) g16_prep_rows_kernel(const float *__restr
   float s, iv;
   g16_scale_of(mx, &s, &iv);
   if (lane == 0) inv[row] = iv;
-  _Float16 *hr = hi + row * (int64_t)kp, *lr = lo + row * (int64_t)kp;
   for (int c = lane * 4; c < kp; c += 256) {
+    const int64_t io = g16_img_off(row, c, kp, kb, rows_p);   // 4 consecutive k stay in one block
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (valid) {
       if (vec && c + 3 < k) {
@@ -110,8 +122,8 @@ __global__ void __launch_bounds__(256) g16_prep_rows_kernel(const float *__restr
       h4[u] = (_Float16)sv;
       l4[u] = (_Float16)(sv - (float)h4[u]);
     }
-    *reinterpret_cast<g16h4 *>(hr + c) = h4;
-    *reinterpret_cast<g16h4 *>(lr + c) = l4;
+    *reinterpret_cast<g16h4 *>(hi + io) = h4;
+    *reinterpret_cast<g16h4 *>(lo + io) = l4;
   }
 }
 
@@ -163,6 +175,24 @@ __global__ void __launch_bounds__(256) g16_colsum_kernel(const float *__restrict
   out[c] = s;
 }
 
+// split-K: out[i] = sum over slices (fixed order: deterministic) of part[slice][i]
+__global__ void __launch_bounds__(256) g16_splitk_reduce_kernel(const float *__restrict__ part, int nsplit,
+                                                                int64_t count, float *__restrict__ out) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= count) return;
+  if (i + 3 < count) {
+    f32x4 acc = *reinterpret_cast<const f32x4 *>(part + i);
+    for (int s = 1; s < nsplit; ++s) acc = acc + *reinterpret_cast<const f32x4 *>(part + (int64_t)s * count + i);
+    *reinterpret_cast<f32x4 *>(out + i) = acc;
+  } else {
+    for (int64_t e = i; e < count; ++e) {
+      float acc = part[e];
+      for (int s = 1; s < nsplit; ++s) acc += part[(int64_t)s * count + e];
+      out[e] = acc;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) g16_zero_kernel(uint32_t *__restrict__ p, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) p[i] = 0u;
@@ -173,7 +203,8 @@ __global__ void __launch_bounds__(256) g16_prep_cols_kernel(const float *__restr
                                                             int kp, const uint32_t *__restrict__ colmax,
                                                             _Float16 *__restrict__ hi,
                                                             _Float16 *__restrict__ lo,
-                                                            float *__restrict__ inv) {
+                                                            float *__restrict__ inv, int kb,
+                                                            int64_t rows_p) {
   __shared__ float tile[64][65];
   __shared__ float s_scale[64];
   const int tid = threadIdx.x;
@@ -196,8 +227,9 @@ __global__ void __launch_bounds__(256) g16_prep_cols_kernel(const float *__restr
   __syncthreads();
   const int col = tid >> 2, seg = (tid & 3) * 16;   // 16 consecutive k of one output column
   const float s = s_scale[col];
-  _Float16 *hr = hi + (int64_t)(n0 + col) * kp + k0 + seg;
-  _Float16 *lr = lo + (int64_t)(n0 + col) * kp + k0 + seg;
+  const int64_t io = g16_img_off(n0 + col, k0 + seg, kp, kb, rows_p);   // kb is a multiple of 64
+  _Float16 *hr = hi + io;
+  _Float16 *lr = lo + io;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     g16h8 h8, l8;
@@ -244,6 +276,10 @@ struct Gemm16Args {
   const float *x0, *x;                 // epilogue operands e0, e1: [m, n] (see the enum below)
   float diag;
   float *out;                          // [m, n]
+  int kb;                              // K block of the images (== kp: plain rows), see g16_img_off
+  int64_t mp, np;                      // padded image rows (block stride of K-blocked images)
+  int kt_per;                          // big kernel, split-K: K steps per blockIdx.y slice (0 = all);
+                                       // slice y writes its partial product to out + y * m * n
 };
 
 __device__ __forceinline__ void g16_dma16(const char *gsrc_lane, const char *lds_wave_base) {
@@ -395,22 +431,32 @@ __global__ void __launch_bounds__(512) gemm16_big_kernel(const Gemm16Args g) {
   const int nbn = (g.n + kB16N - 1) / kB16N;
   const int64_t bm = (int64_t)(blockIdx.x / nbn) * kB16M;
   const int bn = (int)(blockIdx.x % nbn) * kB16N;
-  const int nk = g.kp / kB16K;
+  const int nk_all = g.kp / kB16K;
+  const int kbeg = g.kt_per ? (int)blockIdx.y * g.kt_per : 0;
+  const int nk = g.kt_per ? (nk_all - kbeg < g.kt_per ? nk_all - kbeg : g.kt_per) : nk_all;
+  float *const outp = g.out + (g.kt_per ? (int64_t)blockIdx.y * g.m * g.n : 0);
 
   // staging: one instruction = 32 rows x 2 slots; wave w copies rows [32w, 32w + 32) of each image
   const int sr = lane >> 1, ss = lane & 1;
   const int r = wave * 32 + sr;
   const int ks = ss ^ ((r >> 3) & 1);
   const char *src[4];
-  src[0] = reinterpret_cast<const char *>(g.ah + (bm + r) * g.kp) + ks * 16;
-  src[1] = reinterpret_cast<const char *>(g.al + (bm + r) * g.kp) + ks * 16;
-  src[2] = reinterpret_cast<const char *>(g.bh + (int64_t)(bn + r) * g.kp) + ks * 16;
-  src[3] = reinterpret_cast<const char *>(g.bl + (int64_t)(bn + r) * g.kp) + ks * 16;
+  // (K-blocked images: row pitch kb, block pitch rows_p * kb; plain images: kb == kp, one block)
+  src[0] = reinterpret_cast<const char *>(g.ah + (bm + r) * g.kb) + ks * 16;
+  src[1] = reinterpret_cast<const char *>(g.al + (bm + r) * g.kb) + ks * 16;
+  src[2] = reinterpret_cast<const char *>(g.bh + (int64_t)(bn + r) * g.kb) + ks * 16;
+  src[3] = reinterpret_cast<const char *>(g.bl + (int64_t)(bn + r) * g.kb) + ks * 16;
+  const int steps_per_blk = g.kb / kB16K;
+  const int64_t blk_a = g.mp * (int64_t)g.kb * 2, blk_b = g.np * (int64_t)g.kb * 2;   // bytes
   auto stage = [&](int kt) __attribute__((always_inline)) {
     char *buf = lds + (kt & (kB16Ring - 1)) * kB16Stage;
 #pragma unroll
     for (int im = 0; im < 4; ++im)
-      g16_dma16(src[im] + (int64_t)kt * (kB16K * 2), buf + im * kB16Img + wave * 32 * 32);
+    {
+      const int kq = (kbeg + kt) / steps_per_blk, kr = (kbeg + kt) - kq * steps_per_blk;   // uniform
+      g16_dma16(src[im] + kq * (im < 2 ? blk_a : blk_b) + (int64_t)kr * (kB16K * 2),
+                buf + im * kB16Img + wave * 32 * 32);
+    }
   };
 
   f32x16 acc[2][4];
@@ -503,7 +549,7 @@ __global__ void __launch_bounds__(512) gemm16_big_kernel(const Gemm16Args g) {
         if (row >= g.m) continue;
         const float v = acc[i][jn][q] * (g.inva[row] * cs) + bias;
         const int64_t o = row * g.n + col;
-        g.out[o] = g16_epilogue<EPI>(v, g.x0, g.x, g.diag, o);
+        outp[o] = g16_epilogue<EPI>(v, g.x0, g.x, g.diag, o);
       }
     }
 }
@@ -515,8 +561,29 @@ static inline int64_t g16_pad(int64_t x, int64_t q) { return (x + q - 1) / q * q
 struct G16Layout {
   int64_t mp, np;
   int kp;
-  size_t ah, al, bh, bl, inva, invb, colmax, colmax_a, psum, total;
+  size_t ah, al, bh, bl, inva, invb, colmax, colmax_a, psum, part, total;
+  int nsplit;
 };
+
+// Split-K for long-K products whose 256 x 256 output tiles do not fill the chip (dW = x^T dz:
+// 14 x 14 tiles at d = 3456, K = batch = 65536): the K range is cut into slices so that
+// tiles x slices covers the 256 CUs a whole number of times (within 10 %), every slice writes its
+// partial product, a second kernel sums the slices in fixed order.
+static int g16_splits(int64_t m, int n, int k) {
+  const int64_t tiles = ((m + kB16M - 1) / kB16M) * ((n + kB16N - 1) / kB16N);
+  if (tiles >= 512 || tiles < 8 || k < 8192) return 1;
+  const char *ev = getenv("TFRS_GEMM16_SPLITK");
+  if (ev && *ev) return std::max(1, atoi(ev));
+  int best = 1;
+  double best_eff = 0.0;
+  for (int s = 2; s <= 16; ++s) {
+    if (k / s < 2048) break;
+    const double waves = (double)(tiles * s) / 256.0;
+    const double eff = waves / (double)(int64_t)(waves + 0.999999);
+    if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
+  }
+  return best;
+}
 
 static G16Layout g16_layout(int64_t m, int n, int k) {
   G16Layout L;
@@ -532,6 +599,8 @@ static G16Layout g16_layout(int64_t m, int n, int k) {
   L.colmax = o; o += g16_al((size_t)L.np * 4);
   L.colmax_a = o; o += g16_al((size_t)L.mp * 4);
   L.psum = o; o += g16_al((size_t)((k + kG16Slab - 1) / kG16Slab) * L.np * 4);
+  L.nsplit = g16_splits(m, n, k);
+  L.part = o; o += L.nsplit > 1 ? g16_al((size_t)L.nsplit * m * n * 4) : 0;
   L.total = o;
   return L;
 }
@@ -575,41 +644,58 @@ int gemm16_run_ex(const G16Operand &a, const G16Operand &b, int64_t m, int n, in
   uint32_t *colmax_a = reinterpret_cast<uint32_t *>(w + L.colmax_a);
   float *psum = reinterpret_cast<float *>(w + L.psum);
   const unsigned nslab = (unsigned)((k + kG16Slab - 1) / kG16Slab);
+  // kernel choice first: it decides the image layout
+  const char *tv = getenv("TFRS_GEMM16_TILE");
+  const int forced = (tv && *tv) ? atoi(tv) : 0;
+  const int64_t big_tiles = (L.mp / kB16M) * (L.np / kB16N);
+  const bool splitk = L.nsplit > 1 && epi == kG16EpiBias && !bias && forced != 128;
+  const bool big = forced == 256 || (forced != 128 && big_tiles >= 512) || splitk;
+  const int kb = (big && L.kp > 8192 && L.kp % 1024 == 0) ? 1024 : L.kp;   // K-blocked images for long K
   // column maxima are combined with atomicMax: re-armed by a kernel, not a memset node
   hipLaunchKernelGGL(g16_zero_kernel, dim3((unsigned)((L.np + L.mp + 255) / 256)), dim3(256), 0, s,
                      colmax, (int)(L.np + L.mp));   // colmax and colmax_a are adjacent
   if (!a.t) {
     hipLaunchKernelGGL(g16_prep_rows_kernel, dim3((unsigned)(L.mp / 4)), dim3(256), 0, s, a.p, a.mul, m, k,
-                       L.kp, ah, al, inva, colmax, 0);
+                       L.kp, ah, al, inva, colmax, 0, kb, L.mp);
   } else {   // a.p is [K, M]: image row i = column i of the array
     hipLaunchKernelGGL(g16_colmax_kernel, dim3((unsigned)(L.mp / 64), nslab), dim3(256), 0, s, a.p, a.mul,
                        k, (int)m, colmax_a, (float *)nullptr);
     hipLaunchKernelGGL(g16_prep_cols_kernel, dim3((unsigned)(L.mp / 64), (unsigned)(L.kp / 64)), dim3(256),
-                       0, s, a.p, a.mul, k, (int)m, L.kp, colmax_a, ah, al, inva);
+                       0, s, a.p, a.mul, k, (int)m, L.kp, colmax_a, ah, al, inva, kb, L.mp);
   }
   if (!b.t) {
     hipLaunchKernelGGL(g16_colmax_kernel, dim3((unsigned)(L.np / 64), nslab), dim3(256), 0, s, b.p, b.mul,
                        k, n, colmax, colsum ? psum : (float *)nullptr);
     hipLaunchKernelGGL(g16_prep_cols_kernel, dim3((unsigned)(L.np / 64), (unsigned)(L.kp / 64)), dim3(256),
-                       0, s, b.p, b.mul, k, n, L.kp, colmax, bh, bl, invb);
+                       0, s, b.p, b.mul, k, n, L.kp, colmax, bh, bl, invb, kb, L.np);
     if (colsum)
       hipLaunchKernelGGL(g16_colsum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, psum,
                          (int)nslab, n, colsum);
   } else {   // b.p is [N, K]: already one row per output column
     hipLaunchKernelGGL(g16_prep_rows_kernel, dim3((unsigned)(L.np / 4)), dim3(256), 0, s, b.p, b.mul,
-                       (int64_t)n, k, L.kp, bh, bl, invb, colmax, 0);
+                       (int64_t)n, k, L.kp, bh, bl, invb, colmax, 0, kb, L.np);
   }
   TFRS_LAUNCH_CHECK();
   Gemm16Args g = {};
   g.ah = ah; g.al = al; g.bh = bh; g.bl = bl; g.inva = inva; g.invb = invb;
   g.m = m; g.n = n; g.kp = L.kp;
   g.bias = bias; g.x0 = e0; g.x = e1; g.diag = diag; g.out = out;
+  g.kb = kb; g.mp = L.mp; g.np = L.np;
   // large shapes: 256 x 256 tiles with the 4-deep ring; otherwise (few tiles: fill the chip)
   // the 128 x 128 kernel.  TFRS_GEMM16_TILE = 128 | 256 forces one.
-  const char *tv = getenv("TFRS_GEMM16_TILE");
-  const int forced = (tv && *tv) ? atoi(tv) : 0;
-  const int64_t big_tiles = (L.mp / kB16M) * (L.np / kB16N);
-  const bool big = forced == 256 || (forced != 128 && big_tiles >= 512);
+  if (splitk) {
+    const int nk_all = L.kp / kB16K;
+    g.kt_per = (nk_all + L.nsplit - 1) / L.nsplit;
+    const int slices = (nk_all + g.kt_per - 1) / g.kt_per;
+    g.out = reinterpret_cast<float *>(w + L.part);
+    const dim3 grid((unsigned)(((m + kB16M - 1) / kB16M) * ((n + kB16N - 1) / kB16N)), (unsigned)slices);
+    hipLaunchKernelGGL((gemm16_big_kernel<kG16EpiBias>), grid, dim3(512), 0, s, g);
+    const int64_t count = m * (int64_t)n;
+    hipLaunchKernelGGL(g16_splitk_reduce_kernel, dim3((unsigned)((count / 4 + 256) / 256)), dim3(256), 0, s,
+                       g.out, slices, count, out);
+    TFRS_LAUNCH_CHECK();
+    return TFRS_OK;
+  }
   switch (epi) {
     case kG16EpiCross: g16_launch<kG16EpiCross>(g, big, s); break;
     case kG16EpiCrossDx0: g16_launch<kG16EpiCrossDx0>(g, big, s); break;

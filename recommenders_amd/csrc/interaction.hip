@@ -15,6 +15,8 @@
 //   spread over lanes; the output is written exactly once, coalesced (HBM-bound target:
 //   B*F*D*4 read + B*out_dim*4 written, vs 4-5x that for the reference's
 //   ones_like/band_part/boolean_mask temporaries).
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "mfma_tile.h"
@@ -407,9 +409,11 @@ __global__ void __launch_bounds__(STAGE ? 64 : 256, 2) dot_interaction_mfma_kern
       __builtin_amdgcn_wave_barrier();
       // linear copy-out: sample bases are 8-byte aligned when out_dim is even, else dwords
       if ((out_dim & 1) == 0 && ((reinterpret_cast<uintptr_t>(out) & 7) == 0)) {
+#pragma unroll 8
         for (int e = 2 * lane; e < out_dim; e += 128)
           *reinterpret_cast<float2 *>(ob + e) = *reinterpret_cast<const float2 *>(stage + e);
       } else {
+#pragma unroll 8
         for (int e = lane; e < out_dim; e += 64) ob[e] = stage[e];
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -423,7 +427,10 @@ static bool launch_dot_mfma_nb(const float *x, int64_t batch, int f, int d, int 
                                float *out, hipStream_t s) {
   const int out_dim = skip ? f * f : (self ? f * (f + 1) / 2 : f * (f - 1) / 2);
   const size_t lds = (size_t)(((out_dim + 3) & ~3) + 64) * sizeof(float);  // per wave
-  const bool stage = !skip && lds <= 64 * 1024;
+  // TFRS_DOT_STAGE=0: direct 128-byte-run stores from the accumulators instead of the LDS-staged
+  // linear copy-out (measurement switch)
+  const char *sv = getenv("TFRS_DOT_STAGE");
+  const bool stage = !skip && lds <= 64 * 1024 && !(sv && sv[0] == '0');
   if (stage) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -549,6 +556,179 @@ __global__ void __launch_bounds__(64, 2) dot_interaction_bwd_mfma_kernel(
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();  // LDS is refilled by the next sample
   }
+}
+
+// Backward, third generation (default for packed-triangle outputs): dX = S X with the symmetric
+// S = L + L^T unpacked ONCE per sample into a dense LDS tile.
+//   workgroup = 4 waves = one sample at a time (grid-stride); 2-3 workgroups per CU run out of
+//               phase, so one's unpack / stores overlap another's MFMAs.
+//   unpack    : the packed gradient is read linearly from HBM (coalesced dwords), every element
+//               dy[p] = L[i][j] is written to S[i][j] and S[j][i] (diagonal doubled for
+//               self_interaction).  S rows are KH2 + 4 floats (an ODD number of 16-byte slots),
+//               the diagonal (no self) and the k >= f pad columns stay zero from kernel start.
+//   products  : wave w owns row block w (32 rows of dX).  The k order is the "half split":
+//               lane half h covers k in [h * KH, (h + 1) * KH), so a lane's A operand is KH
+//               CONTIGUOUS floats of its S row -- KH / 4 conflict-free ds_read_b128, every byte
+//               used (the second-generation kernel gathered 4-byte elements through triangular
+//               index arithmetic: 256 scattered LDS reads per row block).  The B operand
+//               X[k][feature] comes straight from global (128-byte runs per half wave; the four
+//               waves' re-reads hit L2).  KH steps of v_mfma_f32_32x32x2_f32 per 32 features.
+//   stores    : dX rows leave as 128-byte runs.
+// Bytes: B * (F*D*2 + out_dim) * 4 algorithmic; MFMA floor at F = 101, D = 32: 52 steps x 4
+// blocks x 64 cycles per sample = 0.71 ms for 131072 samples -- next to the 0.76 ms HBM floor.
+template <int NFB, int MAXE>
+__global__ void __launch_bounds__(256, 2) dot_interaction_bwd_dense_kernel(
+    const float *__restrict__ x, const float *__restrict__ dout, int64_t batch, int f, int d,
+    int self, int kh, float *__restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) float s_lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int ld = 2 * kh + 4;                 // floats per S row: (2 kh + 4) / 4 is odd
+  const int out_dim = self ? f * (f + 1) / 2 : f * (f - 1) / 2;
+  for (int e = tid; e < f * ld; e += 256) s_lds[e] = 0.0f;   // diagonal + pad columns stay zero
+  // Thread t owns the packed elements p = t + 256 e of EVERY sample: their two S positions are
+  // computed once (low half: i * ld + jx, high half: jx * ld + i; equal on the diagonal).
+  // Elements past out_dim go to a per-thread dummy slot behind the tile (branch-free unpack).
+  uint32_t pos[MAXE];
+  uint64_t diag_bits = 0;                    // bit e: element e lies on the diagonal (value doubled)
+  const uint32_t dummy = (uint32_t)(f * ld + tid);
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    const int p = tid + 256 * e;
+    int i = 0, jx = 0;
+    if (p < out_dim) pair_of_index(p, self != 0, &i, &jx);
+    pos[e] = (p < out_dim) ? ((uint32_t)(i * ld + jx) | ((uint32_t)(jx * ld + i) << 16)) : (dummy | (dummy << 16));
+    if (p < out_dim && i == jx) diag_bits |= 1ull << e;
+  }
+  __syncthreads();
+  const int row = wave * 32 + j;             // this lane's S row (A operand) in the product phase
+  const bool row_ok = row < f;
+  const bool active = wave * 32 < f;         // wave-uniform
+  const int nquad = kh >> 2;
+  const int ngrp = (nquad + 3) >> 2;
+
+  // the packed gradient of a sample, MAXE coalesced dwords per thread, held in registers: the
+  // NEXT sample's loads are in flight during the products of the current one
+  float gy[MAXE];
+  auto load_dy = [&](int64_t b) __attribute__((always_inline)) {
+    const float *dy = dout + b * (int64_t)out_dim;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const int p = tid + 256 * e;
+      gy[e] = (p < out_dim) ? dy[p] : 0.0f;
+    }
+  };
+  int64_t b = blockIdx.x;
+  if (b < batch) load_dy(b);
+  for (; b < batch; b += gridDim.x) {
+    const float *xb = x + b * (int64_t)f * d;
+    // B operand X[k][feature] straight from global in groups of 16 k-steps, double-buffered in
+    // registers: group g + 1 is in flight under the 16 MFMAs (1024 pipe cycles) of group g; the
+    // first group is issued before the unpack.
+    auto load_b = [&](float (&bv)[16], int fb, int grp) __attribute__((always_inline)) {
+      const int ft = fb * 32 + j;
+      const float *col = xb + ft;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int k = h * kh + grp * 16 + u;
+        bv[u] = (k < f && ft < d) ? col[(int64_t)k * d] : 0.0f;   // (k >= f also covers the pad steps)
+      }
+    };
+    float b0[16], b1[16];
+    if (active) load_b(b0, 0, 0);
+    // ---- unpack (S was released by the barrier that ended the previous sample) ----------------
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const float v = ((diag_bits >> e) & 1ull) ? 2.0f * gy[e] : gy[e];
+      s_lds[pos[e] & 0xFFFFu] = v;
+      s_lds[pos[e] >> 16] = v;
+    }
+    __syncthreads();
+    if (b + gridDim.x < batch) load_dy(b + gridDim.x);
+    // ---- products: dX[row block `wave`] = S[rows, :] X ----------------------------------------
+    if (active) {
+      const float *srow = s_lds + (row_ok ? row : 0) * ld + h * kh;
+      auto mfma16 = [&](f32x16 &acc, const float (&bv)[16], int grp) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (grp * 4 + q < nquad) {         // uniform
+            f32x4 a4 = *reinterpret_cast<const f32x4 *>(srow + grp * 16 + 4 * q);
+            if (!row_ok) a4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u], bv[4 * q + u], acc, 0, 0, 0);
+          }
+        }
+      };
+#pragma unroll 1
+      for (int fb = 0; fb < NFB; ++fb) {
+        if (fb * 32 >= d) break;
+        if (fb > 0) load_b(b0, fb, 0);
+        const int ft = fb * 32 + j;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll 1
+        for (int grp = 0; grp < ngrp; grp += 2) {
+          if (grp + 1 < ngrp) load_b(b1, fb, grp + 1);
+          mfma16(acc, b0, grp);
+          if (grp + 1 < ngrp) {
+            if (grp + 2 < ngrp) load_b(b0, fb, grp + 2);
+            mfma16(acc, b1, grp + 1);
+          }
+        }
+        float *db = dx + b * (int64_t)f * d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int orow = wave * 32 + tile_row_of_reg(r, h);
+          if (orow < f && ft < d) db[orow * d + ft] = acc[r];
+        }
+      }
+    }
+    __syncthreads();   // S is rewritten by the next sample
+  }
+}
+
+template <int NFB, int MAXE>
+static void launch_dot_bwd_dense_v(const float *x, const float *dout, int64_t batch, int f, int d,
+                                   int self, int kh, size_t lds, dim3 grid, float *dx, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dot_interaction_bwd_dense_kernel<NFB, MAXE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((dot_interaction_bwd_dense_kernel<NFB, MAXE>), grid, dim3(256), lds, s, x, dout, batch,
+                     f, d, self, kh, dx);
+}
+
+template <int NFB>
+static void launch_dot_bwd_dense_e(int maxe, const float *x, const float *dout, int64_t batch, int f,
+                                   int d, int self, int kh, size_t lds, dim3 grid, float *dx,
+                                   hipStream_t s) {
+  if (maxe <= 12) launch_dot_bwd_dense_v<NFB, 12>(x, dout, batch, f, d, self, kh, lds, grid, dx, s);
+  else if (maxe <= 20) launch_dot_bwd_dense_v<NFB, 20>(x, dout, batch, f, d, self, kh, lds, grid, dx, s);
+  else launch_dot_bwd_dense_v<NFB, 33>(x, dout, batch, f, d, self, kh, lds, grid, dx, s);
+}
+
+static bool launch_dot_bwd_dense(const float *x, const float *dout, int64_t batch, int f, int d,
+                                 int self, float *dx, hipStream_t s) {
+  if (f > 128 || d > 128) return false;
+  int kh = (f + 7) / 8 * 4;                  // multiple of 4, 2 * kh >= f
+  if (((2 * kh + 4) / 4) % 2 == 0) kh += 4;  // odd number of 16-byte slots per row
+  const size_t lds = ((size_t)f * (2 * kh + 4) + 256) * sizeof(float);   // tile + 256 dummy slots
+  if (lds > 64 * 1024 || (size_t)f * (2 * kh + 4) + 256 > 0xFFFFu) return false;
+  const int out_dim = self ? f * (f + 1) / 2 : f * (f - 1) / 2;
+  const int maxe = (out_dim + 255) / 256;
+  const int64_t per_cu = std::min<int64_t>(2, std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)lds));
+  const dim3 grid((unsigned)std::min<int64_t>(batch, 256 * per_cu));
+  const int nfb = (d + 31) / 32;
+  if (nfb == 1) launch_dot_bwd_dense_e<1>(maxe, x, dout, batch, f, d, self, kh, lds, grid, dx, s);
+  else if (nfb == 2) launch_dot_bwd_dense_e<2>(maxe, x, dout, batch, f, d, self, kh, lds, grid, dx, s);
+  else launch_dot_bwd_dense_e<4>(maxe, x, dout, batch, f, d, self, kh, lds, grid, dx, s);
+  return true;
 }
 
 template <int DP, int NB>
@@ -889,6 +1069,14 @@ extern "C" int tfrs_dot_interaction_bwd(const float *x, const float *dout, int64
   TFRS_CHECK_ARG(batch >= 0 && f >= 1 && d >= 1, "dot_interaction_bwd: bad shape");
   if (batch == 0) return TFRS_OK;
   TFRS_CHECK_ARG(x && dout && dx, "dot_interaction_bwd: NULL pointer");
+  // TFRS_DOT_BWD=gather selects the second-generation kernel (A operand gathered per element)
+  const char *dv = getenv("TFRS_DOT_BWD");
+  const bool dense_ok = !(dv && dv[0] == 'g');
+  if (!skip_gather && dense_ok &&
+      launch_dot_bwd_dense(x, dout, batch, f, d, self_interaction, dx, (hipStream_t)stream)) {
+    TFRS_LAUNCH_CHECK();
+    return TFRS_OK;
+  }
   if (!skip_gather &&
       launch_dot_bwd_mfma(x, dout, batch, f, d, self_interaction, dx, (hipStream_t)stream)) {
     TFRS_LAUNCH_CHECK();

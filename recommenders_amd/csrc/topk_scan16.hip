@@ -474,8 +474,12 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16f_kernel(c
     // thr = ((lower - qk * norm) - tiny) / (qscale * stage scale); divisions by powers of two
     // commute with the roundings, so this is the first-generation threshold up to the order of
     // the two subtractions (tiny is far below one ulp of lower unless lower is ~0)
+    // .w: entry index of this (query, lane half, split) segment in the survivor buffer (the
+    // launcher guarantees that the whole buffer is indexable with 32 bits)
+    const uint32_t seg_base = (uint32_t)((qrow * (int64_t)a.cap_l) * a.nseg + (2 * split + h));
     qconst[g * 64 + lane] = make_float4(qvalid ? (a.lower[qrow] - kF16Tiny) * qinv : __builtin_inff(),
-                                        qvalid ? a.qk[qrow] * qinv : 0.0f, qsc, 0.0f);
+                                        qvalid ? a.qk[qrow] * qinv : 0.0f, qsc,
+                                        __uint_as_float(seg_base));
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -498,12 +502,12 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16f_kernel(c
         const uint32_t row = hd.z + rofs;
         if (v > __uint_as_float(hd.x) && row < row_limit) {
           const uint32_t src = hd.w;   // g * 64 + source lane
+          // one LDS round trip: the slot (atomic) and the segment's constants together
           const uint32_t slot = lds_atomic_inc(&wcnt[src]);
+          const float2 zc = *reinterpret_cast<const float2 *>(&qconst[src].z);
           if (slot < a.cap_l) {
-            const int64_t qrow = q0 + (src >> 6) * 32 + (src & 31);
-            const int seg = 2 * split + (int)((src >> 5) & 1);
-            const float un = qconst[src].z * __uint_as_float(hd.y);   // qscale * stage scale
-            a.buf[(qrow * (int64_t)a.cap_l + slot) * a.nseg + seg] =
+            const float un = zc.x * __uint_as_float(hd.y);   // qscale * stage scale
+            a.buf[(uint64_t)(__float_as_uint(zc.y) + slot * (uint32_t)a.nseg)] =
                 make_uint2(__float_as_uint(v * un), row);
           }
         }
@@ -685,7 +689,9 @@ int launch_scan16(const Scan16Args &a_in, hipStream_t stream) {
   TFRS_CHECK_ARG(a.dense || a.binmax || a.nseg == 2 * a.n_splits, "scan16: nseg must be 2 * n_splits");
   TFRS_CHECK_ARG(!a.binmax || (a.bin_stages >= 1 && a.stages_per_split % a.bin_stages == 0),
                  "scan16: stages_per_split must be a multiple of bin_stages");
-  if (!a.dense && !a.binmax && scan16_generation() == 2) {
+  // (the second-generation kernel indexes the survivor buffer with 32 bits)
+  const bool fits32 = (uint64_t)a.nq * a.cap_l * (uint64_t)a.nseg < (1ull << 32);
+  if (!a.dense && !a.binmax && fits32 && scan16_generation() == 2) {
     switch (padded_dim16(a.d)) {
       case 16: return launch_scan16f<16>(a, stream);
       case 32: return launch_scan16f<32>(a, stream);

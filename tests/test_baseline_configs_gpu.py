@@ -126,3 +126,132 @@ def test_identical_queries_fill_the_survivor_queue():
   assert layer.last_redo_count() == 0
   np.testing.assert_array_equal(_np(i), np.repeat(ei, nq, axis=0))
   np.testing.assert_array_equal(_np(s), np.repeat(es, nq, axis=0))
+
+
+# ------------------------------------------------------------------------------------------------
+# Cross at BASELINE configs[3] (B = 65536, d = 3456): the 256 x 256-tile split-fp16 GEMM at its real
+# grid, forward + the fused backward, against float64 (oracle formulas of
+# oracle/feature_interaction.py: dcn.py:151-186) on sampled rows and the full dW.
+# ------------------------------------------------------------------------------------------------
+def test_cross_config4_forward_backward_vs_float64():
+  import recommenders_amd as tfrs
+  g = torch.Generator(device="cuda").manual_seed(77)
+  b, d, diag = 65536, 3456, 0.25
+  x0 = torch.randn((b, d), generator=g, device="cuda") * 0.5
+  x = torch.randn((b, d), generator=g, device="cuda") * 0.5
+  layer = tfrs.layers.feature_interaction.Cross(diag_scale=diag)
+  layer.build((b, d), torch.device("cuda"))
+  with torch.no_grad():
+    layer.bias.uniform_(-0.1, 0.1, generator=g)
+  x0g, xg = x0.clone().requires_grad_(True), x.clone().requires_grad_(True)
+  y = layer(x0g, xg)
+  dy = torch.randn((b, d), generator=g, device="cuda")
+  y.backward(dy)
+  rows = torch.tensor(np.r_[0:24, 30000:30016, b - 24:b], device="cuda")
+  w64, b64 = layer.kernel.detach().double(), layer.bias.detach().double()
+  # sampled rows: y, dx0, dx
+  xr, x0r, dyr = x[rows].double(), x0[rows].double(), dy[rows].double()
+  z = xr @ w64 + b64 + diag * xr
+  def close(got, want, what, rtol=2e-5):
+    err = (got.double() - want).abs().max().item()
+    scale = want.abs().max().item()
+    assert err <= rtol * scale, (what, err, scale)
+  close(y[rows], x0r * z + xr, "y")
+  dz = dyr * x0r
+  close(x0g.grad[rows], dyr * z, "dx0", 1e-4)
+  close(xg.grad[rows], dz @ w64.t() + dyr + diag * dz, "dx", 1e-4)
+  # full dW and db in float64 on the GPU, in row chunks (x^T dz)
+  dw = torch.zeros((d, d), dtype=torch.float64, device="cuda")
+  dbias = torch.zeros((d,), dtype=torch.float64, device="cuda")
+  for lo in range(0, b, 8192):
+    dzc = (dy[lo:lo + 8192] * x0[lo:lo + 8192]).double()
+    dw += x[lo:lo + 8192].double().t() @ dzc
+    dbias += dzc.sum(dim=0)
+  close(layer.kernel.grad, dw, "dW", 1e-4)
+  close(layer.bias.grad, dbias, "db", 1e-4)
+
+
+@pytest.mark.parametrize("gemm_mode", ["f32", "f16"])
+def test_cross_lowrank_and_multilayer_gradients(gemm_mode, monkeypatch):
+  """Low-rank Cross (dcn.py:176-180) and MultiLayerDCN (multi_layer_dcn.py:136-153): every
+  parameter and input gradient against float64 autograd of the reference formula."""
+  import recommenders_amd as tfrs
+  monkeypatch.setenv("TFRS_GEMM_MODE", gemm_mode)
+  g = torch.Generator(device="cuda").manual_seed(5)
+  b, d, p = 700, 160, 24
+  x0 = torch.randn((b, d), generator=g, device="cuda")
+  x = torch.randn((b, d), generator=g, device="cuda")
+  layer = tfrs.layers.feature_interaction.Cross(projection_dim=p, diag_scale=0.1)
+  layer.build((b, d), torch.device("cuda"))
+  with torch.no_grad():
+    layer.bias.uniform_(-0.1, 0.1, generator=g)
+  x0g, xg = x0.clone().requires_grad_(True), x.clone().requires_grad_(True)
+  dy = torch.randn((b, d), generator=g, device="cuda")
+  layer(x0g, xg).backward(dy)
+  u, v, bb = (t.detach().double().requires_grad_(True) for t in (layer.kernel_u, layer.kernel_v, layer.bias))
+  x0d, xd = x0.double().requires_grad_(True), x.double().requires_grad_(True)
+  ref = x0d * (xd @ u @ v + bb + 0.1 * xd) + xd
+  ref.backward(dy.double())
+  for got, want, what in ((x0g.grad, x0d.grad, "dx0"), (xg.grad, xd.grad, "dx"), (layer.kernel_u.grad, u.grad, "dU"),
+                          (layer.kernel_v.grad, v.grad, "dV"), (layer.bias.grad, bb.grad, "db")):
+    assert got is not None, what
+    err = (got.double() - want).abs().max().item()
+    assert err <= 1e-4 * want.abs().max().item(), (what, err)
+  # MultiLayerDCN: 3 stacked low-rank layers, gradients of every parameter
+  mdcn = tfrs.layers.feature_interaction.MultiLayerDCN(projection_dim=8, num_layers=3)
+  xin = torch.randn((b, d), generator=g, device="cuda").requires_grad_(True)
+  out = mdcn(xin)
+  out.backward(dy)
+  params = [p_ for p_ in mdcn.parameters()]
+  refs = [p_.detach().double().requires_grad_(True) for p_ in params]
+  names = [n for n, _ in mdcn.named_parameters()]
+  byname = dict(zip(names, refs))
+  xd = xin.detach().double().requires_grad_(True)
+  xl = xd
+  for i in range(3):                                          # multi_layer_dcn.py:147-153
+    ui = byname[[n for n in names if "u_kernels" in n and n.endswith(str(i))][0]]
+    vi = byname[[n for n in names if "v_kernels" in n and n.endswith(str(i))][0]]
+    bi = [n for n in names if "bias" in n and n.endswith(str(i))]
+    prod = xl @ ui @ vi
+    if bi:
+      prod = prod + byname[bi[0]]
+    xl = xd * prod + xl
+  xl.backward(dy.double())
+  assert (out.detach().double() - xl.detach()).abs().max().item() <= 2e-5 * xl.abs().max().item()
+  for p_, r, n in zip(params, refs, names):
+    assert p_.grad is not None, n
+    err = (p_.grad.double() - r.grad).abs().max().item()
+    assert err <= 1e-4 * max(r.grad.abs().max().item(), 1e-6), (n, err)
+  err = (xin.grad.double() - xd.grad).abs().max().item()
+  assert err <= 1e-4 * xd.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("bsz", [16384, 65536])
+def test_inbatch_softmax_large_batch_vs_float64(bsz):
+  """In-batch softmax (tasks/retrieval.py:172-210) at the batch sizes where the 8-wave
+  workgroups switch on: loss, and sampled rows of dq / dc, against float64 (chunked on the GPU)."""
+  from recommenders_amd.tasks.retrieval import in_batch_softmax_loss
+  g = torch.Generator(device="cuda").manual_seed(bsz)
+  d = 64
+  q = (torch.randn((bsz, d), generator=g, device="cuda") * 0.3).requires_grad_(True)
+  c = (torch.randn((bsz, d), generator=g, device="cuda") * 0.3).requires_grad_(True)
+  loss = in_batch_softmax_loss(q, c)
+  loss.backward()
+  q64, c64 = q.detach().double(), c.detach().double()
+  lse = torch.empty((bsz,), dtype=torch.float64, device="cuda")
+  for lo in range(0, bsz, 4096):
+    lse[lo:lo + 4096] = torch.logsumexp(q64[lo:lo + 4096] @ c64.t(), dim=1)
+  pos = (q64 * c64).sum(dim=1)
+  ref_loss = (lse - pos).sum().item()
+  assert abs(loss.item() - ref_loss) <= 1e-5 * abs(ref_loss)
+  rows = torch.tensor(np.r_[0:16, bsz // 2:bsz // 2 + 16, bsz - 16:bsz], device="cuda")
+  # dq[i] = sum_j p_ij c_j - c_i
+  p_rows = torch.exp(q64[rows] @ c64.t() - lse[rows, None])
+  dq_ref = p_rows @ c64 - c64[rows]
+  err = (q.grad[rows].double() - dq_ref).abs().max().item()
+  assert err <= 1e-4 * dq_ref.abs().max().item(), err
+  # dc[j] = sum_i p_ij q_i - q_j  for sampled j
+  p_cols = torch.exp(q64 @ c64[rows].t() - lse[:, None])            # [bsz, 48]
+  dc_ref = p_cols.t() @ q64 - q64[rows]
+  err = (c.grad[rows].double() - dc_ref).abs().max().item()
+  assert err <= 1e-4 * dc_ref.abs().max().item(), err
