@@ -650,7 +650,11 @@ int gemm16_run_ex(const G16Operand &a, const G16Operand &b, int64_t m, int n, in
   const int64_t big_tiles = (L.mp / kB16M) * (L.np / kB16N);
   const bool splitk = L.nsplit > 1 && epi == kG16EpiBias && !bias && forced != 128;
   const bool big = forced == 256 || (forced != 128 && big_tiles >= 512) || splitk;
-  const int kb = (big && L.kp > 8192 && L.kp % 1024 == 0) ? 1024 : L.kp;   // K-blocked images for long K
+  // the 256 x 256 kernel reads K-step-major images (kb = 16 halves): the operand tile of one K
+  // step is 256 rows x 32 bytes CONTIGUOUS, so every direct-to-LDS copy instruction moves eight
+  // full 128-byte lines instead of 32 quarter lines 2 * kp bytes apart
+  const char *kbv = getenv("TFRS_GEMM16_KB");
+  const int kb = big ? ((kbv && *kbv) ? atoi(kbv) : kB16K) : L.kp;
   // column maxima are combined with atomicMax: re-armed by a kernel, not a memset node
   hipLaunchKernelGGL(g16_zero_kernel, dim3((unsigned)((L.np + L.mp + 255) / 256)), dim3(256), 0, s,
                      colmax, (int)(L.np + L.mp));   // colmax and colmax_a are adjacent

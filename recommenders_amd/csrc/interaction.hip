@@ -691,6 +691,163 @@ __global__ void __launch_bounds__(256, 2) dot_interaction_bwd_dense_kernel(
   }
 }
 
+// Backward, fourth generation (d <= 32): the dense-S kernel above with the memory side and the
+// products on DIFFERENT waves.  One workgroup of 8 waves per CU: waves 4-7 (producers) bring
+// sample t + 1 into LDS -- the packed gradient unpacked into one half of a double-buffered S tile,
+// X copied into one half of a double-buffered [2 kh, 32] tile, their global loads for sample t + 2
+// already in flight in registers -- while waves 0-3 (consumers, one per SIMD) run the 52 MFMA
+// steps of sample t with BOTH operands read from LDS, so the matrix pipe only pauses for the one
+// barrier per sample and never waits for HBM.  (In the single-role kernel every wave alternated
+// unpack -> barrier -> products -> barrier and fetched its B operand from global one MFMA group
+// ahead: the MFMA pipe was busy 29 % of the time.)
+template <int MAXE>
+__global__ void __launch_bounds__(512) dot_interaction_bwd_pc_kernel(
+    const float *__restrict__ x, const float *__restrict__ dout, int64_t batch, int f, int d,
+    int self, int kh, float *__restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) float s_lds[];
+  constexpr int MAXX = 16;                   // X elements per producer thread: f * d <= 128 * 32
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 4;           // wave-uniform
+  const int j = lane & 31, h = lane >> 5;
+  const int ld = 2 * kh + 4;                 // floats per S row: (2 kh + 4) / 4 is odd
+  const int tile = f * ld + 256;             // one S buffer: tile + 256 dummy slots
+  const int xtile = 2 * kh * 32;             // one X buffer: rows >= f and columns >= d stay zero
+  float *const xs_base = s_lds + 2 * tile;
+  const int out_dim = self ? f * (f + 1) / 2 : f * (f - 1) / 2;
+  const int xn = f * d;
+  for (int e = tid; e < 2 * tile + 2 * xtile; e += 512) s_lds[e] = 0.0f;
+  const int ptid = tid & 255;                // producer thread index
+  uint32_t pos[MAXE];
+  uint64_t diag_bits = 0;
+  float gy0[MAXE], gx0[MAXX];   // the next sample, in flight during the current one's products
+  const uint32_t dummy = (uint32_t)(f * ld + ptid);
+  if (producer) {
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const int p = ptid + 256 * e;
+      int i = 0, jx = 0;
+      if (p < out_dim) pair_of_index(p, self != 0, &i, &jx);
+      pos[e] = (p < out_dim) ? ((uint32_t)(i * ld + jx) | ((uint32_t)(jx * ld + i) << 16)) : (dummy | (dummy << 16));
+      if (p < out_dim && i == jx) diag_bits |= 1ull << e;
+    }
+  }
+  uint16_t xpos[MAXX];                        // X element p = ptid + 256 e -> row * 32 + column
+#pragma unroll
+  for (int e = 0; e < MAXX; ++e) {
+    const int p = ptid + 256 * e;
+    xpos[e] = (uint16_t)((p / d) * 32 + (p % d));
+  }
+  auto load_sample = [&](float (&gy)[MAXE], float (&gx)[MAXX], int64_t b) __attribute__((always_inline)) {
+    const float *dy = dout + b * (int64_t)out_dim;
+    const float *xb = x + b * (int64_t)xn;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const int p = ptid + 256 * e;
+      gy[e] = (p < out_dim) ? dy[p] : 0.0f;
+    }
+#pragma unroll
+    for (int e = 0; e < MAXX; ++e) {
+      const int p = ptid + 256 * e;
+      gx[e] = (p < xn) ? xb[p] : 0.0f;
+    }
+  };
+  auto unpack = [&](const float (&gy)[MAXE], const float (&gx)[MAXX], float *sb, float *xsb)
+      __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const float v = ((diag_bits >> e) & 1ull) ? 2.0f * gy[e] : gy[e];
+      sb[pos[e] & 0xFFFFu] = v;
+      sb[pos[e] >> 16] = v;
+    }
+#pragma unroll
+    for (int e = 0; e < MAXX; ++e) {
+      const int p = ptid + 256 * e;
+      if (p < xn) xsb[xpos[e]] = gx[e];
+    }
+  };
+  const int row = (wave & 3) * 32 + j;       // consumer: this lane's S row (A operand)
+  const bool row_ok = row < f;
+  const bool active = !producer && wave * 32 < f;
+  const int nquad = kh >> 2;
+  const int64_t stride = gridDim.x;
+  __syncthreads();                           // zero fill done
+  int64_t b = blockIdx.x;
+  if (b < batch && producer) {
+    load_sample(gy0, gx0, b);
+    unpack(gy0, gx0, s_lds, xs_base);
+    if (b + stride < batch) load_sample(gy0, gx0, b + stride);
+  }
+  __syncthreads();
+  for (int t = 0; b < batch; b += stride, ++t) {
+    if (producer) {
+      if (b + stride < batch) {
+        unpack(gy0, gx0, s_lds + ((t + 1) & 1) * tile, xs_base + ((t + 1) & 1) * xtile);
+        if (b + 2 * stride < batch) load_sample(gy0, gx0, b + 2 * stride);
+      }
+    } else if (active) {
+      const float *srow = s_lds + (t & 1) * tile + (row_ok ? row : 0) * ld + h * kh;
+      const float *xcol = xs_base + (t & 1) * xtile + (h * kh) * 32 + j;   // X[h * kh + s][j]
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      // one quad (4 k-steps) ahead: the LDS reads of quad q + 1 are issued before the 4 MFMAs
+      // (256 pipe cycles) of quad q
+      f32x4 a_cur = *reinterpret_cast<const f32x4 *>(srow);
+      float b_cur[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b_cur[u] = xcol[u * 32];
+#pragma unroll 2
+      for (int q = 0; q < nquad; ++q) {
+        f32x4 a_nxt = a_cur;
+        float b_nxt[4] = {0.f, 0.f, 0.f, 0.f};
+        if (q + 1 < nquad) {                 // uniform
+          a_nxt = *reinterpret_cast<const f32x4 *>(srow + 4 * (q + 1));
+#pragma unroll
+          for (int u = 0; u < 4; ++u) b_nxt[u] = xcol[(4 * (q + 1) + u) * 32];
+        }
+        f32x4 a4 = a_cur;
+        if (!row_ok) a4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u], b_cur[u], acc, 0, 0, 0);
+        a_cur = a_nxt;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b_cur[u] = b_nxt[u];
+      }
+      float *db = dx + b * (int64_t)xn;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int orow = wave * 32 + tile_row_of_reg(r, h);
+        if (orow < f && j < d) db[orow * d + j] = acc[r];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+
+template <int MAXE>
+static void launch_dot_bwd_pc_v(const float *x, const float *dout, int64_t batch, int f, int d, int self,
+                                int kh, size_t lds, dim3 grid, float *dx, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dot_interaction_bwd_pc_kernel<MAXE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((dot_interaction_bwd_pc_kernel<MAXE>), grid, dim3(512), lds, s, x, dout, batch, f, d,
+                     self, kh, dx);
+}
+
+static void launch_dot_bwd_pc_e(int maxe, const float *x, const float *dout, int64_t batch, int f, int d,
+                                int self, int kh, size_t lds, dim3 grid, float *dx, hipStream_t s) {
+  if (maxe <= 12) launch_dot_bwd_pc_v<12>(x, dout, batch, f, d, self, kh, lds, grid, dx, s);
+  else if (maxe <= 20) launch_dot_bwd_pc_v<20>(x, dout, batch, f, d, self, kh, lds, grid, dx, s);
+  else launch_dot_bwd_pc_v<33>(x, dout, batch, f, d, self, kh, lds, grid, dx, s);
+}
+
 template <int NFB, int MAXE>
 static void launch_dot_bwd_dense_v(const float *x, const float *dout, int64_t batch, int f, int d,
                                    int self, int kh, size_t lds, dim3 grid, float *dx, hipStream_t s) {
@@ -722,6 +879,14 @@ static bool launch_dot_bwd_dense(const float *x, const float *dout, int64_t batc
   if (lds > 64 * 1024 || (size_t)f * (2 * kh + 4) + 256 > 0xFFFFu) return false;
   const int out_dim = self ? f * (f + 1) / 2 : f * (f - 1) / 2;
   const int maxe = (out_dim + 255) / 256;
+  const char *dv = getenv("TFRS_DOT_BWD");
+  const size_t lds_pc = 2 * lds + (size_t)2 * (2 * kh * 32) * sizeof(float);
+  if (!(dv && dv[0] == 'd') && d <= 32 && lds_pc <= 160 * 1024 && batch >= 512) {
+    // producer / consumer kernel: one 8-wave workgroup per CU, double-buffered S and X tiles
+    const dim3 grid_pc((unsigned)std::min<int64_t>(batch, 256));
+    launch_dot_bwd_pc_e(maxe, x, dout, batch, f, d, self, kh, lds_pc, grid_pc, dx, s);
+    return true;
+  }
   const int64_t per_cu = std::min<int64_t>(2, std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)lds));
   const dim3 grid((unsigned)std::min<int64_t>(batch, 256 * per_cu));
   const int nfb = (d + 31) / 32;

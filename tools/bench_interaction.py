@@ -44,8 +44,8 @@ for stage in ("1", "0"):
   emit(op="dot_interaction_fwd", stage=stage, ms=t * 1e3, gbps=byts / t / 1e9, frac_hbm_peak=byts / t / HBM_PEAK,
        algorithmic_bytes=byts)
 os.environ.pop("TFRS_DOT_STAGE")
-for mode in ("dense", "gather"):
-  os.environ["TFRS_DOT_BWD"] = mode
+for mode in ("pc", "dense", "gather"):
+  os.environ["TFRS_DOT_BWD"] = mode   # "pc" (default kernel): any value not starting with d / g
   t = timeit(lambda: _lib.check(lib.tfrs_dot_interaction_bwd(_lib.ptr(x), _lib.ptr(dout), B, F, D, 0, 0, _lib.ptr(dx), st)),
              iters=6)
   byts = (2 * B * F * D + B * od) * 4
