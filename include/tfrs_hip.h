@@ -210,6 +210,16 @@ int tfrs_embedding_scatter_add_bwd(const float *grad_out, const int64_t *sorted_
                                    const int64_t *perm, int64_t n, int d,
                                    float *grad_table_or_table, float *accum, float lr,
                                    float eps, int adagrad, void *stream);
+/* The same from UNSORTED ids (int32 / int64): the library sorts (id, position) pairs itself
+ * (stable LSD radix sort, 8 bits per pass over the bits of vocab) and then runs the segmented
+ * scatter-add / fused Adagrad.  ids outside [0, vocab) are ignored -- they can never write
+ * outside the table.  workspace from tfrs_embedding_scatter_add_workspace_bytes(n). */
+size_t tfrs_embedding_scatter_add_workspace_bytes(int64_t n);
+int tfrs_embedding_scatter_add_unsorted(const float *grad_out, const void *ids, int ids_are_i64,
+                                        int64_t n, int d, int64_t vocab,
+                                        float *grad_table_or_table, float *accum, float lr,
+                                        float eps, int adagrad, void *workspace,
+                                        size_t workspace_bytes, void *stream);
 
 /* Same result without the sort, for small vocabularies: one wave per table row scans the id
  * list and sums matching gradient rows in occurrence order (O(vocab * n / 64) wave steps;

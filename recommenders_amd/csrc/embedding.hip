@@ -469,6 +469,270 @@ extern "C" int tfrs_embedding_scatter_add_bwd(const float *grad_out, const int64
   return TFRS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Own stable LSD radix sort of (id, position) pairs for the large-vocabulary scatter-add
+// (replaces torch.sort / rocPRIM on the backward path of models/base.py:77-78).
+//   keys   uint32 ids; ids outside [0, vocab) -- the padding slots of sequence features and
+//          anything invalid -- become 0xFFFFFFFF: they sort last and the scatter skips them, so
+//          an out-of-range id can never write outside the table (the gather reads it as zeros)
+//   passes 8 bits each, ceil(bits(vocab) / 8) of them; every pass = tile histograms ->
+//          exclusive scan (digit-major) -> stable scatter
+//   tile   4096 keys per 256-thread workgroup; wave w owns keys [1024 w, 1024 w + 1024) of the
+//          tile and walks them 64 at a time IN ORDER: equal digits of one step are ranked with
+//          8 ballots (lanes with the same digit form a mask; rank = popcount below the lane), the
+//          wave's running per-digit offsets live in LDS.  Stable by construction.
+// Integer work, HBM-trivial (16 bytes per key and pass); launch-latency bound below ~1M keys.
+// ------------------------------------------------------------------------------------------------
+namespace tfrs {
+constexpr int kSortTile = 4096;
+
+__device__ __forceinline__ uint64_t same_digit_mask(uint32_t digit) {
+  uint64_t m = ~0ull;
+#pragma unroll
+  for (int bit = 0; bit < 8; ++bit) {
+    const uint64_t bal = __ballot((digit >> bit) & 1u);
+    m &= ((digit >> bit) & 1u) ? bal : ~bal;
+  }
+  return m;
+}
+
+// keys_out[i] = id or 0xFFFFFFFF, vals_out[i] = i  (pass 0 reads these)
+__global__ void __launch_bounds__(256) sort_init_kernel(const void *__restrict__ ids, int i64, int64_t n,
+                                                        int64_t vocab, uint32_t *__restrict__ keys,
+                                                        uint32_t *__restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t id = i64 ? static_cast<const int64_t *>(ids)[i] : (int64_t)static_cast<const int32_t *>(ids)[i];
+  keys[i] = (id >= 0 && id < vocab) ? (uint32_t)id : 0xFFFFFFFFu;
+  vals[i] = (uint32_t)i;
+}
+
+// hist[tile][wave][digit]
+__global__ void __launch_bounds__(256) sort_hist_kernel(const uint32_t *__restrict__ keys, int64_t n,
+                                                        int shift, uint32_t *__restrict__ hist) {
+  __shared__ uint32_t h[4][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < 1024; e += 256) (&h[0][0])[e] = 0u;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kSortTile + wave * 1024;
+  for (int r = 0; r < 16; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    if (i < n) atomicAdd(&h[wave][(keys[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  for (int e = tid; e < 1024; e += 256) hist[(int64_t)blockIdx.x * 1024 + e] = (&h[0][0])[e];
+}
+
+// Exclusive scan of the segment histograms in digit-major order, two levels (thread = digit):
+//   scan1: workgroup c scans its chunk of 64 segments -> offs[segment][digit] (chunk-local) and
+//          chunk_tot[c][digit];
+//   scan2: one workgroup turns chunk_tot into chunk_base[c][digit] = keys with a smaller digit
+//          anywhere + keys with the same digit in earlier chunks.
+// The scatter kernel adds the two.
+constexpr int kScanChunk = 64;
+__global__ void __launch_bounds__(256) sort_scan1_kernel(const uint32_t *__restrict__ hist, int64_t nseg,
+                                                         uint32_t *__restrict__ offs,
+                                                         uint32_t *__restrict__ chunk_tot) {
+  const int dgt = threadIdx.x;
+  const int64_t s0 = (int64_t)blockIdx.x * kScanChunk;
+  const int64_t s1 = s0 + kScanChunk < nseg ? s0 + kScanChunk : nseg;
+  uint32_t run = 0;
+#pragma unroll 8
+  for (int64_t sgm = s0; sgm < s1; ++sgm) {
+    const uint32_t c = hist[sgm * 256 + dgt];
+    offs[sgm * 256 + dgt] = run;
+    run += c;
+  }
+  chunk_tot[(int64_t)blockIdx.x * 256 + dgt] = run;
+}
+__global__ void __launch_bounds__(256) sort_scan2_kernel(uint32_t *__restrict__ chunk_tot, int64_t nchunk) {
+  __shared__ uint32_t tot[256];
+  const int dgt = threadIdx.x;
+  uint32_t run = 0;
+#pragma unroll 8
+  for (int64_t c = 0; c < nchunk; ++c) {
+    const uint32_t v = chunk_tot[c * 256 + dgt];
+    chunk_tot[c * 256 + dgt] = run;
+    run += v;
+  }
+  tot[dgt] = run;
+  __syncthreads();
+  uint32_t before = 0;
+  for (int e = 0; e < dgt; ++e) before += tot[e];
+#pragma unroll 8
+  for (int64_t c = 0; c < nchunk; ++c) chunk_tot[c * 256 + dgt] += before;
+}
+
+__global__ void __launch_bounds__(256) sort_scatter_kernel(const uint32_t *__restrict__ keys_in,
+                                                           const uint32_t *__restrict__ vals_in, int64_t n,
+                                                           int shift, const uint32_t *__restrict__ offs,
+                                                           const uint32_t *__restrict__ chunk_base,
+                                                           uint32_t *__restrict__ keys_out,
+                                                           uint32_t *__restrict__ vals_out) {
+  __shared__ uint32_t run[4][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {
+    const int64_t sgm = (int64_t)blockIdx.x * 4 + wave;
+    for (int e = lane; e < 256; e += 64)
+      run[wave][e] = offs[sgm * 256 + e] + chunk_base[(sgm / kScanChunk) * 256 + e];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int64_t base = (int64_t)blockIdx.x * kSortTile + wave * 1024;
+  const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int r = 0; r < 16; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    const bool ok = i < n;
+    const uint32_t key = ok ? keys_in[i] : 0u;
+    const uint32_t val = ok ? vals_in[i] : 0u;
+    // inactive tail lanes get a digit of their own class so that they never rank among real keys
+    const uint32_t digit = (key >> shift) & 255u;
+    const uint64_t act = __ballot(ok);
+    const uint64_t same = same_digit_mask(digit) & act;
+    if (ok) {
+      const uint32_t rank = (uint32_t)__builtin_popcountll(same & below);
+      const uint32_t dst = run[wave][digit] + rank;
+      keys_out[dst] = key;
+      vals_out[dst] = val;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (ok && (same & below) == 0ull) run[wave][digit] += (uint32_t)__builtin_popcountll(same);   // leader
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// scatter-add over uint32 sorted keys / positions (see scatter_add_kernel); keys >= vocab are the
+// invalid / padding ids and sort last
+template <int VEC>
+__global__ void __launch_bounds__(256) scatter_add_u32_kernel(
+    const float *__restrict__ grad_out, const uint32_t *__restrict__ sorted_ids,
+    const uint32_t *__restrict__ perm, int64_t n, int d, uint32_t vocab, float *__restrict__ dst,
+    float *__restrict__ accum, float lr, float eps, int adagrad) {
+  const int per_row = d / VEC;
+  const int64_t total = n * per_row;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / per_row;
+    const int c = (int)(t - i * per_row);
+    const uint32_t id = sorted_ids[i];
+    if (id >= vocab) continue;                       // invalid / padding id
+    if (i > 0 && sorted_ids[i - 1] == id) continue;  // not the start of a run
+    float g[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) g[v] = 0.f;
+    for (int64_t p = i; p < n && sorted_ids[p] == id; ++p) {
+      const int64_t src = perm[p];
+      if (VEC == 4) {
+        const float4 e = reinterpret_cast<const float4 *>(grad_out)[src * per_row + c];
+        g[0] += e.x;
+        g[1 % VEC] += e.y;
+        g[2 % VEC] += e.z;
+        g[3 % VEC] += e.w;
+      } else {
+        g[0] += grad_out[src * per_row + c];
+      }
+    }
+    if (VEC == 4) {
+      const int64_t o4 = (int64_t)id * per_row + c;
+      float4 *d4 = reinterpret_cast<float4 *>(dst) + o4;
+      if (adagrad) {
+        float4 *a4 = reinterpret_cast<float4 *>(accum) + o4;
+        float4 a = *a4, w = *d4;
+        a.x += g[0] * g[0]; a.y += g[1 % VEC] * g[1 % VEC]; a.z += g[2 % VEC] * g[2 % VEC]; a.w += g[3 % VEC] * g[3 % VEC];
+        w.x -= lr * g[0] / sqrtf(a.x + eps); w.y -= lr * g[1 % VEC] / sqrtf(a.y + eps);
+        w.z -= lr * g[2 % VEC] / sqrtf(a.z + eps); w.w -= lr * g[3 % VEC] / sqrtf(a.w + eps);
+        *a4 = a;
+        *d4 = w;
+      } else {
+        *d4 = make_float4(g[0], g[1 % VEC], g[2 % VEC], g[3 % VEC]);
+      }
+    } else {
+      const int64_t o = (int64_t)id * per_row + c;
+      if (adagrad) {
+        const float a = accum[o] + g[0] * g[0];
+        accum[o] = a;
+        dst[o] = dst[o] - lr * g[0] / sqrtf(a + eps);
+      } else {
+        dst[o] = g[0];
+      }
+    }
+  }
+}
+
+static inline size_t sort_al(size_t x) { return (x + 255) / 256 * 256; }
+}  // namespace tfrs
+
+extern "C" size_t tfrs_embedding_scatter_add_workspace_bytes(int64_t n) {
+  if (n <= 0) return 256;
+  const size_t tiles = (size_t)((n + tfrs::kSortTile - 1) / tfrs::kSortTile);
+  return 4 * tfrs::sort_al((size_t)n * 4) + 2 * tfrs::sort_al(tiles * 1024 * 4) +
+         tfrs::sort_al((tiles * 4 / tfrs::kScanChunk + 1) * 256 * 4);
+}
+
+// Backward of gather from UNSORTED ids: own radix sort + the segmented scatter-add / fused
+// Adagrad above.  ids outside [0, vocab) are ignored (they read as zero rows in the forward).
+extern "C" int tfrs_embedding_scatter_add_unsorted(const float *grad_out, const void *ids,
+                                                   int ids_are_i64, int64_t n, int d, int64_t vocab,
+                                                   float *grad_table_or_table, float *accum, float lr,
+                                                   float eps, int adagrad, void *workspace,
+                                                   size_t workspace_bytes, void *stream) {
+  using namespace tfrs;
+  TFRS_CHECK_ARG(n >= 0 && d >= 1 && vocab >= 1, "embedding_scatter_add_unsorted: bad shape");
+  TFRS_CHECK_ARG(vocab < 0xFFFFFFFFll && n < 0xFFFFFFFFll,
+                 "embedding_scatter_add_unsorted: vocab / n must fit 32 bits");
+  if (n == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(grad_out && ids && grad_table_or_table && workspace,
+                 "embedding_scatter_add_unsorted: NULL pointer");
+  TFRS_CHECK_ARG(!adagrad || accum, "embedding_scatter_add_unsorted: Adagrad needs an accumulator");
+  if (workspace_bytes < tfrs_embedding_scatter_add_workspace_bytes(n)) {
+    set_error("embedding_scatter_add_unsorted: workspace too small");
+    return TFRS_ENOMEM;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  char *w = static_cast<char *>(workspace);
+  const size_t kb = sort_al((size_t)n * 4);
+  uint32_t *keys[2] = {reinterpret_cast<uint32_t *>(w), reinterpret_cast<uint32_t *>(w + kb)};
+  uint32_t *vals[2] = {reinterpret_cast<uint32_t *>(w + 2 * kb), reinterpret_cast<uint32_t *>(w + 3 * kb)};
+  const int64_t tiles = (n + kSortTile - 1) / kSortTile;
+  uint32_t *hist = reinterpret_cast<uint32_t *>(w + 4 * kb);
+  uint32_t *offs = reinterpret_cast<uint32_t *>(w + 4 * kb + sort_al((size_t)tiles * 1024 * 4));
+  uint32_t *chunk = reinterpret_cast<uint32_t *>(w + 4 * kb + 2 * sort_al((size_t)tiles * 1024 * 4));
+  const int64_t nseg = tiles * 4, nchunk = (nseg + kScanChunk - 1) / kScanChunk;
+  hipLaunchKernelGGL(sort_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ids, ids_are_i64, n,
+                     vocab, keys[0], vals[0]);
+  // digits that can differ: the bits of vocab (0xFFFFFFFF of invalid ids needs the top pass too,
+  // which the last valid pass provides as long as it covers a bit above vocab - 1)
+  int bits = 1;
+  while (bits < 32 && (1ll << bits) <= vocab) ++bits;   // 2^bits > vocab: invalid keys have bit `bits`.. set
+  int passes = (bits + 1 + 7) / 8;
+  if (passes > 4) passes = 4;
+  int cur = 0;
+  for (int p = 0; p < passes; ++p) {
+    const int shift = 8 * p;
+    hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)tiles), dim3(256), 0, s, keys[cur], n, shift, hist);
+    hipLaunchKernelGGL(sort_scan1_kernel, dim3((unsigned)nchunk), dim3(256), 0, s, hist, nseg, offs, chunk);
+    hipLaunchKernelGGL(sort_scan2_kernel, dim3(1), dim3(256), 0, s, chunk, nchunk);
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3((unsigned)tiles), dim3(256), 0, s, keys[cur], vals[cur], n,
+                       shift, offs, chunk, keys[cur ^ 1], vals[cur ^ 1]);
+    cur ^= 1;
+  }
+  TFRS_LAUNCH_CHECK();
+  const bool vec = (d % 4 == 0) && (((uintptr_t)grad_out) % 16 == 0) &&
+                   (((uintptr_t)grad_table_or_table) % 16 == 0) && (!accum || ((uintptr_t)accum) % 16 == 0);
+  const int64_t total = n * (vec ? d / 4 : d);
+  const dim3 grid(grid_for(total, 256 * 64)), block(256);
+  if (vec)
+    hipLaunchKernelGGL((scatter_add_u32_kernel<4>), grid, block, 0, s, grad_out, keys[cur], vals[cur], n, d,
+                       (uint32_t)vocab, grad_table_or_table, accum, lr, eps, adagrad);
+  else
+    hipLaunchKernelGGL((scatter_add_u32_kernel<1>), grid, block, 0, s, grad_out, keys[cur], vals[cur], n, d,
+                       (uint32_t)vocab, grad_table_or_table, accum, lr, eps, adagrad);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
 extern "C" int tfrs_embedding_scatter_add_rowscan(const float *grad_out, const void *ids,
                                                   int ids_are_i64, int64_t n, int d,
                                                   int64_t vocab, float *grad_table_or_table,

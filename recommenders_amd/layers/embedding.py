@@ -65,13 +65,23 @@ def scatter_add_rows(grad_out: torch.Tensor, ids: torch.Tensor, vocab: int) -> t
         _lib.ptr(g), _lib.ptr(flat), 1 if flat.dtype == torch.int64 else 0, flat.numel(), d,
         vocab, _lib.ptr(table_grad), None, 0.0, 0.0, 0, _lib.current_stream()))
     return table_grad
-  flat = ids.reshape(-1).long()
-  sorted_ids, perm = torch.sort(flat, stable=True)
+  flat = ids.reshape(-1).contiguous()
   table_grad = torch.zeros((vocab, d), dtype=torch.float32, device=g.device)
-  _lib.check(_lib.load().tfrs_embedding_scatter_add_bwd(
-      _lib.ptr(g), _lib.ptr(sorted_ids), _lib.ptr(perm), flat.numel(), d,
-      _lib.ptr(table_grad), None, 0.0, 0.0, 0, _lib.current_stream()))
+  _scatter_unsorted(g, flat, vocab, table_grad, None, 0.0, 0.0, 0)
   return table_grad
+
+
+def _scatter_unsorted(g, flat, vocab, dst, accum, lr, eps, adagrad) -> None:
+  """(id, position) radix sort + segmented scatter-add / fused Adagrad in the library
+  (``tfrs_embedding_scatter_add_unsorted``); ids outside ``[0, vocab)`` are ignored."""
+  lib = _lib.load()
+  n = flat.numel()
+  ws = torch.empty((lib.tfrs_embedding_scatter_add_workspace_bytes(n),), dtype=torch.uint8,
+                   device=g.device)
+  _lib.check(lib.tfrs_embedding_scatter_add_unsorted(
+      _lib.ptr(g), _lib.ptr(flat), 1 if flat.dtype == torch.int64 else 0, n, g.shape[-1], vocab,
+      _lib.ptr(dst), _lib.ptr(accum), float(lr), float(eps), adagrad, _lib.ptr(ws), ws.numel(),
+      _lib.current_stream()))
 
 
 def adagrad_sparse_update_(table: torch.Tensor, accum: torch.Tensor, grad_out: torch.Tensor,
@@ -90,11 +100,7 @@ def adagrad_sparse_update_(table: torch.Tensor, accum: torch.Tensor, grad_out: t
         table.shape[0], _lib.ptr(table), _lib.ptr(accum), float(lr), float(eps), 1,
         _lib.current_stream()))
     return
-  flat = ids.reshape(-1).long()
-  sorted_ids, perm = torch.sort(flat, stable=True)
-  _lib.check(_lib.load().tfrs_embedding_scatter_add_bwd(
-      _lib.ptr(g), _lib.ptr(sorted_ids), _lib.ptr(perm), flat.numel(), d,
-      _lib.ptr(table), _lib.ptr(accum), float(lr), float(eps), 1, _lib.current_stream()))
+  _scatter_unsorted(g, ids.reshape(-1).contiguous(), table.shape[0], table, accum, lr, eps, 1)
 
 
 def _emit_table_grad(ctx, grad_out):

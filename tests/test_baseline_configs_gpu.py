@@ -255,3 +255,34 @@ def test_inbatch_softmax_large_batch_vs_float64(bsz):
   dc_ref = p_cols.t() @ q64 - q64[rows]
   err = (c.grad[rows].double() - dc_ref).abs().max().item()
   assert err <= 1e-4 * dc_ref.abs().max().item(), err
+
+
+def test_large_vocab_scatter_add_own_sort_and_bad_ids():
+  """The large-vocabulary backward (own radix sort + segmented scatter-add, no torch.sort):
+  bit-exact occurrence-order sums on a 3M-row table with heavy duplicates, int32 and int64 ids;
+  ids outside [0, vocab) -- sequence padding, corrupt input -- are ignored and can never write
+  outside the table (the row right behind the table is checked)."""
+  from recommenders_amd.layers import embedding as emb
+  from oracle import embedding as o_emb
+  rng = np.random.default_rng(21)
+  vocab, n, d = 3_000_000, 200_000, 32
+  ids = np.where(rng.random(n) < 0.5, rng.integers(0, 5000, size=n), rng.integers(0, vocab, size=n))
+  ids[::97] = -1
+  ids[5::101] = vocab            # one past the end
+  ids[7::103] = vocab + 12345
+  g = rng.normal(size=(n, d)).astype(np.float32)
+  ok = (ids >= 0) & (ids < vocab)
+  ref = o_emb.scatter_add_grad(g[ok], ids[ok], vocab)
+  for dtype in (np.int64, np.int32):
+    got = emb.scatter_add_rows(torch.as_tensor(g).cuda(), torch.as_tensor(ids.astype(dtype)).cuda(), vocab)
+    np.testing.assert_array_equal(_np(got), ref)
+  # fused Adagrad on a table that has a guard row behind it
+  backing = torch.zeros((vocab + 1, d), device="cuda")
+  acc_backing = torch.full((vocab + 1, d), 0.1, device="cuda")
+  table, accum = backing[:vocab], acc_backing[:vocab]
+  emb.adagrad_sparse_update_(table, accum, torch.as_tensor(g).cuda(), torch.as_tensor(ids).cuda(), lr=0.5)
+  assert float(backing[vocab].abs().max()) == 0.0 and float((acc_backing[vocab] - 0.1).abs().max()) == 0.0
+  t_ref, a_ref = o_emb.adagrad_sparse_update(np.zeros((vocab, d), np.float32), np.full((vocab, d), 0.1, np.float32),
+                                             g[ok], ids[ok], lr=0.5)
+  np.testing.assert_allclose(_np(accum), a_ref, rtol=1e-6)
+  np.testing.assert_allclose(_np(table), t_ref, rtol=1e-5, atol=1e-7)
