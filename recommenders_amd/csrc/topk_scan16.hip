@@ -637,6 +637,7 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16f_kernel(c
   }
 }
 
+
 template <int DP>
 static int launch_scan16f(const Scan16Args &a, hipStream_t stream) {
   using G = Scan16FGeom<DP>;
