@@ -131,6 +131,25 @@ int tfrs_streaming_topk_update(const float *queries, int64_t nq, int d,
                                size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------- *
+ * Embedding dims above TFRS_MAX_DIM (the fused scan kernels keep a row in registers): the same
+ * result through materialised score blocks.
+ *   tfrs_compute_scores: scores[nq, nc] = q @ c^T (TopK._compute_score,
+ *     layers/factorized_top_k.py:320-333; also Retrieval.call scores tasks/retrieval.py:172-180),
+ *     the candidate matrix read in place as the transposed operand; f16 != 0 selects the
+ *     split-fp16 MFMA GEMM (workspace from tfrs_gemm_f16_workspace_bytes(nq, nc, d)).
+ *   tfrs_topk_update_from_scores: folds a score block (columns = rows base_row.. of the corpus)
+ *     into the running top-K state exactly like tfrs_streaming_topk_update (:440-472).
+ * Scores of this path are GEMM sums (f32 accuracy, not the bit-defined fma chain).
+ * ------------------------------------------------------------------------- */
+int tfrs_compute_scores(const float *queries, const float *candidates, int64_t nq, int nc, int d,
+                        float *out, int f16, void *workspace, size_t workspace_bytes,
+                        void *stream);
+int tfrs_topk_update_from_scores(const float *scores, int64_t nq, int64_t nb, int64_t ld,
+                                 int64_t base_row, int k, float *state_scores,
+                                 int32_t *state_idx, int32_t state_len, int32_t *new_len_h,
+                                 void *stream);
+
+/* ------------------------------------------------------------------------- *
  * Merge of partial top-K lists (the multi-GPU exchange step and the general form of
  * the Streaming reduce, :459-472): parts are scores[nparts, nq, k_in] /
  * idx[nparts, nq, k_in] (each sorted or not), result out[nq, k_out] under

@@ -743,6 +743,13 @@ int gemm16_cross_bwd(const float *x0, const float *x, const float *kernel, const
 }
 
 
+// scores[nq, nc] = q @ c^T, c read as the transposed operand
+int gemm16_scores(const float *q, const float *c, int64_t nq, int nc, int d, float *out, void *ws,
+                  hipStream_t s) {
+  return gemm16_run_ex({q, nullptr, false}, {c, nullptr, true}, nq, nc, d, nullptr, kG16EpiBias, nullptr,
+                       nullptr, 0.0f, out, nullptr, ws, s);
+}
+
 size_t gemm16_dense_bwd_workspace_bytes(int64_t batch, int din, int dout) {
   return std::max(g16_layout(batch, din, dout).total, g16_layout(din, dout, (int)batch).total);
 }

@@ -1014,6 +1014,8 @@ int gemm16_run(const float *a, const float *b, int64_t m, int n, int k, const fl
                const float *x0, const float *x, float diag, float *out, void *ws, hipStream_t s);
 size_t gemm16_cross_bwd_workspace_bytes(int64_t batch, int d);
 size_t gemm16_dense_bwd_workspace_bytes(int64_t batch, int din, int dout);
+int gemm16_scores(const float *q, const float *c, int64_t nq, int nc, int d, float *out, void *ws,
+                  hipStream_t s);
 int gemm16_dense_bwd(const float *x, const float *kernel, const float *dy, int64_t batch, int din,
                      int dout, float *dx, float *dkernel, float *dbias, void *ws, hipStream_t s);
 int gemm16_cross_bwd(const float *x0, const float *x, const float *kernel, const float *bias,
@@ -1105,6 +1107,33 @@ extern "C" int tfrs_cross_bwd(const float *x0, const float *x, const float *kern
                        nslab, d, dbias);
     TFRS_LAUNCH_CHECK();
   }
+  return TFRS_OK;
+}
+
+// ---- scores = q @ c^T (TopK._compute_score, layers/factorized_top_k.py:320-333: tf.matmul(q, c,
+// transpose_b=True); Retrieval.call scores tasks/retrieval.py:172-180) with the candidate matrix read
+// in place as the transposed operand.  f16 != 0: split-fp16 MFMA (workspace from
+// tfrs_gemm_f16_workspace_bytes(nq, nc, d)); else f32 MFMA, workspace unused. -----------------
+extern "C" int tfrs_compute_scores(const float *q, const float *c, int64_t nq, int nc, int d,
+                                   float *out, int f16, void *workspace, size_t workspace_bytes,
+                                   void *stream) {
+  TFRS_CHECK_ARG(nq >= 0 && nc >= 1 && d >= 1, "compute_scores: bad shape");
+  if (nq == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(q && c && out, "compute_scores: NULL pointer");
+  if (f16) {
+    TFRS_CHECK_ARG(workspace != nullptr, "compute_scores: NULL workspace");
+    if (workspace_bytes < gemm16_workspace_bytes(nq, nc, d)) {
+      set_error("compute_scores: workspace too small");
+      return TFRS_ENOMEM;
+    }
+    return gemm16_scores(q, c, nq, nc, d, out, workspace, (hipStream_t)stream);
+  }
+  GemmArgs g = {};
+  g.a = q; g.b = c; g.m = nq; g.n = nc; g.k = d; g.out = out;
+  hipLaunchKernelGGL((gemm_kernel<kEpiBias, false, true>),
+                     dim3((unsigned)(((nq + kBM - 1) / kBM) * ((nc + kBN - 1) / kBN))), dim3(256), 0,
+                     (hipStream_t)stream, g);
+  TFRS_LAUNCH_CHECK();
   return TFRS_OK;
 }
 

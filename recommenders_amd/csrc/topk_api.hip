@@ -771,6 +771,40 @@ extern "C" int tfrs_streaming_topk_update(const float *queries, int64_t nq, int 
 }
 
 // ----------------------------------------------------------------------------------------
+// top-K update from a materialised score block (embedding dims above TFRS_MAX_DIM)
+// ----------------------------------------------------------------------------------------
+extern "C" int tfrs_topk_update_from_scores(const float *scores, int64_t nq, int64_t nb, int64_t ld,
+                                            int64_t base_row, int k, float *state_scores,
+                                            int32_t *state_idx, int32_t state_len,
+                                            int32_t *new_len_h, void *stream) {
+  TFRS_CHECK_ARG(nq >= 0 && nb >= 0 && ld >= nb, "topk_update_from_scores: bad shape");
+  TFRS_CHECK_ARG(k >= 1 && k <= TFRS_MAX_K, "topk_update_from_scores: k=%d outside [1, %d]", k, TFRS_MAX_K);
+  TFRS_CHECK_ARG(state_len >= 0 && state_len <= k, "topk_update_from_scores: bad state_len");
+  TFRS_CHECK_ARG(base_row >= 0 && base_row + nb <= 0x7FFFFFFFll,
+                 "topk_update_from_scores: row numbers exceed int32");
+  if (new_len_h) *new_len_h = state_len;
+  if (nq == 0 || nb == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(scores && state_scores && state_idx, "topk_update_from_scores: NULL pointer");
+  SelectArgs se = {};
+  se.nq = nq;
+  se.k = k;
+  se.state_scores = state_scores;
+  se.state_idx = state_idx;
+  se.state_len = state_len;
+  se.source = kSrcDense;
+  se.dense = scores;
+  se.ld_dense = ld;
+  se.n_dense = nb;
+  se.idx_base = base_row;
+  se.d = 8;
+  se.out_scores = state_scores;
+  se.out_idx = state_idx;
+  const int rc = launch_select(se, (hipStream_t)stream);
+  if (rc == TFRS_OK && new_len_h) *new_len_h = (int32_t)std::min<int64_t>(k, (int64_t)state_len + nb);
+  return rc;
+}
+
+// ----------------------------------------------------------------------------------------
 // merge of partial lists
 // ----------------------------------------------------------------------------------------
 extern "C" size_t tfrs_topk_merge_workspace_bytes(int64_t, int, int, int) { return 256; }

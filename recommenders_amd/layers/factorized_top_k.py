@@ -63,6 +63,44 @@ def _workspace(nbytes: int) -> Tensor:
   return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=_device())
 
 
+MAX_FUSED_DIM = 128    # TFRS_MAX_DIM: embedding dims the fused scan kernels keep in registers
+_WIDE_BLOCK = 32768    # candidate rows per materialised score block on the wide-dim path
+
+
+def compute_scores(queries: Tensor, candidates: Tensor) -> Tensor:
+  """``tf.matmul(queries, candidates, transpose_b=True)`` (``TopK._compute_score`` :320-333)
+  through ``tfrs_compute_scores``: the candidate matrix is read in place (no transposed copy)."""
+  from recommenders_amd.layers.feature_interaction import dcn
+  q, c = queries.contiguous(), candidates.contiguous()
+  nq, d = q.shape
+  nc = c.shape[0]
+  out = torch.empty((nq, nc), dtype=torch.float32, device=q.device)
+  lib = _lib.load()
+  f16 = 1 if dcn._use_f16_gemm(nq, nc, d) else 0
+  ws = dcn._gemm_workspace(lib.tfrs_gemm_f16_workspace_bytes(nq, nc, d), q.device) if f16 else None
+  _lib.check(lib.tfrs_compute_scores(_lib.ptr(q), _lib.ptr(c), nq, nc, d, _lib.ptr(out), f16,
+                                     _lib.ptr(ws), ws.numel() if ws is not None else 0,
+                                     _lib.current_stream()))
+  return out
+
+
+def _wide_topk_update(q: Tensor, block: Tensor, base_row: int, k: int, state_scores: Tensor,
+                      state_rows: Tensor, state_len: int) -> int:
+  """One candidate block of the wide-dim path (d > 128): materialised scores of at most
+  ``_WIDE_BLOCK`` rows at a time, folded into the running state (:440-472)."""
+  lib = _lib.load()
+  new_len = ctypes.c_int32(state_len)
+  for lo in range(0, block.shape[0], _WIDE_BLOCK):
+    part = block[lo:lo + _WIDE_BLOCK]
+    scores = compute_scores(q, part)
+    _lib.check(lib.tfrs_topk_update_from_scores(
+        _lib.ptr(scores), q.shape[0], part.shape[0], part.shape[0], base_row + lo, k,
+        _lib.ptr(state_scores), _lib.ptr(state_rows), state_len, ctypes.byref(new_len),
+        _lib.current_stream()))
+    state_len = int(new_len.value)
+  return state_len
+
+
 def _check_candidates_with_identifiers(candidates: Iterable) -> None:
   """Precondition of the dataset used for indexing (reference :118-137), checked on
   the first element: either blocks, or 2-tuples with equal leading dimensions."""
@@ -301,6 +339,15 @@ class BruteForce(TopK):
           f" rows (got {nrows} candidates rows and"
           f" {len(identifiers)} identifier rows). ")
     cand = _as_f32_matrix(candidates, "candidates")
+    self._wide = None
+    if cand.shape[1] > MAX_FUSED_DIM:
+      # embedding dims above 128: layer-owned row-major copy (:571-580), scored block by block
+      # through the GEMM kernels (scores are GEMM sums, f32 accuracy)
+      self._wide = cand.clone()
+      self._index = self._wide
+      self._ids = _Identifiers(identifiers, cand.shape[0])
+      self._n, self._d = cand.shape
+      return self
     handle = _IndexHandle()
     _lib.check(handle._lib.tfrs_index_set(handle.handle, _lib.ptr(cand), cand.shape[0],
                                           cand.shape[1], _lib.current_stream()))
@@ -319,6 +366,11 @@ class BruteForce(TopK):
     if total_rows is None:
       return super().index_from_dataset(candidates)
     _check_candidates_with_identifiers(candidates)
+    for first in candidates:
+      first_block = first[1] if isinstance(first, (tuple, list)) else first
+      if first_block.shape[1] > MAX_FUSED_DIM:
+        return super().index_from_dataset(candidates)     # wide dims: plain row-major copy
+      break
     handle, ids, has_ids, n, d = None, [], None, 0, 0
     for element in candidates:
       if isinstance(element, (tuple, list)):
@@ -359,6 +411,14 @@ class BruteForce(TopK):
       raise ValueError(f"Query dimension {q.shape[1]} does not match the index ({self._d}).")
     lib = _lib.load()
     nq = q.shape[0]
+    if getattr(self, "_wide", None) is not None:
+      if k > self._n:
+        raise ValueError(f"input must have at least k columns (k={k}, candidates={self._n})")
+      scores = torch.zeros((nq, k), dtype=torch.float32, device=q.device)
+      rows = torch.zeros((nq, k), dtype=torch.int32, device=q.device)
+      _wide_topk_update(q, self._wide, 0, k, scores, rows, 0)
+      self._last_call = None
+      return scores, rows
     scores = torch.empty((nq, k), dtype=torch.float32, device=q.device)
     rows = torch.empty((nq, k), dtype=torch.int32, device=q.device)
     ws = _workspace(lib.tfrs_bruteforce_topk_workspace_bytes(nq, self._n, self._d, k))
@@ -396,6 +456,8 @@ class BruteForce(TopK):
     k = k if k is not None else self._k
     if self._index is None:
       raise ValueError(NOT_INDEXED_MESSAGE)
+    if getattr(self, "_wide", None) is not None:
+      raise NotImplementedError("make_graphed_call: embedding dims above 128 use per-block launches")
     static_q = self._embed(example_queries).clone()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -423,6 +485,8 @@ class BruteForce(TopK):
     """The indexed candidate matrix (unpacked copy), for checkpointing."""
     if self._index is None:
       raise ValueError(NOT_INDEXED_MESSAGE)
+    if getattr(self, "_wide", None) is not None:
+      return self._wide.clone()
     out = torch.empty((self._n, self._d), dtype=torch.float32, device=_device())
     _lib.check(_lib.load().tfrs_index_unpack(self._index.handle, _lib.ptr(out),
                                              _lib.current_stream()))
@@ -596,6 +660,10 @@ class Streaming(TopK):
         raise ValueError(BATCH_TOO_SMALL_MESSAGE.format(k=k))
       if counter + nb > 0x7FFFFFFF:
         raise ValueError("Streaming: global row numbers exceed int32 (%d)" % (counter + nb))
+      if d > MAX_FUSED_DIM:
+        state_len = _wide_topk_update(q, block, counter, k, state_scores, state_rows, state_len)
+        counter += nb
+        continue
       need = lib.tfrs_streaming_topk_workspace_bytes(nq, nb, d, k)
       if ws is None or ws.numel() < need:
         ws = _workspace(need)

@@ -54,7 +54,11 @@ class AUC:
     self.reset_states()
 
   def reset_states(self) -> None:
-    self._tp = self._fp = self._tn = self._fn = None
+    if getattr(self, "_tp", None) is not None:   # keep the storage (graph replay writes into it)
+      for t in (self._tp, self._fp, self._tn, self._fn):
+        t.zero_()
+    else:
+      self._tp = self._fp = self._tn = self._fn = None
 
   reset_state = reset_states
 
@@ -70,9 +74,12 @@ class AUC:
     fn = (w * (~pred_pos & y[None, :])).sum(dim=1)
     tn = (w * (~pred_pos & ~y[None, :])).sum(dim=1)
     if self._tp is None:
-      self._tp, self._fp, self._tn, self._fn = tp, fp, tn, fn
-    else:
-      self._tp, self._fp, self._tn, self._fn = self._tp + tp, self._fp + fp, self._tn + tn, self._fn + fn
+      self._tp, self._fp, self._tn, self._fn = tp.clone(), fp.clone(), tn.clone(), fn.clone()
+    else:                                  # in place: the state survives HIP-graph replays
+      self._tp.add_(tp)
+      self._fp.add_(fp)
+      self._tn.add_(tn)
+      self._fn.add_(fn)
 
   def result(self) -> torch.Tensor:
     if self._tp is None:

@@ -30,14 +30,18 @@ class Mean:
   def update_state(self, values: torch.Tensor, sample_weight: Optional[torch.Tensor] = None):
     v = values.reshape(-1).to(torch.float32)
     if sample_weight is None:
-      total, count = v.sum(), torch.tensor(float(v.numel()), device=v.device)
+      total, count = v.sum(), torch.full((), float(v.numel()), dtype=torch.float32, device=v.device)
     else:
       w = sample_weight.reshape(-1).to(v.device, torch.float32)
       total, count = (v * w).sum(), w.sum()
+    # persistent state tensors updated IN PLACE: under HIP-graph replay (make_graphed_train_step)
+    # the same storage accumulates across replays (an out-of-place `state = state + x` would
+    # re-add to the captured warm-up value on every replay)
     if self._total is None:
-      self._total, self._count = total, count
+      self._total, self._count = total.clone(), count.clone()
     else:
-      self._total, self._count = self._total + total, self._count + count
+      self._total.add_(total)
+      self._count.add_(count)
 
   def result(self) -> torch.Tensor:
     if self._total is None:
@@ -46,8 +50,9 @@ class Mean:
                        torch.zeros_like(self._total))
 
   def reset_states(self) -> None:
-    self._total = None
-    self._count = None
+    if self._total is not None:       # keep the storage (a captured graph may write into it)
+      self._total.zero_()
+      self._count.zero_()
 
   reset_state = reset_states
 

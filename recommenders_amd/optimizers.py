@@ -43,6 +43,22 @@ class Adagrad(torch.optim.Optimizer):
           p._tfrs_sparse_grad = True        # the lookup's backward now emits slices
           p._tfrs_slices = []
 
+  def close(self) -> None:
+    """Hands the embedding tables back to dense gradients: after ``close()`` (also called when the
+    optimizer is garbage-collected) a lookup's backward produces an ordinary ``.grad`` again, so
+    the tables can be trained by another optimizer."""
+    for group in self.param_groups:
+      for p in group["params"]:
+        if getattr(p, "_tfrs_sparse_grad", False):
+          p._tfrs_sparse_grad = False
+          p._tfrs_slices = []
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:   # interpreter shutdown
+      pass
+
   def _accumulator(self, p: torch.Tensor, init: float) -> torch.Tensor:
     state = self.state[p]
     if "accumulator" not in state:

@@ -286,3 +286,41 @@ def test_large_vocab_scatter_add_own_sort_and_bad_ids():
                                              g[ok], ids[ok], lr=0.5)
   np.testing.assert_allclose(_np(accum), a_ref, rtol=1e-6)
   np.testing.assert_allclose(_np(table), t_ref, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("d", [129, 200, 384])
+def test_wide_embedding_dims_topk_and_retrieval(d):
+  """Embedding dims above 128 (outside the fused kernels' register envelope; the reference has no
+  limit, layers/factorized_top_k.py:320-333, tasks/retrieval.py:172-180) take the GEMM + select
+  path: same top-K as the oracle (scores to 1e-5 relative: they are GEMM sums, not the fma chain),
+  BruteForce / Streaming / exclusions / Retrieval loss and gradients."""
+  import recommenders_amd as tfrs
+  from oracle import retrieval as o_ret
+  ftk = _ftk()
+  rng = np.random.default_rng(d)
+  n, nq, k = 70_000, 50, 60
+  c = (rng.normal(size=(n, d)) / np.sqrt(d)).astype(np.float32)
+  q = (rng.normal(size=(nq, d)) / np.sqrt(d)).astype(np.float32)
+  es, ei = o_topk.brute_force(q, c, k)
+  full = o_topk.scores(q, c)
+  for layer in (ftk.BruteForce(k=k).index(c),
+                ftk.Streaming(k=k).index_from_dataset([c[lo:lo + 9000] for lo in range(0, n, 9000)]),
+                ftk.Streaming(k=k).index_from_dataset([torch.as_tensor(c[lo:lo + 9000]).cuda() for lo in range(0, n, 9000)])):
+    s, i = layer(q)
+    s, i = _np(s), _np(i)
+    np.testing.assert_allclose(s, es, rtol=1e-5, atol=1e-6)
+    # returned rows carry (to tolerance) the scores returned for them; order may only differ on near-ties
+    np.testing.assert_allclose(np.take_along_axis(full, i.astype(np.int64), axis=1), s, rtol=1e-5, atol=1e-6)
+    assert (i == ei).mean() > 0.995
+  # Retrieval default loss at a wide dim: explicit-logits path
+  b = 300
+  qe = torch.as_tensor(q[:b % nq + nq][:nq]).cuda()
+  qe = torch.as_tensor((rng.normal(size=(b, d)) / np.sqrt(d)).astype(np.float32)).cuda().requires_grad_(True)
+  ce = torch.as_tensor((rng.normal(size=(b, d)) / np.sqrt(d)).astype(np.float32)).cuda().requires_grad_(True)
+  loss = tfrs.tasks.Retrieval()(qe, ce, compute_metrics=False)
+  loss.backward()
+  ref = o_ret.loss(_np(qe.detach()), _np(ce.detach()))
+  assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+  dq, dc = o_ret.loss_grads(_np(qe.detach()), _np(ce.detach()))
+  np.testing.assert_allclose(_np(qe.grad), dq, rtol=1e-4, atol=1e-6)
+  np.testing.assert_allclose(_np(ce.grad), dc, rtol=1e-4, atol=1e-6)
