@@ -248,6 +248,15 @@ int tfrs_embedding_scatter_add_rowscan(const float *grad_out, const void *ids, i
                                        int64_t n, int d, int64_t vocab,
                                        float *grad_table_or_table, float *accum, float lr,
                                        float eps, int adagrad, void *stream);
+/* The same for up to 8 small tables in ONE launch (the user and item tables of a two-tower step):
+ * the *_h arguments are HOST arrays of `ntables` entries holding the per-table arguments of
+ * tfrs_embedding_scatter_add_rowscan. */
+int tfrs_embedding_scatter_add_rowscan_multi(int ntables, const float *const *grad_out_h,
+                                             const void *const *ids_h, const int *ids_are_i64_h,
+                                             const int64_t *n_h, const int *d_h,
+                                             const int64_t *vocab_h, float *const *tables_h,
+                                             float *const *accum_h, float lr, float eps,
+                                             int adagrad, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * tf.keras.layers.Hashing(num_bins, salt=[s0, s1]) as UnifiedEmbedding applies it per

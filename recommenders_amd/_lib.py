@@ -63,6 +63,8 @@ SIGNATURES = {
     "tfrs_embedding_scatter_add_workspace_bytes": (c_size_t, [c_i64]),
     "tfrs_embedding_scatter_add_unsorted": (c_int, [P, P, c_int, c_i64, c_int, c_i64, P, P, c_float,
                                                     c_float, c_int, P, c_size_t, P]),
+    "tfrs_embedding_scatter_add_rowscan_multi": (c_int, [c_int, P, P, P, P, P, P, P, P, c_float, c_float,
+                                                         c_int, P]),
     "tfrs_embedding_scatter_add_rowscan": (c_int, [P, P, c_int, c_i64, c_int, c_i64, P, P, c_float,
                                                    c_float, c_int, P]),
     "tfrs_inbatch_softmax_workspace_bytes": (c_size_t, [c_i64, c_i64, c_int]),

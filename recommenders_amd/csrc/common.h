@@ -146,6 +146,8 @@ struct ScanArgs {
   //   buf[(query * cap_l + e) * nseg + seg],  cnt[query * nseg + seg] = number appended
   // (counts may exceed cap_l: the excess was dropped and the query is recomputed exactly).
   const float *thr;      // [nq] current K-th best score per query
+  int tie_ge;            // keep scores >= thr (shuffled index: an equal score later in the image
+                         // may belong to an EARLIER original row and win the tie)
   uint32_t *cnt;         // [nq, nseg]
   uint2 *buf;            // [nq, cap_l, nseg] (score bits, row index)
   uint32_t cap_l;        // entries per segment
@@ -192,6 +194,13 @@ struct Scan16Args {
   float *binmax;
   int64_t ld_binmax;
   int bin_stages;        // stages per bin (stages_per_split must be a multiple of it)
+  // FILTER (second-generation kernel): per-query overflow lists for survivors whose segment is
+  // full (corpora ordered by cluster put a query's survivors into one or two segments):
+  // ovf_cnt[q] entries in ovf_buf[q * ovf_cap ...]; NULL = none (a full segment then flags the
+  // query for the exact redo, as the first-generation kernel does)
+  uint32_t *ovf_cnt;
+  uint2 *ovf_buf;
+  uint32_t ovf_cap;
   int drain_min;         // FILTER (second-generation kernel): queue entries that trigger a
                          // drain at a stage end (0 -> 1)
   uint32_t *zero_word;   // FILTER: word re-armed (= 0) for the kernel that follows (the
@@ -234,6 +243,9 @@ struct SelectArgs {
   int64_t part_stride;  // elements between consecutive parts (0 = dense: nq * k_in)
   // all sources: value added to source-local row numbers
   int64_t idx_base;
+  // shuffled index: image row -> original row (NULL: identity); applied when keys are formed, so
+  // every tie is decided by ORIGINAL row numbers
+  const int32_t *rowmap;
   // outputs
   float *out_scores;   // [nq, k]
   int32_t *out_idx;    // [nq, k]
@@ -252,17 +264,25 @@ int launch_select(const SelectArgs &a, hipStream_t stream);
 // when NULL), one workgroup per query; writes out_scores / out_idx of those queries only
 int launch_recompute(const SelectArgs &a, hipStream_t stream);
 constexpr int kRecomputeChunks = 32;
+// rowmap != NULL: the block is stored SHUFFLED -- image row dst_row + r holds block row
+// (mul * r + add) mod n (mul coprime to n, near n / golden ratio: consecutive block rows land far
+// apart) and rowmap[dst_row + r] = dst_row + that row.
 int launch_pack(const float *cand, int64_t n, int d, char *packed, int64_t dst_row,
-                int64_t zero_rows_to, hipStream_t stream);
-int launch_unpack(const char *packed, int64_t n, int d, float *out, hipStream_t stream);
+                int64_t zero_rows_to, int32_t *rowmap, hipStream_t stream);
+int launch_unpack(const char *packed, int64_t n, int d, const int32_t *rowmap, float *out,
+                  hipStream_t stream);
 // (Re)builds the fp16 image, StageMeta and the global max row norm for the stages that hold
 // rows [row_begin, row_end) from the f32 image (stage-local and idempotent: a partially
 // filled tail stage is simply rebuilt by the next append).  norm_max: atomicMax on float bits.
 int launch_pack16(const char *packed, int d, int64_t row_begin, int64_t row_end, char *packed16,
                   StageMeta *meta, float *norm_max, hipStream_t stream);
 // qk[q] = ||q||_2 * kNormSlack * kF16Kappa;  qscale[q] = 2^ceil(log2 max|q_d|)
+// (also re-arms zero_u32[q] = 0 when given: the per-query overflow counters of the filter pass)
 int launch_query_kappa(const float *q, int64_t nq, int d, float *qk, float *qscale,
-                       hipStream_t stream);
+                       uint32_t *zero_u32, hipStream_t stream);
+constexpr uint32_t kOvfCap = 1024;   // overflow entries per query (= the list kernel's capacity)
+constexpr uint32_t kOvfPerSeg = 256;  // ... of which at most this many from one segment (a segment
+                                      // that overflows by more flags the query for the exact redo)
 // topk_select16.hip: lower[q] = (K-th largest bin maximum) - eps[q]
 int launch_bin_threshold(const float *binmax, int64_t ld, int n_bins, int64_t nq, int k,
                          const float *qk, const float *norm_max, float *lower,
@@ -273,6 +293,7 @@ int launch_bin_threshold(const float *binmax, int64_t ld, int n_bins, int64_t nq
 int launch_list_topk16(const float *q, int64_t nq, int d, const char *packed, const uint2 *buf,
                        const uint32_t *cnt, uint32_t cap_l, int nseg, int k, const float *qk,
                        const float *norm_max, float *out_scores, int32_t *out_idx, uint32_t *redo,
-                       int64_t idx_base, hipStream_t stream);
+                       int64_t idx_base, const uint32_t *ovf_cnt, const uint2 *ovf_buf,
+                       uint32_t ovf_cap, const int32_t *rowmap, hipStream_t stream);
 
 }  // namespace tfrs

@@ -274,10 +274,10 @@ __global__ void __launch_bounds__(256) scatter_add_kernel(
 // when vocab * n is small (the MovieLens-sized tables of BASELINE configs[0]), where it
 // replaces a 40 us radix sort + zero-fill per table with one ~5 us kernel.
 template <typename IdT>
-__global__ void __launch_bounds__(256) scatter_rowscan_kernel(
+__device__ __forceinline__ void scatter_rowscan_body(
     const float *__restrict__ grad_out, const void *__restrict__ ids, int64_t n, int d,
     int64_t vocab, float *__restrict__ dst, float *__restrict__ accum, float lr, float eps,
-    int adagrad) {
+    int adagrad, int64_t block) {
   // the id list goes through LDS in chunks shared by the workgroup's 4 rows, so a wave's scan
   // is 64 LDS reads per 4096 ids instead of 64 dependent global loads
   constexpr int kChunk = 4096;
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256) scatter_rowscan_kernel(
   __shared__ int s_hits[4][kHitCap];
   int *my_hits = s_hits[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63;
-  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t v = block * 4 + (threadIdx.x >> 6);
   const bool row_ok = v < vocab;
   float g[4] = {0.f, 0.f, 0.f, 0.f};  // features lane, lane + 64, lane + 128, lane + 192
   bool touched = false;
@@ -351,6 +351,44 @@ __global__ void __launch_bounds__(256) scatter_rowscan_kernel(
       dst[o] = g[s];  // untouched rows get their zeros here: no separate fill
     }
   }
+}
+
+template <typename IdT>
+__global__ void __launch_bounds__(256) scatter_rowscan_kernel(
+    const float *__restrict__ grad_out, const void *__restrict__ ids, int64_t n, int d,
+    int64_t vocab, float *__restrict__ dst, float *__restrict__ accum, float lr, float eps,
+    int adagrad) {
+  scatter_rowscan_body<IdT>(grad_out, ids, n, d, vocab, dst, accum, lr, eps, adagrad, blockIdx.x);
+}
+
+// Several small tables in ONE launch (the user and item tables of a two-tower step): each table's
+// scan is a chain of dependent latencies (ids -> hits -> gradient rows -> row update), so two
+// launches back to back cost twice the chain while one launch overlaps them.
+struct RowscanTables {
+  int ntab;
+  int first_block[9];          // table t owns blocks [first_block[t], first_block[t + 1])
+  const float *grad_out[8];
+  const void *ids[8];
+  int64_t n[8];
+  int d[8];
+  int64_t vocab[8];
+  float *dst[8];
+  float *accum[8];
+  int i64[8];
+};
+__global__ void __launch_bounds__(256) scatter_rowscan_multi_kernel(const RowscanTables t, float lr, float eps,
+                                                                    int adagrad) {
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if (i < t.ntab && (int)blockIdx.x >= t.first_block[i]) k = i;
+  const int64_t block = (int)blockIdx.x - t.first_block[k];
+  if (t.i64[k])
+    scatter_rowscan_body<int64_t>(t.grad_out[k], t.ids[k], t.n[k], t.d[k], t.vocab[k], t.dst[k], t.accum[k], lr,
+                                  eps, adagrad, block);
+  else
+    scatter_rowscan_body<int32_t>(t.grad_out[k], t.ids[k], t.n[k], t.d[k], t.vocab[k], t.dst[k], t.accum[k], lr,
+                                  eps, adagrad, block);
 }
 
 static unsigned grid_for(int64_t total_threads, int64_t cap = 256 * 8) {
@@ -729,6 +767,37 @@ extern "C" int tfrs_embedding_scatter_add_unsorted(const float *grad_out, const 
   else
     hipLaunchKernelGGL((scatter_add_u32_kernel<1>), grid, block, 0, s, grad_out, keys[cur], vals[cur], n, d,
                        (uint32_t)vocab, grad_table_or_table, accum, lr, eps, adagrad);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+extern "C" int tfrs_embedding_scatter_add_rowscan_multi(int ntables, const float *const *grad_out_h,
+                                                        const void *const *ids_h,
+                                                        const int *ids_are_i64_h, const int64_t *n_h,
+                                                        const int *d_h, const int64_t *vocab_h,
+                                                        float *const *tables_h, float *const *accum_h,
+                                                        float lr, float eps, int adagrad,
+                                                        void *stream) {
+  TFRS_CHECK_ARG(ntables >= 1 && ntables <= 8, "embedding_scatter_add_rowscan_multi: 1..8 tables");
+  TFRS_CHECK_ARG(grad_out_h && ids_h && ids_are_i64_h && n_h && d_h && vocab_h && tables_h,
+                 "embedding_scatter_add_rowscan_multi: NULL argument array");
+  tfrs::RowscanTables t = {};
+  t.ntab = ntables;
+  int blocks = 0;
+  for (int i = 0; i < ntables; ++i) {
+    TFRS_CHECK_ARG(n_h[i] >= 0 && d_h[i] >= 1 && d_h[i] <= 256 && vocab_h[i] >= 1,
+                   "embedding_scatter_add_rowscan_multi: bad shape of table %d", i);
+    TFRS_CHECK_ARG(tables_h[i] && (n_h[i] == 0 || (grad_out_h[i] && ids_h[i])) && (!adagrad || (accum_h && accum_h[i])),
+                   "embedding_scatter_add_rowscan_multi: NULL pointer for table %d", i);
+    t.first_block[i] = blocks;
+    blocks += (int)((vocab_h[i] + 3) / 4);
+    t.grad_out[i] = grad_out_h[i]; t.ids[i] = ids_h[i]; t.n[i] = n_h[i]; t.d[i] = d_h[i];
+    t.vocab[i] = vocab_h[i]; t.dst[i] = tables_h[i]; t.accum[i] = accum_h ? accum_h[i] : nullptr;
+    t.i64[i] = ids_are_i64_h[i];
+  }
+  t.first_block[ntables] = blocks;
+  hipLaunchKernelGGL(tfrs::scatter_rowscan_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     t, lr, eps, adagrad);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
 }

@@ -168,6 +168,8 @@ struct RoundWs {
   float *qscale;    // [nq]
   uint32_t *redo;   // [1 + nq] count + flagged query list
   uint64_t *part_keys;  // [nq, kRecomputeChunks, k] partial lists of the exact-recompute fallback
+  uint32_t *ovf_cnt;    // [nq] fp16 path: survivors beyond their segment's capacity ...
+  uint2 *ovf_buf;       // [nq, kOvfCap] ... go here
   char *end;
 };
 
@@ -179,6 +181,7 @@ static size_t round_ws_bytes(int64_t nq, int64_t n, int k, const TopkTuning &t) 
   b += align_up((size_t)nq * list_entries_per_query(nq, k, t) * 8);      // buf
   b += 2 * align_up((size_t)nq * 4) + align_up((size_t)(nq + 1) * 4);    // qk, qscale, redo
   b += align_up((size_t)nq * kRecomputeChunks * k * 8);                  // part_keys
+  b += align_up((size_t)nq * 4) + align_up((size_t)nq * kOvfCap * 8);    // ovf_cnt, ovf_buf
   return b;
 }
 
@@ -202,6 +205,10 @@ static RoundWs carve_round_ws(char *p, int64_t nq, int64_t n, int k, const TopkT
   p += align_up((size_t)(nq + 1) * 4);
   w.part_keys = reinterpret_cast<uint64_t *>(p);
   p += align_up((size_t)nq * kRecomputeChunks * k * 8);
+  w.ovf_cnt = reinterpret_cast<uint32_t *>(p);
+  p += align_up((size_t)nq * 4);
+  w.ovf_buf = reinterpret_cast<uint2 *>(p);
+  p += align_up((size_t)nq * kOvfCap * 8);
   w.end = p;
   return w;
 }
@@ -227,7 +234,8 @@ static void plan_splits(int64_t rows, int n_qtiles, const TopkTuning &t, int64_t
 static int run_rounds(const float *q, int64_t nq, int d, const char *packed, int64_t n,
                       int64_t idx_base, int64_t seen, int k, float *state_scores,
                       int32_t *state_idx, int state_len, const RoundWs &w,
-                      const TopkTuning &t, hipStream_t stream, int *new_len) {
+                      const TopkTuning &t, hipStream_t stream, int *new_len,
+                      const int32_t *rowmap = nullptr) {
   int len = state_len;
   if (n <= 0 || nq <= 0) {
     *new_len = len;
@@ -248,8 +256,10 @@ static int run_rounds(const float *q, int64_t nq, int d, const char *packed, int
   sa.buf = w.buf;
   sa.dense = w.dense;
   sa.ld_dense = w.ld_dense;
+  sa.tie_ge = rowmap != nullptr;
 
   SelectArgs se = {};
+  se.rowmap = rowmap;
   se.nq = nq;
   se.k = k;
   se.state_scores = state_scores;
@@ -345,10 +355,13 @@ static void plan_stage_splits(int64_t n_stages, int n_qtiles, const TopkTuning &
 static int run_f16(const float *q, int64_t nq, int d, const char *packed, const F16Image &img,
                    int64_t n, int64_t idx_base, int k, const SamplePlan &sp, bool lower_preset,
                    float *out_scores, int32_t *out_idx, const RoundWs &w, const TopkTuning &t,
-                   hipStream_t stream) {
+                   hipStream_t stream, const int32_t *rowmap = nullptr) {
   const int n_qtiles = (int)((nq + kScan16QueriesPerWg - 1) / kScan16QueriesPerWg);
   int rc;
-  if ((rc = launch_query_kappa(q, nq, d, w.qk, w.qscale, stream)) != TFRS_OK) return rc;
+  const char *gen = getenv("TFRS_SCAN16_V");
+  const bool use_ovf = !(gen && gen[0] == '1');   // the first-generation kernel has no overflow lists
+  if ((rc = launch_query_kappa(q, nq, d, w.qk, w.qscale, use_ovf ? w.ovf_cnt : nullptr, stream)) != TFRS_OK)
+    return rc;
 
   Scan16Args s16 = {};
   s16.q = q;
@@ -395,13 +408,17 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
     return TFRS_ENOMEM;
   }
   s16.drain_min = (int)t.drain_min;
+  s16.ovf_cnt = use_ovf ? w.ovf_cnt : nullptr;
+  s16.ovf_buf = w.ovf_buf;
+  s16.ovf_cap = kOvfCap;
   s16.zero_word = reinterpret_cast<uint32_t *>(w.redo);   // the flagged-query counter, re-armed
   if ((rc = timed_scan16(s16, 2.0 * (double)nq * (double)n * d, stream)) != TFRS_OK) return rc;
 
   // prefilter top-K + exact re-scoring; flagged queries (list overflow, retained set too
   // large) are answered by the exact recompute path of the generic select kernel
   if ((rc = launch_list_topk16(q, nq, d, packed, w.buf, w.cnt, s16.cap_l, s16.nseg, k, w.qk,
-                               img.norm_max, out_scores, out_idx, w.redo, idx_base, stream)) != TFRS_OK)
+                               img.norm_max, out_scores, out_idx, w.redo, idx_base, s16.ovf_cnt, w.ovf_buf,
+                               kOvfCap, rowmap, stream)) != TFRS_OK)
     return rc;
   SelectArgs se = {};
   se.nq = nq;
@@ -412,6 +429,7 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
   se.source = kSrcRecompute;
   se.only_flagged = w.redo;
   se.part_keys = w.part_keys;
+  se.rowmap = rowmap;
   se.idx_base = idx_base;
   se.rc_begin = 0;
   se.rc_end = n;
@@ -471,12 +489,21 @@ struct tfrs_index {
   int64_t n = 0;         // valid rows
   int64_t capacity = 0;  // rows allocated (multiple of kTileN)
   int d = 0;
+  // Shuffled storage (default for indexes of >= 65536 rows; TFRS_INDEX_SHUFFLE=0 disables): every
+  // appended block is stored in a pseudo-random row order and rowmap[image row] = original row.
+  // The fp16-prefiltered search takes its threshold from bin maxima of sampled stages, which
+  // presumes that a query's best candidates are spread over the image; a corpus stored cluster by
+  // cluster (any locality in the row order) breaks that -- the shuffle restores it for every
+  // input order.  Keys are formed from ORIGINAL row numbers, so results and tie order are unchanged.
+  int32_t *rowmap = nullptr;
 };
 
 static void index_free(tfrs_index *index) {
   if (index->packed) (void)hipFree(index->packed);
   if (index->packed16) (void)hipFree(index->packed16);
   if (index->meta) (void)hipFree(index->meta);  // norm_max lives in the same block
+  if (index->rowmap) (void)hipFree(index->rowmap);
+  index->rowmap = nullptr;
   index->packed = index->packed16 = nullptr;
   index->meta = nullptr;
   index->norm_max = nullptr;
@@ -518,6 +545,10 @@ extern "C" int tfrs_index_reserve(tfrs_index_t *index, int64_t capacity, int d, 
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&index->packed16), bytes16);
   if (e == hipSuccess)
     e = hipMalloc(reinterpret_cast<void **>(&index->meta), (nstages + 1) * sizeof(StageMeta));
+  const char *sh = getenv("TFRS_INDEX_SHUFFLE");
+  const bool shuffle = capacity >= 65536 && !(sh && sh[0] == '0');
+  if (e == hipSuccess && shuffle)
+    e = hipMalloc(reinterpret_cast<void **>(&index->rowmap), (size_t)index->capacity * sizeof(int32_t));
   if (e != hipSuccess) {
     index_free(index);
     index->capacity = 0;
@@ -538,7 +569,7 @@ extern "C" int tfrs_index_append(tfrs_index_t *index, const float *block, int64_
                  (long long)index->n, (long long)nb, (long long)index->capacity);
   // zero-fill up to the next stage boundary so whole stages can always be read
   const int64_t zero_to = padded_rows(index->n + nb);
-  int rc = launch_pack(block, nb, index->d, index->packed, index->n, zero_to,
+  int rc = launch_pack(block, nb, index->d, index->packed, index->n, zero_to, index->rowmap,
                        (hipStream_t)stream);
   if (rc != TFRS_OK) return rc;
   // (re)build the fp16 image of every stage this block touched, from the f32 image
@@ -562,7 +593,7 @@ extern "C" int tfrs_index_dim(const tfrs_index_t *index) { return index ? index-
 
 extern "C" int tfrs_index_unpack(const tfrs_index_t *index, float *out, void *stream) {
   TFRS_CHECK_ARG(index && index->packed, "index_unpack: not indexed");
-  return launch_unpack(index->packed, index->n, index->d, out, (hipStream_t)stream);
+  return launch_unpack(index->packed, index->n, index->d, index->rowmap, out, (hipStream_t)stream);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -601,13 +632,14 @@ extern "C" int tfrs_bruteforce_topk(const tfrs_index_t *index, const float *quer
     if (sp.n_stages > 0) {
       const F16Image img = {index->packed16, index->meta, index->norm_max};
       return run_f16(queries, nq, index->d, index->packed, img, index->n, /*idx_base=*/0, k, sp,
-                     /*lower_preset=*/false, out_scores, out_idx, w, t, (hipStream_t)stream);
+                     /*lower_preset=*/false, out_scores, out_idx, w, t, (hipStream_t)stream,
+                     index->rowmap);
     }
   }
   int new_len = 0;
   return run_rounds(queries, nq, index->d, index->packed, index->n, /*idx_base=*/0,
                     /*seen=*/0, k, out_scores, out_idx, /*state_len=*/0, w, t,
-                    (hipStream_t)stream, &new_len);
+                    (hipStream_t)stream, &new_len, index->rowmap);
 }
 
 extern "C" int tfrs_bruteforce_topk_redo_count(const void *workspace, int64_t nq, int64_t n, int k,
@@ -644,7 +676,7 @@ extern "C" int tfrs_debug_fp16_scores(const tfrs_index_t *index, const float *qu
   a.d = index->d;
   a.packed16 = index->packed16;
   a.meta = index->meta;
-  int rc = launch_query_kappa(queries, nq, index->d, scratch, scratch + nq, (hipStream_t)stream);
+  int rc = launch_query_kappa(queries, nq, index->d, scratch, scratch + nq, nullptr, (hipStream_t)stream);
   if (rc != TFRS_OK) return rc;
   a.qk = scratch;
   a.qscale = scratch + nq;
@@ -711,7 +743,7 @@ extern "C" int tfrs_streaming_topk_update(const float *queries, int64_t nq, int 
   }
   const RoundWs w = carve_round_ws(static_cast<char *>(workspace), nq, nb, k, t);
   char *packed = w.end;
-  int rc = launch_pack(cand_block, nb, d, packed, 0, padded_rows(nb), (hipStream_t)stream);
+  int rc = launch_pack(cand_block, nb, d, packed, 0, padded_rows(nb), nullptr, (hipStream_t)stream);
   if (rc != TFRS_OK) return rc;
   int new_len = state_len;
   if (stream_block_f16(nb, k, t)) {

@@ -8,7 +8,9 @@ namespace tfrs {
 __global__ void __launch_bounds__(256) pack_kernel(const float *__restrict__ cand,
                                                    int64_t n, int d, int dp,
                                                    char *__restrict__ packed,
-                                                   int64_t dst_row, int64_t total_rows) {
+                                                   int64_t dst_row, int64_t total_rows,
+                                                   int64_t mul, int64_t add,
+                                                   int32_t *__restrict__ rowmap) {
   const int slots = dp / 4 + 1;  // incl. pad slot
   const int half = dp / 8;       // slots per plane
   const int64_t nslots = total_rows * slots;
@@ -17,10 +19,12 @@ __global__ void __launch_bounds__(256) pack_kernel(const float *__restrict__ can
     const int64_t r = t / slots;
     const int s = (int)(t - r * slots);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t src = (rowmap && r < n) ? (mul * r + add) % n : r;   // shuffled block
+    if (rowmap && r < n && s == 0) rowmap[dst_row + r] = (int32_t)(dst_row + src);
     if (r < n && s < 2 * half) {
       const int h = s / half;  // 0: even features, 1: odd features
       const int m = s - h * half;
-      const float *row = cand + r * d;
+      const float *row = cand + src * d;
       const int k0 = 8 * m + h;  // features k0, k0+2, k0+4, k0+6
       v.x = (k0 < d) ? row[k0] : 0.f;
       v.y = (k0 + 2 < d) ? row[k0 + 2] : 0.f;
@@ -34,6 +38,7 @@ __global__ void __launch_bounds__(256) pack_kernel(const float *__restrict__ can
 
 __global__ void __launch_bounds__(256) unpack_kernel(const char *__restrict__ packed,
                                                      int64_t n, int d, int dp,
+                                                     const int32_t *__restrict__ rowmap,
                                                      float *__restrict__ out) {
   const int half = dp / 8;
   const int64_t total = n * d;
@@ -43,33 +48,45 @@ __global__ void __launch_bounds__(256) unpack_kernel(const char *__restrict__ pa
     const int k = (int)(t - r * d);
     const int h = k & 1, s = k >> 1;  // plane, position inside the plane
     const float *row = reinterpret_cast<const float *>(packed + r * (int64_t)row_bytes(dp));
-    out[t] = row[h * half * 4 + s];
+    out[(rowmap ? (int64_t)rowmap[r] : r) * d + k] = row[h * half * 4 + s];
   }
 }
 
 // Packs cand[n, d] into rows dst_row .. dst_row+n-1 and zero-fills rows up to
 // zero_rows_to (exclusive, >= dst_row + n) so that whole kTileN stages can be read.
+static int64_t gcd64(int64_t a, int64_t b) {
+  while (b) { const int64_t t = a % b; a = b; b = t; }
+  return a;
+}
+
 int launch_pack(const float *cand, int64_t n, int d, char *packed, int64_t dst_row,
-                int64_t zero_rows_to, hipStream_t stream) {
+                int64_t zero_rows_to, int32_t *rowmap, hipStream_t stream) {
   const int dp = padded_dim(d);
   const int64_t total_rows = zero_rows_to - dst_row;
   if (total_rows <= 0) return TFRS_OK;
   const int64_t nslots = total_rows * (dp / 4 + 1);
   int64_t blocks = (nslots + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
+  int64_t mul = 1, add = 0;
+  if (rowmap && n > 1) {   // multiplicative shuffle: stride ~ n / golden ratio, coprime to n
+    mul = (int64_t)((double)n * 0.6180339887498949) | 1;
+    while (gcd64(mul, n) != 1) mul += 2;
+    add = n / 3;
+  }
   hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, cand, n, d,
-                     dp, packed, dst_row, total_rows);
+                     dp, packed, dst_row, total_rows, mul, add, rowmap);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
 }
 
-int launch_unpack(const char *packed, int64_t n, int d, float *out, hipStream_t stream) {
+int launch_unpack(const char *packed, int64_t n, int d, const int32_t *rowmap, float *out,
+                  hipStream_t stream) {
   if (n <= 0) return TFRS_OK;
   const int dp = padded_dim(d);
   int64_t blocks = (n * d + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, packed, n,
-                     d, dp, out);
+                     d, dp, rowmap, out);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
 }
@@ -164,9 +181,11 @@ __global__ void __launch_bounds__(256) pack16_stage_kernel(const char *__restric
 
 __global__ void __launch_bounds__(256) query_kappa_kernel(const float *__restrict__ q, int64_t nq,
                                                           int d, float *__restrict__ qk,
-                                                          float *__restrict__ qscale) {
+                                                          float *__restrict__ qscale,
+                                                          uint32_t *__restrict__ zero_u32) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nq) return;
+  if (zero_u32) zero_u32[r] = 0u;
   const float *row = q + r * d;
   float ssq = 0.0f, amax = 0.0f;
   for (int k = 0; k < d; ++k) {
@@ -189,10 +208,10 @@ int launch_pack16(const char *packed, int d, int64_t row_begin, int64_t row_end,
 }
 
 int launch_query_kappa(const float *q, int64_t nq, int d, float *qk, float *qscale,
-                       hipStream_t stream) {
+                       uint32_t *zero_u32, hipStream_t stream) {
   if (nq <= 0) return TFRS_OK;
   hipLaunchKernelGGL(query_kappa_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0,
-                     stream, q, nq, d, qk, qscale);
+                     stream, q, nq, d, qk, qscale, zero_u32);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
 }

@@ -108,7 +108,17 @@ __global__ void __launch_bounds__(kThreads, DP <= 64 ? 4 : 2) scan_kernel(const 
     bq[s] = (qvalid && k < a.d) ? a.q[qrow * a.d + k] : 0.0f;
   }
   float thr = 0.0f;
-  if (!MATERIALIZE) thr = qvalid ? a.thr[qrow] : __builtin_inff();
+  if (!MATERIALIZE) {
+    thr = qvalid ? a.thr[qrow] : __builtin_inff();
+    // shuffled index: `score > nextbelow(thr)` keeps the ties with the K-th best (they are decided
+    // later by original row numbers)
+    if (a.tie_ge && thr > -__builtin_inff() && thr < __builtin_inff()) {
+      const uint32_t u = f32_orderable(thr);
+      float below = f32_from_orderable(u - 1u);
+      if (below == thr) below = f32_from_orderable(u - 2u);   // +0 -> -0 compares equal
+      thr = below;
+    }
+  }
 
   // this lane's private survivor segment
   const int64_t seg = qrow * a.nseg + 2 * split + h;

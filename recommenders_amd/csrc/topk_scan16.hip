@@ -505,10 +505,16 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16f_kernel(c
           // one LDS round trip: the slot (atomic) and the segment's constants together
           const uint32_t slot = lds_atomic_inc(&wcnt[src]);
           const float2 zc = *reinterpret_cast<const float2 *>(&qconst[src].z);
+          const float un = zc.x * __uint_as_float(hd.y);   // qscale * stage scale
           if (slot < a.cap_l) {
-            const float un = zc.x * __uint_as_float(hd.y);   // qscale * stage scale
             a.buf[(uint64_t)(__float_as_uint(zc.y) + slot * (uint32_t)a.nseg)] =
                 make_uint2(__float_as_uint(v * un), row);
+          } else if (a.ovf_cnt && slot - a.cap_l < kOvfPerSeg) {
+            // the segment is full (rows ordered by cluster: a query's survivors sit in one or two
+            // splits): per-query overflow list, one global atomic per such survivor
+            const int64_t qrow = q0 + (src >> 6) * 32 + (src & 31);
+            const uint32_t o = atomicAdd(&a.ovf_cnt[qrow], 1u);
+            if (o < a.ovf_cap) a.ovf_buf[qrow * (int64_t)a.ovf_cap + o] = make_uint2(__float_as_uint(v * un), row);
           }
         }
       }

@@ -168,7 +168,8 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
       uint64_t key = 0ull;
       if (e < m) {
         const int64_t crow = a.rc_begin + e;
-        key = make_key(packed_score(a.packed, crow, dp, qs), (int32_t)(crow + a.idx_base));
+        key = make_key(packed_score(a.packed, crow, dp, qs),
+                       (int32_t)((a.rowmap ? (int64_t)a.rowmap[crow] : crow) + a.idx_base));
       }
       consume(key);
     }
@@ -201,7 +202,8 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
           for (int u = 0; u < 4; ++u) {
             uint64_t key = 0ull;
             if (e0 + u < c)
-              key = make_key(__uint_as_float(ent[u].x), (int32_t)((int64_t)ent[u].y + a.idx_base));
+              key = make_key(__uint_as_float(ent[u].x),
+                             (int32_t)((a.rowmap ? (int64_t)a.rowmap[ent[u].y] : (int64_t)ent[u].y) + a.idx_base));
             consume(key);
           }
         }
@@ -210,7 +212,8 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
   } else if (source == kSrcDense) {
     for (int64_t base = 0; base < a.n_dense; base += 64) {
       const int64_t e = base + lane;
-      consume(e < a.n_dense ? make_key(a.dense[row * a.ld_dense + e], (int32_t)(a.idx_base + e))
+      consume(e < a.n_dense ? make_key(a.dense[row * a.ld_dense + e],
+                                       (int32_t)(a.idx_base + (a.rowmap ? (int64_t)a.rowmap[e] : e)))
                             : 0ull);
     }
   } else {
@@ -294,7 +297,8 @@ __global__ void __launch_bounds__(NW * 64) recompute_kernel(const SelectArgs a) 
     uint64_t key = 0ull;
     if (e < hi) {
       const int64_t crow = a.rc_begin + e;
-      key = make_key(packed_score(a.packed, crow, dp, qs), (int32_t)(crow + a.idx_base));
+      key = make_key(packed_score(a.packed, crow, dp, qs),
+                       (int32_t)((a.rowmap ? (int64_t)a.rowmap[crow] : crow) + a.idx_base));
     }
     consume(key);
   }

@@ -161,6 +161,10 @@ struct List16Args {
   int32_t *out_idx;      // [nq, k] (row + idx_base; -1 marks an empty slot: fewer than k survivors)
   uint32_t *redo;        // [1 + nq]: count, then the queries to answer with the exact recompute path
   int64_t idx_base;      // added to the image-local row numbers
+  const uint32_t *ovf_cnt;   // [nq] or NULL: survivors that did not fit their segment ...
+  const uint2 *ovf_buf;      // [nq, ovf_cap]
+  uint32_t ovf_cap;
+  const int32_t *rowmap;     // shuffled index: image row -> original row (NULL: identity)
 };
 
 // KP: slots for the retained set (>= K + band); the list itself may hold up to 64 * kSlots.
@@ -203,7 +207,14 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
       cnts[b] = (sg < a.nseg) ? a.cnt[row * a.nseg + sg] : 0u;
     }
 #pragma unroll
-    for (int b = 0; b < kCntBatch; ++b) bad = bad || (cnts[b] > a.cap_l);
+    for (int b = 0; b < kCntBatch; ++b) {
+      if (a.ovf_cnt) {   // the excess (up to kOvfPerSeg per segment) went to the overflow list
+        bad = bad || (cnts[b] > a.cap_l + kOvfPerSeg);
+        cnts[b] = min(cnts[b], a.cap_l);
+      } else {
+        bad = bad || (cnts[b] > a.cap_l);
+      }
+    }
     if (__ballot(bad) != 0ull) {   // (uniform) the query is redone anyway
       bad = true;
       break;
@@ -236,6 +247,15 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
         for (int x = 0; x < 4; ++x) push(e0 + x < cnts[b], w[x]);
       }
     }
+  }
+  if (a.ovf_cnt && __ballot(bad) == 0ull) {   // the query's overflow list (usually empty)
+    const uint32_t novf = a.ovf_cnt[row];
+    if (novf > a.ovf_cap) bad = true;
+    else
+      for (uint32_t e0 = 0; e0 < novf; e0 += 64) {
+        const bool p = e0 + lane < novf;
+        push(p, p ? a.ovf_buf[row * (int64_t)a.ovf_cap + e0 + lane] : make_uint2(0u, 0u));
+      }
   }
   if (__ballot(bad) != 0ull || total > kCap) {
     if (lane == 0) a.redo[1 + atomicAdd(a.redo, 1u)] = (uint32_t)row;
@@ -291,7 +311,7 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
       uint64_t kk = 0ull;
       if (u * 64 + lane < m)
         kk = make_key(packed_score16(a.packed, (int64_t)kid[u], dp, qs),
-                      (int32_t)((int64_t)kid[u] + a.idx_base));
+                      (int32_t)((a.rowmap ? (int64_t)a.rowmap[kid[u]] : (int64_t)kid[u]) + a.idx_base));
       ex[u * 64 + lane] = kk;
     }
   }
@@ -318,7 +338,8 @@ static int launch_list16_kp(const List16Args &a, hipStream_t stream) {
 int launch_list_topk16(const float *q, int64_t nq, int d, const char *packed, const uint2 *buf,
                        const uint32_t *cnt, uint32_t cap_l, int nseg, int k, const float *qk,
                        const float *norm_max, float *out_scores, int32_t *out_idx, uint32_t *redo,
-                       int64_t idx_base, hipStream_t stream) {
+                       int64_t idx_base, const uint32_t *ovf_cnt, const uint2 *ovf_buf,
+                       uint32_t ovf_cap, const int32_t *rowmap, hipStream_t stream) {
   if (nq <= 0) return TFRS_OK;
   List16Args a;
   a.idx_base = idx_base;
@@ -336,6 +357,10 @@ int launch_list_topk16(const float *q, int64_t nq, int d, const char *packed, co
   a.out_scores = out_scores;
   a.out_idx = out_idx;
   a.redo = redo;
+  a.ovf_cnt = ovf_cnt;
+  a.ovf_buf = ovf_buf;
+  a.ovf_cap = ovf_cap;
+  a.rowmap = rowmap;
   const int need = 2 * k;  // K + room for the 2*eps band
   if (need <= 128) return launch_list16_kp<128>(a, stream);
   if (need <= 256) return launch_list16_kp<256>(a, stream);

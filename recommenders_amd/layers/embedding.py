@@ -103,6 +103,37 @@ def adagrad_sparse_update_(table: torch.Tensor, accum: torch.Tensor, grad_out: t
   _scatter_unsorted(g, ids.reshape(-1).contiguous(), table.shape[0], table, accum, lr, eps, 1)
 
 
+def adagrad_sparse_update_multi_(updates, lr: float, eps: float = 1e-7) -> None:
+  """``adagrad_sparse_update_`` for several tables of one optimizer step; ``updates`` is a list of
+  ``(table, accum, grad_rows, ids)``.  The small tables (row-scan path) of the step go out in
+  ONE launch (``tfrs_embedding_scatter_add_rowscan_multi``): each table's update is a chain of
+  dependent latencies, so separate launches pay the chain once per table."""
+  small, rest = [], []
+  for table, accum, grad_out, ids in updates:
+    d = grad_out.shape[-1]
+    if ids.dtype not in (torch.int32, torch.int64):
+      ids = ids.long()
+    (small if _use_rowscan(table.shape[0], ids.numel(), d) else rest).append(
+        (table, accum, grad_out.reshape(-1, d).contiguous(), ids.reshape(-1).contiguous()))
+  for table, accum, g, ids in rest:
+    adagrad_sparse_update_(table, accum, g, ids, lr, eps)
+  for lo in range(0, len(small), 8):
+    grp = small[lo:lo + 8]
+    if len(grp) == 1:
+      table, accum, g, ids = grp[0]
+      adagrad_sparse_update_(table, accum, g, ids, lr, eps)
+      continue
+    import ctypes
+    n = len(grp)
+    vp, i64a, ia = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+    _lib.check(_lib.load().tfrs_embedding_scatter_add_rowscan_multi(
+        n, vp(*[g.data_ptr() for _, _, g, _ in grp]), vp(*[i.data_ptr() for _, _, _, i in grp]),
+        ia(*[1 if i.dtype == torch.int64 else 0 for _, _, _, i in grp]),
+        i64a(*[i.numel() for _, _, _, i in grp]), ia(*[g.shape[-1] for _, _, g, _ in grp]),
+        i64a(*[t.shape[0] for t, _, _, _ in grp]), vp(*[t.data_ptr() for t, _, _, _ in grp]),
+        vp(*[a.data_ptr() for _, a, _, _ in grp]), float(lr), float(eps), 1, _lib.current_stream()))
+
+
 def _emit_table_grad(ctx, grad_out):
   """Backward of a lookup.  Default: the dense ``[vocab, d]`` gradient.  When the table is
   owned by ``recommenders_amd.optimizers.Adagrad`` the ``(ids, grad_rows)`` slices are handed

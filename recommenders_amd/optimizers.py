@@ -89,6 +89,7 @@ class Adagrad(torch.optim.Optimizer):
         loss = closure()
     for group in self.param_groups:
       lr, eps = group["learning_rate"], group["epsilon"]
+      sparse = []     # (table, accumulator, grad rows, ids) of every looked-up table of the group
       for p in group["params"]:
         acc = self._accumulator(p, group["initial_accumulator_value"])
         slices = getattr(p, "_tfrs_slices", None)
@@ -98,8 +99,12 @@ class Adagrad(torch.optim.Optimizer):
           else:   # the same table looked up several times: one combined IndexedSlices
             ids = torch.cat([s[0].reshape(-1) for s in slices])
             rows = torch.cat([s[1].reshape(-1, p.shape[1]) for s in slices])
-          emb.adagrad_sparse_update_(p.data, acc, rows, ids, lr, eps)
+          sparse.append((p.data, acc, rows, ids))
           slices.clear()
+      if sparse:
+        emb.adagrad_sparse_update_multi_(sparse, lr, eps)   # small tables: one launch for all
+      for p in group["params"]:
+        acc = self._accumulator(p, group["initial_accumulator_value"])
         if p.grad is not None:
           g = p.grad
           acc.addcmul_(g, g)

@@ -324,3 +324,35 @@ def test_wide_embedding_dims_topk_and_retrieval(d):
   dq, dc = o_ret.loss_grads(_np(qe.detach()), _np(ce.detach()))
   np.testing.assert_allclose(_np(qe.grad), dq, rtol=1e-4, atol=1e-6)
   np.testing.assert_allclose(_np(ce.grad), dc, rtol=1e-4, atol=1e-6)
+
+
+def test_cluster_ordered_corpus_stays_exact():
+  """Rows grouped by cluster are the adversarial order for the sampled-bin threshold: a query's
+  whole top-K sits in a few consecutive stages, so its survivors overflow their list segments
+  (per-query overflow lists) or the list itself (exact-redo path).  Slow, but results stay exact.
+  A moderately clustered corpus (second part: clusters of ~60 rows) must not need the redo path."""
+  ftk = _ftk()
+  rng = np.random.default_rng(99)
+  n, d, nq, k, ncl = 400_000, 64, 512, 100, 200
+  centers = rng.normal(size=(ncl, d)) / np.sqrt(d)
+  cl = np.sort(rng.integers(0, ncl, size=n))                       # grouped by cluster
+  c = (centers[cl] + 0.35 * rng.normal(size=(n, d)) / np.sqrt(d)).astype(np.float32)
+  qcl = rng.integers(0, ncl, size=nq)
+  q = (centers[qcl] + 0.35 * rng.normal(size=(nq, d)) / np.sqrt(d)).astype(np.float32)
+  layer = ftk.BruteForce(k=k).index(c)
+  s, i = layer(q)
+  es, ei = o_topk.brute_force(q, c, k)
+  np.testing.assert_array_equal(_np(i), ei)
+  np.testing.assert_array_equal(_np(s), es)
+  # many small clusters (rows still grouped): survivors concentrate in a few segments only
+  ncl2 = 6000
+  centers2 = rng.normal(size=(ncl2, d)) / np.sqrt(d)
+  cl2 = np.sort(rng.integers(0, ncl2, size=n))
+  c2 = (centers2[cl2] + 0.6 * rng.normal(size=(n, d)) / np.sqrt(d)).astype(np.float32)
+  q2 = (centers2[rng.integers(0, ncl2, size=nq)] + 0.6 * rng.normal(size=(nq, d)) / np.sqrt(d)).astype(np.float32)
+  layer2 = ftk.BruteForce(k=k).index(c2)
+  s2, i2 = layer2(q2)
+  es2, ei2 = o_topk.brute_force(q2, c2, k)
+  np.testing.assert_array_equal(_np(i2), ei2)
+  np.testing.assert_array_equal(_np(s2), es2)
+  assert layer2.last_redo_count() <= nq // 20
