@@ -385,25 +385,45 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
 // A tile that does not fit into the queue any more (adversarial data: near-duplicate clusters)
 // takes a direct per-element path with the same counters; nothing is ever dropped silently (counts
 // beyond cap_l flag the query for the exact redo exactly as before).
-template <int DP>
+template <int DP, int NW, int QG>
 struct Scan16FGeom : Scan16Geom<DP> {
   using B = Scan16Geom<DP>;
+  static_assert(NW * QG * 32 == kScan16QueriesPerWg, "queries per workgroup");
+  static constexpr int kThreads = NW * 64;
+  static constexpr int kLoadsF = (B::kChunks + kThreads - 1) / kThreads;
   static constexpr int kQCap = 32;                       // queue entries per wave
   static constexpr int kEntB = 80;                       // 16 scores + 16-byte header
-  // queue + 128 segment counters + 128 x {flo, fqk, qscale, pad} per-query filter constants
-  static constexpr int kWaveB = kQCap * kEntB + 128 * 4 + 128 * 16;
+  // queue + QG * 64 segment counters + QG * 64 x {flo, fqk, qscale, segment base} filter constants
+  static constexpr int kWaveB = kQCap * kEntB + QG * 64 * 4 + QG * 64 * 16;
   static constexpr int kQueueOff = (B::kLdsBytes + 15) / 16 * 16;
-  static constexpr int kLdsBytesF = kQueueOff + kWaves16 * kWaveB;
+  static constexpr int kLdsBytesF = kQueueOff + NW * kWaveB;
 };
+
+// stage copy with NW waves (see stage16_glds)
+template <int CHUNKS, int LOADS, int THREADS>
+__device__ __forceinline__ void stage16f_glds(const char *gsrc, char *lds_dst, const StageMeta *meta,
+                                              char *lds_meta, int tid, int wave) {
+#pragma unroll
+  for (int i = 0; i < LOADS; ++i) {
+    const int ch0 = i * THREADS + wave * 64;
+    if (ch0 < CHUNKS)  // wave-uniform (CHUNKS is a multiple of 64)
+      glds_copy16(gsrc + (size_t)(i * THREADS + tid) * 16, lds_dst + ch0 * 16);
+  }
+  if (tid == 0) glds_copy16(reinterpret_cast<const char *>(meta), lds_meta);
+}
 
 __device__ __forceinline__ uint32_t lds_atomic_inc(uint32_t *p) {
   return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
 
-template <int DP>
-__global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16f_kernel(const Scan16Args a) {
-  using G = Scan16FGeom<DP>;
+// NW waves x QG query groups of 32 per wave (NW * QG * 32 = 512 queries per workgroup):
+//   <8, 2>  four waves per SIMD at <= 128 VGPRs (two workgroups per CU)
+//   <4, 4>  two waves per SIMD at <= 256 VGPRs: one set of A fragments (4 ds_read_b128) feeds 16
+//           MFMAs instead of 8 -- half the LDS reads per flop, half the waves per barrier
+template <int DP, int NW, int QG>
+__global__ void __launch_bounds__(NW * 64, (DP <= 64 ? 2 : 1) * NW / 4) scan16f_kernel(const Scan16Args a) {
+  using G = Scan16FGeom<DP, NW, QG>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -431,17 +451,17 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16f_kernel(c
   // per-wave LDS: survivor queue + the 128 (group, lane) segment counters
   char *const qbase = smem + G::kQueueOff + wave * G::kWaveB;
   uint32_t *const wcnt = reinterpret_cast<uint32_t *>(qbase + G::kQCap * G::kEntB);
-  wcnt[lane] = 0u;
-  wcnt[64 + lane] = 0u;
-  const int64_t q0 = (int64_t)qt * kScan16QueriesPerWg + wave * (kQG * 32);   // wave's first query
+  #pragma unroll
+  for (int g = 0; g < QG; ++g) wcnt[g * 64 + lane] = 0u;
+  const int64_t q0 = (int64_t)qt * kScan16QueriesPerWg + wave * (QG * 32);   // wave's first query
 
   // ---- this wave's 2 x 32 queries -> fp16 MFMA B operands (resident) -------------
-  f16x8 bq[kQG][G::kSteps];
+  f16x8 bq[QG][G::kSteps];
   // per (group, lane): {(lower - tiny) / qscale, qk / qscale, qscale} parked in LDS (re-read
   // once per stage: three more resident VGPR pairs do not fit under 128)
-  float4 *const qconst = reinterpret_cast<float4 *>(qbase + G::kQCap * G::kEntB + 128 * 4);
+  float4 *const qconst = reinterpret_cast<float4 *>(qbase + G::kQCap * G::kEntB + QG * 64 * 4);
 #pragma unroll
-  for (int g = 0; g < kQG; ++g) {
+  for (int g = 0; g < QG; ++g) {
     const int64_t qrow = q0 + g * 32 + j;
     const bool qvalid = qrow < a.nq;
     const float *qp = a.q + qrow * a.d;
@@ -529,14 +549,14 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16f_kernel(c
   const char *gsrc = a.packed16 + first_stage * (int64_t)G::kStageB;
   const int64_t gstep = (int64_t)a.stage_stride * (int64_t)G::kStageB;
   const StageMeta *mp = a.meta + first_stage;
-  stage16_glds<G::kChunks, G::kLoads>(gsrc, smem, mp, smem + G::kMetaOff, tid, wave);
+  stage16f_glds<G::kChunks, G::kLoadsF, G::kThreads>(gsrc, smem, mp, smem + G::kMetaOff, tid, wave);
   wait_dma();
   __syncthreads();
 
   for (int st = 0; st < nst; ++st) {
     const char *tile = smem + (st & 1) * G::kStageB;
     if (st + 1 < nst) {  // prefetch the next stage into the other buffer (its readers passed the barrier)
-      stage16_glds<G::kChunks, G::kLoads>(gsrc + (int64_t)(st + 1) * gstep,
+      stage16f_glds<G::kChunks, G::kLoadsF, G::kThreads>(gsrc + (int64_t)(st + 1) * gstep,
                                           smem + ((st + 1) & 1) * G::kStageB,
                                           mp + (int64_t)(st + 1) * a.stage_stride,
                                           smem + G::kMetaOff + ((st + 1) & 1) * 16, tid, wave);
@@ -547,9 +567,9 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16f_kernel(c
     const float s_norm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sm.norm)));
     const uint32_t s_scale_bits = __builtin_amdgcn_readfirstlane(__float_as_uint(sm.scale));
     const float s_inv = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sm.inv_scale)));
-    float thr[kQG];
+    float thr[QG];
 #pragma unroll
-    for (int g = 0; g < kQG; ++g) {
+    for (int g = 0; g < QG; ++g) {
       const float4 qc = qconst[g * 64 + lane];
       thr[g] = __builtin_fmaf(-qc.y, s_norm, qc.x) * s_inv;
     }
@@ -560,7 +580,7 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16f_kernel(c
 #pragma unroll
     for (int m = 0; m < G::kSteps; ++m) af[0][m] = *reinterpret_cast<const u32x4 *>(ap + m * 32);
 
-    f32x16 acc[kQG];
+    f32x16 acc[QG];
     auto chain = [&](int g, int sub) __attribute__((always_inline)) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[g][r] = 0.0f;
@@ -604,6 +624,8 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16f_kernel(c
       }
     };
 
+    if constexpr (QG == 2) {
+    // two groups, skewed by half a step: chain(g1, s) || check(g0, s), chain(g0, s + 1) || check(g1, s)
     chain(0, 0);
 #pragma unroll
     for (int sub = 0; sub < kTileN / 32; ++sub) {
@@ -625,6 +647,33 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16f_kernel(c
         check(1, sub);
       }
     }
+    } else {
+    // Software pipeline over the (sub-tile, group) pairs in order: the MFMA chain of pair p is
+    // issued, then the VALU work on the finished tile of pair p - 1 runs under it.  The A
+    // fragments of sub-tile s + 1 are fetched when the chains of sub-tile s start.
+#pragma unroll
+    for (int sub = 0; sub < kTileN / 32; ++sub) {
+      if (sub + 1 < kTileN / 32) {
+#pragma unroll
+        for (int m = 0; m < G::kSteps; ++m)
+          af[(sub + 1) & 1][m] =
+              *reinterpret_cast<const u32x4 *>(ap + (sub + 1) * 32 * G::kRowB + m * 32);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < QG; ++g) {
+        chain(g, sub);
+        if (g > 0) {
+          check(g - 1, sub);
+          interleave();
+        } else if (sub > 0) {
+          check(QG - 1, sub - 1);
+          interleave();
+        }
+      }
+    }
+    check(QG - 1, kTileN / 32 - 1);
+    }
     }
     // The stage copies were issued a whole stage ago and the previous drain's stores before
     // them: nothing recent is outstanding here.
@@ -637,26 +686,34 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16f_kernel(c
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int g = 0; g < kQG; ++g) {
+  for (int g = 0; g < QG; ++g) {
     const int64_t qrow = q0 + g * 32 + j;
     if (qrow < a.nq) a.cnt[qrow * a.nseg + 2 * split + h] = wcnt[g * 64 + lane];
   }
 }
 
 
-template <int DP>
+template <int DP, int NW, int QG>
 static int launch_scan16f(const Scan16Args &a, hipStream_t stream) {
-  using G = Scan16FGeom<DP>;
+  using G = Scan16FGeom<DP, NW, QG>;
   static bool attr_set = false;
   if (!attr_set) {
-    TFRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan16f_kernel<DP>),
+    TFRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan16f_kernel<DP, NW, QG>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytesF));
     attr_set = true;
   }
   const dim3 grid((unsigned)(a.n_qtiles * a.n_splits));
-  hipLaunchKernelGGL((scan16f_kernel<DP>), grid, dim3(kThreads16), G::kLdsBytesF, stream, a);
+  hipLaunchKernelGGL((scan16f_kernel<DP, NW, QG>), grid, dim3(NW * 64), G::kLdsBytesF, stream, a);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
+}
+
+// TFRS_SCAN16_SHAPE = 8x2 (default) | 4x4
+template <int DP>
+static int launch_scan16f_shape(const Scan16Args &a, hipStream_t stream) {
+  const char *e = getenv("TFRS_SCAN16_SHAPE");
+  if (e && e[0] == '4' && DP <= 64) return launch_scan16f<DP, 4, 4>(a, stream);
+  return launch_scan16f<DP, 8, 2>(a, stream);
 }
 
 template <int DP, int MODE>
@@ -700,10 +757,10 @@ int launch_scan16(const Scan16Args &a_in, hipStream_t stream) {
   const bool fits32 = (uint64_t)a.nq * a.cap_l * (uint64_t)a.nseg < (1ull << 32);
   if (!a.dense && !a.binmax && fits32 && scan16_generation() == 2) {
     switch (padded_dim16(a.d)) {
-      case 16: return launch_scan16f<16>(a, stream);
-      case 32: return launch_scan16f<32>(a, stream);
-      case 64: return launch_scan16f<64>(a, stream);
-      case 128: return launch_scan16f<128>(a, stream);
+      case 16: return launch_scan16f_shape<16>(a, stream);
+      case 32: return launch_scan16f_shape<32>(a, stream);
+      case 64: return launch_scan16f_shape<64>(a, stream);
+      case 128: return launch_scan16f_shape<128>(a, stream);
     }
   }
   switch (padded_dim16(a.d)) {

@@ -78,11 +78,11 @@ def main():
   # scatter-add backward (incl. the torch sort it currently relies on)
   go = torch.randn((n, d), generator=g, device=dev)
   t = timeit(lambda: emb.scatter_add_rows(go, ids, vocab), iters=5)
-  emit(op="embedding_scatter_add_bwd(dense grad, incl. zero-fill + sort)", rows=n, dim=d, ms=t * 1e3)
+  emit(op="embedding_scatter_add_bwd(dense grad, incl. zero-fill of the 13 GB table + own sort)", rows=n, dim=d, ms=t * 1e3)
   acc = torch.full_like(table, 0.1)
   t = timeit(lambda: emb.adagrad_sparse_update_(table, acc, go, ids, 0.5), iters=5)
   byts = n * d * 4 + 4 * n * d * 4
-  emit(op="embedding_sparse_adagrad(incl. sort)", rows=n, dim=d, ms=t * 1e3, gbps=byts / t / 1e9)
+  emit(op="embedding_sparse_adagrad(incl. own radix sort)", rows=n, dim=d, ms=t * 1e3, gbps=byts / t / 1e9)
   del table, acc, go
 
   # ---- C1: MovieLens-shaped in-batch softmax train step ----
@@ -133,8 +133,9 @@ def main():
   with torch.no_grad():
     t = timeit(lambda: layer(x0, x0), iters=5)
   fl = 2.0 * Bc * dc * dc
+  # large Cross products run on the split-fp16 GEMM: 3 fp16 MFMA products per f32 product
   emit(op="cross_fwd", batch=Bc, dim=dc, ms=t * 1e3, tflops=fl / t / 1e12,
-       frac_mfma_peak=fl / t / F32_MFMA_PEAK)
+       frac_f16_mfma_peak=3 * fl / t / F16_MFMA_PEAK)
   x0g = x0.clone().requires_grad_(True)
 
   def cross_fb():
@@ -143,8 +144,8 @@ def main():
     layer(x0g, x0g).sum().backward()
 
   t = timeit(cross_fb, warmup=1, iters=3)
-  emit(op="cross_fwd+bwd (bwd = HIP GEMMs + torch element-wise/transposes)", batch=Bc, dim=dc, ms=t * 1e3,
-       tflops=3 * fl / t / 1e12, frac_mfma_peak=3 * fl / t / F32_MFMA_PEAK)
+  emit(op="cross_fwd+bwd (fused tfrs_cross_bwd: 4 GEMMs incl. the z recompute; tflops counts 3 = fwd + 2 bwd)",
+       batch=Bc, dim=dc, ms=t * 1e3, tflops=3 * fl / t / 1e12, frac_f16_mfma_peak=3 * 4 * fl / t / F16_MFMA_PEAK)
   del x0, x0g, layer
 
   # ---- C5: DotInteraction, B = 131072, F = 101, D = 32 ----

@@ -12,10 +12,10 @@ corpus = torch.randn((1_000_000, 64), generator=g, device=dev) / 8.0
 queries = torch.randn((8192, 64), generator=g, device=dev) / 8.0
 index = ftk.BruteForce(k=100).index(corpus)
 lib = _lib.load()
-KEYS = ("TFRS_SCAN16_V", "TFRS_SCAN16_DRAIN", "TFRS_TOPK_SAMPLE", "TFRS_TOPK_WGS")
+KEYS = ("TFRS_SCAN16_V", "TFRS_SCAN16_DRAIN", "TFRS_TOPK_SAMPLE", "TFRS_TOPK_WGS", "TFRS_SCAN16_SHAPE")
 ref = None
-for env in [{"TFRS_SCAN16_V": "1"}, {}, {"TFRS_SCAN16_DRAIN": "4"}, {"TFRS_TOPK_SAMPLE": "3"},
-            {"TFRS_TOPK_SAMPLE": "5"}, {"TFRS_TOPK_WGS": "1024"}]:
+for env in [{"TFRS_SCAN16_V": "1"}, {}, {"TFRS_SCAN16_SHAPE": "4x4"}, {"TFRS_SCAN16_SHAPE": "4x4", "TFRS_TOPK_WGS": "1024"},
+            {}, {"TFRS_SCAN16_SHAPE": "4x4"}]:
   for k in KEYS:
     os.environ.pop(k, None)
   os.environ.update(env)
