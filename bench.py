@@ -391,7 +391,7 @@ def main() -> None:
                             "inside the timed region"),
         },
         "roofline": {
-            "kernel": ("tfrs::scan16f_kernel<64> (fp16 MFMA prefilter scores of all rows + fused top-K "
+            "kernel": ("tfrs::scan16f_kernel<64, 8, 2> (fp16 MFMA prefilter scores of all rows + fused top-K "
                        "filter; survivors re-scored exactly in f32)" if dom >= 1 else
                        "tfrs::scan_kernel<64> (f32 MFMA scores + fused top-K filter)"),
             "bound": "mfma",
@@ -399,7 +399,7 @@ def main() -> None:
             "peak": peak,
             "unit": "TFLOP/s",
             "frac": achieved / peak,
-            "traffic": hbm_traffic("tfrs::scan16f_kernel<64>" if dom >= 1 else "tfrs::scan_kernel<64, false, true>"),
+            "traffic": hbm_traffic("tfrs::scan16f_kernel<64, 8, 2>" if dom >= 1 else "tfrs::scan_kernel<64, false, true>"),
             "launches": launches,
             "avg_launch_ms": scan_ms / max(launches, 1),
             "algorithmic_flop_per_launch": flop / max(launches, 1),

@@ -43,7 +43,7 @@ def main() -> None:
       a[2] = min(a[2], float(r["MinNs"]))
       a[3] = max(a[3], float(r["MaxNs"]))
     total = sum(a[1] for a in agg.values()) or 1.0
-    out += ["## kernel stats (`rocprofv3 --kernel-trace --stats`, bench.py --steps 10 --warmup 2)", "",
+    out += ["## kernel stats (`rocprofv3 --kernel-trace --stats`, bench.py default protocol: 10 warm-up + 50 timed steps)", "",
             "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
     for k, a in agg.items():
       out.append("| `%s` | %d | %.3f | %.1f | %.1f | %.1f | %.2f |" %
