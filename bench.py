@@ -62,6 +62,7 @@ def parse_args():
   ap.add_argument("--no-train-step", action="store_true")
   ap.add_argument("--no-gather", action="store_true")
   ap.add_argument("--no-scale-workload", action="store_true")
+  ap.add_argument("--no-single-gpu-reference", action="store_true")
   return ap.parse_args()
 
 
@@ -451,8 +452,29 @@ def main() -> None:
             "step_ms_median": p["median"], "steps": 5, "warmup": 2,
             "filter_pass_tflops": kk[1][2] / max(kk[1][0] * 1e-3, 1e-12) / 1e12,
             "redo_queries_last_step": big.last_redo_count()}
+    if world > 1 and not args.no_single_gpu_reference:
+      # the SAME workload on one GPU, measured by rank 0 after the timed region (the other ranks
+      # wait at the final barrier): makes the N > 1 line self-contained -- speedup = value / this --
+      # because the N = 1 bench line is the 1M x 64 headline, not this corpus
+      del index, local
+      torch.cuda.empty_cache()
+      single = ftk.BruteForce(k=TOPK).index_from_dataset(corpus_blocks(0, total_rows, dev),
+                                                         total_rows=total_rows)
+      for _ in range(2):
+        single(queries)
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      for _ in range(3):
+        single(queries)
+      torch.cuda.synchronize()
+      one = (time.perf_counter() - t0) / 3
+      result["single_gpu_same_workload"] = {"value": BATCH / one, "unit": "queries/s", "ms_per_step": one * 1e3,
+                                            "steps": 3, "warmup": 2, "measured_on": "rank 0, after the timed region"}
+      result["speedup_vs_single_gpu_same_workload"] = value / (BATCH / one)
+      del single
     print(json.dumps(result), flush=True)
   if world > 1:
+    dist.barrier()
     dist.destroy_process_group()
 
 

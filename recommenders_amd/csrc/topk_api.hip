@@ -358,10 +358,8 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
                    hipStream_t stream, const int32_t *rowmap = nullptr) {
   const int n_qtiles = (int)((nq + kScan16QueriesPerWg - 1) / kScan16QueriesPerWg);
   int rc;
-  const char *gen = getenv("TFRS_SCAN16_V");
-  const bool use_ovf = !(gen && gen[0] == '1');   // the first-generation kernel has no overflow lists
-  if ((rc = launch_query_kappa(q, nq, d, w.qk, w.qscale, use_ovf ? w.ovf_cnt : nullptr, stream)) != TFRS_OK)
-    return rc;
+  // (the per-query overflow counters are re-armed here whether or not the filter pass uses them)
+  if ((rc = launch_query_kappa(q, nq, d, w.qk, w.qscale, w.ovf_cnt, stream)) != TFRS_OK) return rc;
 
   Scan16Args s16 = {};
   s16.q = q;
@@ -408,6 +406,11 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
     return TFRS_ENOMEM;
   }
   s16.drain_min = (int)t.drain_min;
+  // overflow lists exist only in the second-generation filter kernel, which launch_scan16 selects
+  // under exactly this condition (32-bit survivor offsets, TFRS_SCAN16_V != 1)
+  const char *gen = getenv("TFRS_SCAN16_V");
+  const bool use_ovf = !(gen && gen[0] == '1') &&
+                       (uint64_t)nq * s16.cap_l * (uint64_t)s16.nseg < (1ull << 32);
   s16.ovf_cnt = use_ovf ? w.ovf_cnt : nullptr;
   s16.ovf_buf = w.ovf_buf;
   s16.ovf_cap = kOvfCap;
