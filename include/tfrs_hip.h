@@ -105,6 +105,12 @@ int tfrs_bruteforce_topk(const tfrs_index_t *index, const float *queries, int64_
  * Synchronises `stream`. */
 int tfrs_bruteforce_topk_redo_count(const void *workspace, int64_t nq, int64_t n, int k,
                                     int32_t *redo_count_h, void *stream);
+/* Same contract; reasons_h[4] = queries flagged because {0: a survivor segment or the list
+ * overflowed, 1: the statistically chosen bound of a shuffled index did not hold,
+ * 2: the retained set did not fit}; reasons_h[3] = length of the longest survivor list of the call
+ * (the list kernel holds 1024 entries per query). */
+int tfrs_bruteforce_topk_redo_reasons(const void *workspace, int64_t nq, int64_t n, int k,
+                                      int32_t *reasons_h, void *stream);
 
 /* Test hook: raw scores of the fp16 PREFILTER (never returned by the product path) for rows
  * [row_begin, row_end) of the index, row_begin a multiple of 128: out[nq, ld] with

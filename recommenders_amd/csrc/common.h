@@ -203,6 +203,7 @@ struct Scan16Args {
   uint32_t ovf_cap;
   int drain_min;         // FILTER (second-generation kernel): queue entries that trigger a
                          // drain at a stage end (0 -> 1)
+  uint32_t *zero_aux;    // FILTER: four more words re-armed the same way (redo reason counters) or NULL
   uint32_t *zero_word;   // FILTER: word re-armed (= 0) for the kernel that follows (the
                          // flagged-query counter); NULL otherwise.  In-kernel instead of a
                          // hipMemsetAsync because memset nodes are not reliably ordered against
@@ -285,7 +286,7 @@ constexpr uint32_t kOvfPerSeg = 256;  // ... of which at most this many from one
                                       // that overflows by more flags the query for the exact redo)
 // topk_select16.hip: lower[q] = (K-th largest bin maximum) - eps[q]
 int launch_bin_threshold(const float *binmax, int64_t ld, int n_bins, int64_t nq, int k,
-                         const float *qk, const float *norm_max, float *lower,
+                         const float *qk, const float *norm_max, float *lower, float *raw,
                          hipStream_t stream);
 // topk_select16.hip: survivor list of prefilter scores -> exact top-K; queries that need the
 // exact recompute path (list overflow / retained set too large) are appended to the list
@@ -294,6 +295,7 @@ int launch_list_topk16(const float *q, int64_t nq, int d, const char *packed, co
                        const uint32_t *cnt, uint32_t cap_l, int nseg, int k, const float *qk,
                        const float *norm_max, float *out_scores, int32_t *out_idx, uint32_t *redo,
                        int64_t idx_base, const uint32_t *ovf_cnt, const uint2 *ovf_buf,
-                       uint32_t ovf_cap, const int32_t *rowmap, hipStream_t stream);
+                       uint32_t ovf_cap, const int32_t *rowmap, const float *verify_raw,
+                       uint32_t *redo_reason, hipStream_t stream);
 
 }  // namespace tfrs

@@ -33,6 +33,12 @@ struct TopkTuning {
   int64_t sample;   // fp16 path: the threshold pass scans every `sample`-th stage
   int64_t min_bins; // fp16 path: sampled bins required per query, in units of K
   int64_t drain_min; // fp16 filter kernel: queue entries that trigger a drain at a stage end
+  // Shuffled indexes (tfrs_index::rowmap): the threshold pass may sample more sparsely and take
+  // a statistically chosen rank of the bin maxima instead of the K-th (plan_sample); the exact
+  // top-K never depends on that choice -- a query whose bound turns out too high is redone.
+  bool stat;             // TFRS_TOPK_STAT (default 1)
+  int64_t sample_stat;   // sampling stride of the statistical plan (TFRS_TOPK_SAMPLE_STAT, 16)
+  double p_fail;         // accepted probability that a query needs the redo (TFRS_TOPK_STAT_PFAIL)
 };
 
 static TopkTuning tuning() {
@@ -45,7 +51,11 @@ static TopkTuning tuning() {
   t.f16_filter = !(f && (f[0] == 'f' || f[0] == 'F') && f[1] == '3');
   t.sample = std::max<int64_t>(1, env_i64("TFRS_TOPK_SAMPLE", 4));
   t.min_bins = std::max<int64_t>(1, env_i64("TFRS_TOPK_MINBINS", 8));  // in 64-candidate bins
-  t.drain_min = std::max<int64_t>(1, env_i64("TFRS_SCAN16_DRAIN", 1));
+  t.drain_min = std::max<int64_t>(1, env_i64("TFRS_SCAN16_DRAIN", 8));
+  t.stat = env_i64("TFRS_TOPK_STAT", 1) != 0;
+  t.sample_stat = std::max<int64_t>(1, env_i64("TFRS_TOPK_SAMPLE_STAT", 16));
+  const char *pf = getenv("TFRS_TOPK_STAT_PFAIL");
+  t.p_fail = pf ? std::min(1.0, std::max(1e-12, atof(pf))) : 1e-7;
   return t;
 }
 
@@ -99,32 +109,93 @@ static int timed_scan16(const Scan16Args &sa, double flop, hipStream_t stream) {
 }
 
 // fp16 path: stages scanned by the threshold pass (only full stages are sampled) and the
-// stride actually used: the requested one, reduced until min_bins * K bins are available.
+// stride actually used: the requested one, reduced until min_bins * rank bins are available.
 struct SamplePlan {
   int64_t stride;
   int64_t n_stages;    // 0: the fp16 path is not applicable
   int64_t bin_stages;  // stages per bin: 4 when that still leaves 8 * K bins, else 1
+  int rank;            // the bound is the rank-th largest bin maximum (K, or less: statistical plan)
+  bool stat;           // rank < K is possible: the list kernel verifies the bound
   int64_t n_bins() const { return 2 * ((n_stages + bin_stages - 1) / bin_stages); }
 };
-static SamplePlan plan_sample(int64_t n, int k, const TopkTuning &t) {
+
+// Statistical rank.  The image rows are a pseudo-random permutation of the corpus and the
+// threshold pass scores every stride-th stage, i.e. a fraction f = 1 / stride of the rows.  Order
+// the rows by score: the bound taken from the m-th best SAMPLED row has at least K rows above
+// it unless m or more of the K - 1 best rows were sampled, P = P(Binomial(K - 1, f) >= m).  The
+// smallest m with P <= p_fail leaves about m / f survivors per query instead of K / f.  (Bins
+// that hold two of the best sampled rows and the low-discrepancy shuffle both err towards a
+// lower bound, i.e. towards more survivors.)  Nothing is assumed for correctness: the list
+// kernel checks that K survivors score above the bound and flags the query for the exact redo
+// otherwise.
+static int stat_rank(int k, int64_t stride, double p_fail) {
+  if (stride <= 1 || k <= 1) return k;
+  const double f = 1.0 / (double)stride;
+  const int n = k - 1;
+  // tail[m] = P(X >= m), summed from the top
+  double pmf = __builtin_pow(f, n);   // P(X = n)
+  double tail = 0.0;
+  int m = n + 1;                       // P(X >= n + 1) = 0
+  for (int x = n; x >= 1; --x) {
+    tail += pmf;
+    if (tail > p_fail) break;
+    m = x;
+    // P(X = x - 1) = P(X = x) * x / (n - x + 1) * (1 - f) / f
+    pmf = pmf * (double)x / (double)(n - x + 1) * (1.0 - f) / f;
+    if (pmf == 0.0) {                  // underflow far in the tail: restart from the exact term
+      pmf = __builtin_exp(__builtin_lgamma(n + 1.0) - __builtin_lgamma((double)x) -
+                          __builtin_lgamma(n - x + 2.0) + (x - 1) * __builtin_log(f) +
+                          (n - x + 1) * __builtin_log1p(-f));
+    }
+  }
+  return std::max(1, std::min(m, k));
+}
+
+// P(Binomial(n, f) <= x)
+static double binom_cdf(int n, double f, int x) {
+  if (x < 0) return 0.0;
+  if (x >= n) return 1.0;
+  double pmf = __builtin_exp((double)n * __builtin_log1p(-f));   // P(X = 0); n <= 1024: no underflow
+  double cdf = pmf;
+  for (int i = 1; i <= x; ++i) {
+    pmf *= (double)(n - i + 1) / (double)i * f / (1.0 - f);
+    cdf += pmf;
+  }
+  return cdf;
+}
+
+static SamplePlan plan_sample(int64_t n, int k, const TopkTuning &t, bool stat) {
   const int64_t full = n / kTileN;
-  const int64_t want_bins = t.min_bins * (int64_t)k;
-  SamplePlan p = {t.sample, 0, 1};
-  while (p.stride > 1 && 2 * (full / p.stride) < want_bins) --p.stride;
+  SamplePlan p = {stat ? t.sample_stat : t.sample, 0, 1, k, false};
+  for (;; --p.stride) {
+    p.rank = stat ? stat_rank(k, p.stride, t.p_fail) : k;
+    if (p.stride <= 1) break;
+    // The survivor list must fit the list kernel's 1024 slots or the query is redone exactly
+    // (correct, but ~1 ms).  Its length is the position T of the rank-th sampled row among all
+    // rows ordered by score (negative binomial, mean rank * stride), times ~1.3 for the eps band:
+    // P(1.35 T > 1024) = P(Binomial(758, 1 / stride) < rank) must be negligible.
+    if (binom_cdf(758, 1.0 / (double)p.stride, p.rank - 1) > 1e-8) continue;
+    if (2 * (full / p.stride) >= t.min_bins * (int64_t)p.rank) break;
+  }
+  p.stat = stat && p.rank < k;
   const int64_t ns = full / p.stride;
-  if (2 * ns >= std::max<int64_t>(want_bins, k)) p.n_stages = ns;
-  // 4 stages per bin when that still leaves 8 * K bins; beyond 4096 bins per query the bins
+  if (2 * ns >= std::max<int64_t>(t.min_bins * (int64_t)p.rank, k)) p.n_stages = ns;
+  // 4 stages per bin when that still leaves 8 * rank bins; beyond 4096 bins per query the bins
   // are widened further (the threshold kernel merges them down to <= 1024 values anyway), so
   // the bin-maxima buffer stays at nq * 4096 floats however large the corpus is
-  if (2 * (ns / 4) >= 8 * (int64_t)k) p.bin_stages = std::max<int64_t>(4, (2 * ns + 4095) / 4096);
+  if (2 * (ns / 4) >= 8 * (int64_t)p.rank) p.bin_stages = std::max<int64_t>(4, (2 * ns + 4095) / 4096);
   return p;
 }
+// (the statistical plan applies to shuffled indexes only)
+static bool use_stat(const TopkTuning &t, const int32_t *rowmap) { return t.stat && rowmap != nullptr; }
 static int64_t dense_rows(int64_t n, int k, const TopkTuning &t) {
   const int64_t want = std::max<int64_t>(t.prefix, padded_rows(k));
   int64_t cols = std::min<int64_t>(padded_rows(n), want);
   if (t.f16_filter && k <= 512) {
-    const SamplePlan sp = plan_sample(n, k, t);
-    if (sp.n_stages > 0) cols = std::max<int64_t>(cols, padded_rows(sp.n_bins()));
+    for (int stat = 0; stat < 2; ++stat) {   // the workspace serves either plan
+      const SamplePlan sp = plan_sample(n, k, t, stat != 0);
+      if (sp.n_stages > 0) cols = std::max<int64_t>(cols, padded_rows(sp.n_bins()));
+    }
   }
   return cols;
 }
@@ -137,7 +208,8 @@ static int64_t dense_rows(int64_t n, int k, const TopkTuning &t) {
 // an overflow only costs time (the query's range is recomputed exactly), never correctness.
 static int64_t list_mean(int k, const TopkTuning &t) {
   // f32 rounds: K * (rho - 1); fp16 path: K * sample (threshold from 1/sample of the rows)
-  return std::max<int64_t>(256, (3 * (int64_t)k * std::max<int64_t>(t.rho - 1, t.sample)) / 2);
+  const int64_t stat = t.stat ? (int64_t)stat_rank(k, t.sample_stat, t.p_fail) * t.sample_stat : 0;
+  return std::max<int64_t>(256, (3 * std::max<int64_t>((int64_t)k * std::max<int64_t>(t.rho - 1, t.sample), stat)) / 2);
 }
 static uint32_t segment_cap(int k, int nseg, const TopkTuning &t) {
   const double m = (double)list_mean(k, t) / nseg;
@@ -159,6 +231,7 @@ static int64_t list_entries_per_query(int64_t nq, int k, const TopkTuning &t) {
 
 struct RoundWs {
   float *thr;
+  float *thr_raw;   // [nq] fp16 path: the bin maximum the bound was taken from (thr + eps)
   uint32_t *cnt;
   float *dense;
   int64_t ld_dense;
@@ -166,7 +239,7 @@ struct RoundWs {
   int64_t entries;  // per query
   float *qk;        // [nq]
   float *qscale;    // [nq]
-  uint32_t *redo;   // [1 + nq] count + flagged query list
+  uint32_t *redo;   // [1 + nq + 4] count, flagged query list, reason counters (topk_select16.hip)
   uint64_t *part_keys;  // [nq, kRecomputeChunks, k] partial lists of the exact-recompute fallback
   uint32_t *ovf_cnt;    // [nq] fp16 path: survivors beyond their segment's capacity ...
   uint2 *ovf_buf;       // [nq, kOvfCap] ... go here
@@ -175,11 +248,11 @@ struct RoundWs {
 
 static size_t round_ws_bytes(int64_t nq, int64_t n, int k, const TopkTuning &t) {
   size_t b = 0;
-  b += align_up((size_t)nq * 4);                                        // thr
+  b += 2 * align_up((size_t)nq * 4);                                    // thr, thr_raw
   b += align_up((size_t)nq * 2 * max_splits(nq, t) * 4);                 // cnt[nq, nseg]
   b += align_up((size_t)nq * dense_rows(n, k, t) * 4);                   // dense
   b += align_up((size_t)nq * list_entries_per_query(nq, k, t) * 8);      // buf
-  b += 2 * align_up((size_t)nq * 4) + align_up((size_t)(nq + 1) * 4);    // qk, qscale, redo
+  b += 2 * align_up((size_t)nq * 4) + align_up((size_t)(nq + 5) * 4);    // qk, qscale, redo
   b += align_up((size_t)nq * kRecomputeChunks * k * 8);                  // part_keys
   b += align_up((size_t)nq * 4) + align_up((size_t)nq * kOvfCap * 8);    // ovf_cnt, ovf_buf
   return b;
@@ -188,6 +261,8 @@ static size_t round_ws_bytes(int64_t nq, int64_t n, int k, const TopkTuning &t) 
 static RoundWs carve_round_ws(char *p, int64_t nq, int64_t n, int k, const TopkTuning &t) {
   RoundWs w;
   w.thr = reinterpret_cast<float *>(p);
+  p += align_up((size_t)nq * 4);
+  w.thr_raw = reinterpret_cast<float *>(p);
   p += align_up((size_t)nq * 4);
   w.cnt = reinterpret_cast<uint32_t *>(p);
   p += align_up((size_t)nq * 2 * max_splits(nq, t) * 4);
@@ -202,7 +277,7 @@ static RoundWs carve_round_ws(char *p, int64_t nq, int64_t n, int k, const TopkT
   w.qscale = reinterpret_cast<float *>(p);
   p += align_up((size_t)nq * 4);
   w.redo = reinterpret_cast<uint32_t *>(p);
-  p += align_up((size_t)(nq + 1) * 4);
+  p += align_up((size_t)(nq + 5) * 4);
   w.part_keys = reinterpret_cast<uint64_t *>(p);
   p += align_up((size_t)nq * kRecomputeChunks * k * 8);
   w.ovf_cnt = reinterpret_cast<uint32_t *>(p);
@@ -385,8 +460,8 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
   s16.ld_binmax = w.ld_dense;
   if ((rc = timed_scan16(s16, 2.0 * (double)nq * (double)sp.n_stages * kTileN * d, stream)) != TFRS_OK)
     return rc;
-  if ((rc = launch_bin_threshold(w.dense, w.ld_dense, (int)sp.n_bins(), nq, k, w.qk,
-                                 img.norm_max, w.thr, stream)) != TFRS_OK)
+  if ((rc = launch_bin_threshold(w.dense, w.ld_dense, (int)sp.n_bins(), nq, sp.rank, w.qk,
+                                 img.norm_max, w.thr, w.thr_raw, stream)) != TFRS_OK)
     return rc;
   }
 
@@ -415,13 +490,15 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
   s16.ovf_buf = w.ovf_buf;
   s16.ovf_cap = kOvfCap;
   s16.zero_word = reinterpret_cast<uint32_t *>(w.redo);   // the flagged-query counter, re-armed
+  s16.zero_aux = w.redo + 1 + nq;
   if ((rc = timed_scan16(s16, 2.0 * (double)nq * (double)n * d, stream)) != TFRS_OK) return rc;
 
   // prefilter top-K + exact re-scoring; flagged queries (list overflow, retained set too
   // large) are answered by the exact recompute path of the generic select kernel
   if ((rc = launch_list_topk16(q, nq, d, packed, w.buf, w.cnt, s16.cap_l, s16.nseg, k, w.qk,
                                img.norm_max, out_scores, out_idx, w.redo, idx_base, s16.ovf_cnt, w.ovf_buf,
-                               kOvfCap, rowmap, stream)) != TFRS_OK)
+                               kOvfCap, rowmap, (sp.stat && !lower_preset) ? w.thr_raw : nullptr,
+                               w.redo + 1 + nq, stream)) != TFRS_OK)
     return rc;
   SelectArgs se = {};
   se.nq = nq;
@@ -631,7 +708,7 @@ extern "C" int tfrs_bruteforce_topk(const tfrs_index_t *index, const float *quer
   }
   const RoundWs w = carve_round_ws(static_cast<char *>(workspace), nq, index->n, k, t);
   if (t.f16_filter && k <= kMaxKF16) {
-    const SamplePlan sp = plan_sample(index->n, k, t);
+    const SamplePlan sp = plan_sample(index->n, k, t, use_stat(t, index->rowmap));
     if (sp.n_stages > 0) {
       const F16Image img = {index->packed16, index->meta, index->norm_max};
       return run_f16(queries, nq, index->d, index->packed, img, index->n, /*idx_base=*/0, k, sp,
@@ -651,12 +728,27 @@ extern "C" int tfrs_bruteforce_topk_redo_count(const void *workspace, int64_t nq
                  "bruteforce_topk_redo_count: bad argument");
   const TopkTuning t = tuning();
   *redo_count_h = 0;
-  if (!(t.f16_filter && k <= kMaxKF16) || plan_sample(n, k, t).n_stages <= 0) return TFRS_OK;
+  if (!(t.f16_filter && k <= kMaxKF16) || plan_sample(n, k, t, false).n_stages <= 0) return TFRS_OK;
   const RoundWs w = carve_round_ws(static_cast<char *>(const_cast<void *>(workspace)), nq, n, k, t);
   uint32_t v = 0;
   TFRS_HIP(hipMemcpyAsync(&v, w.redo, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
   TFRS_HIP(hipStreamSynchronize((hipStream_t)stream));
   *redo_count_h = (int32_t)v;
+  return TFRS_OK;
+}
+
+extern "C" int tfrs_bruteforce_topk_redo_reasons(const void *workspace, int64_t nq, int64_t n, int k,
+                                                 int32_t *reasons_h, void *stream) {
+  TFRS_CHECK_ARG(workspace && reasons_h && nq > 0 && n > 0 && k > 0,
+                 "bruteforce_topk_redo_reasons: bad argument");
+  const TopkTuning t = tuning();
+  for (int i = 0; i < 4; ++i) reasons_h[i] = 0;
+  if (!(t.f16_filter && k <= kMaxKF16) || plan_sample(n, k, t, false).n_stages <= 0) return TFRS_OK;
+  const RoundWs w = carve_round_ws(static_cast<char *>(const_cast<void *>(workspace)), nq, n, k, t);
+  uint32_t v[4] = {0u, 0u, 0u, 0u};
+  TFRS_HIP(hipMemcpyAsync(v, w.redo + 1 + nq, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  TFRS_HIP(hipStreamSynchronize((hipStream_t)stream));
+  for (int i = 0; i < 4; ++i) reasons_h[i] = (int32_t)v[i];
   return TFRS_OK;
 }
 
@@ -754,7 +846,7 @@ extern "C" int tfrs_streaming_topk_update(const float *queries, int64_t nq, int 
     // pass at all), else from the block's own bin maxima; then merge the block's exact top-K
     // into the state.
     const bool preset = (state_len == k);
-    const SamplePlan sp = preset ? SamplePlan{1, 0, 1} : plan_sample(nb, k, t);
+    const SamplePlan sp = preset ? SamplePlan{1, 0, 1, k, false} : plan_sample(nb, k, t, false);
     if (preset || sp.n_stages > 0) {
       hipStream_t st = (hipStream_t)stream;
       char *p = packed + align_up((size_t)padded_rows(nb) * row_bytes(padded_dim(d)));

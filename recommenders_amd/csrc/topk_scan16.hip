@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (MODE == kModeFilter && a.zero_word && blockIdx.x == 0 && tid == 0) *a.zero_word = 0u;
+  if (MODE == kModeFilter && a.zero_aux && blockIdx.x == 0 && tid < 4) a.zero_aux[tid] = 0u;
   const int j = lane & 31;  // query column of this lane
   const int h = lane >> 5;  // k half of the MFMA step / upper candidate half of the C layout
 
@@ -430,6 +431,7 @@ __global__ void __launch_bounds__(NW * 64, (DP <= 64 ? 2 : 1) * NW / 4) scan16f_
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (a.zero_word && blockIdx.x == 0 && tid == 0) *a.zero_word = 0u;
+  if (a.zero_aux && blockIdx.x == 0 && tid < 4) a.zero_aux[tid] = 0u;
   const int j = lane & 31;
   const int h = lane >> 5;
 
@@ -507,35 +509,49 @@ __global__ void __launch_bounds__(NW * 64, (DP <= 64 ? 2 : 1) * NW / 4) scan16f_
   const bool wave_active = q0 < a.nq;   // wave-uniform
   int qtail = 0;                        // wave-uniform: entries in the queue
 
-  // drain: lane L tests score L % 16 of entry p0 + L / 16
+  // drain: four lanes per entry, lane L tests scores 4 * (L % 4) .. + 3 of entry p0 + L / 4, so up
+  // to 16 entries cost one pass (two dependent LDS round trips); a column rarely holds more than
+  // one survivor, so the per-lane loop over its hits usually runs once
   auto drain = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const int r = lane & 15;
-    const uint32_t rofs = (uint32_t)((r & 3) + 8 * (r >> 2));
-    for (int p0 = 0; p0 < qtail; p0 += 4) {
-      const int e = p0 + (lane >> 4);
+    const uint32_t s4 = (uint32_t)(lane & 3);
+    for (int p0 = 0; p0 < qtail; p0 += 16) {
+      const int e = p0 + (lane >> 2);
       if (e < qtail) {
         const char *ep = qbase + e * G::kEntB;
-        const float v = *reinterpret_cast<const float *>(ep + 4 * r);
+        const float4 v4 = *reinterpret_cast<const float4 *>(ep + 16 * s4);
         const uint4 hd = *reinterpret_cast<const uint4 *>(ep + 64);
-        const uint32_t row = hd.z + rofs;
-        if (v > __uint_as_float(hd.x) && row < row_limit) {
+        const float thr_e = __uint_as_float(hd.x);
+        const uint32_t row0 = hd.z + 8u * s4;   // accumulator register 4 s + i holds row 8 s + i (+ 4 h)
+        uint32_t hits = (v4.x > thr_e ? 1u : 0u) | (v4.y > thr_e ? 2u : 0u) |
+                        (v4.z > thr_e ? 4u : 0u) | (v4.w > thr_e ? 8u : 0u);
+        if (row0 + 3u >= row_limit) {   // the index's last, partly filled stage
+#pragma unroll
+          for (uint32_t i = 0; i < 4u; ++i)
+            if (row0 + i >= row_limit) hits &= ~(1u << i);
+        }
+        if (hits) {
           const uint32_t src = hd.w;   // g * 64 + source lane
-          // one LDS round trip: the slot (atomic) and the segment's constants together
-          const uint32_t slot = lds_atomic_inc(&wcnt[src]);
           const float2 zc = *reinterpret_cast<const float2 *>(&qconst[src].z);
           const float un = zc.x * __uint_as_float(hd.y);   // qscale * stage scale
-          if (slot < a.cap_l) {
-            a.buf[(uint64_t)(__float_as_uint(zc.y) + slot * (uint32_t)a.nseg)] =
-                make_uint2(__float_as_uint(v * un), row);
-          } else if (a.ovf_cnt && slot - a.cap_l < kOvfPerSeg) {
-            // the segment is full (rows ordered by cluster: a query's survivors sit in one or two
-            // splits): per-query overflow list, one global atomic per such survivor
-            const int64_t qrow = q0 + (src >> 6) * 32 + (src & 31);
-            const uint32_t o = atomicAdd(&a.ovf_cnt[qrow], 1u);
-            if (o < a.ovf_cap) a.ovf_buf[qrow * (int64_t)a.ovf_cap + o] = make_uint2(__float_as_uint(v * un), row);
-          }
+          do {
+            const uint32_t i = (uint32_t)__builtin_ctz(hits);
+            hits &= hits - 1u;
+            const float v = i == 0u ? v4.x : i == 1u ? v4.y : i == 2u ? v4.z : v4.w;
+            const uint32_t row = row0 + i;
+            const uint32_t slot = lds_atomic_inc(&wcnt[src]);
+            if (slot < a.cap_l) {
+              a.buf[(uint64_t)(__float_as_uint(zc.y) + slot * (uint32_t)a.nseg)] =
+                  make_uint2(__float_as_uint(v * un), row);
+            } else if (a.ovf_cnt && slot - a.cap_l < kOvfPerSeg) {
+              // the segment is full (rows ordered by cluster: a query's survivors sit in one or two
+              // splits): per-query overflow list, one global atomic per such survivor
+              const int64_t qrow = q0 + (src >> 6) * 32 + (src & 31);
+              const uint32_t o = atomicAdd(&a.ovf_cnt[qrow], 1u);
+              if (o < a.ovf_cap) a.ovf_buf[qrow * (int64_t)a.ovf_cap + o] = make_uint2(__float_as_uint(v * un), row);
+            }
+          } while (hits);
         }
       }
     }

@@ -47,10 +47,13 @@ __device__ __forceinline__ uint32_t radix_kth(const uint32_t (&key)[kSlots], int
 // ---- threshold from the bin maxima ------------------------------------------------------
 // binmax[q, n_bins] (prefilter scores of DISTINCT candidates, one per 64-candidate bin).
 // Adjacent bins are first merged in groups of `group` (the maximum of a group is still the
-// score of one candidate), giving <= 1024 values per query; lower[q] = (K-th largest) - eps.
+// score of one candidate), giving <= 1024 values per query; lower[q] = (k-th largest) - eps,
+// raw[q] = that k-th largest itself.  k is K, or the smaller statistical rank of topk_api.hip's
+// plan_sample -- then the list kernel checks the bound against raw[q].
 __global__ void __launch_bounds__(kSel16Waves * 64) bin_threshold_kernel(
     const float *__restrict__ binmax, int64_t ld, int n_bins, int group, int64_t nq, int k,
-    const float *__restrict__ qk, const float *__restrict__ norm_max, float *__restrict__ lower) {
+    const float *__restrict__ qk, const float *__restrict__ norm_max, float *__restrict__ lower,
+    float *__restrict__ raw) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * kSel16Waves + (threadIdx.x >> 6);
   if (row >= nq) return;
@@ -80,20 +83,21 @@ __global__ void __launch_bounds__(kSel16Waves * 64) bin_threshold_kernel(
   if (lane == 0) {
     const float eps = qk[row] * norm_max[0] + kF16Tiny;
     // no K-th value (fewer than K bins, or -inf scores): no bound
-    lower[row] = (kth > f32_orderable(-__builtin_inff())) ? f32_from_orderable(kth) - eps
-                                                          : -__builtin_inff();
+    const bool have = kth > f32_orderable(-__builtin_inff());
+    lower[row] = have ? f32_from_orderable(kth) - eps : -__builtin_inff();
+    raw[row] = have ? f32_from_orderable(kth) : -__builtin_inff();
   }
 }
 
 int launch_bin_threshold(const float *binmax, int64_t ld, int n_bins, int64_t nq, int k,
-                         const float *qk, const float *norm_max, float *lower,
+                         const float *qk, const float *norm_max, float *lower, float *raw,
                          hipStream_t stream) {
   if (nq <= 0) return TFRS_OK;
   int group = 1;
   if (n_bins > 64 * kSlots) group = ((n_bins + 64 * kSlots - 1) / (64 * kSlots) + 3) / 4 * 4;
   hipLaunchKernelGGL(bin_threshold_kernel, dim3((unsigned)((nq + kSel16Waves - 1) / kSel16Waves)),
                      dim3(kSel16Waves * 64), 0, stream, binmax, ld, n_bins, group, nq, k, qk,
-                     norm_max, lower);
+                     norm_max, lower, raw);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
 }
@@ -165,6 +169,16 @@ struct List16Args {
   const uint2 *ovf_buf;      // [nq, ovf_cap]
   uint32_t ovf_cap;
   const int32_t *rowmap;     // shuffled index: image row -> original row (NULL: identity)
+  // Statistical bound (topk_api.hip plan_sample): raw[q] is the bin maximum the bound came from.
+  // Rows outside the list have prefilter scores <= raw - eps - eps_stage, i.e. exact scores
+  // <= raw - eps; when K list entries have prefilter scores >= raw, their exact scores are
+  // >= raw - eps and the exact top-K is inside the list.  Otherwise the query is redone.  (With
+  // the K-th bin maximum as the bound this holds by construction and verify_raw is NULL.)
+  const float *verify_raw;
+  // [4] or NULL: how many queries were flagged because {0: a segment or the list overflowed,
+  // 1: the statistical bound did not hold, 2: the retained set did not fit}; [3]: the longest
+  // survivor list of the call (capacity 64 * kSlots)
+  uint32_t *redo_reason;
 };
 
 // KP: slots for the retained set (>= K + band); the list itself may hold up to 64 * kSlots.
@@ -257,8 +271,10 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
         push(p, p ? a.ovf_buf[row * (int64_t)a.ovf_cap + e0 + lane] : make_uint2(0u, 0u));
       }
   }
+  if (lane == 0 && a.redo_reason && __ballot(bad) == 0ull) atomicMax(&a.redo_reason[3], (uint32_t)total);
   if (__ballot(bad) != 0ull || total > kCap) {
     if (lane == 0) a.redo[1 + atomicAdd(a.redo, 1u)] = (uint32_t)row;
+    if (lane == 0 && a.redo_reason) atomicAdd(&a.redo_reason[0], 1u);
     return;
   }
   sel16_lds_sync();
@@ -277,7 +293,12 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
     }
   }
   const float eps = a.qk[row] * a.norm_max[0] + kF16Tiny;
-  const uint32_t kth = radix_kth(key, K);
+  const uint32_t kth = radix_kth(key, K);   // (a lower bound of the K-th largest; 0: fewer than K)
+  if (a.verify_raw && (kth == 0u || kth < f32_orderable(a.verify_raw[row]))) {
+    if (lane == 0) a.redo[1 + atomicAdd(a.redo, 1u)] = (uint32_t)row;
+    if (lane == 0 && a.redo_reason) atomicAdd(&a.redo_reason[1], 1u);
+    return;
+  }
   // everything whose prefilter score is within 2*eps of the K-th one may belong to the exact
   // top-K (common.h); kth == 0: fewer than K entries -> keep all of them
   uint32_t lo_key = 0u;
@@ -297,6 +318,7 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
   }
   if (m > KP) {  // retained set does not fit: exact redo
     if (lane == 0) a.redo[1 + atomicAdd(a.redo, 1u)] = (uint32_t)row;
+    if (lane == 0 && a.redo_reason) atomicAdd(&a.redo_reason[2], 1u);
     return;
   }
   sel16_lds_sync();
@@ -339,7 +361,8 @@ int launch_list_topk16(const float *q, int64_t nq, int d, const char *packed, co
                        const uint32_t *cnt, uint32_t cap_l, int nseg, int k, const float *qk,
                        const float *norm_max, float *out_scores, int32_t *out_idx, uint32_t *redo,
                        int64_t idx_base, const uint32_t *ovf_cnt, const uint2 *ovf_buf,
-                       uint32_t ovf_cap, const int32_t *rowmap, hipStream_t stream) {
+                       uint32_t ovf_cap, const int32_t *rowmap, const float *verify_raw,
+                       uint32_t *redo_reason, hipStream_t stream) {
   if (nq <= 0) return TFRS_OK;
   List16Args a;
   a.idx_base = idx_base;
@@ -361,6 +384,8 @@ int launch_list_topk16(const float *q, int64_t nq, int d, const char *packed, co
   a.ovf_buf = ovf_buf;
   a.ovf_cap = ovf_cap;
   a.rowmap = rowmap;
+  a.verify_raw = verify_raw;
+  a.redo_reason = redo_reason;
   const int need = 2 * k;  // K + room for the 2*eps band
   if (need <= 128) return launch_list16_kp<128>(a, stream);
   if (need <= 256) return launch_list16_kp<256>(a, stream);

@@ -439,6 +439,17 @@ class BruteForce(TopK):
         _lib.ptr(ws), nq, self._n, k, ctypes.byref(out), _lib.current_stream()))
     return int(out.value)
 
+  def last_redo_reasons(self) -> dict:
+    """``last_redo_count`` split by cause (include/tfrs_hip.h).  Synchronises the stream."""
+    names = ("list_overflow", "statistical_bound", "retained_set", "longest_list")
+    if getattr(self, "_last_call", None) is None:
+      return dict.fromkeys(names, 0)
+    ws, nq, k = self._last_call
+    out = (ctypes.c_int32 * 4)()
+    _lib.check(_lib.load().tfrs_bruteforce_topk_redo_reasons(
+        _lib.ptr(ws), nq, self._n, k, out, _lib.current_stream()))
+    return {name: int(out[i]) for i, name in enumerate(names)}
+
   def call(self, queries, k: Optional[int] = None):
     k = k if k is not None else self._k
     scores, rows = self._query_rows(queries, k)

@@ -356,3 +356,34 @@ def test_cluster_ordered_corpus_stays_exact():
   np.testing.assert_array_equal(_np(i2), ei2)
   np.testing.assert_array_equal(_np(s2), es2)
   assert layer2.last_redo_count() <= nq // 20
+
+
+@pytest.mark.parametrize("k", [1, 10, 100, 300])
+def test_statistical_threshold_plan_is_exact(k, monkeypatch):
+  """Shuffled indexes take the filter bound from a sparser sample and a statistically chosen rank
+  of the bin maxima (csrc/topk_api.hip plan_sample).  Results must not depend on that choice: the
+  guaranteed plan (TFRS_TOPK_STAT=0), the default one, and a deliberately reckless one whose
+  bound fails for many queries (they are flagged by the list kernel and redone exactly) all
+  equal the oracle bit for bit."""
+  ftk = _ftk()
+  rng = np.random.default_rng(7 + k)
+  n, d, nq = 300_000, 32, 384
+  c = (rng.normal(size=(n, d)) / np.sqrt(d)).astype(np.float32)
+  q = (rng.normal(size=(nq, d)) / np.sqrt(d)).astype(np.float32)
+  es, ei = o_topk.brute_force(q, c, k)
+  layer = ftk.BruteForce(k=k).index(c)
+  for env in ({"TFRS_TOPK_STAT": "0"}, {}, {"TFRS_TOPK_STAT_PFAIL": "0.4"},
+              {"TFRS_TOPK_SAMPLE_STAT": "32", "TFRS_TOPK_STAT_PFAIL": "0.2"}):
+    for key in ("TFRS_TOPK_STAT", "TFRS_TOPK_STAT_PFAIL", "TFRS_TOPK_SAMPLE_STAT"):
+      monkeypatch.delenv(key, raising=False)
+    for key, val in env.items():
+      monkeypatch.setenv(key, val)
+    s, i = layer(q)
+    np.testing.assert_array_equal(_np(i), ei)
+    np.testing.assert_array_equal(_np(s), es)
+    reasons = layer.last_redo_reasons()
+    assert layer.last_redo_count() == reasons["list_overflow"] + reasons["statistical_bound"] + reasons["retained_set"]
+    if not env or env == {"TFRS_TOPK_STAT": "0"}:
+      assert layer.last_redo_count() == 0, reasons
+    if env.get("TFRS_TOPK_STAT_PFAIL") == "0.4" and k >= 10:
+      assert reasons["statistical_bound"] > 0, reasons     # the verification is what kept it exact

@@ -91,11 +91,16 @@ int main(int argc, char **argv) {
   hipMalloc(&in, 512 * 8 * sizeof(f16x8)); hipMalloc(&out, 1024 * 512 * 4);
   _Float16 *h = (_Float16 *)malloc(512 * 8 * 16);
   // operand data decides the power draw and with it the sustained clock: random (default),
-  // "zeros", or "const" (all 0.5)
+  // "zeros", "const" (all 0.5) or "mN" (random, mantissas truncated to N bits)
   const char *mode = argc > 1 ? argv[1] : "random";
   for (int i = 0; i < 512 * 8 * 8; ++i)
     h[i] = mode[0] == 'z' ? (_Float16)0.0f : mode[0] == 'c' ? (_Float16)0.5f
                                           : (_Float16)((rand() % 2001 - 1000) / 1000.0f);
+  if (mode[0] == 'm') {   // "mN": random operands truncated to N mantissa bits (N = 0 .. 10)
+    const int keep = atoi(mode + 1);
+    unsigned short *hu = (unsigned short *)h;
+    for (int i = 0; i < 512 * 8 * 8; ++i) hu[i] &= (unsigned short)(0xFFFFu << (10 - keep));
+  }
   hipMemcpy(in, h, 512 * 8 * 16, hipMemcpyHostToDevice);
   printf("operands: %s\n", mode);
   for (int wgs : {256, 512}) {
