@@ -201,6 +201,7 @@ struct Scan16Args {
   uint32_t *ovf_cnt;
   uint2 *ovf_buf;
   uint32_t ovf_cap;
+  int drain_every;       // FILTER: all waves drain at every drain_every-th stage end (see drain_min)
   int drain_min;         // FILTER (second-generation kernel): queue entries that trigger a
                          // drain at a stage end (0 -> 1)
   uint32_t *zero_aux;    // FILTER: four more words re-armed the same way (redo reason counters) or NULL

@@ -33,6 +33,7 @@ struct TopkTuning {
   int64_t sample;   // fp16 path: the threshold pass scans every `sample`-th stage
   int64_t min_bins; // fp16 path: sampled bins required per query, in units of K
   int64_t drain_min; // fp16 filter kernel: queue entries that trigger a drain at a stage end
+  int64_t drain_every; // ... and the stage period at which every wave drains whatever it holds
   // Shuffled indexes (tfrs_index::rowmap): the threshold pass may sample more sparsely and take
   // a statistically chosen rank of the bin maxima instead of the K-th (plan_sample); the exact
   // top-K never depends on that choice -- a query whose bound turns out too high is redone.
@@ -51,7 +52,8 @@ static TopkTuning tuning() {
   t.f16_filter = !(f && (f[0] == 'f' || f[0] == 'F') && f[1] == '3');
   t.sample = std::max<int64_t>(1, env_i64("TFRS_TOPK_SAMPLE", 4));
   t.min_bins = std::max<int64_t>(1, env_i64("TFRS_TOPK_MINBINS", 8));  // in 64-candidate bins
-  t.drain_min = std::max<int64_t>(1, env_i64("TFRS_SCAN16_DRAIN", 8));
+  t.drain_min = std::max<int64_t>(1, env_i64("TFRS_SCAN16_DRAIN", 24));
+  t.drain_every = std::max<int64_t>(1, env_i64("TFRS_SCAN16_DRAIN_EVERY", 4));
   t.stat = env_i64("TFRS_TOPK_STAT", 1) != 0;
   t.sample_stat = std::max<int64_t>(1, env_i64("TFRS_TOPK_SAMPLE_STAT", 16));
   const char *pf = getenv("TFRS_TOPK_STAT_PFAIL");
@@ -481,6 +483,7 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
     return TFRS_ENOMEM;
   }
   s16.drain_min = (int)t.drain_min;
+  s16.drain_every = (int)t.drain_every;
   // overflow lists exist only in the second-generation filter kernel, which launch_scan16 selects
   // under exactly this condition (32-bit survivor offsets, TFRS_SCAN16_V != 1)
   const char *gen = getenv("TFRS_SCAN16_V");

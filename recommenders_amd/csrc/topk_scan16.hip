@@ -694,7 +694,7 @@ __global__ void __launch_bounds__(NW * 64, (DP <= 64 ? 2 : 1) * NW / 4) scan16f_
     // The stage copies were issued a whole stage ago and the previous drain's stores before
     // them: nothing recent is outstanding here.
     wait_dma();
-    if (qtail >= a.drain_min || (st == nst - 1 && qtail > 0)) drain();
+    if (qtail > 0 && (qtail >= a.drain_min || st == nst - 1 || ((st + 1) % a.drain_every) == 0)) drain();
     __builtin_amdgcn_s_barrier();
   }
 
@@ -763,6 +763,7 @@ int launch_scan16(const Scan16Args &a_in, hipStream_t stream) {
   Scan16Args a = a_in;
   if (a.nq <= 0 || a.n_stages <= 0) return TFRS_OK;
   if (a.drain_min < 1) a.drain_min = 1;
+  if (a.drain_every < 1) a.drain_every = 1;
   TFRS_CHECK_ARG(a.stage_stride >= 1 && a.stages_per_split >= 1 &&
                      (int64_t)a.n_splits * a.stages_per_split >= a.n_stages,
                  "scan16: bad stage split");

@@ -387,3 +387,29 @@ def test_statistical_threshold_plan_is_exact(k, monkeypatch):
       assert layer.last_redo_count() == 0, reasons
     if env.get("TFRS_TOPK_STAT_PFAIL") == "0.4" and k >= 10:
       assert reasons["statistical_bound"] > 0, reasons     # the verification is what kept it exact
+
+
+@pytest.mark.parametrize("d", [16, 32, 64, 100, 128])
+def test_fp16_prefiltered_search_equals_all_f32_search_on_whole_batches(d, monkeypatch):
+  """The fp16-prefiltered search (threshold pass, filter pass with the LDS survivor queue, exact
+  re-scoring) against the all-f32 scan (`TFRS_TOPK_FILTER=f32`: no prefilter, no queue) on every
+  query of a 4096 batch and every kernel instantiation (DP = 16 .. 128), bit for bit.  The
+  oracle comparisons elsewhere look at tens of queries; a survivor lost in the queue shows up
+  in a few percent of the queries only."""
+  ftk = _ftk()
+  g = torch.Generator(device="cuda").manual_seed(500 + d)
+  n, nq, k = 600_000, 4096, 100
+  c = torch.randn((n, d), generator=g, device="cuda") / d ** 0.5
+  q = torch.randn((nq, d), generator=g, device="cuda") / d ** 0.5
+  layer = ftk.BruteForce(k=k).index(c)
+  monkeypatch.setenv("TFRS_TOPK_FILTER", "f32")
+  s32, i32 = layer(q)
+  monkeypatch.delenv("TFRS_TOPK_FILTER")
+  for env in ({}, {"TFRS_TOPK_STAT": "0"}, {"TFRS_SCAN16_DRAIN_EVERY": "1"}, {"TFRS_SCAN16_DRAIN": "1"}):
+    for key, val in env.items():
+      monkeypatch.setenv(key, val)
+    s, i = layer(q)
+    assert layer.last_redo_count() == 0
+    assert torch.equal(i, i32) and torch.equal(s, s32), env
+    for key in env:
+      monkeypatch.delenv(key)
