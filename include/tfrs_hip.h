@@ -108,7 +108,7 @@ int tfrs_bruteforce_topk_redo_count(const void *workspace, int64_t nq, int64_t n
 /* Same contract; reasons_h[4] = queries flagged because {0: a survivor segment or the list
  * overflowed, 1: the statistically chosen bound of a shuffled index did not hold,
  * 2: the retained set did not fit}; reasons_h[3] = length of the longest survivor list of the call
- * (the list kernel holds 1024 entries per query). */
+ * when one exceeded 768 entries, else 0 (the list kernel holds 1024 entries per query). */
 int tfrs_bruteforce_topk_redo_reasons(const void *workspace, int64_t nq, int64_t n, int k,
                                       int32_t *reasons_h, void *stream);
 

@@ -30,7 +30,8 @@ __device__ __forceinline__ void sel16_lds_sync() {
 // Top kRadixBits bits of the k-th largest of the wave's 64 * kSlots orderable keys (0 = empty
 // slot; returns 0 when fewer than k non-empty keys exist).  The result is <= the true k-th
 // largest key, i.e. a lower bound of the k-th largest score.
-__device__ __forceinline__ uint32_t radix_kth(const uint32_t (&key)[kSlots], int k) {
+// Slots >= nslots (wave-uniform) hold no keys and are skipped.
+__device__ __forceinline__ uint32_t radix_kth(const uint32_t (&key)[kSlots], int k, int nslots = kSlots) {
   uint32_t prefix = 0u;
 #pragma unroll 1
   for (int bit = 31; bit >= 32 - kRadixBits; --bit) {
@@ -38,7 +39,8 @@ __device__ __forceinline__ uint32_t radix_kth(const uint32_t (&key)[kSlots], int
     const uint32_t himask = ~((1u << bit) - 1u);
     int cnt = 0;
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s) cnt += (int)__popcll(__ballot((key[s] & himask) == test));
+    for (int s = 0; s < kSlots; ++s)
+      if (s < nslots) cnt += (int)__popcll(__ballot((key[s] & himask) == test));
     if (cnt >= k) prefix = test; else k -= cnt;
   }
   return prefix;
@@ -177,7 +179,7 @@ struct List16Args {
   const float *verify_raw;
   // [4] or NULL: how many queries were flagged because {0: a segment or the list overflowed,
   // 1: the statistical bound did not hold, 2: the retained set did not fit}; [3]: the longest
-  // survivor list of the call (capacity 64 * kSlots)
+  // survivor list of the call if one exceeded 3/4 of the capacity 64 * kSlots (else 0)
   uint32_t *redo_reason;
 };
 
@@ -213,6 +215,30 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
     total += (int)__popcll(mask);
   };
   constexpr int kCntBatch = 16;
+  if (a.nseg <= 64) {
+    // Large batches: one segment per lane, ~7 entries each.  Eight entries per round as one batch
+    // of independent loads (the first round is issued straight behind the count), so the gather
+    // costs 1 + ceil(longest segment / 8) memory latencies.
+    uint32_t c = (lane < a.nseg) ? a.cnt[row * a.nseg + lane] : 0u;
+    if (a.ovf_cnt) {   // the excess (up to kOvfPerSeg per segment) went to the overflow list
+      bad = c > a.cap_l + kOvfPerSeg;
+      c = min(c, a.cap_l);
+    } else {
+      bad = c > a.cap_l;
+    }
+    if (__ballot(bad) == 0ull) {
+      for (uint32_t e0 = 0; __ballot(e0 < c) != 0ull; e0 += 8) {
+        uint2 w[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+          w[x] = make_uint2(0u, 0u);
+          if (e0 + x < c) w[x] = qbuf[(int64_t)(e0 + x) * a.nseg + lane];
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) push(e0 + x < c, w[x]);
+      }
+    }
+  } else
   for (int sb0 = 0; sb0 < a.nseg && !bad; sb0 += 64 * kCntBatch) {
     uint32_t cnts[kCntBatch];
 #pragma unroll
@@ -271,8 +297,11 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
         push(p, p ? a.ovf_buf[row * (int64_t)a.ovf_cap + e0 + lane] : make_uint2(0u, 0u));
       }
   }
-  if (lane == 0 && a.redo_reason && __ballot(bad) == 0ull) atomicMax(&a.redo_reason[3], (uint32_t)total);
-  if (__ballot(bad) != 0ull || total > kCap) {
+  // (only lists beyond 3/4 of the capacity report: one atomic per QUERY on one word costs 60 us per 8192 queries)
+  const bool any_bad = __ballot(bad) != 0ull;
+  if (lane == 0 && a.redo_reason && total > 3 * kCap / 4 && !any_bad)
+    atomicMax(&a.redo_reason[3], (uint32_t)total);
+  if (any_bad || total > kCap) {
     if (lane == 0) a.redo[1 + atomicAdd(a.redo, 1u)] = (uint32_t)row;
     if (lane == 0 && a.redo_reason) atomicAdd(&a.redo_reason[0], 1u);
     return;
@@ -293,7 +322,7 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
     }
   }
   const float eps = a.qk[row] * a.norm_max[0] + kF16Tiny;
-  const uint32_t kth = radix_kth(key, K);   // (a lower bound of the K-th largest; 0: fewer than K)
+  const uint32_t kth = radix_kth(key, K, (total + 63) / 64);   // (a lower bound of the K-th largest; 0: fewer than K)
   if (a.verify_raw && (kth == 0u || kth < f32_orderable(a.verify_raw[row]))) {
     if (lane == 0) a.redo[1 + atomicAdd(a.redo, 1u)] = (uint32_t)row;
     if (lane == 0 && a.redo_reason) atomicAdd(&a.redo_reason[1], 1u);
