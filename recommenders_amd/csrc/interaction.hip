@@ -422,6 +422,169 @@ __global__ void __launch_bounds__(STAGE ? 64 : 256, 2) dot_interaction_mfma_kern
   }
 }
 
+// Split-fp16 form of the staged forward pass (default for D a multiple of 16).  The f32 MFMA chain
+// above costs DP/2 x 64 cycles per 32x32 block -- 10240 matrix-core cycles per sample at F = 101,
+// D = 32, i.e. 0.55 ms of pure MFMA time per 131072 samples, as much as the HBM traffic costs.
+// Here every operand is split x * s = hi + lo (two fp16 values, s a per-sample power of two that
+// puts max |x| at 2^11..2^12 so that neither half leaves fp16's normal range for the elements
+// that matter) and a block is DP/16 steps of three v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo +
+// lo*hi, f32 accumulation; the dropped lo*lo term is 2^-22 relative): 1920 cycles per sample.
+// Representation error 2^-22 |x| per element, i.e. the dot products carry ~2^-21 sum |x_i x_j|
+// -- the same order as the f32 rounding of the chain it replaces.  Staging, copy-out and the
+// prefetch of the next sample are those of dot_interaction_mfma_kernel<.., true>; the 1/s^2 is
+// applied (exactly) on the way out.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pack_h2(float a, float b) {
+  union {
+    h16x2 h;
+    uint32_t u;
+  } v;
+  v.h[0] = (_Float16)a;   // round to nearest even
+  v.h[1] = (_Float16)b;
+  return v.u;
+}
+
+// max over the wave of a non-negative float (positive floats order like their bit patterns), by
+// DPP lane permutations: six VALU operations, no LDS round trips (__shfl_xor is ds_bpermute).
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+  int x = __float_as_int(v);
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false));   // row_half_mirror
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false));   // row_mirror
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xF, 0xF, false));   // row_bcast15
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xF, 0xF, false));   // row_bcast31
+  return __int_as_float(__builtin_amdgcn_readlane(x, 63));
+}
+
+template <int DP, int NB>
+__global__ void __launch_bounds__(64, 2) dot_interaction_f16x3_kernel(const float *__restrict__ x,
+                                                                      int64_t batch, int f, int d, int self,
+                                                                      float *__restrict__ out) {
+  static_assert(DP % 16 == 0, "whole 32x32x16 steps");
+  constexpr int KS = DP / 16;   // MFMA k-steps: lane half h supplies features h*DP/2 + 8t .. +7 in step t
+  extern __shared__ __attribute__((aligned(16))) float smem_dot[];
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const bool vec_ok = (d == DP) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((f * d) % 4 == 0);
+  const int out_dim = self ? f * (f + 1) / 2 : f * (f - 1) / 2;
+  const int stage_len = ((out_dim + 3) & ~3) + 64;  // + one dummy slot per lane
+  float *stage = smem_dot;
+  const int dummy = stage_len - 64 + lane;
+  const int64_t wave_stride = gridDim.x;
+
+  int64_t b = blockIdx.x;
+  float raw[NB][DP / 2];
+  if (b < batch) {
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb)
+      load_row_frag<DP>(raw[rb], x + b * (int64_t)f * d, rb * 32 + j, rb * 32 + j < f, d, h, vec_ok);
+  }
+  for (; b < batch; b += wave_stride) {
+    float *ob = out + b * (int64_t)out_dim;
+    // ---- per-sample scale and the hi / lo operands ----------------------------------------
+    float m = 0.0f;
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+      for (int e = 0; e < DP / 2; ++e) m = fmaxf(m, __builtin_fabsf(raw[rb][e]));
+    m = wave_max_nonneg(m);
+    // s = 2^k with k = 12 - floor(log2 m), clamped so that s, s^2 and their inverses are normal
+    int k = 139 - (int)(__float_as_uint(m) >> 23);
+    k = (m > 0.0f && m < __builtin_inff()) ? min(max(k, -60), 60) : 0;
+    const float sc = __uint_as_float((uint32_t)(127 + k) << 23);
+    const float inv2 = __uint_as_float((uint32_t)(127 - 2 * k) << 23);
+    h16x8 hi[NB][KS], lo[NB][KS];
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+      for (int t = 0; t < KS; ++t) {
+        union {
+          uint32_t u[4];
+          h16x8 v;
+        } ph, pl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a0 = raw[rb][8 * t + 2 * e] * sc, a1 = raw[rb][8 * t + 2 * e + 1] * sc;
+          const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+          union {
+            h16x2 hh;
+            uint32_t u;
+          } q;
+          q.hh[0] = h0;
+          q.hh[1] = h1;
+          ph.u[e] = q.u;
+          pl.u[e] = pack_h2(a0 - (float)h0, a1 - (float)h1);
+        }
+        hi[rb][t] = ph.v;
+        lo[rb][t] = pl.v;
+      }
+    // Opaque zero: keeps the ~160 store predicates / offsets of one sample from being hoisted
+    // out of the sample loop (see dot_interaction_mfma_kernel).
+    int lz = 0;
+    asm volatile("" : "+v"(lz));
+    const int jv = j + lz, hv = h + lz;
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+      if (bi * 32 >= f) continue;  // uniform
+      const int row0 = bi * 32 + 4 * hv;
+      const int tri0 = self ? row0 * (row0 + 1) / 2 : row0 * (row0 - 1) / 2;
+      const int row_lim = f - row0;          // rows row0 + dr with dr < row_lim exist
+      const int diag_t = jv - 4 * hv;        // diagonal block: col < row  <=>  diag_t < dr
+      int pre[16];                           // (tri(row0 + dr) - tri(row0)) * 4: byte offsets
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        pre[r] = 4 * (dr * row0 + (self ? dr * (dr + 1) / 2 : dr * (dr - 1) / 2));
+      }
+#pragma unroll
+      for (int bj = 0; bj <= bi; ++bj) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi[bi][t], hi[bj][t], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi[bi][t], lo[bj][t], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo[bi][t], hi[bj][t], acc, 0, 0, 0);
+        }
+        const int a0 = 4 * (tri0 + bj * 32 + jv);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          bool keep = (bi < NB - 1) || (dr < row_lim);
+          if (bj == bi) keep = keep && (self ? diag_t <= dr : diag_t < dr);
+          // rejected elements land in a per-lane dummy slot
+          *reinterpret_cast<float *>(reinterpret_cast<char *>(stage) + (keep ? a0 + pre[r] : 4 * dummy)) = acc[r];
+        }
+      }
+    }
+    // the operands are dead: fetch the next sample under the copy-out
+    const int64_t bn = b + wave_stride;
+    if (bn < batch) {
+#pragma unroll
+      for (int rb = 0; rb < NB; ++rb)
+        load_row_frag<DP>(raw[rb], x + bn * (int64_t)f * d, rb * 32 + j, rb * 32 + j < f, d, h, vec_ok);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if ((out_dim & 1) == 0 && ((reinterpret_cast<uintptr_t>(out) & 7) == 0)) {
+#pragma unroll 8
+      for (int e = 2 * lane; e < out_dim; e += 128) {
+        const float2 v = *reinterpret_cast<const float2 *>(stage + e);
+        *reinterpret_cast<float2 *>(ob + e) = make_float2(v.x * inv2, v.y * inv2);
+      }
+    } else {
+#pragma unroll 8
+      for (int e = lane; e < out_dim; e += 64) ob[e] = stage[e] * inv2;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the staging buffer is reused by the next sample
+  }
+}
+
 template <int DP, int NB>
 static bool launch_dot_mfma_nb(const float *x, int64_t batch, int f, int d, int self, int skip,
                                float *out, hipStream_t s) {
@@ -440,6 +603,20 @@ static bool launch_dot_mfma_nb(const float *x, int64_t batch, int f, int d, int 
     }
     const int64_t per_cu = std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)lds));
     const dim3 grid((unsigned)std::min<int64_t>(batch, 256 * per_cu * 2));
+    // TFRS_DOT_FWD=f32 keeps the exact-f32 MFMA chain (measurement / comparison switch)
+    const char *fv = getenv("TFRS_DOT_FWD");
+    if constexpr (DP % 16 == 0 && NB * (DP / 2) <= 96) {   // (beyond that the raw + hi + lo operands spill)
+      if (!(fv && fv[0] == 'f' && fv[1] == '3')) {
+        static bool attr16_set = false;
+        if (!attr16_set) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dot_interaction_f16x3_kernel<DP, NB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+          attr16_set = true;
+        }
+        hipLaunchKernelGGL((dot_interaction_f16x3_kernel<DP, NB>), grid, dim3(64), lds, s, x, batch, f, d, self, out);
+        return true;
+      }
+    }
     hipLaunchKernelGGL((dot_interaction_mfma_kernel<DP, NB, true>), grid, dim3(64), lds, s, x, batch, f, d,
                        self, skip, out);
   } else {
