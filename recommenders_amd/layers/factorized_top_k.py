@@ -290,6 +290,9 @@ class TopK(torch.nn.Module, abc.ABC):
     return _as_f32_matrix(queries, "queries")
 
 
+_APPEND_CHUNK_ROWS = 1 << 20   # rows gathered before an index append (BruteForce.index_from_dataset)
+
+
 class _IndexHandle:
   """RAII wrapper of ``tfrs_index_t``."""
 
@@ -372,6 +375,23 @@ class BruteForce(TopK):
         return super().index_from_dataset(candidates)     # wide dims: plain row-major copy
       break
     handle, ids, has_ids, n, d = None, [], None, 0, 0
+    # The index stores every appended block in a pseudo-random row order (the filter bound is
+    # taken from a sample of the stored stages, csrc/topk_api.hip), which only mixes rows WITHIN
+    # a block: small dataset batches (`movies.batch(128)`) are therefore gathered into chunks of
+    # >= _APPEND_CHUNK_ROWS rows before they are appended.  Row order, and with it the returned
+    # identifiers, is unchanged.
+    pending, pending_rows = [], 0
+
+    def flush():
+      nonlocal pending, pending_rows
+      if not pending:
+        return
+      chunk = pending[0] if len(pending) == 1 else torch.cat(pending, dim=0)
+      _lib.check(handle._lib.tfrs_index_append(handle.handle, _lib.ptr(chunk), chunk.shape[0],
+                                               _lib.current_stream()))
+      torch.cuda.current_stream().synchronize()   # the blocks may be temporary uploads
+      pending, pending_rows = [], 0
+
     for element in candidates:
       if isinstance(element, (tuple, list)):
         i, c = element
@@ -389,12 +409,14 @@ class BruteForce(TopK):
         raise ValueError(f"Candidate blocks disagree on the embedding dimension ({block.shape[1]} vs {d}).")
       if n + block.shape[0] > total_rows:
         raise ValueError(f"The dataset holds more than total_rows={total_rows} candidates.")
-      _lib.check(handle._lib.tfrs_index_append(handle.handle, _lib.ptr(block), block.shape[0],
-                                               _lib.current_stream()))
-      torch.cuda.current_stream().synchronize()   # `block` may be a temporary upload
+      pending.append(block)
+      pending_rows += block.shape[0]
       n += block.shape[0]
+      if pending_rows >= _APPEND_CHUNK_ROWS:
+        flush()
     if handle is None:
       raise ValueError("The candidate dataset is empty.")
+    flush()
     self._index = handle
     self._ids = _Identifiers(np.concatenate(ids, axis=0) if has_ids else None, n)
     self._n, self._d = n, d

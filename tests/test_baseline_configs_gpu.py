@@ -413,3 +413,23 @@ def test_fp16_prefiltered_search_equals_all_f32_search_on_whole_batches(d, monke
     assert torch.equal(i, i32) and torch.equal(s, s32), env
     for key in env:
       monkeypatch.delenv(key)
+
+
+def test_small_cluster_blocks_through_index_from_dataset():
+  """`index_from_dataset(total_rows=...)` fed with small batches, one cluster per batch (the row
+  order a catalogue sorted by category gives).  The index mixes rows within an appended block
+  only, so the batches are gathered into large chunks first: results exact and (nearly) no query
+  on the exact-redo path."""
+  ftk = _ftk()
+  rng = np.random.default_rng(321)
+  ncl, per, d, nq, k = 400, 1000, 64, 512, 100
+  centers = rng.normal(size=(ncl, d)) / np.sqrt(d)
+  blocks = [(centers[c] + 0.35 * rng.normal(size=(per, d)) / np.sqrt(d)).astype(np.float32)
+            for c in range(ncl)]
+  q = (centers[rng.integers(0, ncl, size=nq)] + 0.35 * rng.normal(size=(nq, d)) / np.sqrt(d)).astype(np.float32)
+  layer = ftk.BruteForce(k=k).index_from_dataset([torch.from_numpy(b).cuda() for b in blocks], total_rows=ncl * per)
+  s, i = layer(q)
+  es, ei = o_topk.brute_force(q, np.concatenate(blocks), k)
+  np.testing.assert_array_equal(_np(i), ei)
+  np.testing.assert_array_equal(_np(s), es)
+  assert layer.last_redo_count() <= nq // 50, layer.last_redo_reasons()
