@@ -422,7 +422,8 @@ __global__ void __launch_bounds__(STAGE ? 64 : 256, 2) dot_interaction_mfma_kern
   }
 }
 
-// Split-fp16 form of the staged forward pass (default for D a multiple of 16).  The f32 MFMA chain
+// Split-fp16 form of the staged forward pass (TFRS_DOT_FWD=staged; the direct-store kernel below is
+// the default).  The f32 MFMA chain
 // above costs DP/2 x 64 cycles per 32x32 block -- 10240 matrix-core cycles per sample at F = 101,
 // D = 32, i.e. 0.55 ms of pure MFMA time per 131072 samples, as much as the HBM traffic costs.
 // Here every operand is split x * s = hi + lo (two fp16 values, s a per-sample power of two that
@@ -585,6 +586,100 @@ __global__ void __launch_bounds__(64, 2) dot_interaction_f16x3_kernel(const floa
   }
 }
 
+// Split-fp16 forward without LDS staging (default; TFRS_DOT_FWD=staged selects the kernel above):
+// accumulator register r of a block is one row of 32 consecutive packed positions per lane half,
+// so a store instruction writes two 128-byte runs.  No staging buffer and no operand prefetch --
+// occupancy (VGPR-bound, BLOCKS workgroups of four waves per CU) hides the latencies instead.
+// The power-of-two scale is per 32-row block here (a block's operands are converted as soon as
+// its own rows have arrived); block (bi, bj) is unscaled by 1 / (s_bi s_bj).
+template <int DP, int NB, int BLOCKS>
+__global__ void __launch_bounds__(256, BLOCKS) dot_interaction_f16x3_direct_kernel(const float *__restrict__ x,
+                                                                                   int64_t batch, int f, int d, int self,
+                                                                                   float *__restrict__ out) {
+  static_assert(DP % 16 == 0, "whole 32x32x16 steps");
+  constexpr int KS = DP / 16;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const bool vec_ok = (d == DP) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((f * d) % 4 == 0);
+  const int out_dim = self ? f * (f + 1) / 2 : f * (f - 1) / 2;
+  const int64_t wave_stride = (int64_t)gridDim.x * 4;
+  for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < batch; b += wave_stride) {
+    float *ob = out + b * (int64_t)out_dim;
+    h16x8 hi[NB][KS], lo[NB][KS];
+    float inv_s[NB];   // wave-uniform
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb) {
+      float raw[DP / 2];
+      load_row_frag<DP>(raw, x + b * (int64_t)f * d, rb * 32 + j, rb * 32 + j < f, d, h, vec_ok);
+      float m = 0.0f;
+#pragma unroll
+      for (int e = 0; e < DP / 2; ++e) m = fmaxf(m, __builtin_fabsf(raw[e]));
+      m = wave_max_nonneg(m);
+      // s = 2^k with k = 12 - floor(log2 m), clamped so that s and 1/s stay normal
+      int k = 139 - (int)(__float_as_uint(m) >> 23);
+      k = (m > 0.0f && m < __builtin_inff()) ? min(max(k, -60), 60) : 0;
+      const float sc = __uint_as_float((uint32_t)(127 + k) << 23);
+      inv_s[rb] = __uint_as_float((uint32_t)(127 - k) << 23);
+#pragma unroll
+      for (int t = 0; t < KS; ++t) {
+        union {
+          uint32_t u[4];
+          h16x8 v;
+        } ph, pl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a0 = raw[8 * t + 2 * e] * sc, a1 = raw[8 * t + 2 * e + 1] * sc;
+          const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+          union {
+            h16x2 hh;
+            uint32_t u;
+          } q;
+          q.hh[0] = h0;
+          q.hh[1] = h1;
+          ph.u[e] = q.u;
+          pl.u[e] = pack_h2(a0 - (float)h0, a1 - (float)h1);
+        }
+        hi[rb][t] = ph.v;
+        lo[rb][t] = pl.v;
+      }
+    }
+    int lz = 0;   // opaque zero: see dot_interaction_mfma_kernel
+    asm volatile("" : "+v"(lz));
+    const int jv = j + lz, hv = h + lz;
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+      if (bi * 32 >= f) continue;  // uniform
+      const int row0 = bi * 32 + 4 * hv;
+      const int tri0 = self ? row0 * (row0 + 1) / 2 : row0 * (row0 - 1) / 2;
+      const int row_lim = f - row0;
+      const int diag_t = jv - 4 * hv;
+#pragma unroll
+      for (int bj = 0; bj <= bi; ++bj) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi[bi][t], hi[bj][t], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi[bi][t], lo[bj][t], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo[bi][t], hi[bj][t], acc, 0, 0, 0);
+        }
+        const float unscale = inv_s[bi] * inv_s[bj];
+        float *dst = ob + tri0 + bj * 32 + jv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          bool keep = (bi < NB - 1) || (dr < row_lim);
+          if (bj == bi) keep = keep && (self ? diag_t <= dr : diag_t < dr);
+          // tri(row0 + dr) - tri(row0) = dr * row0 + dr (dr -+ 1) / 2
+          if (keep) dst[dr * row0 + (self ? dr * (dr + 1) / 2 : dr * (dr - 1) / 2)] = acc[r] * unscale;
+        }
+      }
+    }
+  }
+}
+
 template <int DP, int NB>
 static bool launch_dot_mfma_nb(const float *x, int64_t batch, int f, int d, int self, int skip,
                                float *out, hipStream_t s) {
@@ -606,6 +701,12 @@ static bool launch_dot_mfma_nb(const float *x, int64_t batch, int f, int d, int 
     // TFRS_DOT_FWD=f32 keeps the exact-f32 MFMA chain (measurement / comparison switch)
     const char *fv = getenv("TFRS_DOT_FWD");
     if constexpr (DP % 16 == 0 && NB * (DP / 2) <= 96) {   // (beyond that the raw + hi + lo operands spill)
+      if (!(fv && (fv[0] == 'f' || fv[0] == 's'))) {   // default: direct stores
+        const dim3 gd((unsigned)std::min<int64_t>((batch + 3) / 4, 256 * 8));
+        // three workgroups per CU: 142 VGPRs, no scratch (four would spill 16 registers: 1.18 vs 1.06 ms)
+        hipLaunchKernelGGL((dot_interaction_f16x3_direct_kernel<DP, NB, 3>), gd, dim3(256), 0, s, x, batch, f, d, self, out);
+        return true;
+      }
       if (!(fv && fv[0] == 'f' && fv[1] == '3')) {
         static bool attr16_set = false;
         if (!attr16_set) {

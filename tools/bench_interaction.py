@@ -1,6 +1,6 @@
 """Cross (BASELINE configs[3]: B = 65536, d = 3456) and DotInteraction (configs[4]: B = 131072,
 F = 101, D = 32) forward / backward timings through the C ABI, with the kernel-variant switches
-(TFRS_DOT_STAGE, TFRS_DOT_BWD) swept in one process.  JSON lines."""
+(TFRS_DOT_FWD, TFRS_DOT_BWD) swept in one process.  JSON lines."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -37,13 +37,13 @@ out = torch.empty((B, od), device=dev)
 dout = torch.randn((B, od), generator=g, device=dev)
 dx = torch.empty_like(x)
 st = _lib.current_stream()
-for stage in ("1", "0"):
-  os.environ["TFRS_DOT_STAGE"] = stage
+for kern in ("direct", "staged", "f32"):   # "direct" = the default (split-fp16 MFMA, stores from the accumulators)
+  os.environ["TFRS_DOT_FWD"] = kern
   t = timeit(lambda: _lib.check(lib.tfrs_dot_interaction_fwd(_lib.ptr(x), B, F, D, 0, 0, _lib.ptr(out), st)))
   byts = (B * F * D + B * od) * 4
-  emit(op="dot_interaction_fwd", stage=stage, ms=t * 1e3, gbps=byts / t / 1e9, frac_hbm_peak=byts / t / HBM_PEAK,
+  emit(op="dot_interaction_fwd", kernel=kern, ms=t * 1e3, gbps=byts / t / 1e9, frac_hbm_peak=byts / t / HBM_PEAK,
        algorithmic_bytes=byts)
-os.environ.pop("TFRS_DOT_STAGE")
+os.environ.pop("TFRS_DOT_FWD")
 for mode in ("pc", "dense", "gather"):
   os.environ["TFRS_DOT_BWD"] = mode   # "pc" (default kernel): any value not starting with d / g
   t = timeit(lambda: _lib.check(lib.tfrs_dot_interaction_bwd(_lib.ptr(x), _lib.ptr(dout), B, F, D, 0, 0, _lib.ptr(dx), st)),
