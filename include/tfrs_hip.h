@@ -112,6 +112,14 @@ int tfrs_bruteforce_topk_redo_count(const void *workspace, int64_t nq, int64_t n
 int tfrs_bruteforce_topk_redo_reasons(const void *workspace, int64_t nq, int64_t n, int k,
                                       int32_t *reasons_h, void *stream);
 
+/* Test hook (host code only, no GPU needed): the threshold-pass plan the fp16-prefiltered search
+ * would use for a corpus of n rows and top-k -- plan_h[5] = {sampling stride, sampled stages,
+ * stages per bin, rank of the bin maximum the bound is taken from, 1 when that rank is a
+ * statistical one (rank < k: the list kernel verifies the bound), else 0}.  shuffled != 0 asks
+ * for the plan of a shuffled index (>= 65536 rows), 0 for the guaranteed plan.  sampled
+ * stages == 0: the corpus is too small for the prefilter (all-f32 rounds are used). */
+int tfrs_debug_topk_plan(int64_t n, int k, int shuffled, int64_t *plan_h);
+
 /* Test hook: raw scores of the fp16 PREFILTER (never returned by the product path) for rows
  * [row_begin, row_end) of the index, row_begin a multiple of 128: out[nq, ld] with
  * ld = (row_end - row_begin) rounded up to 128; scratch: 2 * nq floats.  tests/ check

@@ -38,6 +38,7 @@ SIGNATURES = {
     "tfrs_bruteforce_topk": (c_int, [P, P, c_i64, c_int, P, P, P, c_size_t, P]),
     "tfrs_bruteforce_topk_redo_count": (c_int, [P, c_i64, c_i64, c_int, P, P]),
     "tfrs_bruteforce_topk_redo_reasons": (c_int, [P, c_i64, c_i64, c_int, P, P]),
+    "tfrs_debug_topk_plan": (c_int, [c_i64, c_int, c_int, P]),
     "tfrs_debug_fp16_scores": (c_int, [P, P, c_i64, c_i64, c_i64, P, P, P]),
     "tfrs_streaming_topk_workspace_bytes": (c_size_t, [c_i64, c_i64, c_int, c_int]),
     "tfrs_streaming_topk_update": (c_int, [P, c_i64, c_int, P, c_i64, c_i64, c_int, P, P,

@@ -755,6 +755,19 @@ extern "C" int tfrs_bruteforce_topk_redo_reasons(const void *workspace, int64_t 
   return TFRS_OK;
 }
 
+extern "C" int tfrs_debug_topk_plan(int64_t n, int k, int shuffled, int64_t *plan_h) {
+  TFRS_CHECK_ARG(n > 0 && k >= 1 && k <= TFRS_MAX_K && plan_h, "debug_topk_plan: bad argument");
+  const TopkTuning t = tuning();
+  SamplePlan sp = {1, 0, 1, k, false};
+  if (t.f16_filter && k <= kMaxKF16) sp = plan_sample(n, k, t, shuffled != 0 && t.stat);
+  plan_h[0] = sp.stride;
+  plan_h[1] = sp.n_stages;
+  plan_h[2] = sp.bin_stages;
+  plan_h[3] = sp.rank;
+  plan_h[4] = sp.stat ? 1 : 0;
+  return TFRS_OK;
+}
+
 // Test hook: the raw fp16 prefilter scores of rows [row_begin, row_end) (multiples of 128
 // except at the corpus end), so that tests can check the error bound the filter relies on.
 extern "C" int tfrs_debug_fp16_scores(const tfrs_index_t *index, const float *queries,

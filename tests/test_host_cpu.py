@@ -484,3 +484,34 @@ def test_sharded_embedding_routes_out_of_range_ids_consistently():
   out.sum().backward()
   g = layer.embeddings.grad
   assert g[3].eq(1).all() and g[9].eq(1).all() and g.sum() == 8.0
+
+
+def test_threshold_pass_plan_statistics(lib, monkeypatch):
+  """csrc/topk_api.hip plan_sample / stat_rank (host code): the statistical rank m of a shuffled
+  index is the smallest with P(Binomial(K - 1, 1 / stride) >= m) <= 1e-7, the survivor list it
+  implies fits the list kernel (P(1.35 T > 1024) <= 1e-8 with T the negative-binomial position
+  of the m-th sampled row), and the guaranteed plan keeps rank = K."""
+  from scipy.stats import binom
+  for key in ("TFRS_TOPK_STAT", "TFRS_TOPK_SAMPLE", "TFRS_TOPK_SAMPLE_STAT", "TFRS_TOPK_STAT_PFAIL"):
+    monkeypatch.delenv(key, raising=False)
+  plan = (ctypes.c_int64 * 5)()
+  for n in (1_000_000, 12_500_000, 100_000_000):
+    for k in (1, 10, 100, 256, 512):
+      assert lib.tfrs_debug_topk_plan(n, k, 0, plan) == 0
+      stride, stages, _, rank, stat = list(plan)
+      assert rank == k and stat == 0 and stages > 0 and 1 <= stride <= 4
+      assert lib.tfrs_debug_topk_plan(n, k, 1, plan) == 0
+      stride, stages, _, rank, stat = list(plan)
+      assert 1 <= stride <= 16 and stages == (n // 128) // stride and 1 <= rank <= k
+      assert stat == (1 if rank < k else 0)
+      if stride > 1 and k > 1:
+        f = 1.0 / stride
+        assert binom.sf(rank - 1, k - 1, f) <= 1e-7                 # P(bound too high)
+        assert rank == 1 or binom.sf(rank - 2, k - 1, f) > 1e-7     # ... and no larger than needed
+        assert binom.cdf(rank - 1, 758, f) <= 1e-8                  # the list overflows its 1024 slots
+      assert 2 * stages >= 8 * rank                                 # enough bins for the rank
+  # a corpus too small for the prefilter, and the statistical plan switched off
+  assert lib.tfrs_debug_topk_plan(20_000, 100, 1, plan) == 0 and plan[1] == 0
+  monkeypatch.setenv("TFRS_TOPK_STAT", "0")
+  assert lib.tfrs_debug_topk_plan(1_000_000, 100, 1, plan) == 0
+  assert plan[3] == 100 and plan[4] == 0
