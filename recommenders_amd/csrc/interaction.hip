@@ -52,6 +52,10 @@ struct GemmArgs {
   float *out;         // [m, n]
   // optional elementwise multipliers, same shape/layout as a / b (dz = dy * x0 is never stored)
   const float *amul, *bmul;
+  // split-K (AT && !BT only: K is the row index of both operands): slice blockIdx.y covers
+  // k in [y * kper, min(k, (y + 1) * kper)) and writes its partial product to out + y * m * n
+  // (no bias); kper == 0: no split.
+  int kper;
 };
 
 // AT: `a` holds A^T ([K, M] row-major); BT: `b` holds B^T ([N, K] row-major).  The tiles are
@@ -93,6 +97,11 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
     return v;
   };
 
+  // K range of this workgroup (split-K slices exist for the AT && !BT product only)
+  const bool split = AT && !BT && g.kper > 0;
+  const int k_begin = split ? (int)blockIdx.y * g.kper : 0;
+  const int k_end = split ? min(g.k, k_begin + g.kper) : g.k;
+
   // staging: A tile 128 x 16 = 512 float4 -> 2 per thread; B tile 16 x 128 = 512 float4 -> 2
   f32x4 sa[2], sb[2];
   auto load_tiles = [&](int k0) {
@@ -102,10 +111,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
       if (!AT) {   // A tile 128 (m) x 16 (k): row e >> 2, k (e & 3) * 4 .. + 3
         sa[i] = load4(g.a, g.amul, bm + (e >> 2), k0 + (e & 3) * 4, g.m, g.k, a_vec);
       } else {     // A^T: k row e >> 5, m (e & 31) * 4 .. + 3
-        sa[i] = load4(g.a, g.amul, k0 + (e >> 5), bm + (e & 31) * 4, g.k, g.m, a_vec);
+        sa[i] = load4(g.a, g.amul, k0 + (e >> 5), bm + (e & 31) * 4, k_end, g.m, a_vec);
       }
       if (!BT) {   // B tile 16 (k) x 128 (n): k row e >> 5, n (e & 31) * 4 .. + 3
-        sb[i] = load4(g.b, g.bmul, k0 + (e >> 5), bn + (e & 31) * 4, g.k, g.n, b_vec);
+        sb[i] = load4(g.b, g.bmul, k0 + (e >> 5), bn + (e & 31) * 4, BT ? g.k : k_end, g.n, b_vec);
       } else {     // B^T: n row e >> 2, k (e & 3) * 4 .. + 3
         sb[i] = load4(g.b, g.bmul, bn + (e >> 2), k0 + (e & 3) * 4, g.n, g.k, b_vec);
       }
@@ -138,14 +147,14 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
 
-  const int nk = (g.k + kBK - 1) / kBK;
-  load_tiles(0);
+  const int nk = (k_end - k_begin + kBK - 1) / kBK;
+  load_tiles(k_begin);
   store_tiles(0);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) load_tiles((kt + 1) * kBK);
+    if (kt + 1 < nk) load_tiles(k_begin + (kt + 1) * kBK);
 
     // fragments: A rows (wm*64 + i*32 + j), k = 8h .. 8h+7; B cols (wn*64 + jn*32 + j)
     f32x4 af[2][2];
@@ -181,7 +190,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
     for (int jn = 0; jn < 2; ++jn) {
       const int col = bn + wn * 64 + jn * 32 + j;
       if (col >= g.n) continue;
-      const float bias = g.bias ? g.bias[col] : 0.0f;
+      const float bias = (g.bias && !split) ? g.bias[col] : 0.0f;
+      float *const outp = split ? g.out + (int64_t)blockIdx.y * g.m * g.n : g.out;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = bm + wm * 64 + i * 32 + tile_row_of_reg(r, h);
@@ -197,7 +207,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
           const float dyv = g.x0[o];
           v = v + dyv + g.diag * dyv * g.x[o];
         }
-        g.out[o] = v;
+        outp[o] = v;
       }
     }
 }
@@ -1235,13 +1245,60 @@ static bool launch_dot_mfma(const float *x, int64_t batch, int f, int d, int sel
 
 using namespace tfrs;
 
-static int launch_gemm(const GemmArgs &g, int epi, hipStream_t s, bool at = false, bool bt = false) {
+// ---- split-K for the weight-gradient products (A^T B, K = batch) ---------------------------
+// dW = x^T dy of a layer with a small input or output width is a handful of 128 x 128 output tiles
+// with K = batch: 4 workgroups for a 512 -> 1 layer, 11.5 ms at batch 131072 on a 256-CU chip.  The
+// K range is therefore cut into slices (grid.y) until tiles x slices covers the chip about four
+// times; slices write partial products, splitk_sum_kernel adds them in a fixed order.
+constexpr int kSplitMinK = 4096;          // rows of K per slice at least (whole kBK steps)
+static int splitk_slices(int64_t m, int n, int64_t k) {
+  const int64_t tiles = ((m + kBM - 1) / kBM) * ((n + kBN - 1) / kBN);
+  if (tiles >= 256 || k < 2 * kSplitMinK) return 1;
+  int64_t want = (1024 + tiles - 1) / tiles;
+  want = std::min<int64_t>(want, k / kSplitMinK);
+  // partial products are m * n floats each: keep them under 64 MB
+  want = std::min<int64_t>(want, std::max<int64_t>(1, (int64_t)(16 << 20) / std::max<int64_t>(1, m * n)));
+  return (int)std::max<int64_t>(1, want);
+}
+static size_t splitk_bytes(int64_t m, int n, int64_t k) {
+  const int sl = splitk_slices(m, n, k);
+  return sl > 1 ? (size_t)sl * (size_t)m * (size_t)n * sizeof(float) : 0;
+}
+
+__global__ void __launch_bounds__(256) splitk_sum_kernel(const float *__restrict__ part, int slices,
+                                                         int64_t count, const float *__restrict__ bias,
+                                                         int n, float *__restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float v = bias ? bias[i % n] : 0.0f;
+    for (int z = 0; z < slices; ++z) v += part[(int64_t)z * count + i];
+    out[i] = v;
+  }
+}
+
+// `splitk_ws` (optional): scratch of splitk_bytes(m, n, k) for the at && !bt product.
+static int launch_gemm(const GemmArgs &g_in, int epi, hipStream_t s, bool at = false, bool bt = false,
+                       float *splitk_ws = nullptr) {
+  GemmArgs g = g_in;
+  g.kper = 0;
   const int64_t nbm = (g.m + kBM - 1) / kBM;
   const int nbn = (g.n + kBN - 1) / kBN;
   const dim3 grid((unsigned)(nbm * nbn));
-  if (at)            // dW = x^T dz
-    hipLaunchKernelGGL((gemm_kernel<kEpiBias, true, false>), grid, dim3(256), 0, s, g);
-  else if (bt)       // dx = dz W^T + dy + diag dz
+  if (at) {          // dW = x^T dz
+    const int slices = splitk_ws ? splitk_slices(g.m, g.n, g.k) : 1;
+    if (slices > 1) {
+      g.kper = (int)(((int64_t)g.k + slices - 1) / slices + kBK - 1) / kBK * kBK;
+      const int used = (int)(((int64_t)g.k + g.kper - 1) / g.kper);
+      float *const final_out = g.out;
+      g.out = splitk_ws;
+      hipLaunchKernelGGL((gemm_kernel<kEpiBias, true, false>), dim3(grid.x, (unsigned)used), dim3(256), 0, s, g);
+      const int64_t count = g.m * (int64_t)g.n;
+      hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)std::min<int64_t>((count + 255) / 256, 4096)), dim3(256),
+                         0, s, splitk_ws, used, count, g.bias, g.n, final_out);
+    } else {
+      hipLaunchKernelGGL((gemm_kernel<kEpiBias, true, false>), grid, dim3(256), 0, s, g);
+    }
+  } else if (bt)     // dx = dz W^T + dy + diag dz
     hipLaunchKernelGGL((gemm_kernel<kEpiCrossDx, false, true>), grid, dim3(256), 0, s, g);
   else if (epi == kEpiCross)
     hipLaunchKernelGGL((gemm_kernel<kEpiCross, false, false>), grid, dim3(256), 0, s, g);
@@ -1338,7 +1395,8 @@ __global__ void __launch_bounds__(256) colsum_reduce_kernel(const float *__restr
 extern "C" size_t tfrs_cross_bwd_workspace_bytes(int64_t batch, int d, int f16) {
   if (batch < 1 || d < 1) return 256;
   if (f16) return gemm16_cross_bwd_workspace_bytes(batch, d);
-  return (size_t)((batch + kDbSlab - 1) / kDbSlab) * d * 4 + 256;
+  // dbias partial sums, then the split-K partial products of dW
+  return ((size_t)((batch + kDbSlab - 1) / kDbSlab) * d * 4 + 255) / 256 * 256 + splitk_bytes(d, d, batch) + 256;
 }
 
 static int cross_bwd_check(const char *who, const float *x0, const float *x, const float *kernel,
@@ -1375,7 +1433,9 @@ extern "C" int tfrs_cross_bwd(const float *x0, const float *x, const float *kern
   // dW = x^T (dy * x0)
   g = {};
   g.a = x; g.b = dy; g.bmul = x0; g.m = d; g.n = d; g.k = (int)batch; g.out = dkernel;
-  if ((rc = launch_gemm(g, kEpiBias, s, true, false)) != TFRS_OK) return rc;
+  float *const splitk_ws = reinterpret_cast<float *>(
+      static_cast<char *>(workspace) + ((size_t)((batch + kDbSlab - 1) / kDbSlab) * d * 4 + 255) / 256 * 256);
+  if ((rc = launch_gemm(g, kEpiBias, s, true, false, splitk_ws)) != TFRS_OK) return rc;
   if (dbias) {
     const int nslab = (int)((batch + kDbSlab - 1) / kDbSlab);
     float *part = static_cast<float *>(workspace);
@@ -1421,7 +1481,8 @@ extern "C" int tfrs_compute_scores(const float *q, const float *c, int64_t nq, i
 extern "C" size_t tfrs_dense_bwd_workspace_bytes(int64_t batch, int din, int dout, int f16) {
   if (batch < 1 || din < 1 || dout < 1) return 256;
   if (f16) return gemm16_dense_bwd_workspace_bytes(batch, din, dout);
-  return (size_t)((batch + kDbSlab - 1) / kDbSlab) * dout * 4 + 256;
+  // dbias partial sums, then the split-K partial products of dW
+  return ((size_t)((batch + kDbSlab - 1) / kDbSlab) * dout * 4 + 255) / 256 * 256 + splitk_bytes(din, dout, batch) + 256;
 }
 
 extern "C" int tfrs_dense_bwd(const float *x, const float *kernel, const float *dy, int64_t batch,
@@ -1448,7 +1509,9 @@ extern "C" int tfrs_dense_bwd(const float *x, const float *kernel, const float *
   if (dkernel) {   // dW[i, j] = sum_b x[b, i] dy[b, j]
     g = {};
     g.a = x; g.b = dy; g.m = din; g.n = dout; g.k = (int)batch; g.out = dkernel;
-    if ((rc = launch_gemm(g, kEpiBias, s, true, false)) != TFRS_OK) return rc;
+    float *const splitk_ws = reinterpret_cast<float *>(
+        static_cast<char *>(workspace) + ((size_t)((batch + kDbSlab - 1) / kDbSlab) * dout * 4 + 255) / 256 * 256);
+    if ((rc = launch_gemm(g, kEpiBias, s, true, false, splitk_ws)) != TFRS_OK) return rc;
   }
   if (dbias) {
     const int nslab = (int)((batch + kDbSlab - 1) / kDbSlab);

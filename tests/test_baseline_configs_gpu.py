@@ -433,3 +433,27 @@ def test_small_cluster_blocks_through_index_from_dataset():
   np.testing.assert_array_equal(_np(i), ei)
   np.testing.assert_array_equal(_np(s), es)
   assert layer.last_redo_count() <= nq // 50, layer.last_redo_reasons()
+
+
+@pytest.mark.parametrize("batch,din,dout", [(131072, 512, 1), (65536, 13, 512), (131072, 256, 32),
+                                            (20000, 200, 3), (8191, 129, 130)])
+def test_skinny_dense_backward_split_k(batch, din, dout, monkeypatch):
+  """Weight gradients of layers with a small input or output width (the first / last layers of the
+  ranking models' MLPs at BASELINE batch sizes): x^T dy is a few output tiles with K = batch and is
+  cut into K slices (csrc/interaction.hip launch_gemm).  dW, dx, db against float64."""
+  from recommenders_amd.layers.feature_interaction import dcn
+  monkeypatch.delenv("TFRS_GEMM_MODE", raising=False)
+  g = torch.Generator(device="cuda").manual_seed(batch + din)
+  x = torch.randn((batch, din), generator=g, device="cuda")
+  w = torch.randn((din, dout), generator=g, device="cuda") / din ** 0.5
+  dy = torch.randn((batch, dout), generator=g, device="cuda")
+  dx, dw, db = dcn.dense_backward(x, w, dy, True, True, True)
+  x64, w64, dy64 = x.double(), w.double(), dy.double()
+  ref_dw = x64.t() @ dy64
+  ref_dx = dy64 @ w64.t()
+  ref_db = dy64.sum(0)
+  scale_w = float((x64.abs().t() @ dy64.abs()).max())          # the sum of |terms| bounds the rounding
+  assert float((dw.double() - ref_dw).abs().max()) <= 4e-6 * scale_w
+  assert float((db.double() - ref_db).abs().max()) <= 4e-6 * float(dy64.abs().sum(0).max())
+  scale_x = float((dy64.abs() @ w64.abs().t()).max())
+  assert float((dx.double() - ref_dx).abs().max()) <= 4e-6 * scale_x
