@@ -28,18 +28,77 @@ from recommenders_amd.models import base
 from recommenders_amd.tasks import ranking as ranking_task
 
 
+class _TableView:
+  """One feature's rows of the fused table (``EmbeddingDict.tables[name].embeddings``)."""
+
+  def __init__(self, embeddings: torch.Tensor):
+    self.embeddings = embeddings
+
+
 class EmbeddingDict(torch.nn.Module):
   """``{feature: ids[B]} -> {feature: embeddings[B, dim]}``: one table per feature (the role the
   reference's tests give to ``TPUEmbedding`` with one ``TableConfig`` per feature,
-  ``ranking_test.py:30-59``)."""
+  ``ranking_test.py:30-59``).
 
-  def __init__(self, vocab_sizes: Dict[str, int], dim: int):
+  The tables are the row ranges of ONE parameter ``embeddings[sum(vocab), dim]`` (as on the TPU,
+  where the embedding layer owns one sharded store): the lookups of a step are one gather launch
+  and their gradients one ``(ids, rows)`` slice, i.e. one sort + one fused Adagrad update instead
+  of one chain of ~15 small launches per feature -- 100 features at batch 131072 spent 12 ms of a
+  49 ms train step in those chains.  ``tables[name].embeddings`` is a view of a feature's rows.
+  Ids are not range-checked (like ``layers.embedding.Embedding``): an id >= its table's size
+  reads the next table's rows."""
+
+  def __init__(self, vocab_sizes: Dict[str, int], dim: int, device: Optional[torch.device] = None):
     super().__init__()
-    self.tables = torch.nn.ModuleDict({str(name): embedding_lib.Embedding(int(v), dim)
-                                       for name, v in vocab_sizes.items()})
+    self._names = [str(name) for name in vocab_sizes]
+    self._sizes = [int(v) for v in vocab_sizes.values()]
+    if any(v < 1 for v in self._sizes):
+      raise ValueError("EmbeddingDict: every vocabulary needs at least one row.")
+    starts, total = [], 0
+    for v in self._sizes:
+      starts.append(total)
+      total += v
+    if total > 0xFFFFFFFF:
+      raise ValueError("EmbeddingDict: more than 2^32 rows in total.")
+    self._starts = dict(zip(self._names, starts))
+    dev = device if device is not None else (
+        torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu"))
+    w = torch.empty((total, int(dim)), dtype=torch.float32, device=dev)
+    w.uniform_(-0.05, 0.05)  # Keras "uniform" initialiser
+    self.embeddings = torch.nn.Parameter(w)
+    self.embeddings._tfrs_embedding = True   # lets optimizers.Adagrad ask for sliced gradients
+    self.register_buffer("_start_rows", torch.tensor(starts, dtype=torch.int64, device=dev),
+                         persistent=False)
+
+  @property
+  def tables(self) -> Dict[str, _TableView]:
+    return {name: _TableView(self.embeddings[lo:lo + n])
+            for name, lo, n in zip(self._names, self._starts.values(), self._sizes)}
 
   def forward(self, features: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-    return {name: self.tables[str(name)](ids) for name, ids in features.items()}
+    keys = list(features)
+    ids = []
+    for key in keys:
+      if str(key) not in self._starts:
+        raise KeyError(f"EmbeddingDict: no table for feature {key!r}.")
+      t = features[key]
+      t = t if isinstance(t, torch.Tensor) else torch.as_tensor(t)
+      if t.dtype not in (torch.int32, torch.int64):
+        t = t.long()
+      ids.append(t.to(self.embeddings.device))
+    if not keys:
+      return {}
+    if len(keys) > 1 and all(i.shape == ids[0].shape for i in ids):
+      if [str(k) for k in keys] == self._names:
+        starts = self._start_rows
+      else:
+        starts = torch.tensor([self._starts[str(k)] for k in keys], dtype=torch.int64,
+                              device=self.embeddings.device)
+      rows = torch.stack([i.long() for i in ids]) + starts.view((-1,) + (1,) * ids[0].dim())
+      out = embedding_lib._GatherFn.apply(self.embeddings, rows)        # [F, ..., dim]: one launch
+      return dict(zip(keys, out.unbind(0)))
+    return {key: embedding_lib._GatherFn.apply(self.embeddings, i.long() + self._starts[str(key)])
+            for key, i in zip(keys, ids)}
 
 
 class ConcatCross(torch.nn.Module):

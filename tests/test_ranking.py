@@ -113,7 +113,9 @@ def test_ranking_model_forward_and_training(interaction, concat_dense):
   for _ in range(30):
     last = float(model.train_step(batch)["loss"])
   assert last < first, (first, last)
-  assert len(model.embedding_trainable_variables) == 3
+  # (EmbeddingDict keeps its tables as row ranges of one parameter: one gather, one sparse update)
+  assert len(model.embedding_trainable_variables) == 1
+  assert model.embedding_trainable_variables[0].shape[0] == sum(vocab.values())
   assert len(model.dense_trainable_variables) >= 10
   with pytest.raises(ValueError):
     model.compute_loss((feats,))
