@@ -355,6 +355,17 @@ int tfrs_cross_bwd_f16(const float *x0, const float *x, const float *kernel, con
                        float diag_scale, const float *dy, int64_t batch, int d, float *dx0,
                        float *dx, float *dkernel, float *dbias, void *workspace,
                        size_t workspace_bytes, void *stream);
+/* Training pair that trades 4 * batch * d bytes for one of the three products: the forward also
+ * stores u = x @ kernel + bias + diag_scale * x (u_out[batch, d]; workspace as tfrs_cross_fwd_f16),
+ * the backward forms dx0 = dy * u elementwise and runs the other two fused GEMMs
+ * (workspace from tfrs_cross_bwd_workspace_bytes(batch, d, 1)). */
+int tfrs_cross_fwd_f16_train(const float *x0, const float *x, const float *kernel,
+                             const float *bias, float diag_scale, int64_t batch, int d, float *y,
+                             float *u_out, void *workspace, size_t workspace_bytes, void *stream);
+int tfrs_cross_bwd_f16_saved(const float *x0, const float *x, const float *u, const float *kernel,
+                             float diag_scale, const float *dy, int64_t batch, int d, float *dx0,
+                             float *dx, float *dkernel, float *dbias, void *workspace,
+                             size_t workspace_bytes, void *stream);
 /* Low-rank form (dcn.py:131-148, multi_layer_dcn.py:147-153): a[batch, ka] = x @ U is
  * computed first (tfrs_dense_fwd); this call does  y = x0 * (a @ kernel[ka, d] + bias +
  * diag_scale * x) + x  with the same fused epilogue. */

@@ -85,6 +85,8 @@ SIGNATURES = {
     "tfrs_gemm_f16_workspace_bytes": (c_size_t, [c_i64, c_int, c_int]),
     "tfrs_dense_fwd_f16": (c_int, [P, P, P, c_i64, c_int, c_int, P, P, c_size_t, P]),
     "tfrs_cross_fwd_f16": (c_int, [P, P, P, P, c_float, c_i64, c_int, P, P, c_size_t, P]),
+    "tfrs_cross_fwd_f16_train": (c_int, [P, P, P, P, c_float, c_i64, c_int, P, P, P, c_size_t, P]),
+    "tfrs_cross_bwd_f16_saved": (c_int, [P, P, P, P, c_float, P, c_i64, c_int, P, P, P, P, P, c_size_t, P]),
     "tfrs_dot_interaction_fwd": (c_int, [P, c_i64, c_int, c_int, c_int, c_int, P, P]),
     "tfrs_dot_interaction_bwd": (c_int, [P, P, c_i64, c_int, c_int, c_int, c_int, P, P]),
 }

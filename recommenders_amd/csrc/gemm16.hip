@@ -317,12 +317,16 @@ __global__ void __launch_bounds__(256) g16_prep_cols_kernel(const float *__restr
 //   CrossDx  out = v + e0 + diag * e0 * e1            e0 = dy, e1 = x0  (dx = dz W^T + dy + diag dz)
 enum { kG16EpiBias = 0, kG16EpiCross = 1, kG16EpiCrossDx0 = 2, kG16EpiCrossDx = 3 };
 
+// aux (Cross only, optional): receives u = v + diag * x, the factor the backward multiplies dy by
+// (dx0 = dy * u) -- saved by the training forward so that the backward needs two products, not three.
 template <int EPI>
 __device__ __forceinline__ float g16_epilogue(float v, const float *e0, const float *e1, float diag,
-                                              int64_t o) {
+                                              int64_t o, float *aux = nullptr) {
   if (EPI == kG16EpiCross) {
     const float xv = e1[o];
-    return e0[o] * (v + diag * xv) + xv;
+    const float u = v + diag * xv;
+    if (aux) aux[o] = u;
+    return e0[o] * u + xv;
   }
   if (EPI == kG16EpiCrossDx0) return e0[o] * (v + diag * e1[o]);
   if (EPI == kG16EpiCrossDx) {
@@ -341,6 +345,7 @@ struct Gemm16Args {
   const float *x0, *x;                 // epilogue operands e0, e1: [m, n] (see the enum below)
   float diag;
   float *out;                          // [m, n]
+  float *aux;                          // [m, n] or NULL: see g16_epilogue
   int kb;                              // K block of the images (== kp: plain rows), see g16_img_off
   int64_t mp, np;                      // padded image rows (block stride of K-blocked images)
   int kt_per;                          // big kernel, split-K: K steps per blockIdx.y slice (0 = all);
@@ -462,7 +467,7 @@ __global__ void __launch_bounds__(256, 2) gemm16_kernel(const Gemm16Args g) {
         if (row >= g.m) continue;
         const float v = acc[i][jn][r] * (g.inva[row] * cs) + bias;
         const int64_t o = row * g.n + col;
-        g.out[o] = g16_epilogue<EPI>(v, g.x0, g.x, g.diag, o);
+        g.out[o] = g16_epilogue<EPI>(v, g.x0, g.x, g.diag, o, g.aux);
       }
     }
 }
@@ -614,7 +619,7 @@ __global__ void __launch_bounds__(512) gemm16_big_kernel(const Gemm16Args g) {
         if (row >= g.m) continue;
         const float v = acc[i][jn][q] * (g.inva[row] * cs) + bias;
         const int64_t o = row * g.n + col;
-        outp[o] = g16_epilogue<EPI>(v, g.x0, g.x, g.diag, o);
+        outp[o] = g16_epilogue<EPI>(v, g.x0, g.x, g.diag, o, g.aux);
       }
     }
 }
@@ -699,7 +704,7 @@ static void g16_launch(const Gemm16Args &g, bool big, hipStream_t s) {
 // colsum[n] = sum_k (B * mul)[k, n].  ws from gemm16_workspace_bytes(m, n, k).
 int gemm16_run_ex(const G16Operand &a, const G16Operand &b, int64_t m, int n, int k,
                   const float *bias, int epi, const float *e0, const float *e1, float diag,
-                  float *out, float *colsum, void *ws, hipStream_t s) {
+                  float *out, float *colsum, void *ws, hipStream_t s, float *aux = nullptr) {
   const G16Layout L = g16_layout(m, n, k);
   char *w = static_cast<char *>(ws);
   _Float16 *ah = reinterpret_cast<_Float16 *>(w + L.ah), *al = reinterpret_cast<_Float16 *>(w + L.al);
@@ -754,7 +759,7 @@ int gemm16_run_ex(const G16Operand &a, const G16Operand &b, int64_t m, int n, in
   Gemm16Args g = {};
   g.ah = ah; g.al = al; g.bh = bh; g.bl = bl; g.inva = inva; g.invb = invb;
   g.m = m; g.n = n; g.kp = L.kp;
-  g.bias = bias; g.x0 = e0; g.x = e1; g.diag = diag; g.out = out;
+  g.bias = bias; g.x0 = e0; g.x = e1; g.diag = diag; g.out = out; g.aux = aux;
   g.kb = kb; g.mp = L.mp; g.np = L.np;
   // large shapes: 256 x 256 tiles with the 4-deep ring; otherwise (few tiles: fill the chip)
   // the 128 x 128 kernel.  TFRS_GEMM16_TILE = 128 | 256 forces one.
@@ -783,9 +788,10 @@ int gemm16_run_ex(const G16Operand &a, const G16Operand &b, int64_t m, int n, in
 
 // C = A @ B (+ bias) [cross epilogue when x0 != NULL]; ws from gemm16_workspace_bytes
 int gemm16_run(const float *a, const float *b, int64_t m, int n, int k, const float *bias,
-               const float *x0, const float *x, float diag, float *out, void *ws, hipStream_t s) {
+               const float *x0, const float *x, float diag, float *out, void *ws, hipStream_t s,
+               float *aux) {
   return gemm16_run_ex({a, nullptr, false}, {b, nullptr, false}, m, n, k, bias,
-                       x0 ? kG16EpiCross : kG16EpiBias, x0, x, diag, out, nullptr, ws, s);
+                       x0 ? kG16EpiCross : kG16EpiBias, x0, x, diag, out, nullptr, ws, s, x0 ? aux : nullptr);
 }
 
 // Cross backward (layers/feature_interaction/dcn.py:151-186 under models/base.py:77), full rank,
@@ -800,11 +806,39 @@ size_t gemm16_cross_bwd_workspace_bytes(int64_t batch, int d) {
   return std::max(g16_layout(batch, d, d).total, g16_layout(d, d, (int)batch).total);
 }
 
+__global__ void __launch_bounds__(256) g16_mul_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                      int64_t count, float *__restrict__ out) {
+  const bool vec = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) |
+                     reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    for (; i * 4 + 3 < count; i += stride) {
+      const float4 x = reinterpret_cast<const float4 *>(a)[i], y = reinterpret_cast<const float4 *>(b)[i];
+      reinterpret_cast<float4 *>(out)[i] = make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
+    }
+    for (int64_t t = (count & ~(int64_t)3) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride)
+      out[t] = a[t] * b[t];
+  } else {
+    for (; i < count; i += stride) out[i] = a[i] * b[i];
+  }
+}
+
+// `u` (optional) = x W + b + diag x saved by the training forward (tfrs_cross_fwd_f16_train): the
+// first product is then replaced by the elementwise dx0 = dy * u.
 int gemm16_cross_bwd(const float *x0, const float *x, const float *kernel, const float *bias,
                      float diag, const float *dy, int64_t batch, int d, float *dx0, float *dx,
-                     float *dkernel, float *dbias, void *ws, hipStream_t s) {
-  int rc = gemm16_run_ex({x, nullptr, false}, {kernel, nullptr, false}, batch, d, d, bias,
-                         kG16EpiCrossDx0, dy, x, diag, dx0, nullptr, ws, s);
+                     float *dkernel, float *dbias, void *ws, hipStream_t s, const float *u) {
+  int rc = TFRS_OK;
+  if (u) {
+    const int64_t count = batch * (int64_t)d;
+    hipLaunchKernelGGL(g16_mul_kernel, dim3((unsigned)std::min<int64_t>((count / 4 + 255) / 256 + 1, 256 * 32)),
+                       dim3(256), 0, s, dy, u, count, dx0);
+    TFRS_LAUNCH_CHECK();
+  } else {
+    rc = gemm16_run_ex({x, nullptr, false}, {kernel, nullptr, false}, batch, d, d, bias,
+                       kG16EpiCrossDx0, dy, x, diag, dx0, nullptr, ws, s);
+  }
   if (rc != TFRS_OK) return rc;
   rc = gemm16_run_ex({dy, x0, false}, {kernel, nullptr, true}, batch, d, d, nullptr, kG16EpiCrossDx, dy,
                      x0, diag, dx, nullptr, ws, s);

@@ -1346,7 +1346,8 @@ extern "C" int tfrs_dense_fwd(const float *x, const float *kernel, const float *
 namespace tfrs {
 size_t gemm16_workspace_bytes(int64_t m, int n, int k);
 int gemm16_run(const float *a, const float *b, int64_t m, int n, int k, const float *bias,
-               const float *x0, const float *x, float diag, float *out, void *ws, hipStream_t s);
+               const float *x0, const float *x, float diag, float *out, void *ws, hipStream_t s,
+               float *aux = nullptr);
 size_t gemm16_cross_bwd_workspace_bytes(int64_t batch, int d);
 size_t gemm16_dense_bwd_workspace_bytes(int64_t batch, int din, int dout);
 int gemm16_scores(const float *q, const float *c, int64_t nq, int nc, int d, float *out, void *ws,
@@ -1355,7 +1356,7 @@ int gemm16_dense_bwd(const float *x, const float *kernel, const float *dy, int64
                      int dout, float *dx, float *dkernel, float *dbias, void *ws, hipStream_t s);
 int gemm16_cross_bwd(const float *x0, const float *x, const float *kernel, const float *bias,
                      float diag, const float *dy, int64_t batch, int d, float *dx0, float *dx,
-                     float *dkernel, float *dbias, void *ws, hipStream_t s);
+                     float *dkernel, float *dbias, void *ws, hipStream_t s, const float *u = nullptr);
 
 // db[j] = sum_b dy[b, j] * x0[b, j]: partial sums over slabs of 256 rows (one workgroup per
 // 64 columns x slab, coalesced rows), then a fixed-order reduction: deterministic, no atomics.
@@ -1575,6 +1576,40 @@ extern "C" int tfrs_cross_fwd_f16(const float *x0, const float *x, const float *
   }
   return gemm16_run(x, kernel, batch, d, d, bias, x0, x, diag_scale, y, workspace,
                     (hipStream_t)stream);
+}
+
+// Training forward: also stores u = x W + b + diag x ([batch, d]) for tfrs_cross_bwd_f16_saved.
+extern "C" int tfrs_cross_fwd_f16_train(const float *x0, const float *x, const float *kernel,
+                                        const float *bias, float diag_scale, int64_t batch, int d,
+                                        float *y, float *u_out, void *workspace, size_t workspace_bytes,
+                                        void *stream) {
+  TFRS_CHECK_ARG(batch >= 0 && d >= 1, "cross_fwd_f16_train: bad shape");
+  TFRS_CHECK_ARG(diag_scale >= 0.0f, "`diag_scale` should be non-negative. Got `diag_scale` = %g",
+                 (double)diag_scale);
+  if (batch == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(x0 && x && kernel && y && u_out && workspace, "cross_fwd_f16_train: NULL pointer");
+  if (workspace_bytes < gemm16_workspace_bytes(batch, d, d)) {
+    set_error("cross_fwd_f16_train: workspace too small");
+    return TFRS_ENOMEM;
+  }
+  return gemm16_run(x, kernel, batch, d, d, bias, x0, x, diag_scale, y, workspace, (hipStream_t)stream, u_out);
+}
+
+extern "C" int tfrs_cross_bwd_f16_saved(const float *x0, const float *x, const float *u, const float *kernel,
+                                        float diag_scale, const float *dy, int64_t batch, int d,
+                                        float *dx0, float *dx, float *dkernel, float *dbias,
+                                        void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = cross_bwd_check("cross_bwd_f16_saved", x0, x, kernel, diag_scale, dy, batch, d, dx0, dx, dkernel,
+                           workspace);
+  if (rc != TFRS_OK || batch == 0) return rc;
+  TFRS_CHECK_ARG(u, "cross_bwd_f16_saved: NULL pointer");
+  TFRS_CHECK_ARG(batch <= 0x7FFFFFFFll, "cross_bwd_f16_saved: batch too large");
+  if (workspace_bytes < gemm16_cross_bwd_workspace_bytes(batch, d)) {
+    set_error("cross_bwd_f16_saved: workspace too small");
+    return TFRS_ENOMEM;
+  }
+  return gemm16_cross_bwd(x0, x, kernel, nullptr, diag_scale, dy, batch, d, dx0, dx, dkernel, dbias,
+                          workspace, (hipStream_t)stream, u);
 }
 
 extern "C" int tfrs_dot_interaction_fwd(const float *x, int64_t batch, int f, int d,

@@ -152,33 +152,49 @@ class _CrossFn(torch.autograd.Function):
     x0, x, kernel = x0.contiguous(), x.contiguous(), kernel.contiguous()
     y = torch.empty_like(x0)
     b, d = x0.shape
+    u = None
     if _use_f16_gemm(b, d, d):
       lib = _lib.load()
       ws = _gemm_workspace(lib.tfrs_gemm_f16_workspace_bytes(b, d, d), x0.device)
-      _lib.check(lib.tfrs_cross_fwd_f16(
-          _lib.ptr(x0), _lib.ptr(x), _lib.ptr(kernel), _lib.ptr(bias), float(diag), b, d,
-          _lib.ptr(y), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+      if any(ctx.needs_input_grad[:4]):
+        # training: the epilogue also stores u = x W + b + diag x, which the backward multiplies
+        # dy by -- 4 b d bytes instead of recomputing the product
+        u = torch.empty_like(x0)
+        _lib.check(lib.tfrs_cross_fwd_f16_train(
+            _lib.ptr(x0), _lib.ptr(x), _lib.ptr(kernel), _lib.ptr(bias), float(diag), b, d,
+            _lib.ptr(y), _lib.ptr(u), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+      else:
+        _lib.check(lib.tfrs_cross_fwd_f16(
+            _lib.ptr(x0), _lib.ptr(x), _lib.ptr(kernel), _lib.ptr(bias), float(diag), b, d,
+            _lib.ptr(y), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
     else:
       _lib.check(_lib.load().tfrs_cross_fwd(
           _lib.ptr(x0), _lib.ptr(x), _lib.ptr(kernel), _lib.ptr(bias), float(diag),
           b, d, _lib.ptr(y), _lib.current_stream()))
-    ctx.save_for_backward(x0, x, kernel, bias)
+    ctx.save_for_backward(x0, x, kernel, bias, u)
     ctx.diag = float(diag)
     return y
 
   @staticmethod
   def backward(ctx, dy):
-    """One ``tfrs_cross_bwd[_f16]`` call: dx0 = dy * z (z recomputed in the first GEMM's
-    epilogue), dx = dz W^T + dy + diag dz, dW = x^T dz, db = sum_rows dz with dz = dy * x0
-    formed in the operand loads -- no transposes, no elementwise passes, no z / dz in HBM."""
-    x0, x, kernel, bias = ctx.saved_tensors
+    """One ``tfrs_cross_bwd[_f16[_saved]]`` call: dx0 = dy * u (u = x W + b + diag x: saved by the
+    split-fp16 training forward, else recomputed in the first GEMM's epilogue),
+    dx = dz W^T + dy + diag dz, dW = x^T dz, db = sum_rows dz with dz = dy * x0 formed in the
+    operand loads -- no transposes, no dz in HBM."""
+    x0, x, kernel, bias, u = ctx.saved_tensors
     dy = dy.contiguous()
     b, d = x0.shape
     dx0, dx, dk = torch.empty_like(x0), torch.empty_like(x), torch.empty_like(kernel)
     db = torch.empty_like(bias) if bias is not None else None
     lib = _lib.load()
-    f16 = 1 if _use_f16_gemm(b, d, d) else 0
+    f16 = 1 if (u is not None or _use_f16_gemm(b, d, d)) else 0
     ws = _gemm_workspace(lib.tfrs_cross_bwd_workspace_bytes(b, d, f16), x0.device)
+    if u is not None:
+      _lib.check(lib.tfrs_cross_bwd_f16_saved(
+          _lib.ptr(x0), _lib.ptr(x), _lib.ptr(u), _lib.ptr(kernel), ctx.diag, _lib.ptr(dy), b, d,
+          _lib.ptr(dx0), _lib.ptr(dx), _lib.ptr(dk), _lib.ptr(db), _lib.ptr(ws), ws.numel(),
+          _lib.current_stream()))
+      return dx0, dx, dk, db, None
     fn = lib.tfrs_cross_bwd_f16 if f16 else lib.tfrs_cross_bwd
     _lib.check(fn(_lib.ptr(x0), _lib.ptr(x), _lib.ptr(kernel), _lib.ptr(bias), ctx.diag,
                   _lib.ptr(dy), b, d, _lib.ptr(dx0), _lib.ptr(dx), _lib.ptr(dk), _lib.ptr(db),

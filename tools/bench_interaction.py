@@ -72,4 +72,20 @@ t_b = timeit(lambda: _lib.check(lib.tfrs_cross_bwd_f16(
     _lib.ptr(dx0), _lib.ptr(dxx), _lib.ptr(dk), _lib.ptr(db), _lib.ptr(ws), ws.numel(), st)), iters=5)
 emit(op="cross_bwd (tfrs_cross_bwd_f16: 3 fused GEMMs)", batch=Bc, dim=dc, ms=t_b * 1e3, tflops=3 * fl / t_b / 1e12,
      frac_f16_mfma_peak=9 * fl / t_b / F16_PEAK)
-emit(op="cross_fwd+bwd", batch=Bc, dim=dc, ms=(t_f + t_b) * 1e3, tflops=4 * fl / (t_f + t_b) / 1e12)
+emit(op="cross_fwd+bwd (inference forward + recomputing backward)", batch=Bc, dim=dc, ms=(t_f + t_b) * 1e3,
+     tflops=4 * fl / (t_f + t_b) / 1e12)
+# the training pair: forward also stores u = x W + b + diag x, backward = elementwise dx0 + 2 fused GEMMs
+y, u = torch.empty_like(x0), torch.empty_like(x0)
+wsf = dcn._gemm_workspace(max(lib.tfrs_gemm_f16_workspace_bytes(Bc, dc, dc),
+                              lib.tfrs_cross_bwd_workspace_bytes(Bc, dc, 1)), dev)
+t_ft = timeit(lambda: _lib.check(lib.tfrs_cross_fwd_f16_train(
+    _lib.ptr(x0), _lib.ptr(xi), _lib.ptr(layer.kernel), _lib.ptr(layer.bias), 0.0, Bc, dc, _lib.ptr(y),
+    _lib.ptr(u), _lib.ptr(wsf), wsf.numel(), st)), iters=5)
+t_bs = timeit(lambda: _lib.check(lib.tfrs_cross_bwd_f16_saved(
+    _lib.ptr(x0), _lib.ptr(xi), _lib.ptr(u), _lib.ptr(layer.kernel), 0.0, _lib.ptr(dy), Bc, dc,
+    _lib.ptr(dx0), _lib.ptr(dxx), _lib.ptr(dk), _lib.ptr(db), _lib.ptr(wsf), wsf.numel(), st)), iters=5)
+emit(op="cross_fwd_train (stores u)", batch=Bc, dim=dc, ms=t_ft * 1e3, tflops=fl / t_ft / 1e12)
+emit(op="cross_bwd_saved (tfrs_cross_bwd_f16_saved: dx0 = dy * u + 2 fused GEMMs)", batch=Bc, dim=dc,
+     ms=t_bs * 1e3, tflops=2 * fl / t_bs / 1e12, frac_f16_mfma_peak=6 * fl / t_bs / F16_PEAK)
+emit(op="cross_fwd+bwd (training pair)", batch=Bc, dim=dc, ms=(t_ft + t_bs) * 1e3,
+     tflops=3 * fl / (t_ft + t_bs) / 1e12)
