@@ -613,7 +613,28 @@ class Streaming(TopK):
   def _block_keys(self):
     """(key, blocks, ids) when every block is a cacheable GPU tensor, else None.  Iterates the
     dataset once without touching the device (shapes / pointers / version counters only)."""
-    keys, blocks, ids = [], [], []
+    # Fast path (serving: the same list of blocks call after call): the container and its elements
+    # are the objects seen last time and no tensor changed its storage or version counter -- one
+    # identity test and two attribute reads per block instead of the full probe (0.3 ms for the
+    # 191 blocks of a 12.5 M-row shard, as much as a whole B = 1 search).
+    src = self._candidates
+    fast = getattr(self, "_probe_fast", None)
+    if fast is not None and fast[0] is src and isinstance(src, (list, tuple)) and len(src) == len(fast[1]):
+      same = True
+      for element, (ref, tensors) in zip(src, fast[1]):
+        if element is not ref:
+          same = False
+          break
+        for t, ptr, ver in tensors:
+          if t._version != ver or t.data_ptr() != ptr:
+            same = False
+            break
+        if not same:
+          break
+      if same:
+        return fast[2]
+    self._probe_fast = None
+    keys, blocks, ids, seen = [], [], [], []
     for element in self._candidates:
       block_ids = None
       if isinstance(element, (tuple, list)):
@@ -631,7 +652,14 @@ class Streaming(TopK):
       keys.append((block.data_ptr(), tuple(block.shape), block._version))
       blocks.append(block)
       ids.append(block_ids)
-    return (tuple(keys), blocks, ids) if blocks else None
+      tensors = [(block, block.data_ptr(), block._version)]
+      if block_ids is not None:
+        tensors.append((block_ids, block_ids.data_ptr(), block_ids._version))
+      seen.append((element, tensors))
+    result = (tuple(keys), blocks, ids) if blocks else None
+    if result is not None and isinstance(src, (list, tuple)):
+      self._probe_fast = (src, seen, result)
+    return result
 
   def _cached_index(self, k: int) -> Optional["BruteForce"]:
     if not self._cache_blocks:
