@@ -407,6 +407,17 @@ int tfrs_dot_interaction_fwd(const float *x, int64_t batch, int f, int d,
 int tfrs_dot_interaction_bwd(const float *x, const float *dout, int64_t batch, int f,
                              int d, int self_interaction, int skip_gather, float *dx,
                              void *stream);
+/* Row-strided variants (packed-triangle output only): sample b's pairs live at out + b * out_stride
+ * (dout + b * dout_stride), i.e. inside a wider [batch, out_stride] matrix -- lets the ranking model
+ * write / read the block next to the bottom-stack output it is concatenated with
+ * (experimental/models/ranking.py:225-232) without concat / slice copies.  TFRS_ENOTIMPL for shapes
+ * outside the default kernels (fall back to the contiguous calls). */
+int tfrs_dot_interaction_fwd_strided(const float *x, int64_t batch, int f, int d,
+                                     int self_interaction, float *out, int64_t out_stride,
+                                     void *stream);
+int tfrs_dot_interaction_bwd_strided(const float *x, const float *dout, int64_t dout_stride,
+                                     int64_t batch, int f, int d, int self_interaction, float *dx,
+                                     void *stream);
 
 #ifdef __cplusplus
 }

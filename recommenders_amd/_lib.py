@@ -89,6 +89,8 @@ SIGNATURES = {
     "tfrs_cross_bwd_f16_saved": (c_int, [P, P, P, P, c_float, P, c_i64, c_int, P, P, P, P, P, c_size_t, P]),
     "tfrs_dot_interaction_fwd": (c_int, [P, c_i64, c_int, c_int, c_int, c_int, P, P]),
     "tfrs_dot_interaction_bwd": (c_int, [P, P, c_i64, c_int, c_int, c_int, c_int, P, P]),
+    "tfrs_dot_interaction_fwd_strided": (c_int, [P, c_i64, c_int, c_int, c_int, P, c_i64, P]),
+    "tfrs_dot_interaction_bwd_strided": (c_int, [P, P, c_i64, c_i64, c_int, c_int, c_int, P, P]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

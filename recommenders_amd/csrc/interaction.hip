@@ -605,17 +605,16 @@ __global__ void __launch_bounds__(64, 2) dot_interaction_f16x3_kernel(const floa
 template <int DP, int NB, int BLOCKS>
 __global__ void __launch_bounds__(256, BLOCKS) dot_interaction_f16x3_direct_kernel(const float *__restrict__ x,
                                                                                    int64_t batch, int f, int d, int self,
-                                                                                   float *__restrict__ out) {
+                                                                                   float *__restrict__ out, int64_t out_stride) {
   static_assert(DP % 16 == 0, "whole 32x32x16 steps");
   constexpr int KS = DP / 16;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
   const bool vec_ok = (d == DP) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((f * d) % 4 == 0);
-  const int out_dim = self ? f * (f + 1) / 2 : f * (f - 1) / 2;
   const int64_t wave_stride = (int64_t)gridDim.x * 4;
   for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < batch; b += wave_stride) {
-    float *ob = out + b * (int64_t)out_dim;
+    float *ob = out + b * out_stride;   // (out_stride >= out_dim: rows of a wider matrix, tfrs_dot_interaction_fwd_strided)
     h16x8 hi[NB][KS], lo[NB][KS];
     float inv_s[NB];   // wave-uniform
 #pragma unroll
@@ -692,8 +691,9 @@ __global__ void __launch_bounds__(256, BLOCKS) dot_interaction_f16x3_direct_kern
 
 template <int DP, int NB>
 static bool launch_dot_mfma_nb(const float *x, int64_t batch, int f, int d, int self, int skip,
-                               float *out, hipStream_t s) {
+                               float *out, hipStream_t s, int64_t out_stride) {
   const int out_dim = skip ? f * f : (self ? f * (f + 1) / 2 : f * (f - 1) / 2);
+  const bool strided = out_stride != 0 && out_stride != out_dim;   // only the direct-store kernel takes a row stride
   const size_t lds = (size_t)(((out_dim + 3) & ~3) + 64) * sizeof(float);  // per wave
   // TFRS_DOT_STAGE=0: direct 128-byte-run stores from the accumulators instead of the LDS-staged
   // linear copy-out (measurement switch)
@@ -714,9 +714,11 @@ static bool launch_dot_mfma_nb(const float *x, int64_t batch, int f, int d, int 
       if (!(fv && (fv[0] == 'f' || fv[0] == 's'))) {   // default: direct stores
         const dim3 gd((unsigned)std::min<int64_t>((batch + 3) / 4, 256 * 8));
         // three workgroups per CU: 142 VGPRs, no scratch (four would spill 16 registers: 1.18 vs 1.06 ms)
-        hipLaunchKernelGGL((dot_interaction_f16x3_direct_kernel<DP, NB, 3>), gd, dim3(256), 0, s, x, batch, f, d, self, out);
+        hipLaunchKernelGGL((dot_interaction_f16x3_direct_kernel<DP, NB, 3>), gd, dim3(256), 0, s, x, batch, f, d, self, out,
+                           strided ? out_stride : (int64_t)out_dim);
         return true;
       }
+      if (strided) return false;
       if (!(fv && fv[0] == 'f' && fv[1] == '3')) {
         static bool attr16_set = false;
         if (!attr16_set) {
@@ -728,9 +730,11 @@ static bool launch_dot_mfma_nb(const float *x, int64_t batch, int f, int d, int 
         return true;
       }
     }
+    if (strided) return false;
     hipLaunchKernelGGL((dot_interaction_mfma_kernel<DP, NB, true>), grid, dim3(64), lds, s, x, batch, f, d,
                        self, skip, out);
   } else {
+    if (strided) return false;
     const dim3 grid((unsigned)std::min<int64_t>((batch + 3) / 4, 256 * 16));
     hipLaunchKernelGGL((dot_interaction_mfma_kernel<DP, NB, false>), grid, dim3(256), 0, s, x, batch, f, d,
                        self, skip, out);
@@ -740,14 +744,14 @@ static bool launch_dot_mfma_nb(const float *x, int64_t batch, int f, int d, int 
 
 template <int DP>
 static bool launch_dot_mfma_dp(const float *x, int64_t batch, int f, int d, int self, int skip,
-                               float *out, hipStream_t s) {
+                               float *out, hipStream_t s, int64_t out_stride) {
   const int nb = (f + 31) / 32;
   if (nb * (DP / 2) > 128) return false;  // register budget of the resident X
   switch (nb) {
-    case 1: return launch_dot_mfma_nb<DP, 1>(x, batch, f, d, self, skip, out, s);
-    case 2: return launch_dot_mfma_nb<DP, 2>(x, batch, f, d, self, skip, out, s);
-    case 3: return launch_dot_mfma_nb<DP, 3>(x, batch, f, d, self, skip, out, s);
-    case 4: return launch_dot_mfma_nb<DP, 4>(x, batch, f, d, self, skip, out, s);
+    case 1: return launch_dot_mfma_nb<DP, 1>(x, batch, f, d, self, skip, out, s, out_stride);
+    case 2: return launch_dot_mfma_nb<DP, 2>(x, batch, f, d, self, skip, out, s, out_stride);
+    case 3: return launch_dot_mfma_nb<DP, 3>(x, batch, f, d, self, skip, out, s, out_stride);
+    case 4: return launch_dot_mfma_nb<DP, 4>(x, batch, f, d, self, skip, out, s, out_stride);
     default: return false;
   }
 }
@@ -991,7 +995,7 @@ __global__ void __launch_bounds__(256, 2) dot_interaction_bwd_dense_kernel(
 template <int MAXE>
 __global__ void __launch_bounds__(512) dot_interaction_bwd_pc_kernel(
     const float *__restrict__ x, const float *__restrict__ dout, int64_t batch, int f, int d,
-    int self, int kh, float *__restrict__ dx) {
+    int self, int kh, float *__restrict__ dx, int64_t dout_stride) {
   extern __shared__ __attribute__((aligned(16))) float s_lds[];
   constexpr int MAXX = 16;                   // X elements per producer thread: f * d <= 128 * 32
   const int tid = threadIdx.x;
@@ -1028,7 +1032,7 @@ __global__ void __launch_bounds__(512) dot_interaction_bwd_pc_kernel(
     xpos[e] = (uint16_t)((p / d) * 32 + (p % d));
   }
   auto load_sample = [&](float (&gy)[MAXE], float (&gx)[MAXX], int64_t b) __attribute__((always_inline)) {
-    const float *dy = dout + b * (int64_t)out_dim;
+    const float *dy = dout + b * dout_stride;   // (rows of a wider matrix: tfrs_dot_interaction_bwd_strided)
     const float *xb = x + b * (int64_t)xn;
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
@@ -1118,7 +1122,7 @@ __global__ void __launch_bounds__(512) dot_interaction_bwd_pc_kernel(
 
 template <int MAXE>
 static void launch_dot_bwd_pc_v(const float *x, const float *dout, int64_t batch, int f, int d, int self,
-                                int kh, size_t lds, dim3 grid, float *dx, hipStream_t s) {
+                                int kh, size_t lds, dim3 grid, float *dx, hipStream_t s, int64_t dout_stride) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dot_interaction_bwd_pc_kernel<MAXE>),
@@ -1126,14 +1130,15 @@ static void launch_dot_bwd_pc_v(const float *x, const float *dout, int64_t batch
     attr_set = true;
   }
   hipLaunchKernelGGL((dot_interaction_bwd_pc_kernel<MAXE>), grid, dim3(512), lds, s, x, dout, batch, f, d,
-                     self, kh, dx);
+                     self, kh, dx, dout_stride);
 }
 
 static void launch_dot_bwd_pc_e(int maxe, const float *x, const float *dout, int64_t batch, int f, int d,
-                                int self, int kh, size_t lds, dim3 grid, float *dx, hipStream_t s) {
-  if (maxe <= 12) launch_dot_bwd_pc_v<12>(x, dout, batch, f, d, self, kh, lds, grid, dx, s);
-  else if (maxe <= 20) launch_dot_bwd_pc_v<20>(x, dout, batch, f, d, self, kh, lds, grid, dx, s);
-  else launch_dot_bwd_pc_v<33>(x, dout, batch, f, d, self, kh, lds, grid, dx, s);
+                                int self, int kh, size_t lds, dim3 grid, float *dx, hipStream_t s,
+                                int64_t dout_stride) {
+  if (maxe <= 12) launch_dot_bwd_pc_v<12>(x, dout, batch, f, d, self, kh, lds, grid, dx, s, dout_stride);
+  else if (maxe <= 20) launch_dot_bwd_pc_v<20>(x, dout, batch, f, d, self, kh, lds, grid, dx, s, dout_stride);
+  else launch_dot_bwd_pc_v<33>(x, dout, batch, f, d, self, kh, lds, grid, dx, s, dout_stride);
 }
 
 template <int NFB, int MAXE>
@@ -1159,7 +1164,7 @@ static void launch_dot_bwd_dense_e(int maxe, const float *x, const float *dout, 
 }
 
 static bool launch_dot_bwd_dense(const float *x, const float *dout, int64_t batch, int f, int d,
-                                 int self, float *dx, hipStream_t s) {
+                                 int self, float *dx, hipStream_t s, int64_t dout_stride = 0) {
   if (f > 128 || d > 128) return false;
   int kh = (f + 7) / 8 * 4;                  // multiple of 4, 2 * kh >= f
   if (((2 * kh + 4) / 4) % 2 == 0) kh += 4;  // odd number of 16-byte slots per row
@@ -1172,9 +1177,11 @@ static bool launch_dot_bwd_dense(const float *x, const float *dout, int64_t batc
   if (!(dv && dv[0] == 'd') && d <= 32 && lds_pc <= 160 * 1024 && batch >= 512) {
     // producer / consumer kernel: one 8-wave workgroup per CU, double-buffered S and X tiles
     const dim3 grid_pc((unsigned)std::min<int64_t>(batch, 256));
-    launch_dot_bwd_pc_e(maxe, x, dout, batch, f, d, self, kh, lds_pc, grid_pc, dx, s);
+    launch_dot_bwd_pc_e(maxe, x, dout, batch, f, d, self, kh, lds_pc, grid_pc, dx, s,
+                        dout_stride ? dout_stride : (int64_t)out_dim);
     return true;
   }
+  if (dout_stride != 0 && dout_stride != out_dim) return false;   // only the producer / consumer kernel takes a row stride
   const int64_t per_cu = std::min<int64_t>(2, std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)lds));
   const dim3 grid((unsigned)std::min<int64_t>(batch, 256 * per_cu));
   const int nfb = (d + 31) / 32;
@@ -1230,14 +1237,14 @@ static bool launch_dot_bwd_mfma(const float *x, const float *dout, int64_t batch
 }
 
 static bool launch_dot_mfma(const float *x, int64_t batch, int f, int d, int self, int skip,
-                            float *out, hipStream_t s) {
+                            float *out, hipStream_t s, int64_t out_stride = 0) {
   if (d > 128 || f > 128) return false;
   switch (softmax_padded_dim(d)) {
-    case 8: return launch_dot_mfma_dp<8>(x, batch, f, d, self, skip, out, s);
-    case 16: return launch_dot_mfma_dp<16>(x, batch, f, d, self, skip, out, s);
-    case 32: return launch_dot_mfma_dp<32>(x, batch, f, d, self, skip, out, s);
-    case 64: return launch_dot_mfma_dp<64>(x, batch, f, d, self, skip, out, s);
-    default: return launch_dot_mfma_dp<128>(x, batch, f, d, self, skip, out, s);
+    case 8: return launch_dot_mfma_dp<8>(x, batch, f, d, self, skip, out, s, out_stride);
+    case 16: return launch_dot_mfma_dp<16>(x, batch, f, d, self, skip, out, s, out_stride);
+    case 32: return launch_dot_mfma_dp<32>(x, batch, f, d, self, skip, out, s, out_stride);
+    case 64: return launch_dot_mfma_dp<64>(x, batch, f, d, self, skip, out, s, out_stride);
+    default: return launch_dot_mfma_dp<128>(x, batch, f, d, self, skip, out, s, out_stride);
   }
 }
 
@@ -1631,6 +1638,44 @@ extern "C" int tfrs_dot_interaction_fwd(const float *x, int64_t batch, int f, in
                      (hipStream_t)stream, x, batch, f, d, self_interaction, skip_gather, out);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
+}
+
+// Row-strided variants: the packed pairs are row b of a WIDER matrix (out + b * out_stride), so
+// that the layer's output can be written next to the bottom-stack output it is concatenated with
+// (experimental/models/ranking.py:225-232) and its gradient read from that matrix's gradient in
+// place -- no torch.cat / slice copies of the [batch, F (F - 1) / 2] block.  Packed-triangle output
+// only, on the default kernels; TFRS_ENOTIMPL for shapes those do not cover (the caller falls back
+// to the contiguous calls).
+extern "C" int tfrs_dot_interaction_fwd_strided(const float *x, int64_t batch, int f, int d,
+                                                int self_interaction, float *out, int64_t out_stride,
+                                                void *stream) {
+  TFRS_CHECK_ARG(batch >= 0 && f >= 1 && d >= 1, "dot_interaction_fwd_strided: bad shape");
+  const int out_dim = self_interaction ? f * (f + 1) / 2 : f * (f - 1) / 2;
+  TFRS_CHECK_ARG(out_stride >= out_dim, "dot_interaction_fwd_strided: out_stride < pairs per sample");
+  if (batch == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(x && out, "dot_interaction_fwd_strided: NULL pointer");
+  if (launch_dot_mfma(x, batch, f, d, self_interaction, 0, out, (hipStream_t)stream, out_stride)) {
+    TFRS_LAUNCH_CHECK();
+    return TFRS_OK;
+  }
+  set_error("dot_interaction_fwd_strided: %d features x %d dims are not covered by the strided kernel", f, d);
+  return TFRS_ENOTIMPL;
+}
+
+extern "C" int tfrs_dot_interaction_bwd_strided(const float *x, const float *dout, int64_t dout_stride,
+                                                int64_t batch, int f, int d, int self_interaction,
+                                                float *dx, void *stream) {
+  TFRS_CHECK_ARG(batch >= 0 && f >= 1 && d >= 1, "dot_interaction_bwd_strided: bad shape");
+  const int out_dim = self_interaction ? f * (f + 1) / 2 : f * (f - 1) / 2;
+  TFRS_CHECK_ARG(dout_stride >= out_dim, "dot_interaction_bwd_strided: dout_stride < pairs per sample");
+  if (batch == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(x && dout && dx, "dot_interaction_bwd_strided: NULL pointer");
+  if (launch_dot_bwd_dense(x, dout, batch, f, d, self_interaction, dx, (hipStream_t)stream, dout_stride)) {
+    TFRS_LAUNCH_CHECK();
+    return TFRS_OK;
+  }
+  set_error("dot_interaction_bwd_strided: %d features x %d dims are not covered by the strided kernel", f, d);
+  return TFRS_ENOTIMPL;
 }
 
 extern "C" int tfrs_dot_interaction_bwd(const float *x, const float *dout, int64_t batch, int f,

@@ -35,6 +35,27 @@ class _TableView:
     self.embeddings = embeddings
 
 
+class _GatherWithTailFn(torch.autograd.Function):
+  """``x = table[rows]`` for ``rows[B, F + 1]`` whose last column is the invalid id -1 (reads zeros,
+  takes no gradient), then ``x[:, -1, :] = tail``: the ``[B, F + 1, D]`` block DotInteraction reads,
+  from one gather launch.  Backward: the table receives the ``(rows, dx)`` slice of the lookup
+  (``layers.embedding._emit_table_grad``), ``tail`` the last feature's gradient."""
+
+  @staticmethod
+  def forward(ctx, table, rows, tail):
+    ctx.save_for_backward(rows)
+    ctx.vocab = table.shape[0]
+    ctx.table_ref = table
+    x = embedding_lib.gather_rows(table, rows).contiguous()
+    x[:, -1, :] = tail
+    return x
+
+  @staticmethod
+  def backward(ctx, dx):
+    dx = dx.contiguous()
+    return embedding_lib._emit_table_grad(ctx, dx), None, dx[:, -1, :].contiguous()
+
+
 class EmbeddingDict(torch.nn.Module):
   """``{feature: ids[B]} -> {feature: embeddings[B, dim]}``: one table per feature (the role the
   reference's tests give to ``TPUEmbedding`` with one ``TableConfig`` per feature,
@@ -74,6 +95,25 @@ class EmbeddingDict(torch.nn.Module):
   def tables(self) -> Dict[str, _TableView]:
     return {name: _TableView(self.embeddings[lo:lo + n])
             for name, lo, n in zip(self._names, self._starts.values(), self._sizes)}
+
+  def can_stack(self, features: Dict[str, torch.Tensor]) -> bool:
+    """True when ``stacked`` applies: every feature is a vector of ids ``[B]`` of one length."""
+    shapes = {tuple(t.shape) for t in features.values() if isinstance(t, torch.Tensor)}
+    return (len(features) > 0 and len(shapes) == 1 and len(next(iter(shapes))) == 1
+            and all(isinstance(t, torch.Tensor) and str(k) in self._starts for k, t in features.items()))
+
+  def stacked(self, features: Dict[str, torch.Tensor], tail: torch.Tensor) -> torch.Tensor:
+    """``[B, F + 1, dim]``: the features' embeddings in ``str(name)`` order (the order
+    ``Ranking.call`` flattens the embedding dict in) followed by ``tail[B, dim]`` -- the layout
+    DotInteraction consumes, produced by ONE gather with the ids laid out ``[B, F + 1]`` (last
+    column: the invalid id -1, which reads zeros and takes no gradient) instead of F lookups,
+    a concat of F + 1 tensors and its backward."""
+    keys = sorted(features, key=str)
+    dev = self.embeddings.device
+    starts = torch.tensor([self._starts[str(k)] for k in keys], dtype=torch.int64, device=dev)
+    rows = torch.stack([features[k].to(dev).long() for k in keys], dim=1) + starts        # [B, F]
+    rows = torch.cat([rows, rows.new_full((rows.shape[0], 1), -1)], dim=1)                  # [B, F + 1]
+    return _GatherWithTailFn.apply(self.embeddings, rows, tail.to(torch.float32))             # [B, F + 1, dim]
 
   def forward(self, features: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     keys = list(features)
@@ -159,16 +199,30 @@ class Ranking(base.Model):
   def forward(self, inputs: Dict[str, torch.Tensor]) -> torch.Tensor:                          # :208-236
     dense_features = inputs["dense_features"]
     sparse_features = inputs["sparse_features"]
+    dense_embedding_vec = self._bottom_stack(dense_features.to(torch.float32))
+    fi = self._feature_interaction
+    if (isinstance(self._embedding_layer, EmbeddingDict) and isinstance(fi, dot_lib.DotInteraction)
+        and self._embedding_layer.can_stack(sparse_features)
+        and dense_embedding_vec.shape[1] == self._embedding_layer.embeddings.shape[1]):
+      # DLRM fast path: one gather straight into the [B, F + 1, D] block DotInteraction reads, the
+      # bottom-stack output as its last feature; same values as the generic path below
+      x = self._embedding_layer.stacked(sparse_features, dense_embedding_vec)
+      out = fi.forward_stacked(x, dense_embedding_vec if self._concat_dense else None)
+      return self._top_stack(out).reshape(-1)
     sparse_embeddings = self._embedding_layer(sparse_features)
     vecs: List[torch.Tensor] = []
     for _, e in sorted(sparse_embeddings.items(), key=lambda kv: str(kv[0])):   # tf.nest.flatten order
       vecs.append(e.reshape(e.shape[0], -1) if e.dim() > 2 else e)              # squeeze [B,1,D]
-    dense_embedding_vec = self._bottom_stack(dense_features.to(torch.float32))
-    interaction_output = self._feature_interaction(vecs + [dense_embedding_vec])
-    if self._concat_dense:
-      out = torch.cat([dense_embedding_vec, interaction_output], dim=1)
+    if self._concat_dense and isinstance(fi, dot_lib.DotInteraction):
+      # the pairs are written next to the bottom-stack output: no concat / slice copies of the
+      # [B, F (F - 1) / 2] block in either direction
+      out = fi.forward_concat(vecs + [dense_embedding_vec], dense_embedding_vec)
     else:
-      out = interaction_output
+      interaction_output = fi(vecs + [dense_embedding_vec])
+      if self._concat_dense:
+        out = torch.cat([dense_embedding_vec, interaction_output], dim=1)
+      else:
+        out = interaction_output
     prediction = self._top_stack(out)
     return prediction.reshape(-1)
 

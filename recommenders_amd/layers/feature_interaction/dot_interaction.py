@@ -46,6 +46,40 @@ class _DotInteractionFn(torch.autograd.Function):
     return dx, None, None
 
 
+class _DotConcatFn(torch.autograd.Function):
+  """``concat([prefix, DotInteraction(x)], axis=1)`` without the concat: the packed pairs are written
+  straight into columns ``P ..`` of the ``[B, P + pairs]`` result (``tfrs_dot_interaction_fwd_strided``)
+  and their gradient is read from the result's gradient in place (``..._bwd_strided``)."""
+
+  @staticmethod
+  def forward(ctx, x, prefix, self_interaction):
+    x = x.contiguous()
+    prefix = prefix.contiguous()
+    b, f, d = x.shape
+    p = prefix.shape[1]
+    pairs = _out_dim(f, self_interaction, False)
+    out = torch.empty((b, p + pairs), dtype=torch.float32, device=x.device)
+    out[:, :p] = prefix
+    _lib.check(_lib.load().tfrs_dot_interaction_fwd_strided(
+        _lib.ptr(x), b, f, d, int(self_interaction), out.data_ptr() + 4 * p, p + pairs,
+        _lib.current_stream()))
+    ctx.save_for_backward(x)
+    ctx.meta = (bool(self_interaction), p)
+    return out
+
+  @staticmethod
+  def backward(ctx, dout):
+    (x,) = ctx.saved_tensors
+    self_interaction, p = ctx.meta
+    b, f, d = x.shape
+    dout = dout.contiguous()
+    dx = torch.empty_like(x)
+    _lib.check(_lib.load().tfrs_dot_interaction_bwd_strided(
+        _lib.ptr(x), dout.data_ptr() + 4 * p, dout.shape[1], b, f, d, int(self_interaction),
+        _lib.ptr(dx), _lib.current_stream()))
+    return dx, dout[:, :p].contiguous(), None
+
+
 class DotInteraction(torch.nn.Module):
 
   def __init__(self, self_interaction: bool = False, skip_gather: bool = False,
@@ -66,3 +100,30 @@ class DotInteraction(torch.nn.Module):
     return _DotInteractionFn.apply(x, self._self_interaction, self._skip_gather)
 
   call = forward
+
+  def forward_stacked(self, x: torch.Tensor, prefix: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The layer on an already stacked ``x[B, F, D]`` (``concat_features`` of :74-76), optionally
+    concatenated behind ``prefix[B, P]`` like ``forward_concat``."""
+    batch, _, dim = x.shape
+    x = x.to(torch.float32)
+    if prefix is None:
+      return _DotInteractionFn.apply(x, self._self_interaction, self._skip_gather)
+    fusable = (not self._skip_gather and dim % 16 == 0 and dim <= 32 and x.shape[1] <= 128
+               and batch >= 512 and prefix.dim() == 2 and prefix.is_cuda and prefix.shape[0] == batch)
+    if not fusable:
+      return torch.cat([prefix.to(torch.float32),
+                        _DotInteractionFn.apply(x, self._self_interaction, self._skip_gather)], dim=1)
+    return _DotConcatFn.apply(x, prefix.to(torch.float32), self._self_interaction)
+
+  def forward_concat(self, inputs: List[torch.Tensor], prefix: torch.Tensor) -> torch.Tensor:
+    """``torch.cat([prefix, self(inputs)], dim=1)`` (the ranking model's ``concat_dense`` step,
+    experimental/models/ranking.py:225-232), fused where the strided kernels apply."""
+    dims = {int(t.shape[1]) for t in inputs}
+    batch, dim = inputs[0].shape
+    fusable = (len(dims) == 1 and not self._skip_gather and dim % 16 == 0 and dim <= 32
+               and len(inputs) <= 128 and batch >= 512 and prefix.dim() == 2 and prefix.is_cuda
+               and prefix.shape[0] == batch)
+    if not fusable:
+      return torch.cat([prefix.to(torch.float32), self.forward(inputs)], dim=1)
+    x = torch.cat([t.to(torch.float32) for t in inputs], dim=-1).reshape(batch, -1, dim)
+    return _DotConcatFn.apply(x, prefix.to(torch.float32), self._self_interaction)

@@ -457,3 +457,67 @@ def test_skinny_dense_backward_split_k(batch, din, dout, monkeypatch):
   assert float((db.double() - ref_db).abs().max()) <= 4e-6 * float(dy64.abs().sum(0).max())
   scale_x = float((dy64.abs() @ w64.abs().t()).max())
   assert float((dx.double() - ref_dx).abs().max()) <= 4e-6 * scale_x
+
+
+@pytest.mark.parametrize("self_interaction", [False, True])
+def test_dot_interaction_forward_concat_equals_cat(self_interaction):
+  """`DotInteraction.forward_concat` (pairs written into / read from the wider concat matrix by the
+  strided kernels) against `torch.cat([prefix, layer(inputs)])`: values bit for bit, gradients of
+  every input and of the prefix (which is also the last input, as in the ranking model)."""
+  from recommenders_amd.layers.feature_interaction import DotInteraction
+  g = torch.Generator(device="cuda").manual_seed(77)
+  b, f, d = 2048, 27, 32
+  layer = DotInteraction(self_interaction=self_interaction)
+  base = [torch.randn((b, d), generator=g, device="cuda") for _ in range(f)]
+  outs = []
+  for fused in (False, True):
+    xs = [t.clone().requires_grad_(True) for t in base]
+    if fused:
+      y = layer.forward_concat(xs, xs[-1])
+    else:
+      y = torch.cat([xs[-1], layer(xs)], dim=1)
+    w = torch.linspace(-1.0, 1.0, y.shape[1], device="cuda")
+    (y * w).sum().backward()
+    outs.append((y.detach(), [t.grad.clone() for t in xs]))
+  assert torch.equal(outs[0][0], outs[1][0])
+  for ga, gb in zip(outs[0][1], outs[1][1]):
+    assert torch.allclose(ga, gb, rtol=1e-6, atol=1e-6)
+
+
+def test_ranking_dlrm_fast_path_equals_generic_path():
+  """`experimental.models.Ranking` with `EmbeddingDict` + `DotInteraction`: ids given as `[B]`
+  vectors take the fast path (one gather into the `[B, F + 1, D]` block incl. the invalid-id slot,
+  strided DotInteraction + concat), ids given as `[B, 1]` the generic one.  Same predictions and,
+  after one Adagrad step from identical weights, the same parameters."""
+  import copy
+  import recommenders_amd as tfrs
+  from recommenders_amd.experimental.models import ranking as rk
+  g = torch.Generator(device="cuda").manual_seed(5)
+  B, D, nd = 1024, 32, 13
+  vocab = {"a": 300, "b": 50, "c": 1000, "d": 7}
+
+  def make():
+    torch.manual_seed(123)
+    emb = rk.EmbeddingDict(vocab, D)
+    model = rk.Ranking(emb, bottom_stack=tfrs.layers.blocks.MLP(units=[64, D], final_activation="relu"),
+                       feature_interaction=tfrs.layers.feature_interaction.DotInteraction(),
+                       top_stack=tfrs.layers.blocks.MLP(units=[64, 1], final_activation="sigmoid"))
+    return model
+
+  dense = torch.rand((B, nd), generator=g, device="cuda")
+  ids = {k: torch.randint(0, v, (B,), generator=g, device="cuda") for k, v in vocab.items()}
+  labels = torch.randint(0, 2, (B,), generator=g, device="cuda")
+  fast, generic = make(), make()
+  f_in = {"dense_features": dense, "sparse_features": ids}
+  g_in = {"dense_features": dense, "sparse_features": {k: v[:, None] for k, v in ids.items()}}
+  p_fast = fast(f_in)
+  generic(g_in)
+  generic.load_state_dict(copy.deepcopy(fast.state_dict()))
+  p_gen = generic(g_in)
+  assert torch.allclose(p_fast, p_gen, rtol=1e-6, atol=1e-7)
+  for m, batch in ((fast, f_in), (generic, g_in)):
+    m.compile(optimizer=tfrs.optimizers.Adagrad(m.parameters(), learning_rate=0.1))
+    m.train_step((batch, labels))
+  for (n1, a), (n2, b) in zip(fast.named_parameters(), generic.named_parameters()):
+    assert n1 == n2
+    assert torch.allclose(a, b, rtol=2e-5, atol=2e-6), n1
