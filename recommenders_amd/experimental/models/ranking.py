@@ -152,6 +152,11 @@ class ConcatCross(torch.nn.Module):
   def forward(self, inputs: Sequence[torch.Tensor]) -> torch.Tensor:
     return self.cross(torch.cat(list(inputs), dim=-1))
 
+  def forward_stacked(self, x: torch.Tensor, prefix: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The same on an already concatenated block ``x[B, F, D]`` (``Ranking.call`` fast path)."""
+    out = self.cross(x.reshape(x.shape[0], -1))
+    return out if prefix is None else torch.cat([prefix, out], dim=1)
+
 
 class Ranking(base.Model):
   """A configurable ranking model (reference :27-257)."""
@@ -201,11 +206,12 @@ class Ranking(base.Model):
     sparse_features = inputs["sparse_features"]
     dense_embedding_vec = self._bottom_stack(dense_features.to(torch.float32))
     fi = self._feature_interaction
-    if (isinstance(self._embedding_layer, EmbeddingDict) and isinstance(fi, dot_lib.DotInteraction)
+    if (isinstance(self._embedding_layer, EmbeddingDict) and hasattr(fi, "forward_stacked")
         and self._embedding_layer.can_stack(sparse_features)
         and dense_embedding_vec.shape[1] == self._embedding_layer.embeddings.shape[1]):
-      # DLRM fast path: one gather straight into the [B, F + 1, D] block DotInteraction reads, the
-      # bottom-stack output as its last feature; same values as the generic path below
+      # fast path: one gather straight into the [B, F + 1, D] block the interaction reads (the
+      # concatenation of the feature vectors, `forward_stacked`), the bottom-stack output as its last
+      # feature; same values as the generic path below
       x = self._embedding_layer.stacked(sparse_features, dense_embedding_vec)
       out = fi.forward_stacked(x, dense_embedding_vec if self._concat_dense else None)
       return self._top_stack(out).reshape(-1)

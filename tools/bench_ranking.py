@@ -33,6 +33,12 @@ def run(name, n_tables, vocab, dim, batch, interaction, steps=3):
         for layer in self.layers:
           x = layer(x0, x)
         return x
+      def forward_stacked(self, xs, prefix=None):      # Ranking.call fast path: xs[B, F, D] = the concat
+        x0 = xs.reshape(xs.shape[0], -1)
+        x = x0
+        for layer in self.layers:
+          x = layer(x0, x)
+        return x if prefix is None else torch.cat([prefix, x], dim=1)
     fi = CrossStack()
   else:
     fi = tfrs.layers.feature_interaction.DotInteraction()
