@@ -228,7 +228,9 @@ constexpr int kMaxKF16 = 512;
 // largest segment count bounds every round.
 static int64_t list_entries_per_query(int64_t nq, int k, const TopkTuning &t) {
   const int nseg = 2 * max_splits(nq, t);
-  return (int64_t)nseg * segment_cap(k, nseg, t);
+  // (+ 1 per segment: segment_cap truncates, so nseg * segment_cap(nseg) is monotone in nseg only
+  // up to that rounding -- 254 segments x 57 needed more than 256 x 56)
+  return (int64_t)nseg * ((int64_t)segment_cap(k, nseg, t) + 1);
 }
 
 struct RoundWs {

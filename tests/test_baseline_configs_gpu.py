@@ -521,3 +521,19 @@ def test_ranking_dlrm_fast_path_equals_generic_path():
   for (n1, a), (n2, b) in zip(fast.named_parameters(), generic.named_parameters()):
     assert n1 == n2
     assert torch.allclose(a, b, rtol=2e-5, atol=2e-6), n1
+
+
+def test_survivor_workspace_covers_every_split_count():
+  """Found by tools/fuzz_topk.py: the survivor buffer was sized for the LARGEST segment count, but
+  `segments x truncated capacity` is not monotone in the segment count (254 x 57 > 256 x 56), so
+  K = 400 with 2048 queries on ~2530 stages failed with "survivor workspace too small"."""
+  ftk = _ftk()
+  g = torch.Generator(device="cuda").manual_seed(4)
+  n, d, nq, k = 323_800, 16, 2048, 400
+  c = torch.randn((n, d), generator=g, device="cuda") / d ** 0.5
+  q = torch.randn((nq, d), generator=g, device="cuda") / d ** 0.5
+  layer = ftk.BruteForce(k=k).index(c)
+  s, i = layer(q)
+  es, ei = o_topk.brute_force(_np(q[:8]), _np(c), k)
+  np.testing.assert_array_equal(_np(i[:8]), ei)
+  np.testing.assert_array_equal(_np(s[:8]), es)
