@@ -515,3 +515,28 @@ def test_threshold_pass_plan_statistics(lib, monkeypatch):
   monkeypatch.setenv("TFRS_TOPK_STAT", "0")
   assert lib.tfrs_debug_topk_plan(1_000_000, 100, 1, plan) == 0
   assert plan[3] == 100 and plan[4] == 0
+
+
+def test_embedding_dict_host_logic():
+  """experimental.models.ranking.EmbeddingDict: the tables are row ranges of one parameter
+  (host-side bookkeeping only; the lookups themselves are GPU tests)."""
+  import torch
+  from recommenders_amd.experimental.models import ranking as rk
+  emb = rk.EmbeddingDict({"b": 7, "a": 5, 3: 2}, 4, device=torch.device("cpu"))
+  assert [n for n, _ in emb.named_parameters()] == ["embeddings"]
+  assert tuple(emb.embeddings.shape) == (14, 4)
+  assert float(emb.embeddings.abs().max()) <= 0.05
+  views = emb.tables
+  assert list(views) == ["b", "a", "3"]
+  assert views["a"].embeddings.data_ptr() == emb.embeddings[7:12].data_ptr()
+  assert tuple(views["3"].embeddings.shape) == (2, 4)
+  assert emb._start_rows.tolist() == [0, 7, 12]
+  ids = lambda n: torch.zeros((n,), dtype=torch.int64)
+  assert emb.can_stack({"a": ids(6), "b": ids(6), 3: ids(6)})
+  assert not emb.can_stack({"a": ids(6), "b": ids(5)})               # different batch sizes
+  assert not emb.can_stack({"a": ids(6)[:, None], "b": ids(6)[:, None]})   # [B, 1] ids: generic path
+  assert not emb.can_stack({"a": ids(6), "zz": ids(6)})               # unknown feature
+  with pytest.raises(KeyError, match="no table"):
+    emb({"zz": ids(3)})
+  with pytest.raises(ValueError, match="at least one row"):
+    rk.EmbeddingDict({"a": 0}, 4, device=torch.device("cpu"))
