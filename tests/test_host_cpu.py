@@ -540,3 +540,27 @@ def test_embedding_dict_host_logic():
     emb({"zz": ids(3)})
   with pytest.raises(ValueError, match="at least one row"):
     rk.EmbeddingDict({"a": 0}, 4, device=torch.device("cpu"))
+
+
+def test_headline_kernel_resources(tmp_path):
+  """The fp16 filter kernel of the headline path must keep its register budget: four waves per
+  SIMD (<= 128 VGPRs) and no scratch -- a spill puts `s_waitcnt vmcnt(0)` behind every stage
+  prefetch.  Checked on the cross-compiled ISA metadata, no GPU needed."""
+  import subprocess
+  from recommenders_amd.csrc import build as csrc_build
+  src = os.path.join(os.path.dirname(csrc_build.__file__), "topk_scan16.hip")
+  out = tmp_path / "scan16.s"
+  cmd = [csrc_build.hipcc(), f"--offload-arch={csrc_build.ARCH}", "-O3", "-std=c++17",
+         *csrc_build.EXTRA_FLAGS.get("topk_scan16.hip", []), "-S", "--cuda-device-only", "-o", str(out), src]
+  subprocess.run(cmd, check=True, capture_output=True, cwd=os.path.dirname(src))
+  text = out.read_text()
+  found = 0
+  for block in text.split("- .agpr_count:")[1:]:          # one metadata entry per kernel
+    name = re.search(r"\.name:\s+(\S+)", block).group(1)
+    if "scan16f_kernelILi64ELi8ELi2E" not in name and "scan16f_kernelILi32ELi8ELi2E" not in name:
+      continue
+    found += 1
+    assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1)) == 0, name
+    assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", block).group(1)) == 0, name
+    assert int(re.search(r"\.vgpr_count:\s+(\d+)", block).group(1)) <= 128, name
+  assert found == 2
