@@ -542,25 +542,32 @@ def test_embedding_dict_host_logic():
     rk.EmbeddingDict({"a": 0}, 4, device=torch.device("cpu"))
 
 
-def test_headline_kernel_resources(tmp_path):
-  """The fp16 filter kernel of the headline path must keep its register budget: four waves per
-  SIMD (<= 128 VGPRs) and no scratch -- a spill puts `s_waitcnt vmcnt(0)` behind every stage
-  prefetch.  Checked on the cross-compiled ISA metadata, no GPU needed."""
+@pytest.mark.parametrize("source,patterns,max_vgprs", [
+    # the fp16 filter kernel of the headline path: four waves per SIMD
+    ("topk_scan16.hip", ("scan16f_kernelILi64ELi8ELi2E", "scan16f_kernelILi32ELi8ELi2E"), 128),
+    # the 256 x 256 split-fp16 GEMM (one 8-wave workgroup per CU: two waves per SIMD), all epilogues
+    ("gemm16.hip", ("gemm16_big_kernelILi0E", "gemm16_big_kernelILi1E", "gemm16_big_kernelILi2E",
+                    "gemm16_big_kernelILi3E"), 256),
+])
+def test_hot_kernel_register_budgets(tmp_path, source, patterns, max_vgprs):
+  """Hot kernels must keep their register budget and use no scratch -- a spill in the filter kernel
+  puts `s_waitcnt vmcnt(0)` behind every stage prefetch.  Checked on the
+  cross-compiled ISA metadata, no GPU needed."""
   import subprocess
   from recommenders_amd.csrc import build as csrc_build
-  src = os.path.join(os.path.dirname(csrc_build.__file__), "topk_scan16.hip")
-  out = tmp_path / "scan16.s"
+  src = os.path.join(os.path.dirname(csrc_build.__file__), source)
+  out = tmp_path / "kernel.s"
   cmd = [csrc_build.hipcc(), f"--offload-arch={csrc_build.ARCH}", "-O3", "-std=c++17",
-         *csrc_build.EXTRA_FLAGS.get("topk_scan16.hip", []), "-S", "--cuda-device-only", "-o", str(out), src]
+         *csrc_build.EXTRA_FLAGS.get(source, []), "-S", "--cuda-device-only", "-o", str(out), src]
   subprocess.run(cmd, check=True, capture_output=True, cwd=os.path.dirname(src))
-  text = out.read_text()
-  found = 0
-  for block in text.split("- .agpr_count:")[1:]:          # one metadata entry per kernel
+  found = set()
+  for block in out.read_text().split("- .agpr_count:")[1:]:          # one metadata entry per kernel
     name = re.search(r"\.name:\s+(\S+)", block).group(1)
-    if "scan16f_kernelILi64ELi8ELi2E" not in name and "scan16f_kernelILi32ELi8ELi2E" not in name:
+    hit = [p for p in patterns if p in name]
+    if not hit:
       continue
-    found += 1
+    found.add(hit[0])
     assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1)) == 0, name
     assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", block).group(1)) == 0, name
-    assert int(re.search(r"\.vgpr_count:\s+(\d+)", block).group(1)) <= 128, name
-  assert found == 2
+    assert int(re.search(r"\.vgpr_count:\s+(\d+)", block).group(1)) <= max_vgprs, name
+  assert found == set(patterns)
