@@ -418,6 +418,9 @@ int tfrs_dot_interaction_fwd_strided(const float *x, int64_t batch, int f, int d
 int tfrs_dot_interaction_bwd_strided(const float *x, const float *dout, int64_t dout_stride,
                                      int64_t batch, int f, int d, int self_interaction, float *dx,
                                      void *stream);
+/* 1 when BOTH strided entry points cover (batch, f, d): callers ask before they take the fused
+ * concat path, so a forward can never succeed where its backward would return TFRS_ENOTIMPL. */
+int tfrs_dot_interaction_strided_supported(int64_t batch, int f, int d, int self_interaction);
 
 #ifdef __cplusplus
 }

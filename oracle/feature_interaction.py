@@ -50,6 +50,26 @@ def cross_grads(x0, x, kernel, bias, dy, diag_scale: float = 0.0):
   return tuple(a.astype(np.float32) for a in (dx0, dx, dw, db))
 
 
+def cross_yardsticks(x0, x, kernel, bias, dy, diag_scale: float = 0.0):
+  """Sum of |terms| of every entry of (y, dx0, dx, dW, db) of the full-rank cross above: the
+  scale its floating-point errors are measured in (tests/conftest.py float_gate)."""
+  x0 = np.abs(np.asarray(x0, np.float64)); x = np.abs(np.asarray(x, np.float64))
+  w = np.abs(np.asarray(kernel, np.float64)); dy = np.abs(np.asarray(dy, np.float64))
+  z = x @ w + (0 if bias is None else np.abs(np.asarray(bias, np.float64))) + diag_scale * x
+  dz = dy * x0
+  return (x0 * z + x, dy * z, dz @ w.T + diag_scale * dz + dy, x.T @ dz, dz.sum(axis=0))
+
+
+def dot_interaction_yardsticks(inputs, dy=None, self_interaction=False, skip_gather=False):
+  """Sum of |terms| of every entry of the forward (and, given dy, of the backward)."""
+  ab = [np.abs(np.asarray(a, np.float64)) for a in inputs]
+  fwd = dot_interaction(ab, self_interaction, skip_gather).astype(np.float64)
+  if dy is None:
+    return fwd
+  return fwd, dot_interaction_grad(ab, np.abs(np.asarray(dy, np.float64)), self_interaction,
+                                   skip_gather).astype(np.float64)
+
+
 def multi_layer_dcn(x0, us: Sequence[np.ndarray], vs: Sequence[np.ndarray],
                     biases: Optional[Sequence[Optional[np.ndarray]]] = None):
   """multi_layer_dcn.py:145-153: ``xl = x0 * (V_l(U_l xl) + b_l) + xl``."""

@@ -96,7 +96,7 @@ def loss(query_embeddings, candidate_embeddings, sample_weight=None, **kw) -> np
 def loss_grads(query_embeddings, candidate_embeddings, sample_weight=None,
                temperature=None, candidate_sampling_probability=None,
                candidate_ids=None, score_mask=None,
-               remove_accidental_hits_flag=False):
+               remove_accidental_hits_flag=False, return_yardsticks=False):
   """Analytic gradients of :210 wrt the two embedding matrices (what
   ``tape.gradient`` returns, models/base.py:77): G = w * (softmax(S) - I);
   dQ = G C / T, dC = G^T Q / T.  float64 accumulation."""
@@ -118,6 +118,10 @@ def loss_grads(query_embeddings, candidate_embeddings, sample_weight=None,
     g = g / float(temperature)
   q = np.asarray(query_embeddings, dtype=np.float64)
   c = np.asarray(candidate_embeddings, dtype=np.float64)
+  if return_yardsticks:
+    # sum of |terms| of every gradient entry: the scale floating-point errors are measured in
+    return ((g @ c).astype(np.float32), (g.T @ q).astype(np.float32),
+            np.abs(g) @ np.abs(c), np.abs(g).T @ np.abs(q))
   return (g @ c).astype(np.float32), (g.T @ q).astype(np.float32)
 
 

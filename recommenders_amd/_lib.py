@@ -91,6 +91,7 @@ SIGNATURES = {
     "tfrs_dot_interaction_bwd": (c_int, [P, P, c_i64, c_int, c_int, c_int, c_int, P, P]),
     "tfrs_dot_interaction_fwd_strided": (c_int, [P, c_i64, c_int, c_int, c_int, P, c_i64, P]),
     "tfrs_dot_interaction_bwd_strided": (c_int, [P, P, c_i64, c_i64, c_int, c_int, c_int, P, P]),
+    "tfrs_dot_interaction_strided_supported": (c_int, [c_i64, c_int, c_int, c_int]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

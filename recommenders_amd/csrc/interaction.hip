@@ -1662,6 +1662,28 @@ extern "C" int tfrs_dot_interaction_fwd_strided(const float *x, int64_t batch, i
   return TFRS_ENOTIMPL;
 }
 
+// 1 when BOTH strided entry points cover the shape (the host class asks before choosing the fused
+// concat path: the forward must not succeed where the backward would refuse).  Mirrors the
+// conditions of launch_dot_mfma_nb (direct-store kernel) and launch_dot_bwd_dense (producer /
+// consumer kernel) including the measurement switches, which route to kernels without a row stride.
+extern "C" int tfrs_dot_interaction_strided_supported(int64_t batch, int f, int d, int self_interaction) {
+  if (batch < 512 || f < 1 || d < 1 || f > 128 || d > 32 || d % 16 != 0) return 0;
+  const int out_dim = self_interaction ? f * (f + 1) / 2 : f * (f - 1) / 2;
+  // forward: split-fp16 direct-store kernel
+  const int dp = d <= 16 ? 16 : 32, nb = (f + 31) / 32;
+  if (nb > 4 || nb * (dp / 2) > 96) return 0;
+  if ((size_t)(((out_dim + 3) & ~3) + 64) * sizeof(float) > 64 * 1024) return 0;
+  const char *sv = getenv("TFRS_DOT_STAGE"), *fv = getenv("TFRS_DOT_FWD"), *dv = getenv("TFRS_DOT_BWD");
+  if ((sv && sv[0] == '0') || (fv && (fv[0] == 'f' || fv[0] == 's')) || (dv && (dv[0] == 'd' || dv[0] == 'g'))) return 0;
+  // backward: producer / consumer kernel
+  int kh = (f + 7) / 8 * 4;
+  if (((2 * kh + 4) / 4) % 2 == 0) kh += 4;
+  const size_t lds = ((size_t)f * (2 * kh + 4) + 256) * sizeof(float);
+  if (lds > 64 * 1024 || (size_t)f * (2 * kh + 4) + 256 > 0xFFFFu) return 0;
+  const size_t lds_pc = 2 * lds + (size_t)2 * (2 * kh * 32) * sizeof(float);
+  return lds_pc <= 160 * 1024 ? 1 : 0;
+}
+
 extern "C" int tfrs_dot_interaction_bwd_strided(const float *x, const float *dout, int64_t dout_stride,
                                                 int64_t batch, int f, int d, int self_interaction,
                                                 float *dx, void *stream) {

@@ -567,21 +567,29 @@ class Streaming(TopK):
   (reference :336-512).  Keeps only a reference to the candidate iterable and
   re-reads it on every call; the running state is ``[B, <=K]`` in HBM.
 
-  ``cache_packed_blocks`` (default on; not in the reference): when every element the iterable
-  yields is a GPU-resident tensor whose storage is unchanged since the previous call (the
-  common serving case: a list of device blocks), the packed f32 + fp16 images built from them
-  are kept between calls in ONE device index -- rows in stream order, so global row numbers
-  are the reference's counter (:477-488) -- and a call is then exactly ``BruteForce.call`` on
-  it: no re-upload, no re-pack, no per-block threshold pass.  Any change of a block (new
-  storage, in-place write, different shapes) rebuilds the images; iterables that produce fresh
-  tensors on every pass, or host arrays, take the block-by-block path, whose device footprint
-  is one block.  The cache holds 2.1x the candidate bytes (1.6x at dim 128).
+  ``cache_packed_blocks`` (default on; not in the reference): when the candidates are a
+  **list / tuple of GPU-resident tensors** (the serving case: device blocks held by the caller),
+  the packed f32 + fp16 images built from them are kept between calls in ONE device index --
+  rows in stream order, so global row numbers are the reference's counter (:477-488) -- and a
+  call is then exactly ``BruteForce.call`` on it: no re-upload, no re-pack, no per-block
+  threshold pass.  The cache keeps the tensor objects it packed alive and compares object
+  identity, storage pointer and version counter on every call, so an address recycled by the
+  allocator for a *new* tensor can never match.  Never cached (block-by-block path, device
+  footprint of one block, exactly the reference's behaviour): lazily mapped / generated
+  datasets (e.g. ``candidates.map(item_model)``: re-embedded on every pass), host arrays,
+  tensors that take part in autograd (parameters, outputs with a ``grad_fn``), and corpora
+  whose packed images would exceed ``cache_max_bytes`` (default 64 GiB).  Detached views of a
+  trained table are safe: this package's fused optimizer kernels bump the table's version
+  counter after writing through raw pointers.  A block written in place by a foreign raw
+  kernel or through ``.data`` after the first call must be re-announced with
+  ``index_from_dataset``.
+  The cache holds 2.1x the candidate bytes (1.6x at dim 128).
   """
 
   def __init__(self, query_model: Optional[Callable] = None, k: int = 10,
                handle_incomplete_batches: bool = True,
                num_parallel_calls: Optional[int] = None, sorted_order: bool = True,
-               cache_packed_blocks: bool = True) -> None:
+               cache_packed_blocks: bool = True, cache_max_bytes: int = 64 << 30) -> None:
     super().__init__(k=k)
     self.query_model = query_model
     self._candidates = None
@@ -590,14 +598,17 @@ class Streaming(TopK):
     self._sorted = sorted_order                    # results are always sorted
     self._last_ids: Optional[_Identifiers] = None
     self._cache_blocks = cache_packed_blocks
+    self._cache_max_bytes = int(cache_max_bytes)
     self._cache_key = None
     self._cache: Optional[BruteForce] = None
+    self._cache_alive = None
+    self._probe_fast = None
     self._base_row = 0
 
   def index_from_dataset(self, candidates: Iterable) -> "Streaming":
     _check_candidates_with_identifiers(candidates)                     # :386
     self._candidates = candidates                                      # :388
-    self._cache_key, self._cache = None, None
+    self._cache_key, self._cache, self._cache_alive, self._probe_fast = None, None, None, None
     return self
 
   def index(self, candidates, identifiers=None) -> "Streaming":
@@ -610,16 +621,24 @@ class Streaming(TopK):
     return self._last_ids
 
   # -- cached path ---------------------------------------------------------------------------
+  @staticmethod
+  def _cacheable(t) -> bool:
+    """A tensor whose content the cache may assume stable while (object, storage, version) are:
+    resident f32/integer data that is not part of an autograd graph."""
+    return (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous()
+            and not t.requires_grad and t.grad_fn is None)
+
   def _block_keys(self):
-    """(key, blocks, ids) when every block is a cacheable GPU tensor, else None.  Iterates the
-    dataset once without touching the device (shapes / pointers / version counters only)."""
-    # Fast path (serving: the same list of blocks call after call): the container and its elements
-    # are the objects seen last time and no tensor changed its storage or version counter -- one
-    # identity test and two attribute reads per block instead of the full probe (0.3 ms for the
-    # 191 blocks of a 12.5 M-row shard, as much as a whole B = 1 search).
+    """(key, blocks, ids) when the source is a list / tuple of cacheable GPU tensors, else None.
+    Never iterates a lazy dataset (that would materialise it) and never touches the device.
+    ``key`` holds the tensor OBJECTS (kept alive by the cache) next to their storage pointers
+    and version counters: identity is part of the comparison, so a recycled address of a
+    dead tensor cannot match."""
     src = self._candidates
+    if not isinstance(src, (list, tuple)) or len(src) == 0:
+      return None
     fast = getattr(self, "_probe_fast", None)
-    if fast is not None and fast[0] is src and isinstance(src, (list, tuple)) and len(src) == len(fast[1]):
+    if fast is not None and fast[0] is src and len(src) == len(fast[1]):
       same = True
       for element, (ref, tensors) in zip(src, fast[1]):
         if element is not ref:
@@ -635,30 +654,31 @@ class Streaming(TopK):
         return fast[2]
     self._probe_fast = None
     keys, blocks, ids, seen = [], [], [], []
-    for element in self._candidates:
+    for element in src:
       block_ids = None
       if isinstance(element, (tuple, list)):
+        if len(element) != 2:
+          return None
         block_ids, block = element
       else:
         block = element
-      if not (isinstance(block, torch.Tensor) and block.is_cuda and block.dim() == 2
-              and block.dtype == torch.float32 and block.is_contiguous()):
+      if not (self._cacheable(block) and block.dim() == 2 and block.dtype == torch.float32):
         return None
-      if block_ids is not None:
-        if isinstance(block_ids, torch.Tensor):
-          keys.append((block_ids.data_ptr(), tuple(block_ids.shape), block_ids._version))
-        else:
-          return None     # host identifiers may change silently between calls
-      keys.append((block.data_ptr(), tuple(block.shape), block._version))
-      blocks.append(block)
-      ids.append(block_ids)
       tensors = [(block, block.data_ptr(), block._version)]
       if block_ids is not None:
+        if not self._cacheable(block_ids):
+          return None     # host identifiers may change silently between calls
         tensors.append((block_ids, block_ids.data_ptr(), block_ids._version))
+      keys.append(tuple((id(t), ptr, tuple(t.shape), ver) for t, ptr, ver in tensors))
+      blocks.append(block)
+      ids.append(block_ids)
       seen.append((element, tensors))
-    result = (tuple(keys), blocks, ids) if blocks else None
-    if result is not None and isinstance(src, (list, tuple)):
-      self._probe_fast = (src, seen, result)
+    d = blocks[0].shape[1]
+    packed = sum(b.shape[0] for b in blocks) * (d * 6 + 32 + 4)    # f32 + fp16 images + row map
+    if packed > self._cache_max_bytes:
+      return None
+    result = (tuple(keys), blocks, ids)
+    self._probe_fast = (src, seen, result)
     return result
 
   def _cached_index(self, k: int) -> Optional["BruteForce"]:
@@ -666,7 +686,7 @@ class Streaming(TopK):
       return None
     probe = self._block_keys()
     if probe is None:
-      self._cache_key, self._cache = None, None
+      self._cache_key, self._cache, self._cache_alive = None, None, None
       return None
     key, blocks, ids = probe
     if not self._handle_incomplete_batches and any(b.shape[0] < k for b in blocks):   # :431-436
@@ -680,7 +700,9 @@ class Streaming(TopK):
       bf = BruteForce(k=self._k)
       bf.index_from_dataset([(i, b) for i, b in zip(ids, blocks)] if has_ids else blocks,
                             total_rows=total)
-      self._cache_key, self._cache = key, bf
+      # the packed tensors stay referenced for as long as their images are served: id() in the
+      # key is only meaningful while the object lives
+      self._cache_key, self._cache, self._cache_alive = key, bf, (blocks, ids)
     return self._cache
 
   def _query_rows(self, queries, k: int) -> Tuple[Tensor, Tensor]:

@@ -116,9 +116,12 @@ def dense_backward(x: torch.Tensor, kernel: torch.Tensor, dy: torch.Tensor, need
   (no ``.t().contiguous()`` copies of activations)."""
   x, kernel, dy = x.contiguous(), kernel.contiguous(), dy.contiguous()
   m, k, n = x.shape[0], kernel.shape[0], kernel.shape[1]
+  # (an empty batch returns from the C entry point before any launch: the weight gradients of
+  # an empty batch are zeros, not uninitialised memory)
+  alloc = torch.zeros_like if m == 0 else torch.empty_like
   dx = torch.empty_like(x) if need_dx else None
-  dk = torch.empty_like(kernel) if need_dk else None
-  db = torch.empty((n,), dtype=torch.float32, device=x.device) if need_db else None
+  dk = alloc(kernel) if need_dk else None
+  db = (torch.zeros if m == 0 else torch.empty)((n,), dtype=torch.float32, device=x.device) if need_db else None
   lib = _lib.load()
   f16 = 1 if _use_f16_gemm(m, n, k) else 0
   ws = _gemm_workspace(lib.tfrs_dense_bwd_workspace_bytes(m, k, n, f16), x.device)
@@ -184,8 +187,9 @@ class _CrossFn(torch.autograd.Function):
     x0, x, kernel, bias, u = ctx.saved_tensors
     dy = dy.contiguous()
     b, d = x0.shape
-    dx0, dx, dk = torch.empty_like(x0), torch.empty_like(x), torch.empty_like(kernel)
-    db = torch.empty_like(bias) if bias is not None else None
+    alloc = torch.zeros_like if b == 0 else torch.empty_like     # empty batch: zero weight gradients
+    dx0, dx, dk = torch.empty_like(x0), torch.empty_like(x), alloc(kernel)
+    db = alloc(bias) if bias is not None else None
     lib = _lib.load()
     f16 = 1 if (u is not None or _use_f16_gemm(b, d, d)) else 0
     ws = _gemm_workspace(lib.tfrs_cross_bwd_workspace_bytes(b, d, f16), x0.device)

@@ -101,6 +101,13 @@ class DotInteraction(torch.nn.Module):
 
   call = forward
 
+  def _strided_ok(self, batch: int, f: int, dim: int) -> bool:
+    """The library's own envelope of the strided forward AND backward kernels (one query, so the
+    host gate cannot drift from the C side: F = 123..128 at D = 32 fit the forward but not the
+    backward's 64 KB S tile -- ADVICE round 2)."""
+    return bool(_lib.load().tfrs_dot_interaction_strided_supported(
+        int(batch), int(f), int(dim), int(self._self_interaction)))
+
   def forward_stacked(self, x: torch.Tensor, prefix: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The layer on an already stacked ``x[B, F, D]`` (``concat_features`` of :74-76), optionally
     concatenated behind ``prefix[B, P]`` like ``forward_concat``."""
@@ -108,8 +115,8 @@ class DotInteraction(torch.nn.Module):
     x = x.to(torch.float32)
     if prefix is None:
       return _DotInteractionFn.apply(x, self._self_interaction, self._skip_gather)
-    fusable = (not self._skip_gather and dim % 16 == 0 and dim <= 32 and x.shape[1] <= 128
-               and batch >= 512 and prefix.dim() == 2 and prefix.is_cuda and prefix.shape[0] == batch)
+    fusable = (not self._skip_gather and prefix.dim() == 2 and prefix.is_cuda
+               and prefix.shape[0] == batch and self._strided_ok(batch, x.shape[1], dim))
     if not fusable:
       return torch.cat([prefix.to(torch.float32),
                         _DotInteractionFn.apply(x, self._self_interaction, self._skip_gather)], dim=1)
@@ -120,9 +127,8 @@ class DotInteraction(torch.nn.Module):
     experimental/models/ranking.py:225-232), fused where the strided kernels apply."""
     dims = {int(t.shape[1]) for t in inputs}
     batch, dim = inputs[0].shape
-    fusable = (len(dims) == 1 and not self._skip_gather and dim % 16 == 0 and dim <= 32
-               and len(inputs) <= 128 and batch >= 512 and prefix.dim() == 2 and prefix.is_cuda
-               and prefix.shape[0] == batch)
+    fusable = (len(dims) == 1 and not self._skip_gather and prefix.dim() == 2 and prefix.is_cuda
+               and prefix.shape[0] == batch and self._strided_ok(batch, len(inputs), dim))
     if not fusable:
       return torch.cat([prefix.to(torch.float32), self.forward(inputs)], dim=1)
     x = torch.cat([t.to(torch.float32) for t in inputs], dim=-1).reshape(batch, -1, dim)

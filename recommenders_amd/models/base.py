@@ -56,8 +56,14 @@ class Model(torch.nn.Module):
     group = getattr(self, "_process_group", None)
     params = [p for p in self.parameters()
               if p.requires_grad and not getattr(p, "_tfrs_row_sharded", False)]
-    # dense gradients: flat buckets in parameter order (identical on every rank)
-    dense = [p for p in params if p.grad is not None]
+    # dense gradients: flat buckets in parameter order.  The bucket layout must be identical on
+    # every rank, so it is built from ALL dense trainable parameters, not from those that happen
+    # to have a gradient on this rank: a layer one rank did not use this step contributes zeros
+    # (a rank-dependent bucket size makes reduce_scatter hang or mix parameters).
+    dense = [p for p in params if not getattr(p, "_tfrs_sparse_grad", False)]
+    for p in dense:
+      if p.grad is None:
+        p.grad = torch.zeros_like(p)
     bucket: List[torch.Tensor] = []
     size = 0
 

@@ -20,6 +20,7 @@ formula above is the tf-keras one; the test oracle restates the same formula.
 """
 
 from typing import Iterable
+import weakref
 
 import torch
 
@@ -42,16 +43,26 @@ class Adagrad(torch.optim.Optimizer):
         if getattr(p, "_tfrs_embedding", False):
           p._tfrs_sparse_grad = True        # the lookup's backward now emits slices
           p._tfrs_slices = []
+          # the LATEST optimizer built on a table owns its sparse-gradient mode: an older one
+          # that is closed / collected afterwards must not switch it off
+          p._tfrs_sparse_owner = weakref.ref(self)
+
+  def _owns(self, p) -> bool:
+    owner = getattr(p, "_tfrs_sparse_owner", None)
+    return owner is not None and owner() is self
 
   def close(self) -> None:
     """Hands the embedding tables back to dense gradients: after ``close()`` (also called when the
     optimizer is garbage-collected) a lookup's backward produces an ordinary ``.grad`` again, so
-    the tables can be trained by another optimizer."""
+    the tables can be trained by another optimizer.  Only tables this optimizer still owns are
+    released: a newer ``Adagrad`` built on the same parameters keeps its sparse mode and its
+    pending slices."""
     for group in self.param_groups:
       for p in group["params"]:
-        if getattr(p, "_tfrs_sparse_grad", False):
+        if getattr(p, "_tfrs_sparse_grad", False) and self._owns(p):
           p._tfrs_sparse_grad = False
           p._tfrs_slices = []
+          p._tfrs_sparse_owner = None
 
   def __del__(self):
     try:
@@ -90,6 +101,7 @@ class Adagrad(torch.optim.Optimizer):
     for group in self.param_groups:
       lr, eps = group["learning_rate"], group["epsilon"]
       sparse = []     # (table, accumulator, grad rows, ids) of every looked-up table of the group
+      touched = []
       for p in group["params"]:
         acc = self._accumulator(p, group["initial_accumulator_value"])
         slices = getattr(p, "_tfrs_slices", None)
@@ -100,9 +112,14 @@ class Adagrad(torch.optim.Optimizer):
             ids = torch.cat([s[0].reshape(-1) for s in slices])
             rows = torch.cat([s[1].reshape(-1, p.shape[1]) for s in slices])
           sparse.append((p.data, acc, rows, ids))
+          touched.append(p)
           slices.clear()
       if sparse:
         emb.adagrad_sparse_update_multi_(sparse, lr, eps)   # small tables: one launch for all
+        # the kernels wrote through raw pointers: bump the version counters so that anything
+        # keyed on them (Streaming's packed-block cache over views of a table) sees the change
+        for table in touched:
+          torch.autograd.graph.increment_version(table)
       for p in group["params"]:
         acc = self._accumulator(p, group["initial_accumulator_value"])
         if p.grad is not None:

@@ -72,6 +72,20 @@ def test_argument_validation_without_gpu(lib):
   assert lib.tfrs_inbatch_softmax_workspace_bytes(4096, 4096, 64) > 0
 
 
+def test_dot_interaction_strided_envelope(lib):
+  """tfrs_dot_interaction_strided_supported is the single source of the fused-concat gate: the
+  backward's 64 KB S tile ends at F = 122 for D = 32 although the forward covers F <= 128
+  (a Ranking model with 123..128 features crashed in its first backward)."""
+  q = lib.tfrs_dot_interaction_strided_supported
+  assert q(131072, 101, 32, 0) == 1 and q(131072, 101, 32, 1) == 1        # BASELINE configs[4]
+  assert q(2048, 27, 16, 0) == 1
+  assert q(2048, 122, 32, 0) == 1
+  for f in (123, 127, 128, 129):
+    assert q(2048, f, 32, 0) == 0, f
+  assert q(511, 27, 32, 0) == 0                                            # small batches: contiguous kernels
+  assert q(2048, 27, 64, 0) == 0 and q(2048, 27, 24, 0) == 0
+
+
 def test_host_classes_reference_errors():
   import recommenders_amd as tfrs
   ftk = tfrs.layers.factorized_top_k

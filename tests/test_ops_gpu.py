@@ -10,7 +10,7 @@ from oracle import feature_interaction as o_fi
 from oracle import metrics as o_metrics
 from oracle import retrieval as o_ret
 from oracle import topk as o_topk
-from tests.conftest import load_golden
+from tests.conftest import float_gate, load_golden
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -101,6 +101,13 @@ def test_embedding_combiners():
 
 
 # ---------------------------------------------------------------------------- retrieval
+# Gates relative to the sum of |terms| (tests/conftest.py float_gate); observed maxima on MI355X are
+# listed in profiles/r03_observed_errors.md.
+GATE_SOFTMAX_GRAD = {"f16": 1e-4, "f32": 1e-4}      # provisional; tightened from the observed values
+GATE_CROSS = {"y": 1e-4, "grad": 1e-4}
+GATE_DOT = {"fwd": 1e-4, "bwd": 1e-4}
+
+
 @pytest.fixture(params=["f16", "f32"])
 def softmax_mode(request, monkeypatch):
   """The in-batch softmax has two arithmetic paths that must both meet the tolerances: the
@@ -146,8 +153,9 @@ def test_retrieval_golden_cases(softmax_mode):
 @pytest.mark.parametrize("nq,nc,d", [(2, 2, 3), (64, 64, 64), (100, 333, 20), (257, 300, 128),
                                      (512, 512, 32), (1000, 1024, 64)])
 def test_inbatch_softmax_options_vs_oracle(nq, nc, d, softmax_mode):
-  """loss within 1e-5 relative, gradients within 1e-4 relative (+1e-6 abs) of the
-  float64 oracle, for every fused logit option."""
+  """loss within 1e-5 relative of the float64 oracle; gradients gated relative to the sum of
+  |terms| of each entry (|G| |C|, |G|^T |Q|), limit <= 4x the error observed on MI355X
+  (tests/conftest.py float_gate), for every fused logit option."""
   from recommenders_amd.tasks.retrieval import in_batch_softmax_loss
   rng = np.random.default_rng(nq * 7 + d)
   q = (rng.normal(size=(nq, d)) / np.sqrt(d) * 3).astype(np.float32)
@@ -170,7 +178,7 @@ def test_inbatch_softmax_options_vs_oracle(nq, nc, d, softmax_mode):
   ]
   for kw in variants:
     ref = o_ret.loss(q, c, **kw)
-    dq_ref, dc_ref = o_ret.loss_grads(q, c, **kw)
+    dq_ref, dc_ref, dq_y, dc_y = o_ret.loss_grads(q, c, return_yardsticks=True, **kw)
     tq = _t(q).requires_grad_(True)
     tc = _t(c).requires_grad_(True)
     loss = in_batch_softmax_loss(
@@ -183,12 +191,8 @@ def test_inbatch_softmax_options_vs_oracle(nq, nc, d, softmax_mode):
         score_mask=None if "score_mask" not in kw else _t(kw["score_mask"]))
     np.testing.assert_allclose(float(loss), float(ref), rtol=1e-5, err_msg=str(sorted(kw)))
     (loss * 2.0).backward()   # upstream gradient 2: exercises gloss
-    scale = max(np.abs(dq_ref).max(), 1e-6)
-    np.testing.assert_allclose(_np(tq.grad) / 2.0, dq_ref, rtol=1e-4, atol=1e-5 * scale,
-                               err_msg=str(sorted(kw)))
-    scale = max(np.abs(dc_ref).max(), 1e-6)
-    np.testing.assert_allclose(_np(tc.grad) / 2.0, dc_ref, rtol=1e-4, atol=1e-5 * scale,
-                               err_msg=str(sorted(kw)))
+    float_gate(f"softmax_{softmax_mode}.dq", _np(tq.grad) / 2.0, dq_ref, dq_y, GATE_SOFTMAX_GRAD[softmax_mode])
+    float_gate(f"softmax_{softmax_mode}.dc", _np(tc.grad) / 2.0, dc_ref, dc_y, GATE_SOFTMAX_GRAD[softmax_mode])
 
 
 @pytest.mark.parametrize("waves", ["auto", "4", "8"])
@@ -218,14 +222,14 @@ def test_inbatch_softmax_f16_path_sizes(nq, nc, d, scale, waves, monkeypatch):
   w = (10.0 ** rng.uniform(-2, 2, size=nq)).astype(np.float32)
   for kw in (dict(), dict(sample_weight=w, temperature=0.5)):
     ref = o_ret.loss(q, c, **kw)
-    dq_ref, dc_ref = o_ret.loss_grads(q, c, **kw)
+    dq_ref, dc_ref, dq_y, dc_y = o_ret.loss_grads(q, c, return_yardsticks=True, **kw)
     tq, tc = _t(q).requires_grad_(True), _t(c).requires_grad_(True)
     loss = in_batch_softmax_loss(tq, tc, sample_weight=None if not kw else _t(w),
                                  temperature=kw.get("temperature"))
     np.testing.assert_allclose(float(loss), float(ref), rtol=1e-5)
     (loss * 0.5).backward()
-    for got, want in ((_np(tq.grad) * 2.0, dq_ref), (_np(tc.grad) * 2.0, dc_ref)):
-      np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5 * max(np.abs(want).max(), 1e-6))
+    float_gate("softmax_f16.sizes.dq", _np(tq.grad) * 2.0, dq_ref, dq_y, GATE_SOFTMAX_GRAD["f16"])
+    float_gate("softmax_f16.sizes.dc", _np(tc.grad) * 2.0, dc_ref, dc_y, GATE_SOFTMAX_GRAD["f16"])
 
 
 def test_retrieval_hard_negatives_and_custom_paths():
@@ -333,13 +337,19 @@ def test_cross_random_fwd_bwd(b, d, p, gemm_mode):
   else:
     ref = o_fi.cross(x0, x, u=_np(layer.kernel_u), v=_np(layer.kernel_v), bias=_np(layer.bias),
                      diag_scale=0.3)
-  tol = 2e-5 * np.abs(ref).max()
-  np.testing.assert_allclose(_np(y), ref, rtol=2e-5, atol=tol)
+  if p is None:
+    ys = o_fi.cross_yardsticks(x0, x, kern, bias, dy, diag_scale=0.3)
+    float_gate(f"cross_{gemm_mode}.y", _np(y), ref, ys[0], GATE_CROSS["y"])
+  else:
+    a = [np.abs(t) for t in (x0, x, _np(layer.kernel_u), _np(layer.kernel_v), _np(layer.bias))]
+    float_gate(f"cross_{gemm_mode}.lowrank.y", _np(y), ref,
+               o_fi.cross(a[0], a[1], u=a[2], v=a[3], bias=a[4], diag_scale=0.3), GATE_CROSS["y"])
   y.backward(_t(dy))
   if p is None:
     dx0, dx, dw, db = o_fi.cross_grads(x0, x, kern, bias, dy, diag_scale=0.3)
-    for got, want in ((tx0.grad, dx0), (tx.grad, dx), (layer.kernel.grad, dw), (layer.bias.grad, db)):
-      np.testing.assert_allclose(_np(got), want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
+    for got, want, yard, what in ((tx0.grad, dx0, ys[1], "dx0"), (tx.grad, dx, ys[2], "dx"),
+                                  (layer.kernel.grad, dw, ys[3], "dW"), (layer.bias.grad, db, ys[4], "db")):
+      float_gate(f"cross_{gemm_mode}.{what}", _np(got), want, yard, GATE_CROSS["grad"])
 
 
 @pytest.mark.parametrize("tile", ["128", "256"])
@@ -387,12 +397,15 @@ def test_dot_interaction_golden_and_random():
         txs = [_t(a).requires_grad_(True) for a in xs]
         out = DotInteraction(self_interaction=si, skip_gather=sg)(txs)
         ref = o_fi.dot_interaction(xs, si, sg)
-        np.testing.assert_allclose(_np(out), ref, rtol=1e-5, atol=1e-5)
         dy = rng.normal(size=ref.shape).astype(np.float32)
+        yf, yb = o_fi.dot_interaction_yardsticks(xs, dy, si, sg)
+        keep = yf > 0                                              # (skip_gather: structural zeros must be exact)
+        assert np.array_equal(_np(out)[~keep], ref[~keep])
+        float_gate("dot.fwd", _np(out)[keep], ref[keep], yf[keep], GATE_DOT["fwd"])
         out.backward(_t(dy))
         dref = o_fi.dot_interaction_grad(xs, dy, si, sg)          # [b, f, d]
         got = np.stack([_np(t.grad) for t in txs], axis=1)
-        np.testing.assert_allclose(got, dref, rtol=1e-4, atol=1e-4)
+        float_gate("dot.bwd", got, dref, yb, GATE_DOT["bwd"])
 
 
 # ---------------------------------------------------------------------------- model

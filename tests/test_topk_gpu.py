@@ -283,10 +283,12 @@ def test_topk_merge_matches_oracle():
     np.testing.assert_array_equal(_np(out_i)[r], flat_i[r][order])
 
 
-def test_full_size_properties():
+def test_full_size_properties(filter_mode, monkeypatch):
   """BASELINE config 2 (1M x 64 corpus, batch 8192, top-100): size-independent checks
-  (sorted, unique, in range, scores reproduce) plus exact comparison of a sample of
-  queries against the oracle."""
+  (sorted, unique, in range, scores reproduce), exact comparison of a sample of queries
+  against the oracle, and -- in the default mode -- ALL 8192 queries against the all-f32 scan
+  (`TFRS_TOPK_FILTER=f32`: no fp16 prefilter, no survivor queue), which the 32 oracle queries
+  pin, bit for bit."""
   ftk = _layers()
   g = torch.Generator(device="cuda").manual_seed(42)
   n, nq, d, k = 1_000_000, 8192, 64, 100
@@ -304,6 +306,11 @@ def test_full_size_properties():
   es, ei = o_topk.brute_force(q[sample].cpu().numpy(), c.cpu().numpy(), k)
   np.testing.assert_array_equal(_np(i)[sample], ei)
   np.testing.assert_array_equal(_np(s)[sample], es)
+  if filter_mode == "f16":
+    assert layer.last_redo_count() == 0
+    monkeypatch.setenv("TFRS_TOPK_FILTER", "f32")
+    s32, i32 = layer(q)
+    assert torch.equal(i, i32) and torch.equal(s, s32)         # every one of the 8192 queries
 
 
 def _pow2_ceil(x):
