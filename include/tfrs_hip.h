@@ -208,6 +208,30 @@ int tfrs_id_match_topk(const int32_t *retrieved_ids, const int32_t *true_ids,
                        int64_t nq, int kmax, const int32_t *ks_h, int nks,
                        float *out_hits, void *stream);
 
+/* The same score-based branch WITHOUT the top-K (metrics/factorized_top_k.py:133-137,181-192):
+ * the retrieved list holds the max(ks) best scores of the corpus and in_top_k counts strictly
+ * greater predictions, so for every k <= max(ks)
+ *     hit_k[b] = (#{candidates j : score(q_b, cand_j) > pos_b} < k) && isfinite(pos_b),
+ * i.e. the metric needs ONE count per query, not a sorted list.
+ *   tfrs_rank_count_accumulate: counts[b] += #{j < nc : score(q_b, row_j) > pos_b} for one block of
+ *     candidates, row_j = candidates[cand_ids[j]] (cand_ids int32 / int64; NULL: row_j =
+ *     candidates[j]; ids outside [0, vocab) score as zero rows, like tfrs_embedding_gather_fwd) --
+ *     with an id indirection the reference's `movies.batch(128).map(item_model)` candidate sweep of
+ *     an Embedding tower (README.md:69-80) is one launch: gather, scores, rank.  f32 MFMA, the
+ *     d-ordered fma chain of every scoring kernel (the positive ties with its own copy).  d <= 128.
+ *     `counts` (uint32 [nq]) must be zero before the first block of a sweep (first_block = 1 also
+ *     flags non-finite positives in bit 31); tfrs_topk_hits_update re-arms it.
+ *   tfrs_topk_hits_update: state[i] += sum_b w_b hit_ks[i][b], state[nks + i] += sum_b w_b
+ *     (tf.keras.metrics.Mean per k, :85-89,191-192; sample_weight NULL = ones),
+ *     results[i] = state[i] / state[nks + i] (0 when empty), optional per-example hits[nks, nq];
+ *     zeroes `counts`.  One workgroup, fixed reduction order.  ks_h is a HOST array (<= 16). */
+int tfrs_rank_count_accumulate(const float *queries, const float *true_candidates, int64_t nq, int d,
+                               const float *candidates, const void *cand_ids, int ids_i64, int64_t nc,
+                               int64_t vocab, uint32_t *counts, int first_block, void *stream);
+int tfrs_topk_hits_update(uint32_t *counts, int64_t nq, const int32_t *ks_h, int nks,
+                          const float *sample_weight, float *state, float *results, float *hits,
+                          void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Embedding lookup (tf.keras.layers.Embedding as called at README.md:62-66,77-78;
  * TPUEmbedding CPU branch layers/embedding/tpu_embedding_layer.py:913-919).

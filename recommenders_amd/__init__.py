@@ -10,7 +10,7 @@ of ``include/tfrs_hip.h`` (``libtfrs_hip.so``); torch only carries device memory
 streams and autograd bookkeeping.  There is no CPU fallback.
 """
 
-from recommenders_amd import experimental, layers, losses, metrics, models, optimizers, tasks  # noqa: F401
+from recommenders_amd import data, experimental, layers, losses, metrics, models, optimizers, tasks  # noqa: F401
 from recommenders_amd.models import Model  # noqa: F401
 
 __version__ = "0.1.0"

@@ -52,6 +52,8 @@ SIGNATURES = {
     "tfrs_topk_exclude": (c_int, [P, P, c_i64, c_int, P, c_int, c_int, P, P, P]),
     "tfrs_rank_of_positive": (c_int, [P, P, c_i64, c_int, P, c_int, P, c_int, P, P]),
     "tfrs_id_match_topk": (c_int, [P, P, c_i64, c_int, P, c_int, P, P]),
+    "tfrs_rank_count_accumulate": (c_int, [P, P, c_i64, c_int, P, P, c_int, c_i64, c_i64, P, c_int, P]),
+    "tfrs_topk_hits_update": (c_int, [P, c_i64, P, c_int, P, P, P, P, P]),
     "tfrs_embedding_gather_fwd": (c_int, [P, c_i64, c_int, P, c_int, c_i64, P, P, P]),
     "tfrs_embedding_segment_reduce_fwd": (c_int, [P, c_i64, c_int, P, P, c_int, P, c_i64,
                                                   c_int, P, P, P]),

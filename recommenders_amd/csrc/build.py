@@ -27,6 +27,7 @@ SOURCES = [
     "topk_select.hip",
     "topk_select16.hip",
     "topk_api.hip",
+    "metric_fused.hip",
     "embedding.hip",
     "hashing.hip",
     "softmax.hip",

@@ -6,6 +6,14 @@ names (``factorized_top_k/top_{k}_categorical_accuracy``), ``result`` /
 ``reset_states``.  The corpus sweep uses the top-K layers; the per-example hit tests
 (``in_top_k`` on ``concat([positive, top_k])`` :181-192, or the id match :141-180) run
 in ``tfrs_rank_of_positive`` / ``tfrs_id_match_topk``.
+
+Score-based updates over a raw candidate dataset (the quickstart's
+``FactorizedTopK(candidates=movies.batch(128).map(item_model))``, README.md:69-71) skip the top-K
+altogether: ``in_top_k`` only asks how many corpus rows score strictly above the positive, so the
+sweep is ``tfrs_rank_count_accumulate`` per candidate block (ONE launch for a batched map of an
+``Embedding`` tower: gather + scores + rank through the id indirection) followed by
+``tfrs_topk_hits_update``, which folds the per-k weighted means into the metric state on the
+device -- identical values, no sorted lists, no per-k torch reductions.
 """
 
 import abc
@@ -26,6 +34,17 @@ class Mean:
     self.name = name
     self._total = None
     self._count = None
+    self._result_view = None      # written by a fused update kernel (FactorizedTopK)
+    self._result_fresh = False
+
+  def _bind(self, total: torch.Tensor, count: torch.Tensor, result: torch.Tensor) -> None:
+    """State and result live in a caller-owned buffer (0-dim views): one kernel updates every
+    ``Mean`` of a ``FactorizedTopK`` at once."""
+    if self._total is not None:
+      total.copy_(self._total)
+      count.copy_(self._count)
+    self._total, self._count, self._result_view = total, count, result
+    self._result_fresh = False
 
   def update_state(self, values: torch.Tensor, sample_weight: Optional[torch.Tensor] = None):
     v = values.reshape(-1).to(torch.float32)
@@ -42,10 +61,13 @@ class Mean:
     else:
       self._total.add_(total)
       self._count.add_(count)
+    self._result_fresh = False
 
   def result(self) -> torch.Tensor:
     if self._total is None:
       return torch.tensor(0.0)
+    if self._result_fresh:
+      return self._result_view
     return torch.where(self._count > 0, self._total / self._count,
                        torch.zeros_like(self._total))
 
@@ -53,6 +75,8 @@ class Mean:
     if self._total is not None:       # keep the storage (a captured graph may write into it)
       self._total.zero_()
       self._count.zero_()
+    if self._result_view is not None:
+      self._result_view.zero_()
 
   reset_state = reset_states
 
@@ -84,12 +108,16 @@ class FactorizedTopK(Factorized):
                ks: Sequence[int] = (1, 5, 10, 50, 100), name: str = "factorized_top_k") -> None:
     super().__init__()
     self.name = name
+    self._dataset = None
     if not isinstance(candidates, topk_layers.TopK):                   # :77-81
+      self._dataset = candidates      # raw dataset: score-based updates sweep it with rank counts
       candidates = topk_layers.Streaming(k=max(ks)).index_from_dataset(candidates)
     self._ks = list(ks)
     self._candidates = candidates
     self._top_k_metrics = [
         Mean(name=f"{self.name}/top_{x}_categorical_accuracy") for x in ks]   # :85-89
+    self._fused_state = None          # (state[2 * nks], results[nks]) on the device
+    self._counts = None               # uint32 [nq] rank counts, zero between updates
 
   @property
   def metrics(self) -> List[Mean]:
@@ -109,9 +137,13 @@ class FactorizedTopK(Factorized):
     kmax = max(self._ks)
     lib = _lib.load()
     ks_arr = (ctypes.c_int32 * len(self._ks))(*self._ks)
-    hits = torch.empty((len(self._ks), nq), dtype=torch.float32, device=q.device)
     if sample_weight is not None and not isinstance(sample_weight, torch.Tensor):
       sample_weight = torch.as_tensor(np.asarray(sample_weight))
+    if (true_candidate_ids is None and self._dataset is not None
+        and q.shape[1] <= topk_layers.MAX_FUSED_DIM and len(self._ks) <= 16 and nq > 0):
+      self._update_by_rank_counts(q, c, sample_weight)                  # :181-192 without the top-K
+      return None
+    hits = torch.empty((len(self._ks), nq), dtype=torch.float32, device=q.device)
 
     if true_candidate_ids is not None:                                  # :141-180 id based
       top_scores, rows = self._candidates._query_rows(q, kmax)
@@ -135,3 +167,62 @@ class FactorizedTopK(Factorized):
     for i, metric in enumerate(self._top_k_metrics):
       metric.update_state(hits[i], sample_weight)
     return None
+
+  # -- score-based update over a raw dataset: rank counts instead of sorted lists -----------------
+  def _bound_state(self, device):
+    nks = len(self._ks)
+    if self._fused_state is None or self._fused_state[0].device != device:
+      state = torch.zeros((2 * nks,), dtype=torch.float32, device=device)
+      results = torch.zeros((nks,), dtype=torch.float32, device=device)
+      for i, metric in enumerate(self._top_k_metrics):
+        metric._bind(state[i], state[nks + i], results[i])
+      self._fused_state = (state, results)
+    return self._fused_state
+
+  def _update_by_rank_counts(self, q, c, sample_weight) -> None:
+    """``in_top_k(0, concat([pos, top_k]), k)`` is ``#{scores > pos} < k`` for k <= max(ks)
+    (:181-192; the retrieved list holds the max(ks) best scores): count, do not sort."""
+    from recommenders_amd import data as tfrs_data
+    lib = _lib.load()
+    nq, d = q.shape
+    if c.shape != q.shape:
+      raise ValueError("true_candidate_embeddings must have the shape of query_embeddings")
+    state, results = self._bound_state(q.device)
+    if self._counts is None or self._counts.numel() != nq or self._counts.device != q.device:
+      self._counts = torch.zeros((nq,), dtype=torch.int32, device=q.device)
+    counts = self._counts
+    stream = _lib.current_stream()
+    w = None
+    if sample_weight is not None:
+      w = sample_weight.reshape(-1).to(q.device, torch.float32).contiguous()
+      if w.numel() != nq:
+        raise ValueError("sample_weight must have one entry per query")
+    try:
+      rows = self._dataset.as_embedding_rows() if isinstance(self._dataset, tfrs_data.Dataset) else None
+      if rows is not None and rows[0].shape[1] == d:
+        table, ids = rows                 # candidates ARE table[ids]: gather + scores + rank, one launch
+        ids = ids.contiguous()
+        _lib.check(lib.tfrs_rank_count_accumulate(
+            _lib.ptr(q), _lib.ptr(c), nq, d, _lib.ptr(table), _lib.ptr(ids),
+            1 if ids.dtype == torch.int64 else 0, ids.numel(), table.shape[0], _lib.ptr(counts), 1,
+            stream))
+      else:
+        first = 1
+        for element in self._dataset:
+          block = element[1] if isinstance(element, (tuple, list)) else element
+          block = topk_layers._as_f32_matrix(block, "candidates")
+          if block.shape[1] != d:
+            raise ValueError(f"Candidate dimension {block.shape[1]} does not match queries ({d}).")
+          _lib.check(lib.tfrs_rank_count_accumulate(
+              _lib.ptr(q), _lib.ptr(c), nq, d, _lib.ptr(block), None, 0, block.shape[0],
+              block.shape[0], _lib.ptr(counts), first, stream))
+          first = 0
+      ks_arr = (ctypes.c_int32 * len(self._ks))(*self._ks)
+      _lib.check(lib.tfrs_topk_hits_update(
+          _lib.ptr(counts), nq, ks_arr, len(self._ks), _lib.ptr(w), _lib.ptr(state),
+          _lib.ptr(results), None, stream))
+    except Exception:
+      self._counts = None               # a half-swept count buffer must not be reused
+      raise
+    for metric in self._top_k_metrics:
+      metric._result_fresh = True

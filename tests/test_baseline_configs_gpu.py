@@ -94,6 +94,50 @@ def test_streaming_cache_follows_block_changes():
   del sc
 
 
+def test_streaming_train_eval_train_eval_sees_fresh_candidates():
+  """evaluation after further training must score against the CURRENT
+  candidate embeddings.  (1) a lazily mapped dataset (`candidates.map(item_model)`) whose blocks
+  are fresh tensors on every pass -- very likely at the addresses of the previous pass's freed
+  blocks -- is never cached; (2) a list of detached views of the trained table is cached, and the
+  fused Adagrad kernels (raw-pointer writes) bump the table's version counter so the cache is
+  rebuilt.  Both against the oracle after each of two training phases."""
+  import recommenders_amd as tfrs
+  ftk = _ftk()
+  from recommenders_amd.layers import embedding as emb
+  rng = np.random.default_rng(12)
+  vocab, d, nq, k = 70_000, 32, 64, 10
+  item_model = emb.Embedding(vocab, d).cuda()
+  ids = torch.arange(vocab, device="cuda")
+
+  class Mapped:                                   # movies.batch(8192).map(item_model)
+    def __iter__(self):
+      for lo in range(0, vocab, 8192):
+        with torch.no_grad():
+          yield item_model(ids[lo:lo + 8192])
+
+  lazy = ftk.Streaming(k=k).index_from_dataset(Mapped())
+  views = ftk.Streaming(k=k).index_from_dataset(
+      [item_model.embeddings.detach()[lo:lo + 8192] for lo in range(0, vocab, 8192)])
+  opt = tfrs.optimizers.Adagrad(item_model.parameters(), learning_rate=0.5)
+  q = (rng.normal(size=(nq, d)) / 5).astype(np.float32)
+  tq = torch.as_tensor(q).cuda()
+  for phase in range(3):
+    table = _np(item_model.embeddings.detach())
+    es, ei = o_topk.brute_force(q, table, k)
+    for layer in (lazy, views):
+      s, i = layer(tq)
+      np.testing.assert_array_equal(_np(i), ei)
+      np.testing.assert_array_equal(_np(s), es)
+    assert lazy._cache is None and views._cache is not None
+    # "training": a sparse Adagrad step that moves a few thousand rows, among them the current winners
+    hit = torch.as_tensor(np.unique(np.r_[ei.ravel(), rng.integers(0, vocab, size=4096)]), device="cuda")
+    out = item_model(hit)
+    (out * torch.as_tensor(rng.normal(size=(hit.numel(), d)).astype(np.float32), device="cuda")).sum().backward()
+    opt.step()
+    opt.zero_grad()
+    assert not np.array_equal(_np(item_model.embeddings.detach()), table)
+
+
 def test_index_reserve_append_equals_index_set():
   """tfrs_index_reserve / tfrs_index_append (streamed ingest, ragged blocks that straddle the
   128-row stage boundaries) build the same index as tfrs_index_set."""

@@ -86,6 +86,49 @@ def test_dot_interaction_strided_envelope(lib):
   assert q(2048, 27, 64, 0) == 0 and q(2048, 27, 24, 0) == 0
 
 
+def test_adagrad_sparse_mode_belongs_to_the_latest_optimizer():
+  """A second Adagrad built on the same tables before the first is collected must keep its sparse
+  gradient mode when the first one dies (the old one's __del__ switched it off
+  and training silently fell back to dense [vocab, d] gradients)."""
+  import gc
+  import recommenders_amd as tfrs
+  from recommenders_amd.layers import embedding as emb
+  layer = emb.Embedding(10, 4)
+  first = tfrs.optimizers.Adagrad(layer.parameters(), 0.1)
+  second = tfrs.optimizers.Adagrad(layer.parameters(), 0.1)
+  layer.embeddings._tfrs_slices.append("pending")
+  del first
+  gc.collect()
+  assert layer.embeddings._tfrs_sparse_grad is True
+  assert layer.embeddings._tfrs_slices == ["pending"]          # pending slices survive too
+  second.close()
+  assert layer.embeddings._tfrs_sparse_grad is False
+
+
+def test_streaming_cache_probe_never_iterates_lazy_datasets():
+  """Only a list / tuple of resident tensors is eligible for Streaming's packed-block cache: a
+  lazily mapped dataset (`candidates.map(item_model)`, re-embedded on every pass) must not even
+  be iterated by the probe, let alone cached (ADVICE round 2, high + medium)."""
+  from recommenders_amd.layers import factorized_top_k as ftk
+
+  class Lazy:
+    def __init__(self):
+      self.passes = 0
+    def __iter__(self):
+      self.passes += 1
+      yield np.zeros((4, 3), np.float32)
+
+  ds = Lazy()
+  layer = ftk.Streaming(k=2).index_from_dataset(ds)
+  passes = ds.passes                      # (index_from_dataset may peek at the first element)
+  assert layer._block_keys() is None
+  assert ds.passes == passes
+  assert ftk.Streaming(k=2).index_from_dataset([np.zeros((4, 3), np.float32)])._block_keys() is None   # host blocks
+  import torch
+  p = torch.nn.Parameter(torch.zeros((4, 3)))
+  assert not ftk.Streaming._cacheable(p) and not ftk.Streaming._cacheable(p * 2.0)
+
+
 def test_host_classes_reference_errors():
   import recommenders_amd as tfrs
   ftk = tfrs.layers.factorized_top_k
