@@ -62,6 +62,7 @@ def parse_args():
   ap.add_argument("--no-train-step", action="store_true")
   ap.add_argument("--no-gather", action="store_true")
   ap.add_argument("--no-scale-workload", action="store_true")
+  ap.add_argument("--no-robustness", action="store_true")
   ap.add_argument("--no-single-gpu-reference", action="store_true")
   return ap.parse_args()
 
@@ -286,6 +287,42 @@ def gather_metric(dev) -> dict:
                        "note": "includes the output allocation of layers.embedding.gather_rows"}}
 
 
+def robustness_block(dev, queries, ref_ms: float) -> dict:
+  """The default (fp16-prefiltered) BruteForce path is data dependent: its thresholds come from
+  sampled stages and its error margin from row norms.  Same shapes as the headline (1M x 64,
+  batch 8192, top-100), three corpora that are NOT i.i.d. rows of equal norm: log-normal row norms
+  (sigma 0.5 and 1.0 -- what trained embeddings look like) and a Zipf-duplicated corpus (popular
+  items repeated: exact ties, near-duplicate bursts).  Reported: q/s, ms/step, the ratio to the
+  i.i.d. step, and how many queries took the exact-redo path in the last step."""
+  from recommenders_amd.layers import factorized_top_k as ftk
+  g = torch.Generator(device=dev).manual_seed(99)
+  out = {}
+
+  def corpus(kind):
+    base = torch.randn((N_ROWS, DIM), generator=g, device=dev) / (DIM ** 0.5)
+    if kind.startswith("lognormal"):
+      sigma = float(kind.split("_")[1])
+      return base * torch.exp(sigma * torch.randn((N_ROWS, 1), generator=g, device=dev))
+    # Zipf(1.0) popularity over 100k distinct items: item r has weight 1 / (r + 1)
+    w = 1.0 / torch.arange(1, 100_001, device=dev, dtype=torch.float64)
+    pick = torch.multinomial(w, N_ROWS, replacement=True, generator=g)
+    return base[:100_000][pick].contiguous()
+
+  for kind in ("lognormal_0.5", "lognormal_1.0", "zipf_duplicates"):
+    c = corpus(kind)
+    index = ftk.BruteForce(k=TOPK).index(c)
+    del c
+    for _ in range(3):
+      index(queries)
+    ts = percentiles(event_times_ms(lambda: index(queries), 10, 0))
+    out[kind] = {"value": BATCH / (ts["median"] * 1e-3), "unit": "queries/s", "ms_per_step": ts["median"],
+                 "vs_iid_step": ts["median"] / ref_ms, "redo_queries_last_step": index.last_redo_count(),
+                 "redo_reasons": index.last_redo_reasons()}
+    del index
+    torch.cuda.empty_cache()
+  return out
+
+
 def main() -> None:
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -351,20 +388,34 @@ def main() -> None:
     return idx, hi - lo
 
   def run_timed(index, steps: int, warmup: int):
-    for _ in range(warmup):
+    # The warm-up steps run with EXACTLY the instrumentation of the timed steps (per-step torch
+    # events recorded, per-launch library events enabled): the first use of either costs tens of
+    # milliseconds of one-off runtime set-up on the host (measured: 57 ms in the first instrumented
+    # step), which belongs to the warm-up, not to the K timed steps.
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(steps)]
+    lib.tfrs_profile_enable(1)
+    for i in range(warmup):
+      a, b = ev[i % steps]
+      a.record()
       index(queries)
+      b.record()
     torch.cuda.synchronize()
+    lib.tfrs_profile_read(None, None, None)   # reset the per-launch timings (events stay created)
     if world > 1:
       dist.barrier()
     torch.cuda.synchronize()
     lib.tfrs_profile_enable(1)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(steps)]
     t0 = time.perf_counter()
+    host_t = []
     for a, b in ev:
       a.record()
       out = index(queries)
       b.record()
+      host_t.append(time.perf_counter())
+    if os.environ.get("TFRS_BENCH_TRACE"):
+      gaps = [round((y - x) * 1e3, 3) for x, y in zip([t0] + host_t[:-1], host_t)]
+      print("host issue ms per step:", gaps, file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     if world > 1:
       dist.barrier()
@@ -472,6 +523,8 @@ def main() -> None:
         result["secondary"] = train_step_metric(dev, cpu_baseline=not args.no_cpu_baseline)
       if not args.no_gather:
         result["gather"] = gather_metric(dev)
+      if not args.no_robustness:
+        result["robustness"] = robustness_block(dev, queries, pct["median"])
       if not args.no_scale_workload:
         # the N = 1 point of the strong-scaling configuration (what `value` at N > 1 compares with)
         del index, local

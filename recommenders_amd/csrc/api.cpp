@@ -2,6 +2,10 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "common.h"
 
 namespace tfrs {
@@ -13,6 +17,29 @@ void set_error(const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+hipError_t ensure_dynamic_lds(const void *kernel, int bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  // last (kernel, device, bytes) this thread set or confirmed: the steady state of a launch loop
+  static thread_local const void *t_kernel = nullptr;
+  static thread_local int t_dev = -1, t_bytes = 0;
+  if (t_kernel == kernel && t_dev == dev && t_bytes >= bytes) return hipSuccess;
+  static std::mutex mu;
+  static std::map<std::pair<const void *, int>, int> done;   // (kernel, device) -> bytes granted
+  std::lock_guard<std::mutex> lock(mu);
+  int &have = done[std::make_pair(kernel, dev)];
+  if (have < bytes) {
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    have = bytes;
+  }
+  t_kernel = kernel;
+  t_dev = dev;
+  t_bytes = have;
+  return hipSuccess;
 }
 
 }  // namespace tfrs

@@ -32,6 +32,14 @@ void set_error(const char *fmt, ...);
 
 #define TFRS_LAUNCH_CHECK() TFRS_HIP(hipGetLastError())
 
+// hipFuncSetAttribute(kernel, MaxDynamicSharedMemorySize, bytes), remembered per (kernel, DEVICE):
+// the attribute lives in the per-device function object, so a process that drives several GPUs (or
+// several host threads on distinct streams -- the header promises re-entrancy there) must set it on
+// each device it launches on.  A process-wide `static bool` (round 2) left the second device at the
+// 64 KB default and its first large-LDS launch failed.  Thread-safe; the hit path is one
+// hipGetDevice plus a thread-local compare.
+hipError_t ensure_dynamic_lds(const void *kernel, int bytes);
+
 // ---- packed candidate layout -------------------------------------------------
 // Row r of the packed corpus occupies row_bytes(dp) bytes:
 //   slots 0 .. dp/8-1      : even features  (d = 0, 2, 4, ...)  4 floats per 16-B slot
@@ -252,8 +260,9 @@ struct SelectArgs {
   float *out_scores;   // [nq, k]
   int32_t *out_idx;    // [nq, k]
   float *out_thr;      // [nq] K-th best score, or -inf while fewer than k entries (may be NULL)
-  // launch_recompute: optional buffer [nq, kRecomputeChunks, k] of partial key lists; when set,
-  // each query's rows are spread over kRecomputeChunks workgroups and merged afterwards
+  // launch_recompute: optional buffer of nq * kRecomputeChunks partial key lists of k keys; when
+  // set, each flagged query's rows are spread over recompute_chunks(nq, flagged) workgroups --
+  // the fewer queries are flagged, the more workgroups share one query -- and merged afterwards
   uint64_t *part_keys;
   // kSrcRecompute: exact keys of rows [rc_begin, rc_end) (slow, always correct).
   // launch_recompute only: only_flagged != NULL restricts the work to the listed queries,
@@ -265,7 +274,16 @@ int launch_select(const SelectArgs &a, hipStream_t stream);
 // exact top-K of rows [rc_begin, rc_end) for the queries flagged in a.only_flagged (all queries
 // when NULL), one workgroup per query; writes out_scores / out_idx of those queries only
 int launch_recompute(const SelectArgs &a, hipStream_t stream);
-constexpr int kRecomputeChunks = 32;
+constexpr int kRecomputeChunks = 32;      // partial lists per query the workspace holds (for ALL nq queries)
+constexpr int kRecomputeMaxChunks = 256;  // grid.y of the recompute launch: chunks one flagged query can use
+constexpr int kRecomputeSlotsX = 8;       // grid.x: flagged slots in flight (workgroups stride over the slots)
+// chunks per flagged query, decided on the device from the flagged count: the whole list budget
+// (nq * kRecomputeChunks) is shared by the flagged queries, capped by the grid.  One flagged query
+// of 8192 is scanned by 256 workgroups (~0.1 ms on a 1M x 64 corpus) instead of 32 (1.3 ms).
+__host__ __device__ inline int recompute_chunks(int64_t nq, int64_t flagged) {
+  const int64_t budget = nq * kRecomputeChunks / (flagged > 0 ? flagged : 1);
+  return (int)(budget < kRecomputeMaxChunks ? (budget < 1 ? 1 : budget) : kRecomputeMaxChunks);
+}
 // rowmap != NULL: the block is stored SHUFFLED -- image row dst_row + r holds block row
 // (mul * r + add) mod n (mul coprime to n, near n / golden ratio: consecutive block rows land far
 // apart) and rowmap[dst_row + r] = dst_row + that row.

@@ -282,7 +282,9 @@ __device__ __forceinline__ void scatter_rowscan_body(
   // is 64 LDS reads per 4096 ids instead of 64 dependent global loads
   constexpr int kChunk = 4096;
   constexpr int kHitCap = 128;
-  __shared__ int64_t s_ids[kChunk];
+  // ids as int32 in LDS (anything outside [0, 2^31) can match no row: stored as -1): half the
+  // LDS footprint and half the bytes per scan step of the int64 image
+  __shared__ int32_t s_ids[kChunk];
   __shared__ int s_hits[4][kHitCap];
   int *my_hits = s_hits[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63;
@@ -293,7 +295,22 @@ __device__ __forceinline__ void scatter_rowscan_body(
   for (int64_t c0 = 0; c0 < n; c0 += kChunk) {
     const int m = (int)((n - c0 < kChunk) ? (n - c0) : kChunk);
     __syncthreads();
-    for (int e = threadIdx.x; e < m; e += 256) s_ids[e] = load_id<IdT>(ids, c0 + e);
+    {
+      // all 16 loads of a thread in flight before the first LDS write: one memory round trip per
+      // chunk (the runtime-bound copy loop it replaces was compiled to one round trip per
+      // iteration -- most of this kernel's 24 us at the quickstart shapes)
+      int64_t t[kChunk / 256];
+#pragma unroll
+      for (int i = 0; i < kChunk / 256; ++i) {
+        const int e = threadIdx.x + i * 256;
+        t[i] = e < m ? load_id<IdT>(ids, c0 + e) : (int64_t)-1;
+      }
+#pragma unroll
+      for (int i = 0; i < kChunk / 256; ++i) {
+        const int e = threadIdx.x + i * 256;
+        if (e < m) s_ids[e] = (t[i] >= 0 && t[i] <= 0x7FFFFFFFll) ? (int32_t)t[i] : -1;
+      }
+    }
     __syncthreads();
     if (!row_ok) continue;
     // Two phases per chunk: the scan only records where this row's id occurs (in order); the
@@ -321,7 +338,7 @@ __device__ __forceinline__ void scatter_rowscan_body(
     };
     for (int base = 0; base < m; base += 64) {
       const int p = base + lane;
-      const bool hit = (p < m) && (s_ids[p] == v);
+      const bool hit = (p < m) && ((int64_t)s_ids[p] == v);
       const uint64_t mask = __ballot(hit);
       if (mask == 0ull) continue;
       touched = true;

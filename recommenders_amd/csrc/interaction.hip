@@ -700,12 +700,7 @@ static bool launch_dot_mfma_nb(const float *x, int64_t batch, int f, int d, int 
   const char *sv = getenv("TFRS_DOT_STAGE");
   const bool stage = !skip && lds <= 64 * 1024 && !(sv && sv[0] == '0');
   if (stage) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dot_interaction_mfma_kernel<DP, NB, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-      attr_set = true;
-    }
+    (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&dot_interaction_mfma_kernel<DP, NB, true>), 64 * 1024);
     const int64_t per_cu = std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)lds));
     const dim3 grid((unsigned)std::min<int64_t>(batch, 256 * per_cu * 2));
     // TFRS_DOT_FWD=f32 keeps the exact-f32 MFMA chain (measurement / comparison switch)
@@ -720,12 +715,7 @@ static bool launch_dot_mfma_nb(const float *x, int64_t batch, int f, int d, int 
       }
       if (strided) return false;
       if (!(fv && fv[0] == 'f' && fv[1] == '3')) {
-        static bool attr16_set = false;
-        if (!attr16_set) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dot_interaction_f16x3_kernel<DP, NB>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-          attr16_set = true;
-        }
+        (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&dot_interaction_f16x3_kernel<DP, NB>), 64 * 1024);
         hipLaunchKernelGGL((dot_interaction_f16x3_kernel<DP, NB>), grid, dim3(64), lds, s, x, batch, f, d, self, out);
         return true;
       }
@@ -1123,12 +1113,7 @@ __global__ void __launch_bounds__(512) dot_interaction_bwd_pc_kernel(
 template <int MAXE>
 static void launch_dot_bwd_pc_v(const float *x, const float *dout, int64_t batch, int f, int d, int self,
                                 int kh, size_t lds, dim3 grid, float *dx, hipStream_t s, int64_t dout_stride) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dot_interaction_bwd_pc_kernel<MAXE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&dot_interaction_bwd_pc_kernel<MAXE>), 160 * 1024);
   hipLaunchKernelGGL((dot_interaction_bwd_pc_kernel<MAXE>), grid, dim3(512), lds, s, x, dout, batch, f, d,
                      self, kh, dx, dout_stride);
 }
@@ -1144,12 +1129,7 @@ static void launch_dot_bwd_pc_e(int maxe, const float *x, const float *dout, int
 template <int NFB, int MAXE>
 static void launch_dot_bwd_dense_v(const float *x, const float *dout, int64_t batch, int f, int d,
                                    int self, int kh, size_t lds, dim3 grid, float *dx, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dot_interaction_bwd_dense_kernel<NFB, MAXE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    attr_set = true;
-  }
+  (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&dot_interaction_bwd_dense_kernel<NFB, MAXE>), 64 * 1024);
   hipLaunchKernelGGL((dot_interaction_bwd_dense_kernel<NFB, MAXE>), grid, dim3(256), lds, s, x, dout, batch,
                      f, d, self, kh, dx);
 }
@@ -1197,12 +1177,7 @@ static bool launch_dot_bwd_mfma_nb(const float *x, const float *dout, int64_t ba
   const int out_dim = self ? f * (f + 1) / 2 : f * (f - 1) / 2;
   const size_t lds = (size_t)((out_dim + 3) & ~3) * sizeof(float);
   if (lds > 64 * 1024) return false;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dot_interaction_bwd_mfma_kernel<DP, NB>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    attr_set = true;
-  }
+  (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&dot_interaction_bwd_mfma_kernel<DP, NB>), 64 * 1024);
   const int64_t per_cu = std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)lds));
   const dim3 grid((unsigned)std::min<int64_t>(batch, 256 * per_cu * 2));
   hipLaunchKernelGGL((dot_interaction_bwd_mfma_kernel<DP, NB>), grid, dim3(64), lds, s, x, dout, batch, f,

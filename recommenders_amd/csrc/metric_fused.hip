@@ -60,7 +60,7 @@ struct RankGeom {
 // a wave keeps its 32 queries as the MFMA B operand, operands swapped (A = candidates) so that a
 // lane's 16 accumulators belong to ONE query and the compare with pos[query] is lane-local.
 template <int DP>
-__global__ void __launch_bounds__(256) rank_count_kernel(const RankCountArgs a) {
+__global__ void __launch_bounds__(256, DP <= 32 ? 4 : (DP == 64 ? 2 : 1)) rank_count_kernel(const RankCountArgs a) {
   using G = RankGeom<DP>;
   __shared__ __attribute__((aligned(16))) float tile_s[G::kLdsFloats];
   __shared__ float pos_s[128];
@@ -80,31 +80,65 @@ __global__ void __launch_bounds__(256) rank_count_kernel(const RankCountArgs a) 
   const int d = a.d;
 
   // ---- stage the split's candidate rows (through the id indirection) into LDS ----------------
-  // de-interleaved: feature k of row r -> tile_s[r * kPitch + (k & 1) * DP/2 + (k >> 1)]
+  // de-interleaved: feature k of row r -> tile_s[r * kPitch + (k & 1) * DP/2 + (k >> 1)].
+  // Fully unrolled over the compile-time maximum (predicated): all id loads are issued, then all
+  // row loads, then the LDS writes -- two memory round trips per workgroup, not two per iteration
+  // (a runtime-bound loop serialised them: 23 us at the quickstart shapes instead of 5).
   if ((d & 3) == 0) {
+    constexpr int kIter = G::kMaxTiles * 32 * (DP / 4) / 256;
     const int cpr = d >> 2;                             // float4 chunks per row
-    for (int e = tid; e < nt * 32 * (DP / 4); e += 256) {
+    int64_t src[kIter];
+#pragma unroll
+    for (int i = 0; i < kIter; ++i) {
+      const int e = tid + i * 256;
       const int r = e / (DP / 4), c = e - r * (DP / 4);
-      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      src[i] = -1;
       if (r < rows && c < cpr) {
-        int64_t src = c0 + r;
-        if (a.ids) src = a.ids_i64 ? ((const int64_t *)a.ids)[src] : (int64_t)((const int32_t *)a.ids)[src];
-        if (src >= 0 && src < a.vocab) v = *reinterpret_cast<const f32x4 *>(a.cand + src * d + 4 * c);
+        const int64_t row = c0 + r;
+        src[i] = !a.ids ? row : (a.ids_i64 ? ((const int64_t *)a.ids)[row] : (int64_t)((const int32_t *)a.ids)[row]);
       }
-      float *row = tile_s + r * G::kPitch;
-      *reinterpret_cast<float2 *>(row + 2 * c) = make_float2(v[0], v[2]);             // features 4c, 4c+2
-      *reinterpret_cast<float2 *>(row + DP / 2 + 2 * c) = make_float2(v[1], v[3]);    // features 4c+1, 4c+3
+    }
+    f32x4 v[kIter];
+#pragma unroll
+    for (int i = 0; i < kIter; ++i) {
+      const int e = tid + i * 256;
+      const int c = e % (DP / 4);
+      v[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (src[i] >= 0 && src[i] < a.vocab) v[i] = *reinterpret_cast<const f32x4 *>(a.cand + src[i] * d + 4 * c);
+    }
+#pragma unroll
+    for (int i = 0; i < kIter; ++i) {
+      const int e = tid + i * 256;
+      const int r = e / (DP / 4), c = e - r * (DP / 4);
+      if (r < nt * 32) {
+        float *row = tile_s + r * G::kPitch;
+        *reinterpret_cast<float2 *>(row + 2 * c) = make_float2(v[i][0], v[i][2]);             // features 4c, 4c+2
+        *reinterpret_cast<float2 *>(row + DP / 2 + 2 * c) = make_float2(v[i][1], v[i][3]);    // features 4c+1, 4c+3
+      }
     }
   } else {
-    for (int e = tid; e < nt * 32 * DP; e += 256) {
-      const int r = e / DP, k = e - r * DP;
-      float v = 0.0f;
-      if (r < rows && k < d) {
-        int64_t src = c0 + r;
-        if (a.ids) src = a.ids_i64 ? ((const int64_t *)a.ids)[src] : (int64_t)((const int32_t *)a.ids)[src];
-        if (src >= 0 && src < a.vocab) v = a.cand[src * d + k];
+    constexpr int kIter = G::kMaxTiles * 32 * DP / 256;
+    constexpr int kBatch = kIter < 16 ? kIter : 16;      // 16 loads in flight per thread
+#pragma unroll 1
+    for (int i0 = 0; i0 < kIter; i0 += kBatch) {
+      float v[kBatch];
+#pragma unroll
+      for (int i = 0; i < kBatch; ++i) {
+        const int e = tid + (i0 + i) * 256;
+        const int r = e / DP, k = e - r * DP;
+        v[i] = 0.0f;
+        if (r < rows && k < d) {
+          int64_t src = c0 + r;
+          if (a.ids) src = a.ids_i64 ? ((const int64_t *)a.ids)[src] : (int64_t)((const int32_t *)a.ids)[src];
+          if (src >= 0 && src < a.vocab) v[i] = a.cand[src * d + k];
+        }
       }
-      tile_s[r * G::kPitch + (k & 1) * (DP / 2) + (k >> 1)] = v;
+#pragma unroll
+      for (int i = 0; i < kBatch; ++i) {
+        const int e = tid + (i0 + i) * 256;
+        const int r = e / DP, k = e - r * DP;
+        if (r < nt * 32) tile_s[r * G::kPitch + (k & 1) * (DP / 2) + (k >> 1)] = v[i];
+      }
     }
   }
 
@@ -129,12 +163,51 @@ __global__ void __launch_bounds__(256) rank_count_kernel(const RankCountArgs a) 
   }
   if (tid < 128) {
     // the d-ordered fma chain from +0 of the scoring kernels (oracle/c/oracle_core.c), so that the
-    // positive ties exactly with its own copy among the candidates
+    // positive ties exactly with its own copy among the candidates.  All loads are issued before
+    // the chain (one memory round trip, not d dependent ones); padded features add +0 * 0.
     const int64_t r = (int64_t)qt * 128 + tid;
     float p = 0.0f;
     if (r < a.nq) {
       const float *qr = a.q + r * d, *cr = a.true_c + r * d;
-      for (int k = 0; k < d; ++k) p = __builtin_fmaf(qr[k], cr[k], p);
+      if ((d & 3) == 0) {
+        // (two round trips for DP >= 64: 64 staging registers instead of 128)
+        constexpr int kPer = DP >= 64 ? DP / 8 : DP / 4;
+#pragma unroll
+        for (int c0 = 0; c0 < DP / 4; c0 += kPer) {
+          f32x4 qv[kPer], cv[kPer];
+#pragma unroll
+          for (int c = 0; c < kPer; ++c) {
+            const bool in = 4 * (c0 + c) < d;
+            qv[c] = in ? *reinterpret_cast<const f32x4 *>(qr + 4 * (c0 + c)) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            cv[c] = in ? *reinterpret_cast<const f32x4 *>(cr + 4 * (c0 + c)) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          }
+#pragma unroll
+          for (int c = 0; c < kPer; ++c) {
+            if (4 * (c0 + c) < d) {
+              p = __builtin_fmaf(qv[c][0], cv[c][0], p);
+              p = __builtin_fmaf(qv[c][1], cv[c][1], p);
+              p = __builtin_fmaf(qv[c][2], cv[c][2], p);
+              p = __builtin_fmaf(qv[c][3], cv[c][3], p);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);   // keep the rounds apart (else all loads are hoisted: +64 VGPRs)
+        }
+      } else {
+        // (odd dims: 16 features per round trip keeps the register footprint of this branch small)
+        constexpr int kChunk = DP < 16 ? DP : 16;
+#pragma unroll 1
+        for (int k0 = 0; k0 < d; k0 += kChunk) {
+          float qv[kChunk], cv[kChunk];
+#pragma unroll
+          for (int k = 0; k < kChunk; ++k) {
+            qv[k] = k0 + k < d ? qr[k0 + k] : 0.0f;
+            cv[k] = k0 + k < d ? cr[k0 + k] : 0.0f;
+          }
+#pragma unroll
+          for (int k = 0; k < kChunk; ++k)
+            if (k0 + k < d) p = __builtin_fmaf(qv[k], cv[k], p);
+        }
+      }
     }
     pos_s[tid] = p;
   }
@@ -190,24 +263,37 @@ __global__ void __launch_bounds__(1024) hits_update_kernel(const HitsArgs a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) tot[i] = 0.0f;
   float wsum = 0.0f;
-  for (int64_t q = tid; q < a.nq; q += 1024) {
-    const uint32_t c = a.counts[q];
-    a.counts[q] = 0u;
-    const float w = a.weight ? a.weight[q] : 1.0f;
-    wsum += w;
-    const bool finite = (c & kNonFiniteBit) == 0u;
+  for (int64_t q0 = 0; q0 < a.nq; q0 += 4 * 1024) {      // four independent loads per thread in flight
+    uint32_t cv[4];
+    float wv[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      if (i < a.nks) {
-        const float hit = (finite && c < (uint32_t)a.ks[i]) ? 1.0f : 0.0f;
-        tot[i] += w * hit;
-        if (a.hits) a.hits[(int64_t)i * a.nq + q] = hit;
+    for (int u = 0; u < 4; ++u) {
+      const int64_t q = q0 + u * 1024 + tid;
+      cv[u] = q < a.nq ? a.counts[q] : 0u;
+      wv[u] = q < a.nq ? (a.weight ? a.weight[q] : 1.0f) : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t q = q0 + u * 1024 + tid;
+      if (q < a.nq) {
+        a.counts[q] = 0u;                                 // re-arm for the next sweep
+        wsum += wv[u];
+        const bool finite = (cv[u] & kNonFiniteBit) == 0u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (i < a.nks) {
+            const float hit = (finite && cv[u] < (uint32_t)a.ks[i]) ? 1.0f : 0.0f;
+            tot[i] += wv[u] * hit;
+            if (a.hits) a.hits[(int64_t)i * a.nq + q] = hit;
+          }
+        }
       }
     }
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i)
-    for (int off = 32; off > 0; off >>= 1) tot[i] += __shfl_xor(tot[i], off);
+    if (i < a.nks)                                        // (uniform: unused slots cost nothing)
+      for (int off = 32; off > 0; off >>= 1) tot[i] += __shfl_xor(tot[i], off);
   for (int off = 32; off > 0; off >>= 1) wsum += __shfl_xor(wsum, off);
   if (lane == 0) {
 #pragma unroll
@@ -256,8 +342,9 @@ extern "C" int tfrs_rank_count_accumulate(const float *queries, const float *tru
   const int dp = padded_dim(d);
   const int max_tiles = dp <= 64 ? 4 : 2;
   const int64_t ntiles = (nc + 31) / 32;
-  // enough workgroups to cover the chip about four times, at most max_tiles tiles each
-  int64_t want_splits = std::max<int64_t>(1, 1024 / a.n_qtiles);
+  // about two workgroups per CU (what the register footprint at D = 64 admits: one residency
+  // round), at most max_tiles tiles each
+  int64_t want_splits = std::max<int64_t>(1, 512 / a.n_qtiles);
   int64_t tps = std::min<int64_t>(max_tiles, std::max<int64_t>(1, (ntiles + want_splits - 1) / want_splits));
   const int64_t nsplits = (ntiles + tps - 1) / tps;
   TFRS_CHECK_ARG(nsplits * a.n_qtiles <= 0x7FFFFFFF, "rank_count: grid too large (%lld x %d workgroups)",

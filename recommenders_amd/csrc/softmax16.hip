@@ -433,15 +433,24 @@ __global__ void __launch_bounds__(64) sm16_finalize_kernel(const Sm16Args a, flo
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);   // fixed tree: reproducible
+  uint32_t t = 0;
   if (threadIdx.x == 0) {
     __hip_atomic_store(&block_part[blockIdx.x], local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == gridDim.x - 1) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      double total = 0.0;
-      for (unsigned b = 0; b < gridDim.x; ++b)
-        total += __hip_atomic_load(&block_part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  t = __shfl(t, 0);
+  if (t == gridDim.x - 1) {
+    // last block to arrive: all 64 lanes fetch the partials (64 independent loads per pass, not a
+    // serial walk by one lane) and add them in a fixed order -- lane l takes blocks l, l + 64, ...
+    // in order, then the fixed xor tree -- so the loss does not depend on scheduling
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    double total = 0.0;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += 64)
+      total += __hip_atomic_load(&block_part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+    if (threadIdx.x == 0) {
       *out_loss = (float)total;
       __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -256,12 +256,7 @@ __global__ void __launch_bounds__(kThreads, DP <= 64 ? 4 : 2) scan_kernel(const 
 template <int DP, bool MAT, bool GLDS>
 static int launch_scan_variant(const ScanArgs &a, hipStream_t stream) {
   using G = ScanGeom<DP>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    TFRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<DP, MAT, GLDS>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
-    attr_set = true;
-  }
+  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&scan_kernel<DP, MAT, GLDS>), G::kLdsBytes));
   const dim3 grid((unsigned)(a.n_qtiles * a.n_splits));
   hipLaunchKernelGGL((scan_kernel<DP, MAT, GLDS>), grid, dim3(kThreads), G::kLdsBytes, stream, a);
   TFRS_LAUNCH_CHECK();

@@ -712,12 +712,7 @@ __global__ void __launch_bounds__(NW * 64, (DP <= 64 ? 2 : 1) * NW / 4) scan16f_
 template <int DP, int NW, int QG>
 static int launch_scan16f(const Scan16Args &a, hipStream_t stream) {
   using G = Scan16FGeom<DP, NW, QG>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    TFRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan16f_kernel<DP, NW, QG>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytesF));
-    attr_set = true;
-  }
+  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&scan16f_kernel<DP, NW, QG>), G::kLdsBytesF));
   const dim3 grid((unsigned)(a.n_qtiles * a.n_splits));
   hipLaunchKernelGGL((scan16f_kernel<DP, NW, QG>), grid, dim3(NW * 64), G::kLdsBytesF, stream, a);
   TFRS_LAUNCH_CHECK();
@@ -735,12 +730,7 @@ static int launch_scan16f_shape(const Scan16Args &a, hipStream_t stream) {
 template <int DP, int MODE>
 static int launch_scan16_variant(const Scan16Args &a, hipStream_t stream) {
   using G = Scan16Geom<DP>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    TFRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan16_kernel<DP, MODE>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes));
-    attr_set = true;
-  }
+  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&scan16_kernel<DP, MODE>), G::kLdsBytes));
   const dim3 grid((unsigned)(a.n_qtiles * a.n_splits));
   hipLaunchKernelGGL((scan16_kernel<DP, MODE>), grid, dim3(kThreads16), G::kLdsBytes, stream, a);
   TFRS_LAUNCH_CHECK();

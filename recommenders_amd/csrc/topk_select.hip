@@ -258,10 +258,14 @@ __global__ void __launch_bounds__(NW * 64) recompute_kernel(const SelectArgs a) 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nchunks = gridDim.y, chunk_id = blockIdx.y;  // the row range is cut into gridDim.y chunks
   // flagged queries: a.only_flagged[0] = count, a.only_flagged[1 + s] = query of slot s
   // (NULL: every query, slot = query); workgroups stride over the slots
   const int64_t nslots = a.only_flagged ? (int64_t)a.only_flagged[0] : a.nq;
+  // the row range is cut into chunks: gridDim.y of them without a partial-list buffer, else as many
+  // as the list budget allows for this many flagged queries (surplus workgroups exit)
+  const int nchunks = a.part_keys ? recompute_chunks(a.nq, nslots) : (int)gridDim.y;
+  const int chunk_id = blockIdx.y;
+  if (chunk_id >= nchunks) return;
   for (int64_t slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
   const int64_t row = a.only_flagged ? (int64_t)a.only_flagged[1 + slot] : slot;
   __syncthreads();  // LDS reuse across slots
@@ -316,7 +320,7 @@ __global__ void __launch_bounds__(NW * 64) recompute_kernel(const SelectArgs a) 
     }
   }
   if (fill > 0) absorb_chunk<KP>(best, chunk, fill, lane);
-  if (nchunks > 1) {  // partial list of this chunk: merged by recompute_merge_kernel
+  if (a.part_keys) {  // partial list of this chunk: merged by recompute_merge_kernel
     uint64_t *dst = a.part_keys + ((size_t)slot * nchunks + chunk_id) * K;
     for (int i = lane; i < K; i += 64) dst[i] = best[i];
     continue;
@@ -331,13 +335,14 @@ __global__ void __launch_bounds__(NW * 64) recompute_kernel(const SelectArgs a) 
 
 // One wave per flagged query: top-K of the nchunks sorted partial key lists.
 template <int KP>
-__global__ void __launch_bounds__(64) recompute_merge_kernel(const SelectArgs a, int nchunks) {
+__global__ void __launch_bounds__(64) recompute_merge_kernel(const SelectArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
   uint64_t *best = reinterpret_cast<uint64_t *>(smem);
   uint64_t *chunk = best + KP;
   const int K = a.k;
   const int64_t nslots = a.only_flagged ? (int64_t)a.only_flagged[0] : a.nq;
+  const int nchunks = recompute_chunks(a.nq, nslots);
   for (int64_t slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
   const int64_t row = a.only_flagged ? (int64_t)a.only_flagged[1 + slot] : slot;
   wave_lds_sync();
@@ -347,19 +352,27 @@ __global__ void __launch_bounds__(64) recompute_merge_kernel(const SelectArgs a,
   uint64_t kth = 0ull;
   const uint64_t *src = a.part_keys + (size_t)slot * nchunks * K;
   const int total = nchunks * K;
-  for (int base = 0; base < total; base += 64) {
-    const int e = base + lane;
-    const uint64_t key = e < total ? src[e] : 0ull;
-    const bool p = key > kth;
-    const uint64_t mask = __ballot(p);
-    if (mask == 0ull) continue;
-    if (fill + 64 > KP) {
-      absorb_chunk<KP>(best, chunk, fill, lane);
-      fill = 0;
-      kth = best[K - 1];
+  for (int base0 = 0; base0 < total; base0 += 4 * 64) {
+    uint64_t keys[4];      // four independent loads per round trip (up to 25600 keys per query)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = base0 + u * 64 + lane;
+      keys[u] = e < total ? src[e] : 0ull;
     }
-    if (p) chunk[fill + sel_mbcnt(mask)] = key;
-    fill += (int)__popcll(mask);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint64_t key = keys[u];
+      const bool p = key > kth;
+      const uint64_t mask = __ballot(p);
+      if (mask == 0ull) continue;
+      if (fill + 64 > KP) {
+        absorb_chunk<KP>(best, chunk, fill, lane);
+        fill = 0;
+        kth = best[K - 1];
+      }
+      if (p) chunk[fill + sel_mbcnt(mask)] = key;
+      fill += (int)__popcll(mask);
+    }
   }
   if (fill > 0) absorb_chunk<KP>(best, chunk, fill, lane);
   for (int i = lane; i < K; i += 64) {
@@ -373,22 +386,19 @@ __global__ void __launch_bounds__(64) recompute_merge_kernel(const SelectArgs a,
 template <int KP, int NW>
 static int launch_recompute_kp(const SelectArgs &a, hipStream_t stream) {
   const size_t lds = (size_t)NW * 2 * KP * sizeof(uint64_t) + TFRS_MAX_DIM * sizeof(float);
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    TFRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&recompute_kernel<KP, NW>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  // with a partial-list buffer the rows of a flagged query are spread over kRecomputeChunks
-  // workgroups (a single CU streams only ~30 GB/s of candidate rows), then merged
-  const int nchunks = a.part_keys ? kRecomputeChunks : 1;
+  if (lds > 64 * 1024) TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&recompute_kernel<KP, NW>), (int)lds));
+  // with a partial-list buffer the rows of a flagged query are spread over up to
+  // kRecomputeMaxChunks workgroups (a single CU streams only ~30 GB/s of candidate rows) -- how
+  // many is decided on the device from the flagged count (recompute_chunks) -- then merged
+  const int gy = a.part_keys ? kRecomputeMaxChunks : 1;
   // small fixed grid striding over the flagged slots (usually none: the launch costs ~3 us)
-  const unsigned gx = a.only_flagged ? (unsigned)std::min<int64_t>(a.nq, 64) : (unsigned)a.nq;
-  hipLaunchKernelGGL((recompute_kernel<KP, NW>), dim3(gx, (unsigned)nchunks), dim3(NW * 64), lds, stream, a);
+  const unsigned gx = a.part_keys ? (unsigned)std::min<int64_t>(a.nq, kRecomputeSlotsX)
+                                  : (a.only_flagged ? (unsigned)std::min<int64_t>(a.nq, 64) : (unsigned)a.nq);
+  hipLaunchKernelGGL((recompute_kernel<KP, NW>), dim3(gx, (unsigned)gy), dim3(NW * 64), lds, stream, a);
   TFRS_LAUNCH_CHECK();
-  if (nchunks > 1) {
-    hipLaunchKernelGGL((recompute_merge_kernel<KP>), dim3(gx), dim3(64),
-                       (size_t)2 * KP * sizeof(uint64_t), stream, a, nchunks);
+  if (a.part_keys) {
+    hipLaunchKernelGGL((recompute_merge_kernel<KP>), dim3((unsigned)std::min<int64_t>(a.nq, 64)), dim3(64),
+                       (size_t)2 * KP * sizeof(uint64_t), stream, a);
     TFRS_LAUNCH_CHECK();
   }
   return TFRS_OK;
@@ -407,12 +417,7 @@ int launch_recompute(const SelectArgs &a, hipStream_t stream) {
 template <int KP>
 static int launch_select_kp(const SelectArgs &a, hipStream_t stream) {
   const size_t lds = (size_t)kSelWaves * (2 * KP * sizeof(uint64_t) + TFRS_MAX_DIM * sizeof(float));
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    TFRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_kernel<KP>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  if (lds > 64 * 1024) TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&select_kernel<KP>), (int)lds));
   const dim3 grid((unsigned)((a.nq + kSelWaves - 1) / kSelWaves));
   hipLaunchKernelGGL((select_kernel<KP>), grid, dim3(kSelWaves * 64), lds, stream, a);
   TFRS_LAUNCH_CHECK();

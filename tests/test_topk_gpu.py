@@ -313,6 +313,51 @@ def test_full_size_properties(filter_mode, monkeypatch):
     assert torch.equal(i, i32) and torch.equal(s, s32)         # every one of the 8192 queries
 
 
+def test_two_host_threads_two_streams():
+  """include/tfrs_hip.h promises re-entrancy on distinct streams / handles: two host threads, each
+  on its own HIP stream, run BruteForce calls at the same time -- one shares an index handle with
+  the other (read-only during queries), one has its own -- and every result must equal the oracle.
+  (ctypes releases the GIL during the C call, so the launches really interleave.)"""
+  import threading
+  ftk = _layers()
+  rng = np.random.default_rng(77)
+  n, d, k = 150_000, 32, 40
+  c = (rng.normal(size=(n, d)) / 5).astype(np.float32)
+  c2 = (rng.normal(size=(70_000, d)) / 5).astype(np.float32)
+  qs = [(rng.normal(size=(96, d)) / 5).astype(np.float32) for _ in range(2)]
+  shared = ftk.BruteForce(k=k).index(c)
+  own = ftk.BruteForce(k=k).index(c2)
+  torch.cuda.synchronize()
+  results, errors = {}, []
+
+  def worker(t):
+    try:
+      stream = torch.cuda.Stream()
+      with torch.cuda.stream(stream):
+        q = torch.as_tensor(qs[t]).cuda()
+        outs = []
+        for it in range(6):
+          layer = shared if (t == 0 or it % 2 == 0) else own
+          s, i = layer(q)
+          outs.append((layer is shared, _np(s), _np(i)))      # (.cpu() synchronises this stream)
+        results[t] = outs
+    except Exception as e:      # pragma: no cover
+      errors.append(e)
+
+  threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+  for th in threads:
+    th.start()
+  for th in threads:
+    th.join()
+  assert not errors, errors
+  for t in range(2):
+    es, ei = o_topk.brute_force(qs[t], c, k)
+    es2, ei2 = o_topk.brute_force(qs[t], c2, k)
+    for was_shared, s, i in results[t]:
+      np.testing.assert_array_equal(i, ei if was_shared else ei2)
+      np.testing.assert_array_equal(s, es if was_shared else es2)
+
+
 def _pow2_ceil(x):
   x = np.asarray(x, np.float64)
   out = np.ones_like(x)

@@ -21,5 +21,6 @@ for nflag in (0, 1, 8, 64, 512):
   t0 = time.perf_counter()
   for _ in range(5): index(queries)
   torch.cuda.synchronize()
-  print(f"flagged queries ~{nflag}: {(time.perf_counter() - t0) / 5 * 1e3:.3f} ms/step", flush=True)
+  print(f"flagged queries ~{nflag}: {(time.perf_counter() - t0) / 5 * 1e3:.3f} ms/step, redo "
+        f"{index.last_redo_count()} {index.last_redo_reasons()}", flush=True)
   del index

@@ -7,7 +7,8 @@ import torch
 import recommenders_amd as tfrs
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(0)
-B, D, V = 4096, 64, 2000
+B, D, V, ITEMS = 4096, 64, 2000, 1682
+METRICS = os.environ.get("TFRS_EXP_METRICS", "1") == "1"   # README step: FactorizedTopK updated every step
 
 
 class TwoTower(tfrs.Model):
@@ -15,11 +16,16 @@ class TwoTower(tfrs.Model):
     super().__init__()
     self.user_model = tfrs.layers.embedding.Embedding(V, D)
     self.item_model = tfrs.layers.embedding.Embedding(V, D)
-    self.task = tfrs.tasks.Retrieval()
+    if METRICS:
+      movies = tfrs.data.Dataset.from_tensor_slices(torch.arange(ITEMS, device=dev))
+      self.task = tfrs.tasks.Retrieval(metrics=tfrs.metrics.FactorizedTopK(
+          candidates=movies.batch(128).map(self.item_model)))
+    else:
+      self.task = tfrs.tasks.Retrieval()
 
   def compute_loss(self, inputs, training=False):
     return self.task(self.user_model(inputs["user_id"]), self.item_model(inputs["movie_id"]),
-                     compute_metrics=False)
+                     compute_metrics=METRICS)
 
 
 model = TwoTower()
