@@ -103,6 +103,16 @@ int tfrs_bruteforce_topk(const tfrs_index_t *index, const float *queries, int64_
  * exact-recompute ("redo") path of the fp16-prefiltered search (survivor list overflow or
  * retained set too large; 0 on well-behaved data, and always 0 on the all-f32 path).
  * Synchronises `stream`. */
+/* Paged search for k beyond TFRS_MAX_K (tf.math.top_k has no limit, layers/factorized_top_k.py:605):
+ * the best k <= TFRS_MAX_K rows among those strictly AFTER (last_scores[q * last_ld],
+ * last_rows[q * last_ld]) in the result order (score descending, row ascending); NULL / NULL = the
+ * first page.  Concatenated pages are exactly the sorted top-(sum of k); the caller keeps
+ * sum of k <= rows.  All-f32 rounds.  Workspace: tfrs_bruteforce_topk_below_workspace_bytes. */
+size_t tfrs_bruteforce_topk_below_workspace_bytes(int64_t nq, int64_t n, int d, int k);
+int tfrs_bruteforce_topk_below(const tfrs_index_t *index, const float *queries, int64_t nq, int k,
+                               const float *last_scores, const int32_t *last_rows, int64_t last_ld,
+                               float *out_scores, int32_t *out_idx, void *workspace,
+                               size_t workspace_bytes, void *stream);
 int tfrs_bruteforce_topk_redo_count(const void *workspace, int64_t nq, int64_t n, int k,
                                     int32_t *redo_count_h, void *stream);
 /* Same contract; reasons_h[4] = queries flagged because {0: a survivor segment or the list
@@ -228,6 +238,15 @@ int tfrs_id_match_topk(const int32_t *retrieved_ids, const int32_t *true_ids,
 int tfrs_rank_count_accumulate(const float *queries, const float *true_candidates, int64_t nq, int d,
                                const float *candidates, const void *cand_ids, int ids_i64, int64_t nc,
                                int64_t vocab, uint32_t *counts, int first_block, void *stream);
+/* tfrs_rank_count_accumulate for the LAST block of a sweep with tfrs_topk_hits_update folded into
+ * the same launch: the last workgroup to finish turns the counts into the metric update (no second
+ * launch; hits == NULL).  `counts` must have nq + 1 words (the last one is the arrival ticket, zero
+ * between launches like the counts). */
+int tfrs_rank_count_update_hits(const float *queries, const float *true_candidates, int64_t nq, int d,
+                                const float *candidates, const void *cand_ids, int ids_i64, int64_t nc,
+                                int64_t vocab, uint32_t *counts, int first_block, const int32_t *ks_h,
+                                int nks, const float *sample_weight, float *state, float *results,
+                                void *stream);
 int tfrs_topk_hits_update(uint32_t *counts, int64_t nq, const int32_t *ks_h, int nks,
                           const float *sample_weight, float *state, float *results, float *hits,
                           void *stream);
@@ -419,6 +438,24 @@ int tfrs_dense_fwd_f16(const float *x, const float *kernel, const float *bias, i
 int tfrs_cross_fwd_f16(const float *x0, const float *x, const float *kernel, const float *bias,
                        float diag_scale, int64_t batch, int d, float *y, void *workspace,
                        size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Row-sharded embedding lookup, owner bucketing (the multi-device
+ * embedding of the reference is TPUEmbedding, layers/embedding/tpu_embedding_layer.py:699-720):
+ * rank r owns table rows [r * rows_per_rank, (r + 1) * rows_per_rank).  For n lookups:
+ *   counts[o]    (int64, DEVICE) = lookups served by owner o  (the all-to-all split sizes)
+ *   send_ids[p]  (int64) shard-local row of the lookup in send slot p, owner by owner, STABLE
+ *                within an owner (-1: id outside [0, input_dim) -> zero row, routed to owner 0)
+ *   perm[i] = send slot of lookup i;  order[p] = lookup in send slot p   (int32)
+ * so the rows that come back are gathered to their final positions through `perm`
+ * (tfrs_embedding_gather_fwd with ids = perm) and the gradient rows are laid out for the way
+ * back through `order`.  No sort, no host synchronisation, three short launches.
+ * ------------------------------------------------------------------------- */
+size_t tfrs_shard_route_workspace_bytes(int64_t n, int world);
+int tfrs_shard_route_ids(const void *ids, int ids_are_i64, int64_t n, int64_t input_dim,
+                         int64_t rows_per_rank, int world, int64_t *send_ids, int32_t *perm,
+                         int32_t *order, int64_t *counts, void *workspace, size_t workspace_bytes,
+                         void *stream);
 
 /* ------------------------------------------------------------------------- *
  * DotInteraction.call (layers/feature_interaction/dot_interaction.py:53-104):

@@ -36,6 +36,8 @@ SIGNATURES = {
     "tfrs_index_unpack": (c_int, [P, P, P]),
     "tfrs_bruteforce_topk_workspace_bytes": (c_size_t, [c_i64, c_i64, c_int, c_int]),
     "tfrs_bruteforce_topk": (c_int, [P, P, c_i64, c_int, P, P, P, c_size_t, P]),
+    "tfrs_bruteforce_topk_below_workspace_bytes": (c_size_t, [c_i64, c_i64, c_int, c_int]),
+    "tfrs_bruteforce_topk_below": (c_int, [P, P, c_i64, c_int, P, P, c_i64, P, P, P, c_size_t, P]),
     "tfrs_bruteforce_topk_redo_count": (c_int, [P, c_i64, c_i64, c_int, P, P]),
     "tfrs_bruteforce_topk_redo_reasons": (c_int, [P, c_i64, c_i64, c_int, P, P]),
     "tfrs_debug_topk_plan": (c_int, [c_i64, c_int, c_int, P]),
@@ -53,7 +55,11 @@ SIGNATURES = {
     "tfrs_rank_of_positive": (c_int, [P, P, c_i64, c_int, P, c_int, P, c_int, P, P]),
     "tfrs_id_match_topk": (c_int, [P, P, c_i64, c_int, P, c_int, P, P]),
     "tfrs_rank_count_accumulate": (c_int, [P, P, c_i64, c_int, P, P, c_int, c_i64, c_i64, P, c_int, P]),
+    "tfrs_rank_count_update_hits": (c_int, [P, P, c_i64, c_int, P, P, c_int, c_i64, c_i64, P, c_int, P, c_int,
+                                            P, P, P, P]),
     "tfrs_topk_hits_update": (c_int, [P, c_i64, P, c_int, P, P, P, P, P]),
+    "tfrs_shard_route_workspace_bytes": (c_size_t, [c_i64, c_int]),
+    "tfrs_shard_route_ids": (c_int, [P, c_int, c_i64, c_i64, c_i64, c_int, P, P, P, P, P, c_size_t, P]),
     "tfrs_embedding_gather_fwd": (c_int, [P, c_i64, c_int, P, c_int, c_i64, P, P, P]),
     "tfrs_embedding_segment_reduce_fwd": (c_int, [P, c_i64, c_int, P, P, c_int, P, c_i64,
                                                   c_int, P, P, P]),

@@ -29,6 +29,7 @@ SOURCES = [
     "topk_api.hip",
     "metric_fused.hip",
     "embedding.hip",
+    "shard_route.hip",
     "hashing.hip",
     "softmax.hip",
     "softmax16.hip",

@@ -163,6 +163,10 @@ struct ScanArgs {
   // MATERIALIZE mode
   float *dense;          // [nq, ld_dense] scores for rows c_begin..c_end
   int64_t ld_dense;
+  // FILTER mode, paged search (K beyond TFRS_MAX_K: tfrs_bruteforce_topk_below): scores above
+  // ceil_score[query] belong to rows returned by an earlier page and are not appended (NULL: no
+  // ceiling); the exact (score, row) ceiling is applied when keys are formed (SelectArgs::ceil_key)
+  const float *ceil_score;
 };
 
 int launch_scan(const ScanArgs &a, bool materialize, hipStream_t stream);
@@ -260,6 +264,9 @@ struct SelectArgs {
   float *out_scores;   // [nq, k]
   int32_t *out_idx;    // [nq, k]
   float *out_thr;      // [nq] K-th best score, or -inf while fewer than k entries (may be NULL)
+  // paged search: only keys strictly BELOW ceil_key[query] -- i.e. after it in (score descending,
+  // row ascending) order -- are candidates (NULL: no ceiling)
+  const uint64_t *ceil_key;
   // launch_recompute: optional buffer of nq * kRecomputeChunks partial key lists of k keys; when
   // set, each flagged query's rows are spread over recompute_chunks(nq, flagged) workgroups --
   // the fewer queries are flagged, the more workgroups share one query -- and merged afterwards

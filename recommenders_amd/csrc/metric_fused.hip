@@ -43,16 +43,108 @@ struct RankCountArgs {
   int tiles_per_split;   // 32-row tiles per workgroup
   int n_qtiles;          // ceil(nq / 128)
   int mark_nonfinite;    // 1: this launch also flags non-finite positives (first block of a stream)
+  // fold == 1 (last block of a sweep): the LAST workgroup to finish turns the counts into the metric
+  // update (hits_fold) -- no second launch.  ticket: one word behind the counts, zero between launches.
+  int fold;
+  uint32_t *ticket;
+  int32_t ks[16];
+  int nks;
+  const float *weight;
+  float *state;
+  float *results;
 };
 
 constexpr uint32_t kNonFiniteBit = 0x80000000u;
 
 template <int DP>
 struct RankGeom {
-  static constexpr int kMaxTiles = DP <= 64 ? 4 : 2;
+  static constexpr int kMaxTiles = DP <= 64 ? 7 : 3;     // <= 61 KB of LDS
   static constexpr int kPitch = DP + 4;            // floats per LDS row: even plane | odd plane | pad
   static constexpr int kLdsFloats = kMaxTiles * 32 * kPitch;
 };
+
+struct HitsArgs {
+  uint32_t *counts;      // [nq]; re-armed (zeroed) for the next update
+  int64_t nq;
+  int32_t ks[16];
+  int nks;
+  const float *weight;   // [nq] or nullptr (all ones)
+  float *state;          // [2 * nks]: weighted hit totals, then weight totals (tf.keras.metrics.Mean)
+  float *results;        // [nks]: total / count after this update (0 when count == 0)
+  float *hits;           // [nks, nq] per-example hit indicators, or nullptr
+};
+
+// counts -> weighted hit totals of every k, by ONE workgroup of NT threads (NT / 64 <= 16 waves).
+// The reduction order is fixed (lane -> xor tree -> wave partials in order), so the metric state is
+// bit-reproducible from run to run.  COHERENT: the counts were written by other workgroups of the
+// same launch (device-scope atomics): read them past the non-coherent caches.
+template <int NT, bool COHERENT>
+__device__ __forceinline__ void hits_fold(const HitsArgs &a, float (*part_s)[17]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float tot[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) tot[i] = 0.0f;
+  float wsum = 0.0f;
+  for (int64_t q0 = 0; q0 < a.nq; q0 += 4 * NT) {        // four independent loads per thread in flight
+    uint32_t cv[4];
+    float wv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t q = q0 + u * NT + tid;
+      cv[u] = 0u;
+      if (q < a.nq)
+        cv[u] = COHERENT ? __hip_atomic_load(a.counts + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                         : a.counts[q];
+      wv[u] = q < a.nq ? (a.weight ? a.weight[q] : 1.0f) : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t q = q0 + u * NT + tid;
+      if (q < a.nq) {
+        // re-arm for the next sweep (write-through: the next launch's atomics act on memory)
+        __hip_atomic_store(a.counts + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wsum += wv[u];
+        const bool finite = (cv[u] & kNonFiniteBit) == 0u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (i < a.nks) {
+            const float hit = (finite && cv[u] < (uint32_t)a.ks[i]) ? 1.0f : 0.0f;
+            tot[i] += wv[u] * hit;
+            if (a.hits) a.hits[(int64_t)i * a.nq + q] = hit;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (i < a.nks)                                        // (uniform: unused slots cost nothing)
+      for (int off = 32; off > 0; off >>= 1) tot[i] += __shfl_xor(tot[i], off);
+  for (int off = 32; off > 0; off >>= 1) wsum += __shfl_xor(wsum, off);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part_s[wave][i] = tot[i];
+    part_s[wave][16] = wsum;
+  }
+  __syncthreads();
+  if (tid < a.nks) {
+    float t = 0.0f, w = 0.0f;
+    for (int v = 0; v < NT / 64; ++v) {
+      t += part_s[v][tid];
+      w += part_s[v][16];
+    }
+    const float total = a.state[tid] + t;
+    const float count = a.state[a.nks + tid] + w;
+    a.state[tid] = total;
+    a.state[a.nks + tid] = count;
+    a.results[tid] = count > 0.0f ? total / count : 0.0f;
+  }
+}
+
+__global__ void __launch_bounds__(1024) hits_update_kernel(const HitsArgs a) {
+  __shared__ float part_s[16][17];
+  hits_fold<1024, false>(a, part_s);
+}
 
 // One workgroup = 4 waves = 128 queries x one split of <= kMaxTiles candidate tiles.  The split's
 // rows are staged ONCE into LDS in the packed layout of common.h (even features | odd features |
@@ -60,10 +152,12 @@ struct RankGeom {
 // a wave keeps its 32 queries as the MFMA B operand, operands swapped (A = candidates) so that a
 // lane's 16 accumulators belong to ONE query and the compare with pos[query] is lane-local.
 template <int DP>
-__global__ void __launch_bounds__(256, DP <= 32 ? 4 : (DP == 64 ? 2 : 1)) rank_count_kernel(const RankCountArgs a) {
+__global__ void __launch_bounds__(256, 1) rank_count_kernel(const RankCountArgs a) {
   using G = RankGeom<DP>;
   __shared__ __attribute__((aligned(16))) float tile_s[G::kLdsFloats];
   __shared__ float pos_s[128];
+  __shared__ float part_s[16][17];
+  __shared__ uint32_t last_s;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -142,25 +236,11 @@ __global__ void __launch_bounds__(256, DP <= 32 ? 4 : (DP == 64 ? 2 : 1)) rank_c
     }
   }
 
-  // ---- this wave's 32 queries -> MFMA B operand; positives ---------------------------------------
-  const int64_t qrow = (int64_t)qt * 128 + wave * 32 + j;
-  const bool qvalid = qrow < a.nq;
-  float bq[DP / 2];
-  if ((d & 3) == 0) {
-#pragma unroll
-    for (int c = 0; c < DP / 4; ++c) {
-      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (qvalid && 4 * c < d) v = *reinterpret_cast<const f32x4 *>(a.q + qrow * d + 4 * c);
-      bq[2 * c] = h ? v[1] : v[0];
-      bq[2 * c + 1] = h ? v[3] : v[2];
-    }
-  } else {
-#pragma unroll
-    for (int s = 0; s < DP / 2; ++s) {
-      const int k = 2 * s + h;
-      bq[s] = (qvalid && k < d) ? a.q[qrow * d + k] : 0.0f;
-    }
-  }
+  // (no barrier between the phases: the compiler hoists every phase's loads to the top, so the
+  // workgroup pays ~two memory round trips in total -- ids -> rows, with the query / positive rows
+  // alongside -- instead of one or two per phase; the price is registers, which are free at one
+  // workgroup per CU)
+  // ---- positives ----------------------------------------------------------------------------------
   if (tid < 128) {
     // the d-ordered fma chain from +0 of the scoring kernels (oracle/c/oracle_core.c), so that the
     // positive ties exactly with its own copy among the candidates.  All loads are issued before
@@ -170,8 +250,7 @@ __global__ void __launch_bounds__(256, DP <= 32 ? 4 : (DP == 64 ? 2 : 1)) rank_c
     if (r < a.nq) {
       const float *qr = a.q + r * d, *cr = a.true_c + r * d;
       if ((d & 3) == 0) {
-        // (two round trips for DP >= 64: 64 staging registers instead of 128)
-        constexpr int kPer = DP >= 64 ? DP / 8 : DP / 4;
+        constexpr int kPer = DP / 4;     // every load of both rows in flight at once
 #pragma unroll
         for (int c0 = 0; c0 < DP / 4; c0 += kPer) {
           f32x4 qv[kPer], cv[kPer];
@@ -190,7 +269,6 @@ __global__ void __launch_bounds__(256, DP <= 32 ? 4 : (DP == 64 ? 2 : 1)) rank_c
               p = __builtin_fmaf(qv[c][3], cv[c][3], p);
             }
           }
-          __builtin_amdgcn_sched_barrier(0);   // keep the rounds apart (else all loads are hoisted: +64 VGPRs)
         }
       } else {
         // (odd dims: 16 features per round trip keeps the register footprint of this branch small)
@@ -210,6 +288,26 @@ __global__ void __launch_bounds__(256, DP <= 32 ? 4 : (DP == 64 ? 2 : 1)) rank_c
       }
     }
     pos_s[tid] = p;
+  }
+
+  // ---- this wave's 32 queries -> MFMA B operand ---------------------------------------
+  const int64_t qrow = (int64_t)qt * 128 + wave * 32 + j;
+  const bool qvalid = qrow < a.nq;
+  float bq[DP / 2];
+  if ((d & 3) == 0) {
+#pragma unroll
+    for (int c = 0; c < DP / 4; ++c) {
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (qvalid && 4 * c < d) v = *reinterpret_cast<const f32x4 *>(a.q + qrow * d + 4 * c);
+      bq[2 * c] = h ? v[1] : v[0];
+      bq[2 * c + 1] = h ? v[3] : v[2];
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < DP / 2; ++s) {
+      const int k = 2 * s + h;
+      bq[s] = (qvalid && k < d) ? a.q[qrow * d + k] : 0.0f;
+    }
   }
   __syncthreads();
   const float pos = pos_s[wave * 32 + j];
@@ -241,78 +339,27 @@ __global__ void __launch_bounds__(256, DP <= 32 ? 4 : (DP == 64 ? 2 : 1)) rank_c
     if (a.mark_nonfinite && split == 0 && !__builtin_isfinite(pos)) cnt |= kNonFiniteBit;
     if (cnt != 0u) atomicAdd(a.counts + qrow, cnt);
   }
-}
-
-struct HitsArgs {
-  uint32_t *counts;      // [nq]; re-armed (zeroed) for the next update
-  int64_t nq;
-  int32_t ks[16];
-  int nks;
-  const float *weight;   // [nq] or nullptr (all ones)
-  float *state;          // [2 * nks]: weighted hit totals, then weight totals (tf.keras.metrics.Mean)
-  float *results;        // [nks]: total / count after this update (0 when count == 0)
-  float *hits;           // [nks, nq] per-example hit indicators, or nullptr
-};
-
-// One workgroup: the reduction order is fixed (lane -> wave tree -> 16 wave partials in order), so
-// the metric state is bit-reproducible from run to run.
-__global__ void __launch_bounds__(1024) hits_update_kernel(const HitsArgs a) {
-  __shared__ float part_s[16][17];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float tot[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) tot[i] = 0.0f;
-  float wsum = 0.0f;
-  for (int64_t q0 = 0; q0 < a.nq; q0 += 4 * 1024) {      // four independent loads per thread in flight
-    uint32_t cv[4];
-    float wv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t q = q0 + u * 1024 + tid;
-      cv[u] = q < a.nq ? a.counts[q] : 0u;
-      wv[u] = q < a.nq ? (a.weight ? a.weight[q] : 1.0f) : 0.0f;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t q = q0 + u * 1024 + tid;
-      if (q < a.nq) {
-        a.counts[q] = 0u;                                 // re-arm for the next sweep
-        wsum += wv[u];
-        const bool finite = (cv[u] & kNonFiniteBit) == 0u;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          if (i < a.nks) {
-            const float hit = (finite && cv[u] < (uint32_t)a.ks[i]) ? 1.0f : 0.0f;
-            tot[i] += wv[u] * hit;
-            if (a.hits) a.hits[(int64_t)i * a.nq + q] = hit;
-          }
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 16; ++i)
-    if (i < a.nks)                                        // (uniform: unused slots cost nothing)
-      for (int off = 32; off > 0; off >>= 1) tot[i] += __shfl_xor(tot[i], off);
-  for (int off = 32; off > 0; off >>= 1) wsum += __shfl_xor(wsum, off);
-  if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) part_s[wave][i] = tot[i];
-    part_s[wave][16] = wsum;
+  if (!a.fold) return;
+  // ---- last workgroup to arrive folds the counts into the metric state ------------------------------
+  // The counts are device-scope atomics (performed at the memory side, not in this XCD's L2) and the
+  // fold reads them with device-scope loads, so no cache write-back / invalidate is needed: every
+  // wave only waits until its own atomics have been performed (vmcnt), the barrier collects the waves,
+  // one lane takes the ticket.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_s = (t == gridDim.x - 1) ? 1u : 0u;
   }
   __syncthreads();
-  if (tid < a.nks) {
-    float t = 0.0f, w = 0.0f;
-    for (int v = 0; v < 16; ++v) {
-      t += part_s[v][tid];
-      w += part_s[v][16];
-    }
-    const float total = a.state[tid] + t;
-    const float count = a.state[a.nks + tid] + w;
-    a.state[tid] = total;
-    a.state[a.nks + tid] = count;
-    a.results[tid] = count > 0.0f ? total / count : 0.0f;
-  }
+  if (last_s == 0u) return;
+  HitsArgs ha;
+  ha.counts = a.counts; ha.nq = a.nq; ha.nks = a.nks; ha.weight = a.weight; ha.state = a.state;
+  ha.results = a.results; ha.hits = nullptr;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) ha.ks[i] = a.ks[i];
+  hits_fold<256, true>(ha, part_s);
+  if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int DP>
@@ -322,10 +369,11 @@ static void launch_rank_count(const RankCountArgs &a, int nsplits, hipStream_t s
 
 }  // namespace tfrs
 
-extern "C" int tfrs_rank_count_accumulate(const float *queries, const float *true_candidates, int64_t nq,
-                                          int d, const float *candidates, const void *cand_ids,
-                                          int ids_i64, int64_t nc, int64_t vocab, uint32_t *counts,
-                                          int first_block, void *stream) {
+static int rank_count_launch(const float *queries, const float *true_candidates, int64_t nq, int d,
+                             const float *candidates, const void *cand_ids, int ids_i64, int64_t nc,
+                             int64_t vocab, uint32_t *counts, int first_block, int fold,
+                             const int32_t *ks_h, int nks, const float *sample_weight, float *state,
+                             float *results, void *stream) {
   using namespace tfrs;
   TFRS_CHECK_ARG(nq >= 0 && nc >= 0 && d >= 1 && vocab >= 0, "rank_count: bad shape");
   if (d > 128) {
@@ -338,13 +386,18 @@ extern "C" int tfrs_rank_count_accumulate(const float *queries, const float *tru
   RankCountArgs a;
   a.q = queries; a.true_c = true_candidates; a.nq = nq; a.d = d; a.cand = candidates; a.ids = cand_ids;
   a.ids_i64 = ids_i64; a.nc = nc; a.vocab = vocab; a.counts = counts; a.mark_nonfinite = first_block ? 1 : 0;
+  a.fold = fold; a.ticket = counts + nq; a.nks = nks; a.weight = sample_weight; a.state = state; a.results = results;
+  for (int i = 0; i < 16; ++i) a.ks[i] = (fold && i < nks) ? ks_h[i] : 0;
   a.n_qtiles = (int)((nq + 127) / 128);
   const int dp = padded_dim(d);
-  const int max_tiles = dp <= 64 ? 4 : 2;
+  const int max_tiles = dp <= 64 ? 7 : 3;
   const int64_t ntiles = (nc + 31) / 32;
-  // about two workgroups per CU (what the register footprint at D = 64 admits: one residency
-  // round), at most max_tiles tiles each
-  int64_t want_splits = std::max<int64_t>(1, 512 / a.n_qtiles);
+  // One workgroup per CU where the problem allows it: the launch is bound by the f32 matrix pipe
+  // (64 cycles per 32x32x2 step), so what matters is that every SIMD gets the same number of
+  // wave-tiles -- 256 workgroups x 4 waves put exactly one wave on each of the 1024 SIMDs (at the
+  // quickstart shapes 7 tiles each against 6.6 ideal) -- and that each workgroup pays its load
+  // latencies once.  At most max_tiles tiles per workgroup (LDS).
+  int64_t want_splits = std::max<int64_t>(1, 256 / a.n_qtiles);
   int64_t tps = std::min<int64_t>(max_tiles, std::max<int64_t>(1, (ntiles + want_splits - 1) / want_splits));
   const int64_t nsplits = (ntiles + tps - 1) / tps;
   TFRS_CHECK_ARG(nsplits * a.n_qtiles <= 0x7FFFFFFF, "rank_count: grid too large (%lld x %d workgroups)",
@@ -360,6 +413,28 @@ extern "C" int tfrs_rank_count_accumulate(const float *queries, const float *tru
   }
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
+}
+
+extern "C" int tfrs_rank_count_accumulate(const float *queries, const float *true_candidates, int64_t nq,
+                                          int d, const float *candidates, const void *cand_ids,
+                                          int ids_i64, int64_t nc, int64_t vocab, uint32_t *counts,
+                                          int first_block, void *stream) {
+  return rank_count_launch(queries, true_candidates, nq, d, candidates, cand_ids, ids_i64, nc, vocab, counts,
+                           first_block, 0, nullptr, 0, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int tfrs_rank_count_update_hits(const float *queries, const float *true_candidates, int64_t nq,
+                                           int d, const float *candidates, const void *cand_ids,
+                                           int ids_i64, int64_t nc, int64_t vocab, uint32_t *counts,
+                                           int first_block, const int32_t *ks_h, int nks,
+                                           const float *sample_weight, float *state, float *results,
+                                           void *stream) {
+  using namespace tfrs;
+  TFRS_CHECK_ARG(ks_h && nks >= 1 && nks <= 16, "need between 1 and 16 values of k");
+  TFRS_CHECK_ARG(state && results, "rank_count_update_hits: NULL pointer");
+  TFRS_CHECK_ARG(nq > 0 && nc > 0, "rank_count_update_hits: empty queries or candidates (use tfrs_topk_hits_update)");
+  return rank_count_launch(queries, true_candidates, nq, d, candidates, cand_ids, ids_i64, nc, vocab, counts,
+                           first_block, 1, ks_h, nks, sample_weight, state, results, stream);
 }
 
 extern "C" int tfrs_topk_hits_update(uint32_t *counts, int64_t nq, const int32_t *ks_h, int nks,

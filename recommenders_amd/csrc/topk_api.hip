@@ -314,7 +314,8 @@ static int run_rounds(const float *q, int64_t nq, int d, const char *packed, int
                       int64_t idx_base, int64_t seen, int k, float *state_scores,
                       int32_t *state_idx, int state_len, const RoundWs &w,
                       const TopkTuning &t, hipStream_t stream, int *new_len,
-                      const int32_t *rowmap = nullptr) {
+                      const int32_t *rowmap = nullptr, const float *ceil_score = nullptr,
+                      const uint64_t *ceil_key = nullptr) {
   int len = state_len;
   if (n <= 0 || nq <= 0) {
     *new_len = len;
@@ -336,8 +337,10 @@ static int run_rounds(const float *q, int64_t nq, int d, const char *packed, int
   sa.dense = w.dense;
   sa.ld_dense = w.ld_dense;
   sa.tie_ge = rowmap != nullptr;
+  sa.ceil_score = ceil_score;
 
   SelectArgs se = {};
+  se.ceil_key = ceil_key;
   se.rowmap = rowmap;
   se.nq = nq;
   se.k = k;
@@ -725,6 +728,66 @@ extern "C" int tfrs_bruteforce_topk(const tfrs_index_t *index, const float *quer
   return run_rounds(queries, nq, index->d, index->packed, index->n, /*idx_base=*/0,
                     /*seen=*/0, k, out_scores, out_idx, /*state_len=*/0, w, t,
                     (hipStream_t)stream, &new_len, index->rowmap);
+}
+
+// ---- paged search: K beyond TFRS_MAX_K --------------------------------------------------------
+// tf.math.top_k has no limit on k (layers/factorized_top_k.py:605); the selection kernels hold K
+// slots per wave.  A caller that wants more asks page by page: page p returns the best
+// k <= TFRS_MAX_K rows among those that come strictly AFTER the last row of page p - 1 in the
+// result order (score descending, row ascending), so the concatenated pages are exactly the sorted
+// top-(sum of k).  Always the all-f32 rounds (the ceiling is applied where scores are compared and
+// where keys are formed).
+namespace tfrs {
+__global__ void ceil_keys_kernel(const float *scores, const int32_t *rows, int64_t nq, int64_t ld,
+                                 float *ceil_score, uint64_t *ceil_key) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nq) return;
+  const float s = scores[r * ld];
+  ceil_score[r] = s;
+  ceil_key[r] = make_key(s, rows[r * ld]);
+}
+}  // namespace tfrs
+
+extern "C" size_t tfrs_bruteforce_topk_below_workspace_bytes(int64_t nq, int64_t n, int d, int k) {
+  if (nq <= 0 || n <= 0 || k <= 0 || d <= 0) return 256;
+  return round_ws_bytes(nq, n, k, tuning()) + align_up((size_t)nq * 4) + align_up((size_t)nq * 8);
+}
+
+extern "C" int tfrs_bruteforce_topk_below(const tfrs_index_t *index, const float *queries, int64_t nq, int k,
+                                          const float *last_scores, const int32_t *last_rows, int64_t last_ld,
+                                          float *out_scores, int32_t *out_idx, void *workspace,
+                                          size_t workspace_bytes, void *stream) {
+  if (!index || !index->packed) {
+    set_error("bruteforce_topk_below: the index has not been built");
+    return TFRS_ESTATE;
+  }
+  TFRS_CHECK_ARG(nq >= 0 && k >= 1 && k <= TFRS_MAX_K, "bruteforce_topk_below: k=%d outside [1, %d]", k, TFRS_MAX_K);
+  TFRS_CHECK_ARG((int64_t)k <= index->n, "input must have at least k columns (k=%d, candidates=%lld)", k,
+                 (long long)index->n);
+  if (nq == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(queries && out_scores && out_idx && workspace, "bruteforce_topk_below: NULL pointer");
+  TFRS_CHECK_ARG((last_scores == nullptr) == (last_rows == nullptr) && (last_scores == nullptr || last_ld >= 1),
+                 "bruteforce_topk_below: last_scores / last_rows must both be given (with their row stride) or both be NULL");
+  const TopkTuning t = tuning();
+  const size_t need = tfrs_bruteforce_topk_below_workspace_bytes(nq, index->n, index->d, k);
+  if (workspace_bytes < need) {
+    set_error("bruteforce_topk_below: workspace %zu < required %zu", workspace_bytes, need);
+    return TFRS_ENOMEM;
+  }
+  const RoundWs w = carve_round_ws(static_cast<char *>(workspace), nq, index->n, k, t);
+  float *ceil_score = nullptr;
+  uint64_t *ceil_key = nullptr;
+  if (last_scores) {
+    ceil_key = reinterpret_cast<uint64_t *>(w.end);
+    ceil_score = reinterpret_cast<float *>(w.end + align_up((size_t)nq * 8));
+    hipLaunchKernelGGL(tfrs::ceil_keys_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, last_scores, last_rows, nq, last_ld, ceil_score, ceil_key);
+    TFRS_LAUNCH_CHECK();
+  }
+  int new_len = 0;
+  return run_rounds(queries, nq, index->d, index->packed, index->n, /*idx_base=*/0, /*seen=*/0, k, out_scores,
+                    out_idx, /*state_len=*/0, w, t, (hipStream_t)stream, &new_len, index->rowmap, ceil_score,
+                    ceil_key);
 }
 
 extern "C" int tfrs_bruteforce_topk_redo_count(const void *workspace, int64_t nq, int64_t n, int k,

@@ -120,6 +120,9 @@ __global__ void __launch_bounds__(kThreads, DP <= 64 ? 4 : 2) scan_kernel(const 
     }
   }
 
+  // paged search: rows already returned by an earlier page score above the query's ceiling
+  const float ceil = (!MATERIALIZE && a.ceil_score && qvalid) ? a.ceil_score[qrow] : __builtin_inff();
+
   // this lane's private survivor segment
   const int64_t seg = qrow * a.nseg + 2 * split + h;
   // entry-major list: entry e of this segment lives at buf[(qrow * cap_l + e) * nseg + seg]
@@ -225,7 +228,7 @@ __global__ void __launch_bounds__(kThreads, DP <= 64 ? 4 : 2) scan_kernel(const 
             for (int rr = 0; rr < 4; ++rr) {
               const int r = 4 * g4 + rr;
               const uint32_t off = off0 + rr + 8 * g4;
-              bool p = acc[r] > thr;
+              bool p = acc[r] > thr && acc[r] <= ceil;
               if (ragged) p = p && (c0 + (int64_t)off < c1);
               if (p) {
                 if (mycnt < a.cap_l)

@@ -134,7 +134,12 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
   // ---- seed with the prior state (already sorted by construction) -----------------
   for (int i = lane; i < KP; i += 64) {
     uint64_t key = 0ull;
-    if (i < a.state_len) key = make_key(a.state_scores[row * K + i], a.state_idx[row * K + i]);
+    if (i < a.state_len) {
+      // (a paged search can leave a query with fewer than state_len candidates below its ceiling:
+      // empty slots carry row -1 and must not come back as a real (0.0, row 0) entry)
+      const int32_t si = a.state_idx[row * K + i];
+      if (si >= 0) key = make_key(a.state_scores[row * K + i], si);
+    }
     best[i] = key;
   }
   if (source == kSrcList || source == kSrcRecompute) {  // the query, zero-padded, for exact scoring
@@ -144,11 +149,12 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
 
   int fill = 0;                           // wave-uniform
   uint64_t kth = best[K - 1];             // 0 while fewer than K entries: everything passes
+  const uint64_t ceil = a.ceil_key ? a.ceil_key[row] : ~0ull;   // paged search: candidates lie below it
 
   // Offers one key per lane: keys that cannot beat the current bound are dropped, the rest
   // are compacted into `chunk`, which is sorted and merged into `best` when it fills.
   auto consume = [&](uint64_t key) {
-    const bool p = key > kth;  // key 0 (empty) never passes
+    const bool p = key > kth && key < ceil;  // key 0 (empty) never passes
     const uint64_t mask = __ballot(p);
     if (mask == 0ull) return;
     if (fill + 64 > KP) {
@@ -238,7 +244,7 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
     for (int i = lane; i < K; i += 64) {
       const uint64_t key = best[i];
       a.out_scores[row * K + i] = key ? key_score(key) : 0.0f;
-      a.out_idx[row * K + i] = key ? key_index(key) : 0;
+      a.out_idx[row * K + i] = key ? key_index(key) : -1;   // -1 marks an empty slot
     }
   }
   if (a.out_thr && lane == 0) {
@@ -280,8 +286,9 @@ __global__ void __launch_bounds__(NW * 64) recompute_kernel(const SelectArgs a) 
 
   int fill = 0;
   uint64_t kth = 0ull;
+  const uint64_t ceil = a.ceil_key ? a.ceil_key[row] : ~0ull;
   auto consume = [&](uint64_t key) {
-    const bool p = key > kth;
+    const bool p = key > kth && key < ceil;
     const uint64_t mask = __ballot(p);
     if (mask == 0ull) return;
     if (fill + 64 > KP) {
@@ -328,7 +335,7 @@ __global__ void __launch_bounds__(NW * 64) recompute_kernel(const SelectArgs a) 
   for (int i = lane; i < K; i += 64) {
     const uint64_t key = best[i];
     a.out_scores[row * K + i] = key ? key_score(key) : 0.0f;
-    a.out_idx[row * K + i] = key ? key_index(key) : 0;
+    a.out_idx[row * K + i] = key ? key_index(key) : -1;   // -1 marks an empty slot
   }
   }  // slot loop
 }
@@ -378,7 +385,7 @@ __global__ void __launch_bounds__(64) recompute_merge_kernel(const SelectArgs a)
   for (int i = lane; i < K; i += 64) {
     const uint64_t key = best[i];
     a.out_scores[row * K + i] = key ? key_score(key) : 0.0f;
-    a.out_idx[row * K + i] = key ? key_index(key) : 0;
+    a.out_idx[row * K + i] = key ? key_index(key) : -1;   // -1 marks an empty slot
   }
   }  // slot loop
 }

@@ -64,6 +64,7 @@ def _workspace(nbytes: int) -> Tensor:
 
 
 MAX_FUSED_DIM = 128    # TFRS_MAX_DIM: embedding dims the fused scan kernels keep in registers
+MAX_FUSED_K = 1024     # TFRS_MAX_K: results per query the selection kernels hold in one pass
 _WIDE_BLOCK = 32768    # candidate rows per materialised score block on the wide-dim path
 
 
@@ -441,6 +442,8 @@ class BruteForce(TopK):
       _wide_topk_update(q, self._wide, 0, k, scores, rows, 0)
       self._last_call = None
       return scores, rows
+    if k > MAX_FUSED_K:
+      return self._query_rows_paged(q, k)
     scores = torch.empty((nq, k), dtype=torch.float32, device=q.device)
     rows = torch.empty((nq, k), dtype=torch.int32, device=q.device)
     ws = _workspace(lib.tfrs_bruteforce_topk_workspace_bytes(nq, self._n, self._d, k))
@@ -448,6 +451,38 @@ class BruteForce(TopK):
         self._index.handle, _lib.ptr(q), nq, k, _lib.ptr(scores), _lib.ptr(rows),
         _lib.ptr(ws), ws.numel(), _lib.current_stream()))               # :603-605
     self._last_call = (ws, nq, k)
+    return scores, rows
+
+  def _query_rows_paged(self, q: Tensor, k: int) -> Tuple[Tensor, Tensor]:
+    """``k`` beyond the selection kernels' 1024 slots (``tf.math.top_k`` has no limit, :605): pages
+    of up to 1024 results, each the best rows strictly after the previous page's last (score, row)
+    in the result order (``tfrs_bruteforce_topk_below``); the pages are written side by side into
+    the ``[B, k]`` outputs, which are therefore exactly the sorted top-k.  One all-f32 scan of the
+    corpus per page."""
+    if k > self._n:
+      raise ValueError(f"input must have at least k columns (k={k}, candidates={self._n})")
+    lib = _lib.load()
+    nq = q.shape[0]
+    scores = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+    rows = torch.empty((nq, k), dtype=torch.int32, device=q.device)
+    ws = _workspace(lib.tfrs_bruteforce_topk_below_workspace_bytes(nq, self._n, self._d, MAX_FUSED_K))
+    page_s = torch.empty((nq, MAX_FUSED_K), dtype=torch.float32, device=q.device)
+    page_r = torch.empty((nq, MAX_FUSED_K), dtype=torch.int32, device=q.device)
+    done = 0
+    while done < k:
+      kk = min(MAX_FUSED_K, k - done)
+      ps, pr = (page_s, page_r) if kk == MAX_FUSED_K else (page_s[:, :kk].contiguous(), page_r[:, :kk].contiguous())
+      last_s = None if done == 0 else scores[:, done - 1:]        # row stride k: element [q, done - 1]
+      last_r = None if done == 0 else rows[:, done - 1:]
+      _lib.check(lib.tfrs_bruteforce_topk_below(
+          self._index.handle, _lib.ptr(q), nq, kk,
+          None if last_s is None else ctypes.c_void_p(last_s.data_ptr()),
+          None if last_r is None else ctypes.c_void_p(last_r.data_ptr()), k,
+          _lib.ptr(ps), _lib.ptr(pr), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+      scores[:, done:done + kk] = ps
+      rows[:, done:done + kk] = pr
+      done += kk
+    self._last_call = None
     return scores, rows
 
   def last_redo_count(self) -> int:
@@ -716,6 +751,16 @@ class Streaming(TopK):
       kk = min(k, cached._n)     # handle_incomplete_batches semantics: fewer rows than k (:465-468)
       scores, rows = cached._query_rows(q, kk, embedded=True)
       self._last_ids = cached._ids
+      return scores, (rows + self._base_row if self._base_row else rows)
+    if k > MAX_FUSED_K:
+      # more results than one pass of the selection kernels holds: the paged search of BruteForce
+      # needs the corpus resident (one scan per 1024 results), so the stream is ingested once
+      # for this call -- rows in stream order, i.e. the reference's counter (:477-488)
+      bf = BruteForce(k=self._k).index_from_dataset(self._candidates)
+      if q.shape[1] != bf._d:
+        raise ValueError(f"Candidate dimension {bf._d} does not match queries ({q.shape[1]}).")
+      scores, rows = bf._query_rows(q, min(k, bf._n), embedded=True)
+      self._last_ids = bf._ids
       return scores, (rows + self._base_row if self._base_row else rows)
     lib = _lib.load()
     nq, d = q.shape

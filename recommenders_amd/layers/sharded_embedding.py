@@ -6,7 +6,12 @@ Rank r owns rows ``[r * rows_per_rank, (r + 1) * rows_per_rank)`` of the ``[voca
 classic two-exchange pattern, one process per GPU, ``torch.distributed`` backend ``nccl``
 (= RCCL over xGMI):
 
-    ids --bucket by owner--> all_to_all (ids) --> local HIP gather --> all_to_all (rows) --> unpermute
+    ids --owner bucketing (HIP: count / scan / stable place, csrc/shard_route.hip)-->
+        all_to_all (ids) --> local HIP gather --> all_to_all (rows) --> HIP gather through the
+        inverse permutation (rows land in their final positions)
+
+with ONE small collective and ONE device->host copy per lookup for the split sizes of both
+all-to-alls (``torch.distributed`` needs them on the host).
 
 and the backward mirrors it: gradient rows travel to the owners (one all_to_all), where they
 become ``(ids, rows)`` slices for ``optimizers.Adagrad`` (fused sparse update on the shard) or
@@ -58,29 +63,81 @@ def all_to_all_v(send: torch.Tensor, send_counts: List[int], recv_counts: List[i
   return out
 
 
+def _route_hip(flat: torch.Tensor, input_dim: int, rows_per_rank: int, world: int):
+  """Owner bucketing on the device (``tfrs_shard_route_ids``: count, scan, stable placement -- no
+  sort, no host synchronisation): ``(send_ids int64, perm int32, order int32, counts int64[world])``."""
+  from recommenders_amd import _lib
+  lib = _lib.load()
+  n = flat.numel()
+  dev = flat.device
+  send_ids = torch.empty((n,), dtype=torch.int64, device=dev)
+  perm = torch.empty((n,), dtype=torch.int32, device=dev)
+  order = torch.empty((n,), dtype=torch.int32, device=dev)
+  counts = torch.empty((world,), dtype=torch.int64, device=dev)
+  ws = torch.empty((max(int(lib.tfrs_shard_route_workspace_bytes(n, world)), 256),), dtype=torch.uint8, device=dev)
+  _lib.check(lib.tfrs_shard_route_ids(
+      _lib.ptr(flat), 1 if flat.dtype == torch.int64 else 0, n, input_dim, rows_per_rank, world,
+      _lib.ptr(send_ids), _lib.ptr(perm), _lib.ptr(order), _lib.ptr(counts), _lib.ptr(ws), ws.numel(),
+      _lib.current_stream()))
+  return send_ids, perm, order, counts
+
+
+def _route_torch(flat: torch.Tensor, input_dim: int, rows_per_rank: int, world: int):
+  """The same routing with torch ops: host tensors only (the gloo tests on CPU boxes)."""
+  flat = flat.long()
+  bad = (flat < 0) | (flat >= input_dim)
+  owner = torch.div(flat, rows_per_rank, rounding_mode="floor")
+  owner = torch.where(bad, torch.zeros_like(owner), owner)
+  order = torch.argsort(owner, stable=True)
+  perm = torch.empty_like(order)
+  perm[order] = torch.arange(order.numel(), device=order.device)
+  send_ids = torch.where(bad, torch.full_like(flat, -1), flat - owner * rows_per_rank)[order]
+  counts = torch.bincount(owner, minlength=world)
+  return send_ids, perm.to(torch.int32), order.to(torch.int32), counts
+
+
+def _exchange_counts(counts: torch.Tensor, group):
+  """Split sizes of both all-to-alls from ONE collective and ONE device->host copy: every rank
+  contributes its ``counts[world]`` row to the ``[world, world]`` matrix (round 2 paid two host
+  synchronisations and a separate all-to-all of the counts per lookup)."""
+  world, me = _world(group), _rank(group)
+  if world == 1:
+    return None, None                           # nothing to exchange: no synchronisation at all
+  if dist.get_backend(group) == "nccl":
+    matrix = torch.empty((world * world,), dtype=torch.int64, device=counts.device)
+    dist.all_gather_into_tensor(matrix, counts.contiguous(), group=group)
+    m = matrix.view(world, world).tolist()      # the one host synchronisation of the lookup
+  else:
+    rows = [None] * world
+    dist.all_gather_object(rows, counts.tolist(), group=group)
+    m = rows
+  return [int(v) for v in m[me]], [int(m[p][me]) for p in range(world)]
+
+
 class _ShardedLookup(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, shard, ids, layer):
     group, world = layer._group, _world(layer._group)
-    flat = ids.reshape(-1).long()
+    flat = ids.reshape(-1)
+    if flat.dtype not in (torch.int32, torch.int64):
+      flat = flat.long()
+    flat = flat.contiguous()
     # ids outside [0, input_dim) read as a zero row and receive no gradient, like the plain
     # gather kernel; they are routed to rank 0 as row -1 so that every rank's split sizes stay
     # consistent (an unchecked owner >= world would desynchronise the all_to_all and hang)
-    bad = (flat < 0) | (flat >= layer.input_dim)
-    owner = torch.div(flat, layer.rows_per_rank, rounding_mode="floor")
-    owner = torch.where(bad, torch.zeros_like(owner), owner)
-    flat = torch.where(bad, torch.full_like(flat, -1), flat)
-    order = torch.argsort(owner, stable=True)
-    send_counts = torch.bincount(owner, minlength=world).tolist()
-    counts_t = torch.tensor(send_counts, dtype=torch.int64, device=flat.device)
-    recv_counts = all_to_all_v(counts_t, [1] * world, [1] * world, group).tolist()
-    send_ids = torch.where(bad, flat, flat - owner * layer.rows_per_rank)[order]   # shard-local rows
-    recv_ids = all_to_all_v(send_ids, send_counts, recv_counts, group)
+    route = _route_hip if (flat.is_cuda and layer._native) else _route_torch
+    send_ids, perm, order, counts = route(flat, layer.input_dim, layer.rows_per_rank, world)
+    send_counts, recv_counts = _exchange_counts(counts, group)
+    if world == 1:
+      recv_ids = send_ids
+    else:
+      recv_ids = all_to_all_v(send_ids, send_counts, recv_counts, group)   # shard-local rows I serve
     rows = layer._gather(shard, recv_ids)                             # HIP gather on the owner
-    back = all_to_all_v(rows, recv_counts, send_counts, group)        # rows in `order` order
-    out = torch.empty_like(back)
-    out[order] = back
+    back = rows if world == 1 else all_to_all_v(rows, recv_counts, send_counts, group)
+    # rows arrive in send-slot order; lookup i sits in slot perm[i]: one gather through perm puts
+    # every row in its final position (no argsort, no index_put)
+    out = layer._gather(back, perm)
     ctx.save_for_backward(order, recv_ids)
     ctx.counts = (send_counts, recv_counts)
     ctx.layer = layer
@@ -93,8 +150,9 @@ class _ShardedLookup(torch.autograd.Function):
     order, recv_ids = ctx.saved_tensors
     send_counts, recv_counts = ctx.counts
     layer = ctx.layer
-    g = grad_out.reshape(-1, grad_out.shape[-1]).contiguous()[order]
-    recv_g = all_to_all_v(g, send_counts, recv_counts, layer._group)  # gradient rows of MY shard
+    g = grad_out.reshape(-1, grad_out.shape[-1]).contiguous()
+    g = layer._gather(g, order)                                       # gradient rows in send-slot order
+    recv_g = g if send_counts is None else all_to_all_v(g, send_counts, recv_counts, layer._group)
     table = ctx.table_ref
     if getattr(table, "_tfrs_sparse_grad", False):                    # slices for optimizers.Adagrad
       table._tfrs_slices.append((recv_ids, recv_g))
@@ -123,7 +181,10 @@ class ShardedEmbedding(torch.nn.Module):
     self.embeddings = torch.nn.Parameter(w)
     self.embeddings._tfrs_embedding = True
     self.embeddings._tfrs_row_sharded = True   # rank-local rows: excluded from the DP gradient sum
-    # injection points so the exchange logic can be exercised on CPU (gloo) in tests
+    # injection points: a CPU convenience so the exchange logic can be exercised under gloo on boxes
+    # without a GPU (the tests then also take the torch routing); with a GPU the tests run the HIP
+    # routing, gather and scatter
+    self._native = local_gather is None and local_scatter is None
     self._gather = local_gather if local_gather is not None else emb.gather_rows
     self._scatter = local_scatter if local_scatter is not None else emb.scatter_add_rows
 

@@ -343,7 +343,7 @@ def test_factorized_top_k_rank_count_paths_vs_oracle(d, id_dtype):
     metric.update_state(_t(q), _t(true_c), sample_weight=_t(w))
     got = [float(v) for v in metric.result()]
     np.testing.assert_allclose(got, want, rtol=2e-6, err_msg=name)
-    assert int(metric._counts.abs().max()) == 0                  # re-armed for the next update
+    assert int(metric._counts.abs().max()) == 0                  # counts and ticket re-armed for the next update
     metric.update_state(_t(q), _t(true_c), sample_weight=_t(w))   # running mean of two equal updates
     np.testing.assert_allclose([float(v) for v in metric.result()], want, rtol=2e-6, err_msg=name)
     metric.reset_states()
@@ -608,6 +608,48 @@ def test_adagrad_optimizer_sparse_slices_match_dense_formula():
     dvec = dvec - lr * gd / np.sqrt(dacc + 1e-7)
     np.testing.assert_allclose(_np(layer.embeddings.detach()), table, rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(_np(dense.detach()), dvec, rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,world,dtype", [(1, 2, np.int64), (4097, 8, np.int32), (300_000, 8, np.int64),
+                                           (70_001, 3, np.int64), (5000, 64, np.int32)])
+def test_shard_route_ids_equals_stable_bucketing(n, world, dtype):
+  """csrc/shard_route.hip (count / scan / stable place) against the stable argsort-by-owner it
+  replaces: send ids, the permutation and its inverse, the per-owner counts -- exactly, including ids
+  outside the table (owner 0, row -1) and a table size that is not a multiple of the world."""
+  from recommenders_amd.layers import sharded_embedding as se
+  rng = np.random.default_rng(n + world)
+  input_dim = 1_000_003
+  rows_per_rank = (input_dim + world - 1) // world
+  ids = rng.integers(0, input_dim, size=n).astype(dtype)
+  if n > 10:
+    ids[3] = -5
+    ids[7] = input_dim
+    ids[n // 2] = input_dim + 99 if dtype == np.int64 else np.iinfo(np.int32).max
+  flat = _t(ids)
+  send_ids, perm, order, counts = se._route_hip(flat, input_dim, rows_per_rank, world)
+  r_send, r_perm, r_order, r_counts = se._route_torch(flat, input_dim, rows_per_rank, world)
+  assert torch.equal(counts, r_counts)
+  assert torch.equal(send_ids, r_send)
+  assert torch.equal(perm, r_perm) and torch.equal(order, r_order)
+  assert torch.equal(order[perm.long()].long(), torch.arange(n, device="cuda"))
+
+
+def test_sharded_embedding_single_rank_is_a_plain_embedding():
+  """World of one: the HIP routing + gather-through-perm path gives exactly `table[ids]` (zero rows
+  for ids outside the table) and the plain scatter-add gradient, with no host synchronisation."""
+  from recommenders_amd.layers.sharded_embedding import ShardedEmbedding
+  rng = np.random.default_rng(5)
+  V, D, B = 70_000, 32, 100_000
+  layer = ShardedEmbedding(V, D)
+  table = _np(layer.embeddings.detach())
+  ids = rng.integers(-3, V + 3, size=(B,))
+  out = layer(_t(ids))
+  ok = (ids >= 0) & (ids < V)
+  want = np.where(ok[:, None], o_emb.gather(table, np.clip(ids, 0, V - 1)), 0.0).astype(np.float32)
+  np.testing.assert_array_equal(_np(out), want)
+  w = rng.normal(size=(B, D)).astype(np.float32)
+  (out * _t(w)).sum().backward()
+  np.testing.assert_array_equal(_np(layer.embeddings.grad), o_emb.scatter_add_grad(w[ok], ids[ok], V))
 
 
 _SHARDED_EMB_WORKER = r"""

@@ -313,6 +313,39 @@ def test_full_size_properties(filter_mode, monkeypatch):
     assert torch.equal(i, i32) and torch.equal(s, s32)         # every one of the 8192 queries
 
 
+@pytest.mark.parametrize("n,k,ties", [(5000, 1025, False), (70_000, 3000, True), (200_000, 2500, False),
+                                      (4000, 4000, True)])
+def test_k_beyond_1024_pages(n, k, ties, filter_mode):
+  """`tf.math.top_k(scores, k)` has no limit on k (layers/factorized_top_k.py:605); the selection
+  kernels hold 1024 slots.  Larger k is answered in pages below a per-query ceiling key
+  (`tfrs_bruteforce_topk_below`): indices and scores `==` the oracle, including integer-valued
+  embeddings whose scores tie by the hundreds ACROSS page boundaries (tie order = lower row first),
+  on unshuffled (< 65536 rows) and shuffled indexes, k == n, and through Streaming."""
+  if filter_mode != "f16":
+    pytest.skip("the paged search always runs the all-f32 rounds")
+  ftk = _layers()
+  rng = np.random.default_rng(n + k)
+  d, nq = 16, 40
+  if ties:
+    c = rng.integers(-2, 3, size=(n, d)).astype(np.float32)
+    q = rng.integers(-2, 3, size=(nq, d)).astype(np.float32)
+  else:
+    c = (rng.normal(size=(n, d)) / 4).astype(np.float32)
+    q = (rng.normal(size=(nq, d)) / 4).astype(np.float32)
+  es, ei = o_topk.brute_force(q, c, k)
+  s, i = ftk.BruteForce(k=k).index(c)(q)
+  np.testing.assert_array_equal(_np(i), ei)
+  np.testing.assert_array_equal(_np(s), es)
+  if n <= 70_000:
+    s2, i2 = ftk.Streaming(k=k).index_from_dataset(_Dataset(c, None, 9000))(q)
+    np.testing.assert_array_equal(_np(i2), ei)
+    np.testing.assert_array_equal(_np(s2), es)
+    s3, i3 = ftk.BruteForce(k=10).index(c)(q, k=k)             # k given at call time
+    np.testing.assert_array_equal(_np(i3), ei)
+  with pytest.raises(ValueError, match="at least k columns"):
+    ftk.BruteForce(k=n + 1).index(c)(q)
+
+
 def test_two_host_threads_two_streams():
   """include/tfrs_hip.h promises re-entrancy on distinct streams / handles: two host threads, each
   on its own HIP stream, run BruteForce calls at the same time -- one shares an index handle with
