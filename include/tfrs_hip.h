@@ -238,15 +238,6 @@ int tfrs_id_match_topk(const int32_t *retrieved_ids, const int32_t *true_ids,
 int tfrs_rank_count_accumulate(const float *queries, const float *true_candidates, int64_t nq, int d,
                                const float *candidates, const void *cand_ids, int ids_i64, int64_t nc,
                                int64_t vocab, uint32_t *counts, int first_block, void *stream);
-/* tfrs_rank_count_accumulate for the LAST block of a sweep with tfrs_topk_hits_update folded into
- * the same launch: the last workgroup to finish turns the counts into the metric update (no second
- * launch; hits == NULL).  `counts` must have nq + 1 words (the last one is the arrival ticket, zero
- * between launches like the counts). */
-int tfrs_rank_count_update_hits(const float *queries, const float *true_candidates, int64_t nq, int d,
-                                const float *candidates, const void *cand_ids, int ids_i64, int64_t nc,
-                                int64_t vocab, uint32_t *counts, int first_block, const int32_t *ks_h,
-                                int nks, const float *sample_weight, float *state, float *results,
-                                void *stream);
 int tfrs_topk_hits_update(uint32_t *counts, int64_t nq, const int32_t *ks_h, int nks,
                           const float *sample_weight, float *state, float *results, float *hits,
                           void *stream);

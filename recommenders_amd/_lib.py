@@ -55,8 +55,6 @@ SIGNATURES = {
     "tfrs_rank_of_positive": (c_int, [P, P, c_i64, c_int, P, c_int, P, c_int, P, P]),
     "tfrs_id_match_topk": (c_int, [P, P, c_i64, c_int, P, c_int, P, P]),
     "tfrs_rank_count_accumulate": (c_int, [P, P, c_i64, c_int, P, P, c_int, c_i64, c_i64, P, c_int, P]),
-    "tfrs_rank_count_update_hits": (c_int, [P, P, c_i64, c_int, P, P, c_int, c_i64, c_i64, P, c_int, P, c_int,
-                                            P, P, P, P]),
     "tfrs_topk_hits_update": (c_int, [P, c_i64, P, c_int, P, P, P, P, P]),
     "tfrs_shard_route_workspace_bytes": (c_size_t, [c_i64, c_int]),
     "tfrs_shard_route_ids": (c_int, [P, c_int, c_i64, c_i64, c_i64, c_int, P, P, P, P, P, c_size_t, P]),

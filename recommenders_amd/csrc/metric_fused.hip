@@ -43,15 +43,6 @@ struct RankCountArgs {
   int tiles_per_split;   // 32-row tiles per workgroup
   int n_qtiles;          // ceil(nq / 128)
   int mark_nonfinite;    // 1: this launch also flags non-finite positives (first block of a stream)
-  // fold == 1 (last block of a sweep): the LAST workgroup to finish turns the counts into the metric
-  // update (hits_fold) -- no second launch.  ticket: one word behind the counts, zero between launches.
-  int fold;
-  uint32_t *ticket;
-  int32_t ks[16];
-  int nks;
-  const float *weight;
-  float *state;
-  float *results;
 };
 
 constexpr uint32_t kNonFiniteBit = 0x80000000u;
@@ -76,29 +67,30 @@ struct HitsArgs {
 
 // counts -> weighted hit totals of every k, by ONE workgroup of NT threads (NT / 64 <= 16 waves).
 // The reduction order is fixed (lane -> xor tree -> wave partials in order), so the metric state is
-// bit-reproducible from run to run.  COHERENT: the counts were written by other workgroups of the
-// same launch (device-scope atomics): read them past the non-coherent caches.
-template <int NT, bool COHERENT>
+// bit-reproducible from run to run.  (Folding this into the last workgroup of the counting launch was
+// measured: 30 us against 24 us for the two launches -- every workgroup then pays a vmcnt drain, two
+// barriers and a ticket round trip, and the fold runs on 256 threads behind the slowest one.)
+template <int NT>
 __device__ __forceinline__ void hits_fold(const HitsArgs &a, float (*part_s)[17]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float tot[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) tot[i] = 0.0f;
   float wsum = 0.0f;
-  for (int64_t q0 = 0; q0 < a.nq; q0 += 4 * NT) {        // four independent loads per thread in flight
-    uint32_t cv[4];
-    float wv[4];
+  constexpr int kB = 16;                                  // loads per thread in flight: one memory round
+  for (int64_t q0 = 0; q0 < a.nq; q0 += kB * NT) {       // trip covers 4096 queries at NT = 256
+    uint32_t cv[kB];
+    float wv[kB];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kB; ++u) {
       const int64_t q = q0 + u * NT + tid;
       cv[u] = 0u;
       if (q < a.nq)
-        cv[u] = COHERENT ? __hip_atomic_load(a.counts + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                         : a.counts[q];
+        cv[u] = a.counts[q];
       wv[u] = q < a.nq ? (a.weight ? a.weight[q] : 1.0f) : 0.0f;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kB; ++u) {
       const int64_t q = q0 + u * NT + tid;
       if (q < a.nq) {
         // re-arm for the next sweep (write-through: the next launch's atomics act on memory)
@@ -143,7 +135,7 @@ __device__ __forceinline__ void hits_fold(const HitsArgs &a, float (*part_s)[17]
 
 __global__ void __launch_bounds__(1024) hits_update_kernel(const HitsArgs a) {
   __shared__ float part_s[16][17];
-  hits_fold<1024, false>(a, part_s);
+  hits_fold<1024>(a, part_s);
 }
 
 // One workgroup = 4 waves = 128 queries x one split of <= kMaxTiles candidate tiles.  The split's
@@ -156,8 +148,6 @@ __global__ void __launch_bounds__(256, 1) rank_count_kernel(const RankCountArgs 
   using G = RankGeom<DP>;
   __shared__ __attribute__((aligned(16))) float tile_s[G::kLdsFloats];
   __shared__ float pos_s[128];
-  __shared__ float part_s[16][17];
-  __shared__ uint32_t last_s;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -339,27 +329,6 @@ __global__ void __launch_bounds__(256, 1) rank_count_kernel(const RankCountArgs 
     if (a.mark_nonfinite && split == 0 && !__builtin_isfinite(pos)) cnt |= kNonFiniteBit;
     if (cnt != 0u) atomicAdd(a.counts + qrow, cnt);
   }
-  if (!a.fold) return;
-  // ---- last workgroup to arrive folds the counts into the metric state ------------------------------
-  // The counts are device-scope atomics (performed at the memory side, not in this XCD's L2) and the
-  // fold reads them with device-scope loads, so no cache write-back / invalidate is needed: every
-  // wave only waits until its own atomics have been performed (vmcnt), the barrier collects the waves,
-  // one lane takes the ticket.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    const uint32_t t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    last_s = (t == gridDim.x - 1) ? 1u : 0u;
-  }
-  __syncthreads();
-  if (last_s == 0u) return;
-  HitsArgs ha;
-  ha.counts = a.counts; ha.nq = a.nq; ha.nks = a.nks; ha.weight = a.weight; ha.state = a.state;
-  ha.results = a.results; ha.hits = nullptr;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) ha.ks[i] = a.ks[i];
-  hits_fold<256, true>(ha, part_s);
-  if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int DP>
@@ -369,11 +338,10 @@ static void launch_rank_count(const RankCountArgs &a, int nsplits, hipStream_t s
 
 }  // namespace tfrs
 
-static int rank_count_launch(const float *queries, const float *true_candidates, int64_t nq, int d,
-                             const float *candidates, const void *cand_ids, int ids_i64, int64_t nc,
-                             int64_t vocab, uint32_t *counts, int first_block, int fold,
-                             const int32_t *ks_h, int nks, const float *sample_weight, float *state,
-                             float *results, void *stream) {
+extern "C" int tfrs_rank_count_accumulate(const float *queries, const float *true_candidates, int64_t nq,
+                                          int d, const float *candidates, const void *cand_ids,
+                                          int ids_i64, int64_t nc, int64_t vocab, uint32_t *counts,
+                                          int first_block, void *stream) {
   using namespace tfrs;
   TFRS_CHECK_ARG(nq >= 0 && nc >= 0 && d >= 1 && vocab >= 0, "rank_count: bad shape");
   if (d > 128) {
@@ -386,8 +354,6 @@ static int rank_count_launch(const float *queries, const float *true_candidates,
   RankCountArgs a;
   a.q = queries; a.true_c = true_candidates; a.nq = nq; a.d = d; a.cand = candidates; a.ids = cand_ids;
   a.ids_i64 = ids_i64; a.nc = nc; a.vocab = vocab; a.counts = counts; a.mark_nonfinite = first_block ? 1 : 0;
-  a.fold = fold; a.ticket = counts + nq; a.nks = nks; a.weight = sample_weight; a.state = state; a.results = results;
-  for (int i = 0; i < 16; ++i) a.ks[i] = (fold && i < nks) ? ks_h[i] : 0;
   a.n_qtiles = (int)((nq + 127) / 128);
   const int dp = padded_dim(d);
   const int max_tiles = dp <= 64 ? 7 : 3;
@@ -413,28 +379,6 @@ static int rank_count_launch(const float *queries, const float *true_candidates,
   }
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
-}
-
-extern "C" int tfrs_rank_count_accumulate(const float *queries, const float *true_candidates, int64_t nq,
-                                          int d, const float *candidates, const void *cand_ids,
-                                          int ids_i64, int64_t nc, int64_t vocab, uint32_t *counts,
-                                          int first_block, void *stream) {
-  return rank_count_launch(queries, true_candidates, nq, d, candidates, cand_ids, ids_i64, nc, vocab, counts,
-                           first_block, 0, nullptr, 0, nullptr, nullptr, nullptr, stream);
-}
-
-extern "C" int tfrs_rank_count_update_hits(const float *queries, const float *true_candidates, int64_t nq,
-                                           int d, const float *candidates, const void *cand_ids,
-                                           int ids_i64, int64_t nc, int64_t vocab, uint32_t *counts,
-                                           int first_block, const int32_t *ks_h, int nks,
-                                           const float *sample_weight, float *state, float *results,
-                                           void *stream) {
-  using namespace tfrs;
-  TFRS_CHECK_ARG(ks_h && nks >= 1 && nks <= 16, "need between 1 and 16 values of k");
-  TFRS_CHECK_ARG(state && results, "rank_count_update_hits: NULL pointer");
-  TFRS_CHECK_ARG(nq > 0 && nc > 0, "rank_count_update_hits: empty queries or candidates (use tfrs_topk_hits_update)");
-  return rank_count_launch(queries, true_candidates, nq, d, candidates, cand_ids, ids_i64, nc, vocab, counts,
-                           first_block, 1, ks_h, nks, sample_weight, state, results, stream);
 }
 
 extern "C" int tfrs_topk_hits_update(uint32_t *counts, int64_t nq, const int32_t *ks_h, int nks,

@@ -188,8 +188,8 @@ class FactorizedTopK(Factorized):
     if c.shape != q.shape:
       raise ValueError("true_candidate_embeddings must have the shape of query_embeddings")
     state, results = self._bound_state(q.device)
-    if self._counts is None or self._counts.numel() != nq + 1 or self._counts.device != q.device:
-      self._counts = torch.zeros((nq + 1,), dtype=torch.int32, device=q.device)   # + the arrival ticket
+    if self._counts is None or self._counts.numel() != nq or self._counts.device != q.device:
+      self._counts = torch.zeros((nq,), dtype=torch.int32, device=q.device)
     counts = self._counts
     stream = _lib.current_stream()
     w = None
@@ -201,13 +201,13 @@ class FactorizedTopK(Factorized):
     try:
       rows = self._dataset.as_embedding_rows() if isinstance(self._dataset, tfrs_data.Dataset) else None
       if rows is not None and rows[0].shape[1] == d and rows[1].numel() > 0:
-        # candidates ARE table[ids]: gather + scores + rank + the metric update, ONE launch
+        # candidates ARE table[ids]: gather + scores + rank of the positive, ONE launch
         table, ids = rows
         ids = ids.contiguous()
-        _lib.check(lib.tfrs_rank_count_update_hits(
+        _lib.check(lib.tfrs_rank_count_accumulate(
             _lib.ptr(q), _lib.ptr(c), nq, d, _lib.ptr(table), _lib.ptr(ids),
             1 if ids.dtype == torch.int64 else 0, ids.numel(), table.shape[0], _lib.ptr(counts), 1,
-            ks_arr, len(self._ks), _lib.ptr(w), _lib.ptr(state), _lib.ptr(results), stream))
+            stream))
       else:
         first = 1
         for element in self._dataset:
@@ -219,9 +219,9 @@ class FactorizedTopK(Factorized):
               _lib.ptr(q), _lib.ptr(c), nq, d, _lib.ptr(block), None, 0, block.shape[0],
               block.shape[0], _lib.ptr(counts), first, stream))
           first = 0
-        _lib.check(lib.tfrs_topk_hits_update(
-            _lib.ptr(counts), nq, ks_arr, len(self._ks), _lib.ptr(w), _lib.ptr(state),
-            _lib.ptr(results), None, stream))
+      _lib.check(lib.tfrs_topk_hits_update(
+          _lib.ptr(counts), nq, ks_arr, len(self._ks), _lib.ptr(w), _lib.ptr(state),
+          _lib.ptr(results), None, stream))
     except Exception:
       self._counts = None               # a half-swept count buffer must not be reused
       raise
