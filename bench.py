@@ -562,9 +562,13 @@ def main() -> None:
       result["speedup_vs_single_gpu_same_workload"] = value / (BATCH / one)
       del single
     print(json.dumps(result), flush=True)
+  sys.stdout.flush()
   if world > 1:
-    dist.barrier()
-    dist.destroy_process_group()
+    try:
+      dist.barrier()
+      dist.destroy_process_group()
+    except Exception as e:   # the result line is out: a teardown hiccup must not fail the run
+      print(f"bench.py: process-group teardown: {e}", file=sys.stderr, flush=True)
 
 
 if __name__ == "__main__":
