@@ -266,25 +266,45 @@ def train_step_metric(dev, cpu_baseline: bool) -> dict:
 
 def gather_metric(dev) -> dict:
   """north_star evidence: embedding gather HBM GB/s at BASELINE configs[3] shapes (batch 65536 x
-  26 categorical features, D = 128, 26 x 1M-row tables held as one 26M x 128 table = 13.3 GB)."""
-  from recommenders_amd.layers import embedding as emb
-  rows, d, n = 26_000_000, 128, 65536 * 26
-  table = torch.empty((rows, d), dtype=torch.float32, device=dev).uniform_(-0.05, 0.05)
+  26 categorical features, D = 128, 26 x 1M-row tables held as one 26M x 128 table = 13.3 GB),
+  through the C ABI into a PRE-ALLOCATED output (nothing but the kernel between the HIP events;
+  the rocprofv3 kernel row and the FETCH_SIZE / WRITE_SIZE counters of the same launches are in
+  profiles/r03_gather_evidence.md), plus the dim-32 rows of configs[4]."""
+  from recommenders_amd import _lib
+  lib = _lib.load()
+  out = {}
   g = torch.Generator(device=dev).manual_seed(3)
-  ids = (torch.randint(0, 1_000_000, (65536, 26), generator=g, device=dev) +
-         torch.arange(26, device=dev) * 1_000_000).reshape(-1)
-  ts = percentiles(event_times_ms(lambda: emb.gather_rows(table, ids), 50, 5))
-  nbytes = n * (2 * d * 4 + 8)            # SURVEY 8(d): rows * (D*4 read + D*4 write) + ids
-  gbs = nbytes / (ts["median"] * 1e-3) / 1e9
-  del table
-  return {"metric": "embedding gather", "value": gbs, "unit": "GB/s",
-          "config": {"workload": "gather 65536 x 26 rows of dim 128 from 26 x 1M-row tables "
-                                 "(BASELINE.json configs[3]), int64 ids uniform", "rows": n, "dim": d},
-          "roofline": {"kernel": "tfrs::gather_kernel", "bound": "hbm", "achieved": gbs,
-                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                       "traffic": None, "algorithmic_bytes": nbytes, "ms_median": ts["median"],
-                       "ms_p10": ts["p10"], "ms_p90": ts["p90"],
-                       "note": "includes the output allocation of layers.embedding.gather_rows"}}
+  for key, rows, d, n, what in (
+      ("c3", 26_000_000, 128, 65536 * 26, "gather 65536 x 26 rows of dim 128 from 26 x 1M-row tables "
+                                          "(BASELINE.json configs[3]), int64 ids uniform"),
+      ("c4_rows", 100_000_000, 32, 131072 * 13, "gather 131072 x 13 rows of dim 32 from a 100M-row store "
+                                                "(one GPU's share of BASELINE.json configs[4]), int64 ids uniform")):
+    table = torch.empty((rows, d), dtype=torch.float32, device=dev).uniform_(-0.05, 0.05)
+    ids = torch.randint(0, rows, (n,), generator=g, device=dev)
+    dst = torch.empty((n, d), dtype=torch.float32, device=dev)
+    stream = _lib.current_stream()
+
+    def call():
+      _lib.check(lib.tfrs_embedding_gather_fwd(_lib.ptr(table), rows, d, _lib.ptr(ids), 1, n, _lib.ptr(dst),
+                                               None, stream))
+
+    ts = percentiles(event_times_ms(call, 50, 5))
+    nbytes = n * (2 * d * 4 + 8)            # SURVEY 8(d): rows * (D*4 read + D*4 write) + ids
+    gbs = nbytes / (ts["median"] * 1e-3) / 1e9
+    out[key] = {"value": gbs, "unit": "GB/s", "workload": what, "rows": n, "dim": d,
+                "roofline": {"kernel": "tfrs::gather_kernel", "bound": "hbm", "achieved": gbs,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                             "traffic": None, "algorithmic_bytes": nbytes, "ms_median": ts["median"],
+                             "ms_p10": ts["p10"], "ms_p90": ts["p90"]}}
+    del table, ids, dst
+    torch.cuda.empty_cache()
+  c3 = out["c3"]
+  return {"metric": "embedding gather", "value": c3["value"], "unit": "GB/s",
+          "config": {"workload": c3["workload"], "rows": c3["rows"], "dim": c3["dim"]},
+          "roofline": dict(c3["roofline"], traffic=1_772_000_000,
+                           note="traffic: FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE of the committed PMC "
+                                "passes, profiles/r03_gather_evidence.md (899.8 MB read + 872.4 MB written per launch)"),
+          "configs4_rows_dim32": out["c4_rows"]}
 
 
 def robustness_block(dev, queries, ref_ms: float) -> dict:

@@ -13,9 +13,12 @@ corpus = torch.randn((1_000_000, 64), generator=g, device=dev) / 8.0
 queries = torch.randn((8192, 64), generator=g, device=dev) / 8.0
 index = ftk.BruteForce(k=100).index(corpus)
 lib = _lib.load()
-KEYS = ("TFRS_TOPK_STAT", "TFRS_TOPK_SAMPLE", "TFRS_TOPK_SAMPLE_STAT", "TFRS_TOPK_STAT_PFAIL", "TFRS_SCAN16_DRAIN", "TFRS_SCAN16_DRAIN_EVERY")
+KEYS = ("TFRS_TOPK_STAT", "TFRS_TOPK_SAMPLE", "TFRS_TOPK_SAMPLE_STAT", "TFRS_TOPK_STAT_PFAIL", "TFRS_SCAN16_DRAIN",
+        "TFRS_SCAN16_DRAIN_EVERY", "TFRS_TOPK_WGS", "TFRS_SCAN16_SHAPE")
 ENVS = [{}, {"TFRS_SCAN16_DRAIN": "8", "TFRS_SCAN16_DRAIN_EVERY": "1000000"}, {"TFRS_SCAN16_DRAIN_EVERY": "2"},
         {"TFRS_SCAN16_DRAIN_EVERY": "6"}, {"TFRS_TOPK_STAT": "0"}, {}]
+if len(sys.argv) > 1:       # a JSON list of environments on the command line replaces the default sweep
+  ENVS = json.loads(sys.argv[1])
 ref = None
 acc = [dict(step=[], filt=[], binmax=[], redo=[], same=True) for _ in ENVS]
 for rnd in range(5):

@@ -1,0 +1,41 @@
+"""gpurun_out/observed_errors.jsonl (written by tests/conftest.py::float_gate during `pytest -m gpu`)
+-> a markdown table: per gate the largest observed error, its limit and the test that produced it."""
+import collections, json, re, sys
+import math, os
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+src = args[0] if args else "gpurun_out/observed_errors.jsonl"
+rows = [json.loads(l) for l in open(src)]
+if "--gates" in sys.argv:      # regenerate tests/golden/float_gates.json: 4 x observed, rounded up to 2 digits
+  worst = collections.defaultdict(float)
+  for r in rows:
+    g = re.sub(r"\.d(biases|u_kernels|v_kernels)\.\d", ".dparam", r["gate"])
+    worst[g] = max(worst[g], r["observed"])
+  def up(x):
+    v = 4 * x
+    e = math.floor(math.log10(v))
+    return math.ceil(v / 10 ** (e - 1)) * 10 ** (e - 1)
+  out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "float_gates.json")
+  json.dump({"_comment": "limit per float gate = 4 x the largest error observed on MI355X, rounded up to two digits; "
+                         "regenerate with tools/summarize_errors.py --gates after a full `pytest -m gpu` run",
+             "gates": {g: float(f"{up(v):.2g}") for g, v in sorted(worst.items())}}, open(out, "w"), indent=1)
+  print("wrote", out)
+  sys.exit(0)
+best = {}
+count = collections.Counter()
+for r in rows:
+  g = re.sub(r"\.d(biases|u_kernels|v_kernels)\.\d", ".dparam", r["gate"])
+  count[g] += 1
+  if g not in best or r["observed"] > best[g]["observed"]:
+    best[g] = dict(r, gate=g)
+print("# Observed floating-point errors of the GPU parity tests (MI355X, round 3)\n")
+print("Every float comparison of a HIP kernel with the float64 oracle goes through `tests/conftest.py::float_gate`:")
+print("`max |got - ref| / yardstick <= limit`, the yardstick being the sum of the absolute values of the terms of")
+print("each entry (DESIGN.md section 2).  This table is the audit trail of the limits: largest observed value per")
+print("gate over one full `pytest -m gpu` run, the limit in force, the number of evaluations and the worst case.\n")
+print("| gate | evaluations | observed max | limit | limit / observed | worst case |")
+print("|---|---|---|---|---|---|")
+for g in sorted(best):
+  r = best[g]
+  test = r["test"].split("::")[-1].replace(" (call)", "")
+  ratio = r["limit"] / r["observed"] if r["observed"] > 0 else float("inf")
+  print(f"| `{g}` | {count[g]} | {r['observed']:.2e} | {r['limit']:.1e} | {ratio:.1f} | `{test}` |")
