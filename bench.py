@@ -313,7 +313,9 @@ def robustness_block(dev, queries, ref_ms: float) -> dict:
   batch 8192, top-100), three corpora that are NOT i.i.d. rows of equal norm: log-normal row norms
   (sigma 0.5 and 1.0 -- what trained embeddings look like) and a Zipf-duplicated corpus (popular
   items repeated: exact ties, near-duplicate bursts).  Reported: q/s, ms/step, the ratio to the
-  i.i.d. step, and how many queries took the exact-redo path in the last step."""
+  i.i.d. step, and how many queries took the exact-redo path in the last step.  `BruteForce.index`
+  detects bit-identical rows and indexes the distinct ones: the Zipf corpus is
+  reported with the detection on (default) and off."""
   from recommenders_amd.layers import factorized_top_k as ftk
   g = torch.Generator(device=dev).manual_seed(99)
   out = {}
@@ -331,14 +333,25 @@ def robustness_block(dev, queries, ref_ms: float) -> dict:
   for kind in ("lognormal_0.5", "lognormal_1.0", "zipf_duplicates"):
     c = corpus(kind)
     index = ftk.BruteForce(k=TOPK).index(c)
-    del c
     for _ in range(3):
       index(queries)
     ts = percentiles(event_times_ms(lambda: index(queries), 10, 0))
+    dup = getattr(index, "_dup", None)
     out[kind] = {"value": BATCH / (ts["median"] * 1e-3), "unit": "queries/s", "ms_per_step": ts["median"],
                  "vs_iid_step": ts["median"] / ref_ms, "redo_queries_last_step": index.last_redo_count(),
-                 "redo_reasons": index.last_redo_reasons()}
-    del index
+                 "redo_reasons": index.last_redo_reasons(),
+                 "distinct_rows_indexed": None if dup is None else dup.count}
+    if kind == "zipf_duplicates":
+      # the same corpus with the duplicate detection switched off: every copy of a top row ties for
+      # the K-th place, survivor lists overflow, queries fall to the exact-recompute path
+      plain = ftk.BruteForce(k=TOPK, dedup=False).index(c)
+      for _ in range(2):
+        plain(queries)
+      tp = percentiles(event_times_ms(lambda: plain(queries), 3, 0))
+      out[kind]["without_dedup"] = {"ms_per_step": tp["median"], "vs_iid_step": tp["median"] / ref_ms,
+                                    "redo_queries_last_step": plain.last_redo_count()}
+      del plain
+    del index, c
     torch.cuda.empty_cache()
   return out
 

@@ -103,6 +103,20 @@ int tfrs_bruteforce_topk(const tfrs_index_t *index, const float *queries, int64_
  * exact-recompute ("redo") path of the fp16-prefiltered search (survivor list overflow or
  * retained set too large; 0 on well-behaved data, and always 0 on the all-f32 path).
  * Synchronises `stream`. */
+/* De-duplicated index (BruteForce.call on corpora with many EXACT copies of a row; tf.math.top_k
+ * breaks ties by the lower index, layers/factorized_top_k.py:605, so every copy of a top-K row is a
+ * candidate and no threshold separates them).  The host indexes the distinct rows:
+ *   tfrs_row_hash64: out[r] = 63-bit hash of row r's bit pattern (equal rows hash equal; the caller
+ *     compares hash neighbours exactly);
+ *   tfrs_topk_expand_duplicates: scores / distinct_rows[nq, k_in] = the best distinct rows of each
+ *     query (descending; row < 0 = empty); distinct row u stands for the original rows
+ *     dup_rows[dup_start[u] .. dup_start[u + 1]) (ascending).  Writes the exact top-k_out of the
+ *     ORIGINAL corpus, order (score descending, original row ascending); empty slots carry row -1. */
+int tfrs_row_hash64(const float *rows, int64_t n, int d, uint64_t *out, void *stream);
+int tfrs_topk_expand_duplicates(const float *scores, const int32_t *distinct_rows, int64_t nq, int k_in,
+                                const int64_t *dup_start, const int32_t *dup_rows, int k_out,
+                                float *out_scores, int32_t *out_rows, void *stream);
+
 /* Paged search for k beyond TFRS_MAX_K (tf.math.top_k has no limit, layers/factorized_top_k.py:605):
  * the best k <= TFRS_MAX_K rows among those strictly AFTER (last_scores[q * last_ld],
  * last_rows[q * last_ld]) in the result order (score descending, row ascending); NULL / NULL = the

@@ -36,6 +36,8 @@ SIGNATURES = {
     "tfrs_index_unpack": (c_int, [P, P, P]),
     "tfrs_bruteforce_topk_workspace_bytes": (c_size_t, [c_i64, c_i64, c_int, c_int]),
     "tfrs_bruteforce_topk": (c_int, [P, P, c_i64, c_int, P, P, P, c_size_t, P]),
+    "tfrs_row_hash64": (c_int, [P, c_i64, c_int, P, P]),
+    "tfrs_topk_expand_duplicates": (c_int, [P, P, c_i64, c_int, P, P, c_int, P, P, P]),
     "tfrs_bruteforce_topk_below_workspace_bytes": (c_size_t, [c_i64, c_i64, c_int, c_int]),
     "tfrs_bruteforce_topk_below": (c_int, [P, P, c_i64, c_int, P, P, c_i64, P, P, P, c_size_t, P]),
     "tfrs_bruteforce_topk_redo_count": (c_int, [P, c_i64, c_i64, c_int, P, P]),

@@ -28,6 +28,7 @@ SOURCES = [
     "topk_select16.hip",
     "topk_api.hip",
     "metric_fused.hip",
+    "dedup.hip",
     "embedding.hip",
     "shard_route.hip",
     "hashing.hip",

@@ -225,7 +225,7 @@ struct Scan16Args {
 int launch_scan16(const Scan16Args &a, hipStream_t stream);
 constexpr int kScan16QueriesPerWg = 512;
 
-enum SelectSource { kSrcDense = 0, kSrcList = 1, kSrcParts = 2, kSrcRecompute = 3 };
+enum SelectSource { kSrcDense = 0, kSrcList = 1, kSrcParts = 2, kSrcRecompute = 3, kSrcExpand = 4 };
 
 struct SelectArgs {
   int64_t nq;
@@ -264,6 +264,12 @@ struct SelectArgs {
   float *out_scores;   // [nq, k]
   int32_t *out_idx;    // [nq, k]
   float *out_thr;      // [nq] K-th best score, or -inf while fewer than k entries (may be NULL)
+  // kSrcExpand (de-duplicated index): part_scores / part_idx[nq, k_in] are the best DISTINCT rows
+  // (idx = distinct-row number, < 0 empty); distinct row u stands for the original rows
+  // dup_rows[dup_start[u] .. dup_start[u + 1]) (ascending).  Every original row is a candidate with
+  // its distinct row's score; at most k rows per distinct row can matter.
+  const int64_t *dup_start;
+  const int32_t *dup_rows;
   // paged search: only keys strictly BELOW ceil_key[query] -- i.e. after it in (score descending,
   // row ascending) order -- are candidates (NULL: no ceiling)
   const uint64_t *ceil_key;

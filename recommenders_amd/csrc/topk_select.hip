@@ -222,6 +222,48 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
                                        (int32_t)(a.idx_base + (a.rowmap ? (int64_t)a.rowmap[e] : e)))
                             : 0ull);
     }
+  } else if (source == kSrcExpand) {
+    // 64 distinct results per pass: every lane fetches its result's score, distinct row and
+    // duplicate range (three dependent loads for 64 results at once).  Results that stand for ONE
+    // original row -- the common case -- are offered in a single consume; the others are walked
+    // one by one, <= K rows each, and skipped outright once K entries with a better score are held
+    // (results arrive in descending score order, so on a corpus of popular duplicates the walk
+    // ends after the first few).
+    for (int j0 = 0; j0 < a.k_in; j0 += 64) {
+      const int jj = j0 + lane;
+      int32_t u = -1;
+      float sc = 0.0f;
+      if (jj < a.k_in) {
+        u = a.part_idx[row * a.k_in + jj];
+        sc = a.part_scores[row * a.k_in + jj];
+      }
+      int64_t lo = 0;
+      int cnt = 0;
+      if (u >= 0) {
+        lo = a.dup_start[u];
+        const int64_t c = a.dup_start[u + 1] - lo;
+        cnt = (int)(c < (int64_t)K ? c : (int64_t)K);
+      }
+      consume(cnt == 1 ? make_key(sc, (int32_t)(a.dup_rows[lo] + a.idx_base)) : 0ull);
+      uint64_t multi = __ballot(cnt > 1);
+      while (multi != 0ull) {
+        const int src = (int)__builtin_ctzll(multi);
+        multi &= multi - 1ull;
+        const float s1 = __shfl(sc, src);
+        const int c1 = __shfl(cnt, src);
+        const int64_t l1 = ((int64_t)__shfl((int)(lo >> 32), src) << 32) | (uint32_t)__shfl((int)lo, src);
+        if (kth != 0ull && fill == 0 && key_score(kth) > s1) continue;   // K better entries are held
+        for (int base = 0; base < c1; base += 64) {
+          const int e = base + lane;
+          consume(e < c1 ? make_key(s1, (int32_t)(a.dup_rows[l1 + e] + a.idx_base)) : 0ull);
+        }
+        if (fill > 0) {   // settle, so that the early exit above sees the true K-th key
+          absorb_chunk<KP>(best, chunk, fill, lane);
+          fill = 0;
+          kth = best[K - 1];
+        }
+      }
+    }
   } else {
     const int64_t m = (int64_t)a.nparts * a.k_in;
     for (int64_t base = 0; base < m; base += 64) {

@@ -312,22 +312,96 @@ class _IndexHandle:
         pass
 
 
+class _Duplicates:
+  """Bookkeeping of a de-duplicated index: ``start[u] .. start[u + 1]`` delimits, in ``rows``, the
+  ascending original row numbers that distinct row ``u`` stands for; ``distinct_of_row[r]`` is the
+  distinct row of original row ``r`` (to rebuild the corpus)."""
+
+  def __init__(self, start: Tensor, rows: Tensor, distinct_of_row: Tensor, max_multiplicity: int):
+    self.start, self.rows, self.distinct_of_row = start, rows, distinct_of_row
+    self.count = int(start.numel() - 1)
+    self.max_multiplicity = max_multiplicity
+
+
+def _find_duplicates(cand: Tensor, min_multiplicity: int = 16, min_fraction: float = 0.1):
+  """Groups bit-identical rows of ``cand`` (64-bit row hash from ``tfrs_row_hash64``, stable sort,
+  exact comparison of hash neighbours -- a hash collision only costs a missed merge).  Returns
+  ``(canonical_rows, _Duplicates)`` when de-duplication pays -- some row occurs at least
+  ``min_multiplicity`` times or at least ``min_fraction`` of the rows are copies -- else ``None``.
+  Index-time work: one pass over the rows, one sort of n 64-bit keys."""
+  n, d = cand.shape
+  if n < 2:
+    return None
+  lib = _lib.load()
+  h = torch.empty((n,), dtype=torch.int64, device=cand.device)
+  _lib.check(lib.tfrs_row_hash64(_lib.ptr(cand), n, d, _lib.ptr(h), _lib.current_stream()))
+  hs, perm = torch.sort(h, stable=True)            # equal hashes: ascending original row
+  same_hash = hs[1:] == hs[:-1]
+  if not bool(same_hash.any()):
+    return None
+  # exact comparison, only where neighbouring hashes agree
+  pos = torch.nonzero(same_hash).reshape(-1) + 1
+  eq = torch.zeros((n,), dtype=torch.bool, device=cand.device)
+  for lo in range(0, pos.numel(), 1 << 20):        # bounded temporaries
+    p = pos[lo:lo + (1 << 20)]
+    a, b = cand.index_select(0, perm[p]), cand.index_select(0, perm[p - 1])
+    eq[p] = (a.view(torch.int32) == b.view(torch.int32)).all(dim=1)
+  new_group = ~eq                                   # position 0 starts a group
+  group = torch.cumsum(new_group.to(torch.int64), 0) - 1          # group of every sorted position
+  n_groups = int(group[-1].item()) + 1
+  sizes = torch.bincount(group, minlength=n_groups)
+  max_mult = int(sizes.max().item())
+  if n_groups == n or (max_mult < min_multiplicity and n - n_groups < min_fraction * n):
+    return None
+  # canonical (lowest) original row of every group; distinct rows are numbered by ascending
+  # canonical row so that the distinct index keeps the corpus order
+  first_pos = torch.nonzero(new_group).reshape(-1)
+  canon = perm[first_pos]
+  canon_sorted, by_canon = torch.sort(canon)
+  rank_of_group = torch.empty_like(by_canon)
+  rank_of_group[by_canon] = torch.arange(n_groups, device=cand.device)
+  distinct_of_sorted = rank_of_group[group]
+  distinct_of_row = torch.empty((n,), dtype=torch.int64, device=cand.device)
+  distinct_of_row[perm] = distinct_of_sorted
+  # rows grouped by distinct row, ascending within a group (stable sort of 0..n-1 by distinct row)
+  _, rows = torch.sort(distinct_of_row, stable=True)
+  counts = torch.bincount(distinct_of_row, minlength=n_groups)
+  start = torch.zeros((n_groups + 1,), dtype=torch.int64, device=cand.device)
+  start[1:] = torch.cumsum(counts, 0)
+  return canon_sorted, _Duplicates(start.contiguous(), rows.to(torch.int32).contiguous(),
+                                   distinct_of_row.to(torch.int32).contiguous(), max_mult)
+
+
 class BruteForce(TopK):
   """Brute force retrieval (reference :515-610): exact top-K of ``q @ candidates^T``.
 
   ``index`` copies the candidates into a layer-owned, MFMA-friendly packed corpus in
   HBM (:559-584); ``call`` is one fused scan, the ``[B, N]`` score matrix is never
   materialised.
+
+  ``dedup`` (default ``"auto"``; not in the reference): ``tf.math.top_k`` breaks ties by the lower
+  index (:605), so on a corpus with many EXACT copies of a row (default / cold-start embeddings,
+  popularity-weighted duplicates) every copy of a top-K row is a candidate for the K-th place, no
+  score threshold separates them and the filtered scans degrade to their exact-recompute path
+  (68x slower at BASELINE configs[1] shapes on a Zipf-duplicated corpus).  ``index`` therefore
+  looks for bit-identical rows and, when some row occurs >= 16 times or >= 10 % of the rows are
+  copies, indexes the DISTINCT rows only; a call searches those and expands the best of them back
+  into the exact top-K of the original corpus (``tfrs_topk_expand_duplicates``: same scores, same
+  row order as the full search).  ``False`` switches the detection off, ``True`` forces it for any
+  duplicate.
   """
 
   def __init__(self, query_model: Optional[Callable] = None, k: int = 10,
-               name: Optional[str] = None):
+               name: Optional[str] = None, dedup="auto"):
     super().__init__(k=k, name=name)
     self.query_model = query_model
     self._index: Optional[_IndexHandle] = None
     self._ids: Optional[_Identifiers] = None
     self._n = 0
     self._d = 0
+    self._dedup = dedup
+    self._dup: Optional[_Duplicates] = None
+    self._plain: Optional["BruteForce"] = None
 
   def index(self, candidates: ArrayLike, identifiers: Optional[ArrayLike] = None) -> "BruteForce":
     if isinstance(candidates, torch.Tensor):
@@ -352,14 +426,26 @@ class BruteForce(TopK):
       self._ids = _Identifiers(identifiers, cand.shape[0])
       self._n, self._d = cand.shape
       return self
+    self._dup, self._plain = None, None
+    packed_rows = cand
+    if self._dedup and cand.shape[0] >= 4096:
+      found = (_find_duplicates(cand, 2, 0.0) if self._dedup is True else _find_duplicates(cand))
+      if found is not None:
+        canonical, self._dup = found
+        packed_rows = cand.index_select(0, canonical)      # the distinct rows, in corpus order
     handle = _IndexHandle()
-    _lib.check(handle._lib.tfrs_index_set(handle.handle, _lib.ptr(cand), cand.shape[0],
-                                          cand.shape[1], _lib.current_stream()))
+    _lib.check(handle._lib.tfrs_index_set(handle.handle, _lib.ptr(packed_rows), packed_rows.shape[0],
+                                          packed_rows.shape[1], _lib.current_stream()))
     torch.cuda.current_stream().synchronize()  # `cand` may be a temporary upload
     self._index = handle                       # the previous index (if any) is dropped
     self._ids = _Identifiers(identifiers, cand.shape[0])
     self._n, self._d = cand.shape
     return self
+
+  @property
+  def _index_rows(self) -> int:
+    """Rows held by the device index: the distinct rows of a de-duplicated corpus, else all."""
+    return self._dup.count if self._dup is not None else self._n
 
   def index_from_dataset(self, candidates: Iterable, total_rows: Optional[int] = None) -> "BruteForce":
     """``TopK.index_from_dataset`` (:179-215).  With ``total_rows`` (the dataset's cardinality)
@@ -419,6 +505,7 @@ class BruteForce(TopK):
       raise ValueError("The candidate dataset is empty.")
     flush()
     self._index = handle
+    self._dup, self._plain = None, None        # (streamed ingest: blocks are indexed as they come)
     self._ids = _Identifiers(np.concatenate(ids, axis=0) if has_ids else None, n)
     self._n, self._d = n, d
     return self
@@ -442,16 +529,31 @@ class BruteForce(TopK):
       _wide_topk_update(q, self._wide, 0, k, scores, rows, 0)
       self._last_call = None
       return scores, rows
+    if k > self._n:
+      raise ValueError(f"input must have at least k columns (k={k}, candidates={self._n})")
     if k > MAX_FUSED_K:
+      if self._dup is not None:     # pages + expansion: (rare) search a plain copy of the corpus
+        if self._plain is None:
+          self._plain = BruteForce(k=self._k, dedup=False).index(self.candidates())
+        return self._plain._query_rows_paged(q, k)
       return self._query_rows_paged(q, k)
-    scores = torch.empty((nq, k), dtype=torch.float32, device=q.device)
-    rows = torch.empty((nq, k), dtype=torch.int32, device=q.device)
-    ws = _workspace(lib.tfrs_bruteforce_topk_workspace_bytes(nq, self._n, self._d, k))
+    kk = min(k, self._index_rows)                   # (de-duplicated: the best kk DISTINCT rows)
+    scores = torch.empty((nq, kk), dtype=torch.float32, device=q.device)
+    rows = torch.empty((nq, kk), dtype=torch.int32, device=q.device)
+    ws = _workspace(lib.tfrs_bruteforce_topk_workspace_bytes(nq, self._index_rows, self._d, kk))
     _lib.check(lib.tfrs_bruteforce_topk(
-        self._index.handle, _lib.ptr(q), nq, k, _lib.ptr(scores), _lib.ptr(rows),
+        self._index.handle, _lib.ptr(q), nq, kk, _lib.ptr(scores), _lib.ptr(rows),
         _lib.ptr(ws), ws.numel(), _lib.current_stream()))               # :603-605
-    self._last_call = (ws, nq, k)
-    return scores, rows
+    self._last_call = (ws, nq, kk)
+    if self._dup is None:
+      return scores, rows
+    # every original row is a candidate with its distinct row's score: exact top-k of the corpus
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+    out_r = torch.empty((nq, k), dtype=torch.int32, device=q.device)
+    _lib.check(lib.tfrs_topk_expand_duplicates(
+        _lib.ptr(scores), _lib.ptr(rows), nq, kk, _lib.ptr(self._dup.start), _lib.ptr(self._dup.rows), k,
+        _lib.ptr(out_s), _lib.ptr(out_r), _lib.current_stream()))
+    return out_s, out_r
 
   def _query_rows_paged(self, q: Tensor, k: int) -> Tuple[Tensor, Tensor]:
     """``k`` beyond the selection kernels' 1024 slots (``tf.math.top_k`` has no limit, :605): pages
@@ -493,7 +595,7 @@ class BruteForce(TopK):
     ws, nq, k = self._last_call
     out = ctypes.c_int32(0)
     _lib.check(_lib.load().tfrs_bruteforce_topk_redo_count(
-        _lib.ptr(ws), nq, self._n, k, ctypes.byref(out), _lib.current_stream()))
+        _lib.ptr(ws), nq, self._index_rows, k, ctypes.byref(out), _lib.current_stream()))
     return int(out.value)
 
   def last_redo_reasons(self) -> dict:
@@ -504,7 +606,7 @@ class BruteForce(TopK):
     ws, nq, k = self._last_call
     out = (ctypes.c_int32 * 4)()
     _lib.check(_lib.load().tfrs_bruteforce_topk_redo_reasons(
-        _lib.ptr(ws), nq, self._n, k, out, _lib.current_stream()))
+        _lib.ptr(ws), nq, self._index_rows, k, out, _lib.current_stream()))
     return {name: int(out[i]) for i, name in enumerate(names)}
 
   def call(self, queries, k: Optional[int] = None):
@@ -555,9 +657,11 @@ class BruteForce(TopK):
       raise ValueError(NOT_INDEXED_MESSAGE)
     if getattr(self, "_wide", None) is not None:
       return self._wide.clone()
-    out = torch.empty((self._n, self._d), dtype=torch.float32, device=_device())
+    out = torch.empty((self._index_rows, self._d), dtype=torch.float32, device=_device())
     _lib.check(_lib.load().tfrs_index_unpack(self._index.handle, _lib.ptr(out),
                                              _lib.current_stream()))
+    if self._dup is not None:       # every original row from its distinct row
+      out = out.index_select(0, self._dup.distinct_of_row.long())
     return out
 
   def is_exact(self) -> bool:

@@ -346,6 +346,80 @@ def test_k_beyond_1024_pages(n, k, ties, filter_mode):
     ftk.BruteForce(k=n + 1).index(c)(q)
 
 
+@pytest.mark.parametrize("distinct,d,k", [(300, 16, 100), (5000, 64, 100), (60_000, 32, 10), (2, 8, 50)])
+def test_duplicate_heavy_corpus_is_searched_on_its_distinct_rows(distinct, d, k, filter_mode):
+  """Corpora with many EXACT copies of a row (Zipf popularity over `distinct` rows): tf.math.top_k
+  breaks ties by the lower index (layers/factorized_top_k.py:605), so every copy of a top row is a
+  candidate.  `BruteForce.index` finds the bit-identical rows, indexes the distinct ones and
+  `tfrs_topk_expand_duplicates` rebuilds the exact top-K of the ORIGINAL corpus: indices (lowest
+  original rows first among equal scores) and scores `==` the oracle, identifiers, exclusions, the
+  unpacked corpus, k above the number of distinct rows and k > 1024 included; no query may need the
+  exact-redo path any more."""
+  ftk = _layers()
+  rng = np.random.default_rng(distinct + d)
+  n, nq = 70_000, 64
+  base = (rng.normal(size=(distinct, d)) / np.sqrt(d)).astype(np.float32)
+  if distinct == 300:
+    base = np.round(base * 4) / 4                      # distinct rows that tie with each other, too
+  w = 1.0 / np.arange(1, distinct + 1)
+  pick = rng.choice(distinct, size=n, p=w / w.sum())
+  c = base[pick]
+  q = (rng.normal(size=(nq, d)) / np.sqrt(d)).astype(np.float32)
+  if distinct == 300:
+    q = np.round(q * 4) / 4
+  ids = (np.arange(n) * 3 + 7).astype(np.int64)
+  layer = ftk.BruteForce(k=k).index(c, ids)
+  assert layer._dup is not None and layer._dup.count == len(np.unique(pick))
+  es, ei = o_topk.brute_force(q, c, k, ids)
+  s, got = layer(q)
+  np.testing.assert_array_equal(_np(got), ei)
+  np.testing.assert_array_equal(_np(s), es)
+  assert layer.last_redo_count() == 0
+  np.testing.assert_array_equal(_np(layer.candidates()), c)          # every original row is rebuilt
+  # the same corpus without de-duplication gives the same answer (slowly: ties flood the lists)
+  if distinct >= 5000:
+    s2, g2 = ftk.BruteForce(k=k, dedup=False).index(c, ids)(q)
+    np.testing.assert_array_equal(_np(g2), ei)
+    np.testing.assert_array_equal(_np(s2), es)
+  # exclusions (query k + E, mask, re-top-k; :242-288)
+  excl = ei[:, :3]
+  s3, g3 = layer.query_with_exclusions(q, excl, k=5)
+  es3, ei3 = o_topk.exclude(*o_topk.brute_force(q, c, 5 + 3, ids), excl, 5)
+  np.testing.assert_array_equal(_np(g3), ei3)
+  np.testing.assert_array_equal(_np(s3), es3)
+  if filter_mode == "f16" and distinct == 5000:
+    big = 1500                                         # pages + duplicates
+    esb, eib = o_topk.brute_force(q[:8], c, big)
+    sb, ib = ftk.BruteForce(k=big).index(c)(q[:8])
+    np.testing.assert_array_equal(_np(ib), eib)
+    np.testing.assert_array_equal(_np(sb), esb)
+
+
+def test_dedup_detection_thresholds():
+  """A few accidental duplicates do not switch the distinct-row index on (`auto`: some row >= 16
+  times or >= 10 % copies); `dedup=True` forces it, `False` never looks."""
+  ftk = _layers()
+  rng = np.random.default_rng(3)
+  c = rng.normal(size=(20_000, 8)).astype(np.float32)
+  c[100] = c[5]
+  c[7000] = c[5]
+  q = rng.normal(size=(9, 8)).astype(np.float32)
+  es, ei = o_topk.brute_force(q, c, 20)
+  for mode, expect in (("auto", False), (True, True), (False, False)):
+    layer = ftk.BruteForce(k=20, dedup=mode).index(c)
+    assert (layer._dup is not None) == expect
+    s, i = layer(q)
+    np.testing.assert_array_equal(_np(i), ei)
+    np.testing.assert_array_equal(_np(s), es)
+  c[1000:1016] = c[5]                                  # 19 copies of one row: auto switches on
+  layer = ftk.BruteForce(k=20).index(c)
+  assert layer._dup is not None and layer._dup.max_multiplicity == 19
+  es, ei = o_topk.brute_force(q, c, 20)
+  s, i = layer(q)
+  np.testing.assert_array_equal(_np(i), ei)
+  np.testing.assert_array_equal(_np(s), es)
+
+
 def test_two_host_threads_two_streams():
   """include/tfrs_hip.h promises re-entrancy on distinct streams / handles: two host threads, each
   on its own HIP stream, run BruteForce calls at the same time -- one shares an index handle with
