@@ -428,7 +428,7 @@ class BruteForce(TopK):
       return self
     self._dup, self._plain = None, None
     packed_rows = cand
-    if self._dedup and cand.shape[0] >= 4096:
+    if self._dedup is True or (self._dedup and cand.shape[0] >= 4096):
       found = (_find_duplicates(cand, 2, 0.0) if self._dedup is True else _find_duplicates(cand))
       if found is not None:
         canonical, self._dup = found
