@@ -51,6 +51,14 @@ const char *tfrs_last_error(void);
 /* Fills compute-unit count, LDS bytes per CU and the gcnArchName of device `dev`. */
 int tfrs_device_info(int dev, int *cu_count_h, int *lds_bytes_h, char *arch_h,
                      int arch_len);
+/* The library's configuration plane: every measurement / test switch (the TFRS_* names listed in
+ * INTEGRATION.md "Runtime switches") is read through one accessor -- a value set here wins, else
+ * the process environment is consulted at the time of the call.  value == NULL removes the
+ * override.  tfrs_get_option returns 1 and the value in force, 0 when the option is unset.
+ * Process-wide (like the environment); defaults are what bench.py and the tests run. */
+int tfrs_set_option(const char *name, const char *value);
+int tfrs_get_option(const char *name, char *value_h, int value_len);
+
 
 /* Measurement hook (bench.py): while enabled, every launch of the fused score+filter scan
  * kernel is bracketed by HIP events on its launch stream.  tfrs_profile_read returns the

@@ -23,6 +23,8 @@ SIGNATURES = {
     "tfrs_version": (c_int, []),
     "tfrs_last_error": (ctypes.c_char_p, []),
     "tfrs_device_info": (c_int, [c_int, P, P, P, c_int]),
+    "tfrs_set_option": (c_int, [ctypes.c_char_p, ctypes.c_char_p]),
+    "tfrs_get_option": (c_int, [ctypes.c_char_p, ctypes.c_char_p, c_int]),
     "tfrs_profile_enable": (c_int, [c_int]),
     "tfrs_profile_read": (c_int, [P, P, P]),
     "tfrs_profile_read_kind": (c_int, [c_int, P, P, P]),
@@ -130,6 +132,17 @@ def load() -> ctypes.CDLL:
     fn.argtypes = args
   _lib = lib
   return lib
+
+
+def set_option(name: str, value: Optional[str]) -> None:
+  """One of the library's TFRS_* switches, overriding the environment; ``None``
+  removes the override."""
+  check(load().tfrs_set_option(name.encode(), None if value is None else str(value).encode()))
+
+
+def get_option(name: str) -> Optional[str]:
+  buf = ctypes.create_string_buffer(256)
+  return buf.value.decode() if load().tfrs_get_option(name.encode(), buf, 256) == 1 else None
 
 
 def last_error() -> str:

@@ -2,8 +2,12 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include <map>
 #include <mutex>
+#include <set>
+#include <string>
 #include <utility>
 
 #include "common.h"
@@ -17,6 +21,23 @@ void set_error(const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+namespace {
+std::mutex g_opt_mu;
+std::map<std::string, const char *> g_opt;      // overrides set through tfrs_set_option
+std::set<std::string> g_opt_values;             // interned values: pointers handed out stay valid
+}  // namespace
+
+const char *option(const char *name) {
+  {
+    std::lock_guard<std::mutex> lock(g_opt_mu);
+    if (!g_opt.empty()) {
+      auto it = g_opt.find(name);
+      if (it != g_opt.end()) return it->second;
+    }
+  }
+  return getenv(name);
 }
 
 hipError_t ensure_dynamic_lds(const void *kernel, int bytes) {
@@ -43,6 +64,29 @@ hipError_t ensure_dynamic_lds(const void *kernel, int bytes) {
 }
 
 }  // namespace tfrs
+
+extern "C" int tfrs_set_option(const char *name, const char *value) {
+  TFRS_CHECK_ARG(name && strncmp(name, "TFRS_", 5) == 0, "set_option: option names start with TFRS_");
+  std::lock_guard<std::mutex> lock(tfrs::g_opt_mu);
+  if (!value) {
+    tfrs::g_opt.erase(name);          // back to the environment (or unset)
+  } else {
+    tfrs::g_opt[name] = tfrs::g_opt_values.insert(value).first->c_str();
+  }
+  return TFRS_OK;
+}
+
+extern "C" int tfrs_get_option(const char *name, char *value_h, int value_len) {
+  TFRS_CHECK_ARG(name && value_h && value_len > 0, "get_option: bad argument");
+  const char *v = tfrs::option(name);
+  if (!v) {
+    value_h[0] = '\0';
+    return 0;                          // unset
+  }
+  strncpy(value_h, v, (size_t)value_len - 1);
+  value_h[value_len - 1] = '\0';
+  return 1;
+}
 
 extern "C" int tfrs_version(void) { return 100; /* 0.1.0 */ }
 

@@ -40,6 +40,14 @@ void set_error(const char *fmt, ...);
 // hipGetDevice plus a thread-local compare.
 hipError_t ensure_dynamic_lds(const void *kernel, int bytes);
 
+// ---- the library's ONE configuration plane ----------------------------------------------------
+// Every measurement / test switch (the TFRS_* names listed in INTEGRATION.md) is read through
+// option(): a value set with tfrs_set_option() wins, else the process environment is consulted, so
+// the switches are addressable through the C ABI (and enumerable: tfrs_get_option) instead of being
+// scattered getenv calls.  Returns nullptr when the option is unset.  The returned pointer stays
+// valid until the same option is set again from this thread's point of view (values are interned).
+const char *option(const char *name);
+
 // ---- packed candidate layout -------------------------------------------------
 // Row r of the packed corpus occupies row_bytes(dp) bytes:
 //   slots 0 .. dp/8-1      : even features  (d = 0, 2, 4, ...)  4 floats per 16-B slot

@@ -642,7 +642,7 @@ struct G16Layout {
 static int g16_splits(int64_t m, int n, int k) {
   const int64_t tiles = ((m + kB16M - 1) / kB16M) * ((n + kB16N - 1) / kB16N);
   if (tiles >= 512 || tiles < 8 || k < 8192) return 1;
-  const char *ev = getenv("TFRS_GEMM16_SPLITK");
+  const char *ev = option("TFRS_GEMM16_SPLITK");
   if (ev && *ev) return std::max(1, atoi(ev));
   int best = 1;
   double best_eff = 0.0;
@@ -715,7 +715,7 @@ int gemm16_run_ex(const G16Operand &a, const G16Operand &b, int64_t m, int n, in
   float *psum = reinterpret_cast<float *>(w + L.psum);
   const unsigned nslab = (unsigned)((k + kG16Slab - 1) / kG16Slab);
   // kernel choice first: it decides the image layout
-  const char *tv = getenv("TFRS_GEMM16_TILE");
+  const char *tv = option("TFRS_GEMM16_TILE");
   const int forced = (tv && *tv) ? atoi(tv) : 0;
   const int64_t big_tiles = (L.mp / kB16M) * (L.np / kB16N);
   const bool splitk = L.nsplit > 1 && epi == kG16EpiBias && !bias && forced != 128;
@@ -723,7 +723,7 @@ int gemm16_run_ex(const G16Operand &a, const G16Operand &b, int64_t m, int n, in
   // the 256 x 256 kernel reads K-step-major images (kb = 16 halves): the operand tile of one K
   // step is 256 rows x 32 bytes CONTIGUOUS, so every direct-to-LDS copy instruction moves eight
   // full 128-byte lines instead of 32 quarter lines 2 * kp bytes apart
-  const char *kbv = getenv("TFRS_GEMM16_KB");
+  const char *kbv = option("TFRS_GEMM16_KB");
   const int kb = big ? ((kbv && *kbv) ? atoi(kbv) : kB16K) : L.kp;
   // column maxima are combined with atomicMax: re-armed by a kernel, not a memset node
   hipLaunchKernelGGL(g16_zero_kernel, dim3((unsigned)((L.np + L.mp + 255) / 256)), dim3(256), 0, s,

@@ -697,14 +697,14 @@ static bool launch_dot_mfma_nb(const float *x, int64_t batch, int f, int d, int 
   const size_t lds = (size_t)(((out_dim + 3) & ~3) + 64) * sizeof(float);  // per wave
   // TFRS_DOT_STAGE=0: direct 128-byte-run stores from the accumulators instead of the LDS-staged
   // linear copy-out (measurement switch)
-  const char *sv = getenv("TFRS_DOT_STAGE");
+  const char *sv = option("TFRS_DOT_STAGE");
   const bool stage = !skip && lds <= 64 * 1024 && !(sv && sv[0] == '0');
   if (stage) {
     (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&dot_interaction_mfma_kernel<DP, NB, true>), 64 * 1024);
     const int64_t per_cu = std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)lds));
     const dim3 grid((unsigned)std::min<int64_t>(batch, 256 * per_cu * 2));
     // TFRS_DOT_FWD=f32 keeps the exact-f32 MFMA chain (measurement / comparison switch)
-    const char *fv = getenv("TFRS_DOT_FWD");
+    const char *fv = option("TFRS_DOT_FWD");
     if constexpr (DP % 16 == 0 && NB * (DP / 2) <= 96) {   // (beyond that the raw + hi + lo operands spill)
       if (!(fv && (fv[0] == 'f' || fv[0] == 's'))) {   // default: direct stores
         const dim3 gd((unsigned)std::min<int64_t>((batch + 3) / 4, 256 * 8));
@@ -1152,7 +1152,7 @@ static bool launch_dot_bwd_dense(const float *x, const float *dout, int64_t batc
   if (lds > 64 * 1024 || (size_t)f * (2 * kh + 4) + 256 > 0xFFFFu) return false;
   const int out_dim = self ? f * (f + 1) / 2 : f * (f - 1) / 2;
   const int maxe = (out_dim + 255) / 256;
-  const char *dv = getenv("TFRS_DOT_BWD");
+  const char *dv = option("TFRS_DOT_BWD");
   const size_t lds_pc = 2 * lds + (size_t)2 * (2 * kh * 32) * sizeof(float);
   if (!(dv && dv[0] == 'd') && d <= 32 && lds_pc <= 160 * 1024 && batch >= 512) {
     // producer / consumer kernel: one 8-wave workgroup per CU, double-buffered S and X tiles
@@ -1648,7 +1648,7 @@ extern "C" int tfrs_dot_interaction_strided_supported(int64_t batch, int f, int 
   const int dp = d <= 16 ? 16 : 32, nb = (f + 31) / 32;
   if (nb > 4 || nb * (dp / 2) > 96) return 0;
   if ((size_t)(((out_dim + 3) & ~3) + 64) * sizeof(float) > 64 * 1024) return 0;
-  const char *sv = getenv("TFRS_DOT_STAGE"), *fv = getenv("TFRS_DOT_FWD"), *dv = getenv("TFRS_DOT_BWD");
+  const char *sv = option("TFRS_DOT_STAGE"), *fv = option("TFRS_DOT_FWD"), *dv = option("TFRS_DOT_BWD");
   if ((sv && sv[0] == '0') || (fv && (fv[0] == 'f' || fv[0] == 's')) || (dv && (dv[0] == 'd' || dv[0] == 'g'))) return 0;
   // backward: producer / consumer kernel
   int kh = (f + 7) / 8 * 4;
@@ -1682,7 +1682,7 @@ extern "C" int tfrs_dot_interaction_bwd(const float *x, const float *dout, int64
   if (batch == 0) return TFRS_OK;
   TFRS_CHECK_ARG(x && dout && dx, "dot_interaction_bwd: NULL pointer");
   // TFRS_DOT_BWD=gather selects the second-generation kernel (A operand gathered per element)
-  const char *dv = getenv("TFRS_DOT_BWD");
+  const char *dv = option("TFRS_DOT_BWD");
   const bool dense_ok = !(dv && dv[0] == 'g');
   if (!skip_gather && dense_ok &&
       launch_dot_bwd_dense(x, dout, batch, f, d, self_interaction, dx, (hipStream_t)stream)) {

@@ -346,7 +346,7 @@ static void plan(int64_t n_rows, int64_t n_stream, int *nsplit, int64_t *split_l
   const int64_t row_blocks = (n_rows + 31) / 32;
   const int64_t tiles = (n_stream + 31) / 32;
   static const int64_t target_waves = [] {
-    const char *v = getenv("TFRS_SOFTMAX_WAVES");
+    const char *v = option("TFRS_SOFTMAX_WAVES");
     return (v && *v) ? (int64_t)atoll(v) : (int64_t)2048;  // ~2 waves per SIMD on 256 CUs
   }();
   int64_t want = (target_waves + row_blocks - 1) / row_blocks;
@@ -391,7 +391,7 @@ int softmax16_backward(const float *q, const float *c, int64_t nq, int64_t nc, i
 // TFRS_SOFTMAX_MODE=f32 keeps everything on the f32-MFMA kernels; default: the split-fp16 path
 // whenever no logit option that needs per-element side inputs is set.
 static bool use_f16_path(const float *corr, const int64_t *ids, const uint8_t *mask) {
-  const char *v = getenv("TFRS_SOFTMAX_MODE");   // read per call: tests switch it
+  const char *v = option("TFRS_SOFTMAX_MODE");   // read per call: tests switch it
   const bool f32_only = v && v[0] == 'f' && v[1] == '3';
   return !f32_only && !corr && !ids && !mask;
 }

@@ -686,7 +686,7 @@ static inline size_t al16(size_t x) { return (x + 255) / 256 * 256; }
 static inline int64_t pad128(int64_t n) { return (n + 255) / 256 * 256; }   // records cover whole 256-row blocks
 // waves per workgroup for a side with n_rows owned rows
 static inline int nw_of(int64_t n_rows) {
-  const char *v = getenv("TFRS_SOFTMAX_NW");   // read per call: tests switch it
+  const char *v = option("TFRS_SOFTMAX_NW");   // read per call: tests switch it
   const int forced = (v && *v) ? atoi(v) : 0;
   if (forced == 4 || forced == 8) return forced;
   return n_rows >= 16384 ? 8 : 4;
@@ -701,7 +701,7 @@ static void plan16(int64_t n_rows, int64_t n_stream, int *nsplit, int64_t *split
   const int64_t row_blocks = (n_rows + per_wg - 1) / per_wg;
   const int64_t tiles = (n_stream + 31) / 32;
   static const int64_t target = [] {
-    const char *v = getenv("TFRS_SOFTMAX_WGS");
+    const char *v = option("TFRS_SOFTMAX_WGS");
     return (v && *v) ? (int64_t)atoll(v) : (int64_t)512;   // 2 workgroups per CU
   }();
   int64_t want = (target + row_blocks - 1) / row_blocks;

@@ -20,7 +20,7 @@
 namespace tfrs {
 
 static int64_t env_i64(const char *name, int64_t dflt) {
-  const char *v = getenv(name);
+  const char *v = option(name);
   if (!v || !*v) return dflt;
   return atoll(v);
 }
@@ -48,7 +48,7 @@ static TopkTuning tuning() {
   t.prefix = padded_rows(t.prefix);
   t.rho = std::max<int64_t>(2, env_i64("TFRS_TOPK_RHO", 8));
   t.target_wgs = std::max<int64_t>(1, env_i64("TFRS_TOPK_WGS", 512));
-  const char *f = getenv("TFRS_TOPK_FILTER");
+  const char *f = option("TFRS_TOPK_FILTER");
   t.f16_filter = !(f && (f[0] == 'f' || f[0] == 'F') && f[1] == '3');
   t.sample = std::max<int64_t>(1, env_i64("TFRS_TOPK_SAMPLE", 4));
   t.min_bins = std::max<int64_t>(1, env_i64("TFRS_TOPK_MINBINS", 8));  // in 64-candidate bins
@@ -56,7 +56,7 @@ static TopkTuning tuning() {
   t.drain_every = std::max<int64_t>(1, env_i64("TFRS_SCAN16_DRAIN_EVERY", 4));
   t.stat = env_i64("TFRS_TOPK_STAT", 1) != 0;
   t.sample_stat = std::max<int64_t>(1, env_i64("TFRS_TOPK_SAMPLE_STAT", 16));
-  const char *pf = getenv("TFRS_TOPK_STAT_PFAIL");
+  const char *pf = option("TFRS_TOPK_STAT_PFAIL");
   t.p_fail = pf ? std::min(1.0, std::max(1e-12, atof(pf))) : 1e-7;
   return t;
 }
@@ -491,7 +491,7 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
   s16.drain_every = (int)t.drain_every;
   // overflow lists exist only in the second-generation filter kernel, which launch_scan16 selects
   // under exactly this condition (32-bit survivor offsets, TFRS_SCAN16_V != 1)
-  const char *gen = getenv("TFRS_SCAN16_V");
+  const char *gen = option("TFRS_SCAN16_V");
   const bool use_ovf = !(gen && gen[0] == '1') &&
                        (uint64_t)nq * s16.cap_l * (uint64_t)s16.nseg < (1ull << 32);
   s16.ovf_cnt = use_ovf ? w.ovf_cnt : nullptr;
@@ -633,7 +633,7 @@ extern "C" int tfrs_index_reserve(tfrs_index_t *index, int64_t capacity, int d, 
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&index->packed16), bytes16);
   if (e == hipSuccess)
     e = hipMalloc(reinterpret_cast<void **>(&index->meta), (nstages + 1) * sizeof(StageMeta));
-  const char *sh = getenv("TFRS_INDEX_SHUFFLE");
+  const char *sh = option("TFRS_INDEX_SHUFFLE");
   const bool shuffle = capacity >= 65536 && !(sh && sh[0] == '0');
   if (e == hipSuccess && shuffle)
     e = hipMalloc(reinterpret_cast<void **>(&index->rowmap), (size_t)index->capacity * sizeof(int32_t));

@@ -267,7 +267,7 @@ static int launch_scan_variant(const ScanArgs &a, hipStream_t stream) {
 }
 
 static int env_int(const char *name, int dflt) {
-  const char *v = getenv(name);
+  const char *v = option(name);
   return (v && *v) ? atoi(v) : dflt;
 }
 

@@ -722,7 +722,7 @@ static int launch_scan16f(const Scan16Args &a, hipStream_t stream) {
 // TFRS_SCAN16_SHAPE = 8x2 (default) | 4x4
 template <int DP>
 static int launch_scan16f_shape(const Scan16Args &a, hipStream_t stream) {
-  const char *e = getenv("TFRS_SCAN16_SHAPE");
+  const char *e = option("TFRS_SCAN16_SHAPE");
   if (e && e[0] == '4' && DP <= 64) return launch_scan16f<DP, 4, 4>(a, stream);
   return launch_scan16f<DP, 8, 2>(a, stream);
 }
@@ -745,7 +745,7 @@ static int launch_scan16_dp(const Scan16Args &a, hipStream_t stream) {
 }
 
 static int scan16_generation() {
-  const char *e = getenv("TFRS_SCAN16_V");   // read per call: one process can compare both
+  const char *e = option("TFRS_SCAN16_V");   // read per call: one process can compare both
   return (e && e[0] == '1') ? 1 : 2;
 }
 

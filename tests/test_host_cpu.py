@@ -129,6 +129,27 @@ def test_streaming_cache_probe_never_iterates_lazy_datasets():
   assert not ftk.Streaming._cacheable(p) and not ftk.Streaming._cacheable(p * 2.0)
 
 
+def test_options_are_addressable_through_the_c_abi(lib, monkeypatch):
+  """The TFRS_* switches are one configuration plane read through `tfrs::option`: a value set with
+  tfrs_set_option wins over the environment, NULL removes the override (the
+  switches were 19 scattered getenv calls)."""
+  from recommenders_amd import _lib
+  monkeypatch.delenv("TFRS_TOPK_STAT", raising=False)
+  plan = (ctypes.c_int64 * 5)()
+  assert _lib.get_option("TFRS_TOPK_STAT") is None
+  assert lib.tfrs_debug_topk_plan(1_000_000, 100, 1, plan) == 0 and plan[4] == 1      # statistical plan
+  _lib.set_option("TFRS_TOPK_STAT", "0")
+  assert _lib.get_option("TFRS_TOPK_STAT") == "0"
+  assert lib.tfrs_debug_topk_plan(1_000_000, 100, 1, plan) == 0 and plan[4] == 0 and plan[3] == 100
+  monkeypatch.setenv("TFRS_TOPK_STAT", "1")                  # the override still wins
+  assert lib.tfrs_debug_topk_plan(1_000_000, 100, 1, plan) == 0 and plan[4] == 0
+  _lib.set_option("TFRS_TOPK_STAT", None)                    # back to the environment
+  assert _lib.get_option("TFRS_TOPK_STAT") == "1"
+  assert lib.tfrs_debug_topk_plan(1_000_000, 100, 1, plan) == 0 and plan[4] == 1
+  with pytest.raises(ValueError, match="TFRS_"):
+    _lib.set_option("PATH", "x")
+
+
 def test_host_classes_reference_errors():
   import recommenders_amd as tfrs
   ftk = tfrs.layers.factorized_top_k
