@@ -310,9 +310,10 @@ def gather_metric(dev) -> dict:
 def robustness_block(dev, queries, ref_ms: float) -> dict:
   """The default (fp16-prefiltered) BruteForce path is data dependent: its thresholds come from
   sampled stages and its error margin from row norms.  Same shapes as the headline (1M x 64,
-  batch 8192, top-100), three corpora that are NOT i.i.d. rows of equal norm: log-normal row norms
-  (sigma 0.5 and 1.0 -- what trained embeddings look like) and a Zipf-duplicated corpus (popular
-  items repeated: exact ties, near-duplicate bursts).  Reported: q/s, ms/step, the ratio to the
+  batch 8192, top-100), four corpora that are NOT i.i.d. rows of equal norm: log-normal row norms
+  (sigma 0.5 and 1.0 -- what trained embeddings look like), a cluster of 600 near-duplicates with a
+  quarter of the queries aligned with it, and a Zipf-duplicated corpus (popular items repeated up to
+  83 000 times: exact ties).  Reported: q/s, ms/step, the ratio to the
   i.i.d. step, and how many queries took the exact-redo path in the last step.  `BruteForce.index`
   detects bit-identical rows and indexes the distinct ones: the Zipf corpus is
   reported with the detection on (default) and off."""
@@ -325,17 +326,28 @@ def robustness_block(dev, queries, ref_ms: float) -> dict:
     if kind.startswith("lognormal"):
       sigma = float(kind.split("_")[1])
       return base * torch.exp(sigma * torch.randn((N_ROWS, 1), generator=g, device=dev))
+    if kind == "near_duplicates":
+      return base
     # Zipf(1.0) popularity over 100k distinct items: item r has weight 1 / (r + 1)
     w = 1.0 / torch.arange(1, 100_001, device=dev, dtype=torch.float64)
     pick = torch.multinomial(w, N_ROWS, replacement=True, generator=g)
     return base[:100_000][pick].contiguous()
 
-  for kind in ("lognormal_0.5", "lognormal_1.0", "zipf_duplicates"):
+  for kind in ("lognormal_0.5", "lognormal_1.0", "near_duplicates", "zipf_duplicates"):
     c = corpus(kind)
+    q_used = queries
+    if kind == "near_duplicates":
+      # a cluster of 600 rows within 2 eps of each other (distinct bit patterns) spread over the corpus,
+      # and a quarter of the batch aligned with it: every such query's retained set exceeds K + band
+      anchor = torch.randn((1, DIM), generator=g, device=dev) / (DIM ** 0.5)
+      rows = torch.randperm(N_ROWS, generator=g, device=dev)[:600]
+      c[rows] = anchor + 1e-7 * torch.randn((600, DIM), generator=g, device=dev)
+      q_used = queries.clone()
+      q_used[:BATCH // 4] = anchor * (1.0 + 3.0 * torch.rand((BATCH // 4, 1), generator=g, device=dev))
     index = ftk.BruteForce(k=TOPK).index(c)
     for _ in range(3):
-      index(queries)
-    ts = percentiles(event_times_ms(lambda: index(queries), 10, 0))
+      index(q_used)
+    ts = percentiles(event_times_ms(lambda: index(q_used), 10, 0))
     dup = getattr(index, "_dup", None)
     out[kind] = {"value": BATCH / (ts["median"] * 1e-3), "unit": "queries/s", "ms_per_step": ts["median"],
                  "vs_iid_step": ts["median"] / ref_ms, "redo_queries_last_step": index.last_redo_count(),

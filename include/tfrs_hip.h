@@ -139,7 +139,9 @@ int tfrs_bruteforce_topk_redo_count(const void *workspace, int64_t nq, int64_t n
                                     int32_t *redo_count_h, void *stream);
 /* Same contract; reasons_h[4] = queries flagged because {0: a survivor segment or the list
  * overflowed, 1: the statistically chosen bound of a shuffled index did not hold,
- * 2: the retained set did not fit}; reasons_h[3] = length of the longest survivor list of the call
+ * 2: NOT redone -- queries whose retained set (rows within 2 eps of the K-th prefilter score: near-
+ * duplicate clusters) exceeded K + band and was re-scored in full inside the list kernel};
+ * reasons_h[3] = length of the longest survivor list of the call
  * when one exceeded 768 entries, else 0 (the list kernel holds 1024 entries per query). */
 int tfrs_bruteforce_topk_redo_reasons(const void *workspace, int64_t nq, int64_t n, int k,
                                       int32_t *reasons_h, void *stream);

@@ -342,12 +342,36 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
     const bool kp = key[s] != 0u && key[s] >= lo_key;
     const uint64_t mask = __ballot(kp);
     const int pos = m + (int)sel16_mbcnt(mask);
-    if (kp && pos < KP) keep[pos] = rowid[s];
+    if (kp && pos < kCap) keep[pos] = rowid[s];   // (m <= total <= kCap: the region holds them all)
     m += (int)__popcll(mask);
   }
-  if (m > KP) {  // retained set does not fit: exact redo
-    if (lane == 0) a.redo[1 + atomicAdd(a.redo, 1u)] = (uint32_t)row;
+  if (m > KP) {
+    // The retained set is larger than the usual K + band (near-duplicate clusters: hundreds of rows
+    // within 2 eps of the K-th score).  Round 2 sent such a query to the corpus-wide exact recompute
+    // (0.13 ms each); every retained row is already in LDS, so they are all re-scored here -- up to
+    // the list capacity, 64 * kSlots, whose 8 bytes per entry are exactly the room their exact keys
+    // need -- and sorted once.  (Reason 2 of redo_reason counts these queries; nothing is redone.)
     if (lane == 0 && a.redo_reason) atomicAdd(&a.redo_reason[2], 1u);
+    sel16_lds_sync();
+    uint32_t kall[kSlots];
+#pragma unroll
+    for (int u = 0; u < kSlots; ++u) kall[u] = (u * 64 + lane < m) ? keep[u * 64 + lane] : 0u;
+    sel16_lds_sync();  // `keep` is dead: the region becomes `ex`
+#pragma unroll 1
+    for (int u = 0; u < kSlots; ++u) {
+      uint64_t kk = 0ull;
+      if (u * 64 + lane < m)
+        kk = make_key(packed_score16(a.packed, (int64_t)kall[u], dp, qs),
+                      (int32_t)((a.rowmap ? (int64_t)a.rowmap[kall[u]] : (int64_t)kall[u]) + a.idx_base));
+      ex[u * 64 + lane] = kk;
+    }
+    sel16_lds_sync();
+    sort_desc16<kCap>(ex, lane);
+    for (int i = lane; i < K; i += 64) {
+      const uint64_t kk = ex[i];
+      a.out_scores[row * K + i] = kk ? key_score(kk) : -__builtin_inff();
+      a.out_idx[row * K + i] = kk ? key_index(kk) : -1;
+    }
     return;
   }
   sel16_lds_sync();

@@ -464,7 +464,8 @@ def test_statistical_threshold_plan_is_exact(k, monkeypatch):
     np.testing.assert_array_equal(_np(i), ei)
     np.testing.assert_array_equal(_np(s), es)
     reasons = layer.last_redo_reasons()
-    assert layer.last_redo_count() == reasons["list_overflow"] + reasons["statistical_bound"] + reasons["retained_set"]
+    assert layer.last_redo_count() == reasons["list_overflow"] + reasons["statistical_bound"]   # (large retained
+    # sets are re-scored inside the list kernel since round 3: counted, not redone)
     if not env or env == {"TFRS_TOPK_STAT": "0"}:
       assert layer.last_redo_count() == 0, reasons
     if env.get("TFRS_TOPK_STAT_PFAIL") == "0.4" and k >= 10:

@@ -517,11 +517,12 @@ def test_f16_prefilter_error_bound(d, filter_mode):
   assert acc_err.max() <= d * 2.0 ** -22, acc_err.max()  # accumulation-order term of the bound
 
 
-def test_f16_prefilter_adversarial_norms_and_clusters():
+def test_f16_prefilter_adversarial_norms_and_clusters(filter_mode):
   """Cases built to stress the prefilter's margins: one huge-norm outlier row per stage
   (inflates the per-stage bound), near-duplicate candidates whose scores differ in the last
-  bits (the whole cluster sits inside the 2*eps band: retention overflow -> exact redo), and a
-  zero query."""
+  bits (the whole cluster of 600 sits inside the 2*eps band: since round 3 such a retained set is
+  re-scored in full inside the list kernel instead of sending the query to the corpus-wide exact
+  redo -- half of the batch is aligned with the cluster), and a zero query."""
   ftk = _layers()
   rng = np.random.default_rng(17)
   n, nq, d, k = 60000, 64, 64, 100
@@ -532,10 +533,41 @@ def test_f16_prefilter_adversarial_norms_and_clusters():
   q = (rng.normal(size=(nq, d)) / 8).astype(np.float32)
   q[0] = base[0] * 3.0                                   # query aligned with the cluster
   q[1] = 0.0
+  q[2:34] = base * rng.uniform(1.0, 4.0, size=(32, 1)).astype(np.float32)
   es, ei = o_topk.brute_force(q, c, k)
-  s, i = ftk.BruteForce(k=k).index(c)(q)
+  layer = ftk.BruteForce(k=k).index(c)
+  s, i = layer(q)
   np.testing.assert_array_equal(_np(i), ei)
   np.testing.assert_array_equal(_np(s), es)
+  reasons = layer.last_redo_reasons()
+  assert layer.last_redo_count() == reasons["list_overflow"] + reasons["statistical_bound"], reasons
+
+
+def test_near_duplicate_cluster_is_rescored_in_place(filter_mode):
+  """A cluster of 400 near-duplicates (relative differences 1e-6: all within 2 eps of each other,
+  not bit-identical, so the distinct-row index does not apply) spread over a shuffled 300k-row index,
+  40 queries aligned with it: their retained sets exceed K + band.  Round 2 sent each such query to
+  the corpus-wide exact recompute; the list kernel now re-scores the whole retained set in LDS --
+  results `==` the oracle, the reason counter records them, nothing is redone."""
+  if filter_mode == "f32":
+    pytest.skip("property of the fp16-prefiltered path")
+  ftk = _layers()
+  rng = np.random.default_rng(29)
+  n, nq, d, k = 300_000, 96, 64, 100
+  c = (rng.normal(size=(n, d)) / 8).astype(np.float32)
+  base = (rng.normal(size=(1, d)) / 8).astype(np.float32)
+  rows = rng.choice(n, size=400, replace=False)
+  c[rows] = base + (1e-7 * rng.normal(size=(400, d))).astype(np.float32)      # every row distinct
+  q = (rng.normal(size=(nq, d)) / 8).astype(np.float32)
+  q[:40] = base * rng.uniform(1.0, 4.0, size=(40, 1)).astype(np.float32)
+  es, ei = o_topk.brute_force(q, c, k)
+  layer = ftk.BruteForce(k=k).index(c)
+  assert layer._dup is None
+  s, i = layer(q)
+  np.testing.assert_array_equal(_np(i), ei)
+  np.testing.assert_array_equal(_np(s), es)
+  reasons = layer.last_redo_reasons()
+  assert reasons["retained_set"] >= 40 and layer.last_redo_count() == 0, reasons
 
 
 _SHARD_WORKER = r"""
