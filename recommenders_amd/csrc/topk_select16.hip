@@ -81,7 +81,9 @@ __global__ void __launch_bounds__(kSel16Waves * 64) bin_threshold_kernel(
     }
     key[s] = (b0 < n_bins) ? f32_orderable(m) : 0u;
   }
-  const uint32_t kth = radix_kth(key, k);
+  // (slots past the last bin hold no keys: at configs[1] 355 bins occupy 6 of the 16 slots)
+  const int nslots = min(kSlots, (n_bins + group * 64 - 1) / (group * 64));
+  const uint32_t kth = radix_kth(key, k, nslots);
   if (lane == 0) {
     const float eps = qk[row] * norm_max[0] + kF16Tiny;
     // no K-th value (fewer than K bins, or -inf scores): no bound
