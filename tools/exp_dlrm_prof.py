@@ -1,5 +1,5 @@
 import os, sys, time, json
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import recommenders_amd as tfrs
 from recommenders_amd.experimental.models import ranking as rk

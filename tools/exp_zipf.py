@@ -13,7 +13,7 @@ for distinct in (100_000, 10_000):
   w = 1.0 / torch.arange(1, distinct + 1, device=dev, dtype=torch.float64)
   pick = torch.multinomial(w, N, replacement=True, generator=g)
   c = base[:distinct][pick].contiguous()
-  index = ftk.BruteForce(k=K).index(c)
+  index = ftk.BruteForce(k=K, dedup=(os.environ.get("TFRS_EXP_DEDUP", "0") == "1")).index(c)
   for mode in ("f16", "f32"):
     os.environ["TFRS_TOPK_FILTER"] = mode
     for _ in range(2): index(queries)

@@ -12,7 +12,7 @@ w = 1.0 / torch.arange(1, distinct + 1, device=dev, dtype=torch.float64)
 pick = torch.multinomial(w, N, replacement=True, generator=g)
 c = base[:distinct][pick].contiguous()
 torch.cuda.synchronize(); print("corpus ok", flush=True)
-index = ftk.BruteForce(k=K).index(c)
+index = ftk.BruteForce(k=K, dedup=False).index(c)
 torch.cuda.synchronize(); print("index ok", flush=True)
 for mode in sys.argv[1:]:
   os.environ["TFRS_TOPK_FILTER"] = mode

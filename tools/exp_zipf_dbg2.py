@@ -11,7 +11,7 @@ distinct = 100_000
 w = 1.0 / torch.arange(1, distinct + 1, device=dev, dtype=torch.float64)
 pick = torch.multinomial(w, N, replacement=True, generator=g)
 c = base[:distinct][pick].contiguous()
-index = ftk.BruteForce(k=K).index(c)
+index = ftk.BruteForce(k=K, dedup=False).index(c)
 torch.cuda.synchronize(); print("index ok", flush=True)
 n = int(sys.argv[1])
 keep = []
