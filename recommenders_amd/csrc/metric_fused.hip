@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256, 1) rank_count_kernel(const RankCountArgs 
   // row loads, then the LDS writes -- two memory round trips per workgroup, not two per iteration
   // (a runtime-bound loop serialised them: 23 us at the quickstart shapes instead of 5).
   if ((d & 3) == 0) {
-    constexpr int kIter = G::kMaxTiles * 32 * (DP / 4) / 256;
+    constexpr int kIter = (G::kMaxTiles * 32 * (DP / 4) + 255) / 256;   // (7 tiles: not a multiple of 256 at DP <= 16)
     const int cpr = d >> 2;                             // float4 chunks per row
     int64_t src[kIter];
 #pragma unroll
@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(256, 1) rank_count_kernel(const RankCountArgs 
       }
     }
   } else {
-    constexpr int kIter = G::kMaxTiles * 32 * DP / 256;
+    constexpr int kIter = (G::kMaxTiles * 32 * DP + 255) / 256;
     constexpr int kBatch = kIter < 16 ? kIter : 16;      // 16 loads in flight per thread
 #pragma unroll 1
     for (int i0 = 0; i0 < kIter; i0 += kBatch) {

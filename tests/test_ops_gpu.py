@@ -290,7 +290,8 @@ def test_factorized_top_k_metric_golden():
     assert float(metric.result()[0]) == pytest.approx(g["expected_metric"])
 
 
-@pytest.mark.parametrize("d,id_dtype", [(64, np.int64), (7, np.int32), (20, np.int64), (128, np.int32)])
+@pytest.mark.parametrize("d,id_dtype", [(64, np.int64), (7, np.int32), (20, np.int64), (128, np.int32),
+                                        (4, np.int64), (8, np.int32), (12, np.int64), (16, np.int32), (100, np.int64)])
 def test_factorized_top_k_rank_count_paths_vs_oracle(d, id_dtype):
   """Score-based `FactorizedTopK.update_state` over a raw dataset counts the corpus rows that beat
   the positive instead of retrieving a sorted top-K (metrics/factorized_top_k.py:133-137,181-192).
