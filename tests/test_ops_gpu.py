@@ -358,6 +358,26 @@ def test_factorized_top_k_rank_count_paths_vs_oracle(d, id_dtype):
     np.testing.assert_allclose([float(v) for v in metric.result()], want_keep, rtol=2e-6)
 
 
+def test_factorized_top_k_rank_counts_large_blocks_and_batches():
+  """The rank-count sweep at its other geometries: one 50 000-row candidate block (7 tiles per
+  workgroup, ragged last split) with 3 000 queries, and 20 000 queries (more than one 16 384-query
+  batch of the update kernel's load loop) against small blocks -- per-k accuracies vs the oracle."""
+  import recommenders_amd as tfrs
+  rng = np.random.default_rng(77)
+  ks = [1, 5, 10, 50, 100]
+  for nq, nc, d, bs in ((3000, 50_000, 32, 50_000), (20_000, 3000, 16, 1000)):
+    cand = rng.normal(size=(nc, d)).astype(np.float32)
+    q = rng.normal(size=(nq, d)).astype(np.float32)
+    true_c = cand[rng.integers(0, nc, size=nq)]
+    true_c[::5] += 0.1
+    hits = o_metrics.update(lambda qq, kk: o_topk.brute_force(qq, cand, kk), ks, q, true_c)
+    want = [float(h.mean()) for h in hits]
+    blocks = [_t(cand[lo:lo + bs]) for lo in range(0, nc, bs)]
+    metric = tfrs.metrics.FactorizedTopK(candidates=blocks, ks=ks)
+    metric.update_state(_t(q), _t(true_c))
+    np.testing.assert_allclose([float(v) for v in metric.result()], want, rtol=2e-6)
+
+
 # ---------------------------------------------------------------------------- cross / dcn
 def test_cross_golden():
   from recommenders_amd.layers.feature_interaction import Cross, MultiLayerDCN
