@@ -125,25 +125,46 @@ __global__ void __launch_bounds__(256) segment_reduce_kernel(
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
     float wsum = 0.f, wsq = 0.f;
-    for (int64_t p = lo; p < hi; ++p) {
-      const int64_t id = load_id<IdT>(ids, p);
-      const float w = weights ? weights[p] : 1.0f;
-      wsum += w;
-      wsq = __builtin_fmaf(w, w, wsq);
-      if (id < 0 || id >= vocab) {
-        if (err_flag) *err_flag = 1;
-        continue;
+    // Eight entries per round: their ids and weights are fetched as one batch of independent loads,
+    // then their row pieces as a second batch, then they are added IN ORDER (the float32 sum order
+    // stays the id order).  The entry-at-a-time loop it replaces paid two dependent memory round
+    // trips per entry (0.61 of HBM at bags of 8).
+    constexpr int kU = 8;
+    for (int64_t p0 = lo; p0 < hi; p0 += kU) {
+      int64_t idv[kU];
+      float wv[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const bool in = p0 + u < hi;
+        idv[u] = in ? load_id<IdT>(ids, p0 + u) : (int64_t)-1;
+        wv[u] = in ? (weights ? weights[p0 + u] : 1.0f) : 0.0f;
       }
-      if (VEC == 4) {
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        const f4 ev = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(table) + (id * per_row + c));
-        const float4 e = make_float4(ev[0], ev[1], ev[2], ev[3]);
-        acc[0] += w * e.x;
-        acc[1 % VEC] += w * e.y;
-        acc[2 % VEC] += w * e.z;
-        acc[3 % VEC] += w * e.w;
-      } else {
-        acc[0] += w * table[id * per_row + c];
+      float ev[kU][VEC];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const bool ok = idv[u] >= 0 && idv[u] < vocab;
+        if (VEC == 4) {
+          typedef float f4 __attribute__((ext_vector_type(4)));
+          f4 x = {0.f, 0.f, 0.f, 0.f};
+          if (ok) x = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(table) + (idv[u] * per_row + c));
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) ev[u][v] = x[v];
+        } else {
+          ev[u][0] = ok ? table[idv[u] * per_row + c] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (p0 + u < hi) {
+          wsum += wv[u];
+          wsq = __builtin_fmaf(wv[u], wv[u], wsq);
+          if (idv[u] < 0 || idv[u] >= vocab) {
+            if (err_flag) *err_flag = 1;
+          } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] += wv[u] * ev[u][v];
+          }
+        }
       }
     }
     float scale = 1.0f;
