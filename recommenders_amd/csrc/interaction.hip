@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "mfma_tile.h"
 
@@ -1110,6 +1111,318 @@ __global__ void __launch_bounds__(512) dot_interaction_bwd_pc_kernel(
 }
 
 
+// Backward, fifth generation (d == 32, default): split-fp16 matrix cores on the PACKED gradient.
+//
+// What round 3 measured on the producer / consumer kernel above (tools/exp_dotbwd.py, 2.0 ms box):
+// the consumers alone (no loads, no unpack) take 1.57 ms -- 52 dependent v_mfma_f32_32x32x2_f32 per
+// 32-row block with the LDS reads of the next quad between them run at ~100 cycles each, not 64 --
+// and the producers alone 1.2 ms: one sample of loads in flight per CU, issued right before the
+// barrier and awaited right after it, so every sample pays a full HBM round trip.  Both are removed:
+//
+// * operands are split fp16 (x s = hi + lo, s a power of two PER SAMPLE from the sample's max |dy| and
+//   max |x|): a 32 x 32 x 16 step is three v_mfma_f32_32x32x16_f16 (hi hi + hi lo + lo hi), 96 pipe cycles
+//   for what took 512; 21 MFMAs per row block and sample instead of 52 four-times-slower ones;
+// * the gradient stays PACKED in LDS (row-major lower triangle, as it arrives): element p of the
+//   sample becomes ONE 32-bit word {hi, lo} at word p -- one ds_write_b128 per four elements, no
+//   transposed second copy (half of the old kernel's LDS cycles were its bank conflicts), 25 KB per
+//   sample instead of 45.  The wave that owns rows [32 rb, 32 rb + 32) of dX = (L + L^T) X walks the 16-wide
+//   k steps s of S = L + L^T: below the diagonal block (s < 2 rb) its A operand is 8 consecutive words of
+//   its row of L; right of it (s >= 2 rb + 2) it is 8 words of COLUMN i of L -- lanes are consecutive
+//   columns, so those reads are conflict-free too; the two steps on the diagonal take both, masked,
+//   added as packed halves (which also doubles the diagonal for self_interaction);
+// * the producers keep NSET samples in registers: at iteration n they convert sample n + 1 (its scale
+//   was reduced into LDS during iteration n - 1: wave max by DPP, one ds_max per wave), issue the
+//   loads of sample n + NSET + 1 into the registers that freed, and reduce the max of sample n + 2 --
+//   so NSET - 2 samples of 16-byte loads are always in flight and none is awaited for two iterations;
+// * the per-iteration barrier waits for LDS only, not for the consumers' dX stores.
+//
+// The region of an L buffer beyond the packed triangle is zero-filled once and never written: reads of
+// rows / columns >= f land there.  X is words [16 NSTEP][32], rows >= f zero.  Error: 2^-22 per
+// operand element relative to the element (for elements within 2^-18 of the sample maximum), the
+// dropped lo lo term 2^-22: the same bound as the forward's.
+template <int NSTEP, int NEY, int NSET>
+__global__ void __launch_bounds__(512) dot_interaction_bwd_h16_kernel(
+    const float *__restrict__ x, const float *__restrict__ dout, int64_t batch, int f, int self,
+    int lwords, float *__restrict__ dx, int64_t dout_stride) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t w_lds[];
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int D = 32, NEX = 4;             // f * 32 / 4 / 256 <= 4 chunks of X per producer thread
+  constexpr int XW = 16 * NSTEP * D;         // X words per buffer
+  const int bufw = lwords + XW;
+  uint32_t *const slots = w_lds + 2 * bufw;  // [4][2]: bits of max |dy|, max |x| of samples n % 4
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int out_dim = self ? f * (f + 1) / 2 : f * (f - 1) / 2;
+  const int xn = f * D;
+  const int64_t stride = gridDim.x;
+  const int64_t b0 = blockIdx.x;
+  for (int e = tid; e < 2 * bufw + 8; e += 512) w_lds[e] = 0u;
+  __syncthreads();
+  // LDS-only barrier: every wave's LDS traffic is complete, global stores may still be in flight
+  auto lds_barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  auto pow2_exponent = [](uint32_t mbits) __attribute__((always_inline)) -> int {
+    // k with max * 2^k in [2^12, 2^13): twice that (the diagonal) stays far below fp16's 65504
+    int k = 139 - (int)(mbits >> 23);
+    return (mbits > 0u && mbits < 0x7F800000u) ? min(max(k, -60), 60) : 0;
+  };
+
+  if (wave >= 4) {
+    // ---------------------------------- producers ----------------------------------
+    const int ptid = tid & 255;
+    const int tail_e = (out_dim & 3) ? ((out_dim >> 2) >> 8) : -1;   // the chunk that straddles the end of the row
+    f32x4 ry[NSET][NEY], rx[NSET][NEX];
+    auto load_sample = [&](f32x4 (&gy)[NEY], f32x4 (&gx)[NEX], int64_t b) __attribute__((always_inline)) {
+      const bool live = b < batch;                                   // uniform
+      const float *dy = dout + (live ? b : 0) * dout_stride;         // (rows of a wider matrix: _bwd_strided)
+      const float *xb = x + (live ? b : 0) * (int64_t)xn;
+#pragma unroll
+      for (int e = 0; e < NEY; ++e) {
+        const int p0 = 4 * (ptid + 256 * e);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+          if (e == tail_e) {                                         // uniform: no read past the row's end
+            if (p0 + 3 < out_dim) {
+              v = __builtin_nontemporal_load(reinterpret_cast<const f4u *>(dy + p0));
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                if (p0 + c < out_dim) v[c] = dy[p0 + c];
+            }
+          } else if (p0 < out_dim) {
+            v = __builtin_nontemporal_load(reinterpret_cast<const f4u *>(dy + p0));
+          }
+        }
+        gy[e] = v;
+      }
+#pragma unroll
+      for (int e = 0; e < NEX; ++e) {
+        const int p0 = 4 * (ptid + 256 * e);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (live && p0 < xn) v = *reinterpret_cast<const f4u *>(xb + p0);
+        gx[e] = v;
+      }
+    };
+    auto max_sample = [&](const f32x4 (&gy)[NEY], const f32x4 (&gx)[NEX], int slot) __attribute__((always_inline)) {
+      float my = 0.0f, mx = 0.0f;
+#pragma unroll
+      for (int e = 0; e < NEY; ++e)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) my = fmaxf(my, __builtin_fabsf(gy[e][c]));
+#pragma unroll
+      for (int e = 0; e < NEX; ++e)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mx = fmaxf(mx, __builtin_fabsf(gx[e][c]));
+      my = wave_max_nonneg(my);
+      mx = wave_max_nonneg(mx);
+      if (lane == 0) {
+        atomicMax(&slots[2 * slot], __float_as_uint(my));
+        atomicMax(&slots[2 * slot + 1], __float_as_uint(mx));
+      }
+    };
+    auto split_word = [](float a) __attribute__((always_inline)) -> uint32_t {
+      union {
+        h16x2 h;
+        uint32_t u;
+      } w;
+      const _Float16 hi = (_Float16)a;      // round to nearest even
+      w.h[0] = hi;
+      w.h[1] = (_Float16)(a - (float)hi);
+      return w.u;
+    };
+    auto convert_sample = [&](const f32x4 (&gy)[NEY], const f32x4 (&gx)[NEX], int slot, uint32_t *buf)
+        __attribute__((always_inline)) {
+      const float sy = __uint_as_float((uint32_t)(127 + pow2_exponent(slots[2 * slot])) << 23);
+      const float sx = __uint_as_float((uint32_t)(127 + pow2_exponent(slots[2 * slot + 1])) << 23);
+#pragma unroll
+      for (int e = 0; e < NEY; ++e) {
+        const int p0 = 4 * (ptid + 256 * e);
+        if (p0 < out_dim) {
+          u32x4 w;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) w[c] = split_word(gy[e][c] * sy);
+          *reinterpret_cast<u32x4 *>(buf + p0) = w;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < NEX; ++e) {
+        const int p0 = 4 * (ptid + 256 * e);
+        if (p0 < xn) {
+          u32x4 w;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) w[c] = split_word(gx[e][c] * sx);
+          *reinterpret_cast<u32x4 *>(buf + lwords + p0) = w;
+        }
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < NSET; ++s) load_sample(ry[s], rx[s], b0 + s * stride);
+    max_sample(ry[0], rx[0], 0);
+    lds_barrier();
+    convert_sample(ry[0], rx[0], 0, w_lds);
+    load_sample(ry[0], rx[0], b0 + NSET * stride);
+    max_sample(ry[1 % NSET], rx[1 % NSET], 1);
+    lds_barrier();
+    for (int64_t n = 0;; n += NSET) {
+      bool done = false;
+#pragma unroll
+      for (int u = 0; u < NSET; ++u) {
+        const int64_t bn = b0 + (n + u) * stride;
+        if (bn >= batch) {
+          done = true;
+          break;
+        }
+        const int sl = (int)((n + u) & 3);
+        convert_sample(ry[(u + 1) % NSET], rx[(u + 1) % NSET], (sl + 1) & 3, w_lds + ((n + u + 1) & 1) * bufw);
+        load_sample(ry[(u + 1) % NSET], rx[(u + 1) % NSET], bn + (NSET + 1) * stride);
+        max_sample(ry[(u + 2) % NSET], rx[(u + 2) % NSET], (sl + 2) & 3);
+        if (ptid == 0) {                       // the slot of sample n + 3: last read two iterations ago
+          slots[2 * ((sl + 3) & 3)] = 0u;
+          slots[2 * ((sl + 3) & 3) + 1] = 0u;
+        }
+        lds_barrier();
+      }
+      if (done) break;
+    }
+    return;
+  }
+
+  // ---------------------------------- consumers ----------------------------------
+  const int r = lane & 31, h = lane >> 5, P = 8 * h;
+  const int i = wave * 32 + r;                 // this lane's row of S (A operand) = its column of L
+  const int ic = min(i, f);                    // rows >= f read the zero region behind the triangle
+  const int ra = (self ? ic * (ic + 1) / 2 : ic * (ic - 1) / 2) + P;   // L[ic][P + m] = word ra + m
+  // L[m + P][i] = word tri(m + P) + self (m + P) + i = ca + m cb + tri(m), tri(t) = t (t - 1) / 2
+  const int ca = i + P * (P - 1) / 2 + self * P, cb = P + self;
+  const int xa = lwords + 32 * P + r;          // X[P + m][r] = word xa + 32 m
+  uint32_t mlo[2][8], mup[2][8];               // the two steps on the diagonal: which slots are below / above it
+#pragma unroll
+  for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = r - P - 16 * ss;           // slot u is column q of the lane's row, relative to the diagonal
+      mlo[ss][u] = (u <= q + self - 1) ? 0xFFFFFFFFu : 0u;
+      mup[ss][u] = (u >= q - self + 1) ? 0xFFFFFFFFu : 0u;
+    }
+  const bool active = wave * 32 < f;
+  auto halves = [](const uint32_t (&w)[8], h16x8 *hi, h16x8 *lo) __attribute__((always_inline)) {
+    union {
+      uint32_t u[4];
+      h16x8 v;
+    } a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a.u[e] = __builtin_amdgcn_perm(w[2 * e + 1], w[2 * e], 0x05040100u);   // {hi of 2e, hi of 2e + 1}
+      b.u[e] = __builtin_amdgcn_perm(w[2 * e + 1], w[2 * e], 0x07060302u);   // {lo of 2e, lo of 2e + 1}
+    }
+    *hi = a.v;
+    *lo = b.v;
+  };
+  auto consume = [&](auto rbc, const uint32_t *buf, int slot, int64_t b) __attribute__((always_inline)) {
+    constexpr int RB = decltype(rbc)::value;
+    const int k = pow2_exponent(slots[2 * slot]) + pow2_exponent(slots[2 * slot + 1]);
+    const float inv = __uint_as_float((uint32_t)(127 - k) << 23);
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      uint32_t w[8], xw[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xw[u] = buf[xa + 32 * (16 * s + u)];
+      {
+        if (s < 2 * RB) {                      // below the diagonal block: 8 consecutive words of row i
+#pragma unroll
+          for (int u = 0; u < 8; ++u) w[u] = buf[ra + 16 * s + u];
+        } else if (s < 2 * RB + 2) {           // on it: row part + column part (the diagonal from both)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int m = 16 * s + u;
+            union {
+              uint32_t u32;
+              h16x2 h2;
+            } lo_w, up_w, sum;
+            lo_w.u32 = buf[ra + m] & mlo[s - 2 * RB][u];
+            up_w.u32 = buf[ca + __mul24(m, cb) + m * (m - 1) / 2] & mup[s - 2 * RB][u];
+            sum.h2 = lo_w.h2 + up_w.h2;
+            w[u] = sum.u32;
+          }
+        } else {                               // right of it: 8 words of column i of L (rows 16 s + P + u)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int m = 16 * s + u;
+            w[u] = buf[ca + __mul24(m, cb) + m * (m - 1) / 2];
+          }
+        }
+      }
+      h16x8 ah, al, xh, xl;
+      halves(w, &ah, &al);
+      halves(xw, &xh, &xl);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc, 0, 0, 0);
+    }
+    float *db = dx + b * (int64_t)xn;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int orow = RB * 32 + tile_row_of_reg(q, h);
+      if (orow < f) db[orow * D + r] = acc[q] * inv;
+    }
+  };
+  auto consumer_loop = [&](auto rbc) __attribute__((always_inline)) {
+    lds_barrier();
+    lds_barrier();
+    for (int64_t n = 0;; ++n) {
+      const int64_t bn = b0 + n * stride;
+      if (bn >= batch) break;
+      if (active) consume(rbc, w_lds + (n & 1) * bufw, (int)(n & 3), bn);
+      lds_barrier();
+    }
+  };
+  switch (wave) {
+    case 0: consumer_loop(std::integral_constant<int, 0>{}); break;
+    case 1: consumer_loop(std::integral_constant<int, 1>{}); break;
+    case 2: consumer_loop(std::integral_constant<int, 2>{}); break;
+    default: consumer_loop(std::integral_constant<int, 3>{}); break;
+  }
+}
+
+// L words per buffer: the packed triangle of 16 NSTEP rows (reads of rows / columns beyond f stay
+// inside the zero region) + one 128-word row of slack for columns >= f
+static int dot_bwd_h16_lwords(int nstep, int self) {
+  const int n = 16 * nstep;
+  return ((self ? n * (n + 1) / 2 : n * (n - 1) / 2) + 128 + 3) & ~3;
+}
+
+template <int NSTEP, int NEY, int NSET>
+static void launch_dot_bwd_h16_v(const float *x, const float *dout, int64_t batch, int f, int self, dim3 grid,
+                                 float *dx, hipStream_t s, int64_t dout_stride) {
+  const int lwords = dot_bwd_h16_lwords(NSTEP, self);
+  const size_t lds = ((size_t)2 * (lwords + 16 * NSTEP * 32) + 8) * sizeof(uint32_t);
+  (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&dot_interaction_bwd_h16_kernel<NSTEP, NEY, NSET>), 160 * 1024);
+  hipLaunchKernelGGL((dot_interaction_bwd_h16_kernel<NSTEP, NEY, NSET>), grid, dim3(512), lds, s, x, dout, batch, f,
+                     self, lwords, dx, dout_stride);
+}
+
+// d == 32, f <= 128: which instantiation covers (f, self), or false
+static bool launch_dot_bwd_h16(const float *x, const float *dout, int64_t batch, int f, int d, int self,
+                               float *dx, hipStream_t s, int64_t dout_stride, bool probe_only = false) {
+  if (d != 32 || f < 2 || f > 128 || batch < 512) return false;
+  const int out_dim = self ? f * (f + 1) / 2 : f * (f - 1) / 2;
+  const int nstep = (f + 15) / 16, ney = ((out_dim + 3) / 4 + 255) / 256;
+  if (ney > 8) return false;                   // f = 128 with self interaction: 8256 pairs
+  if (probe_only) return true;
+  const dim3 grid((unsigned)std::min<int64_t>(batch, 256));
+  const int64_t st = dout_stride ? dout_stride : (int64_t)out_dim;
+  if (nstep <= 4 && ney <= 3) launch_dot_bwd_h16_v<4, 3, 4>(x, dout, batch, f, self, grid, dx, s, st);
+  else if (nstep <= 7 && ney <= 5) launch_dot_bwd_h16_v<7, 5, 4>(x, dout, batch, f, self, grid, dx, s, st);
+  else if (nstep <= 7 && ney <= 6) launch_dot_bwd_h16_v<7, 6, 4>(x, dout, batch, f, self, grid, dx, s, st);
+  else launch_dot_bwd_h16_v<8, 8, 3>(x, dout, batch, f, self, grid, dx, s, st);
+  return true;
+}
+
 template <int MAXE>
 static void launch_dot_bwd_pc_v(const float *x, const float *dout, int64_t batch, int f, int d, int self,
                                 int kh, size_t lds, dim3 grid, float *dx, hipStream_t s, int64_t dout_stride) {
@@ -1153,6 +1466,11 @@ static bool launch_dot_bwd_dense(const float *x, const float *dout, int64_t batc
   const int out_dim = self ? f * (f + 1) / 2 : f * (f - 1) / 2;
   const int maxe = (out_dim + 255) / 256;
   const char *dv = option("TFRS_DOT_BWD");
+  // default: split-fp16 kernel on the packed gradient (d == 32); TFRS_DOT_BWD=pc / dense / gather select
+  // the earlier generations (measurement switches)
+  if (!(dv && (dv[0] == 'd' || dv[0] == 'p')) &&
+      launch_dot_bwd_h16(x, dout, batch, f, d, self, dx, s, dout_stride))
+    return true;
   const size_t lds_pc = 2 * lds + (size_t)2 * (2 * kh * 32) * sizeof(float);
   if (!(dv && dv[0] == 'd') && d <= 32 && lds_pc <= 160 * 1024 && batch >= 512) {
     // producer / consumer kernel: one 8-wave workgroup per CU, double-buffered S and X tiles

@@ -567,6 +567,39 @@ def test_dot_interaction_forward_concat_equals_cat(self_interaction):
     assert torch.allclose(ga, gb, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("f,self_interaction", [(2, False), (3, True), (17, True), (32, False), (33, True), (64, True),
+                                                (65, False), (96, True), (97, False), (101, True), (112, False),
+                                                (113, True), (127, True), (128, False)])
+def test_dot_backward_packed_fp16_kernel_shapes(f, self_interaction):
+  """`dot_interaction_bwd_h16_kernel` (the default backward at D = 32, batch >= 512) at every
+  instantiation and at the edges of its tiling -- feature counts around the 16-wide k steps and the
+  32-row blocks, the last chunk of a packed row cut at 1, 2 and 3 elements, a batch that is neither a
+  multiple of the grid nor of the register-set rotation -- against the float64 oracle on EVERY sample
+  (`layers/feature_interaction/dot_interaction.py:53-104` differentiated).  Samples span eight
+  decades of gradient and input magnitude (the power-of-two scale is per sample), one sample has an
+  all-zero gradient and one an all-zero input."""
+  from oracle import feature_interaction as o_fi
+  from recommenders_amd.layers.feature_interaction import DotInteraction
+  g = torch.Generator(device="cuda").manual_seed(100 * f + int(self_interaction))
+  b, d = 777, 32
+  x = torch.randn((b, f, d), generator=g, device="cuda")
+  x *= torch.exp(4.0 * torch.randn((b, 1, 1), generator=g, device="cuda"))
+  x[5] = 0.0
+  x.requires_grad_(True)
+  pairs = f * (f + 1) // 2 if self_interaction else f * (f - 1) // 2
+  dy = torch.randn((b, pairs), generator=g, device="cuda")
+  dy *= torch.exp(4.0 * torch.randn((b, 1), generator=g, device="cuda"))
+  dy[3] = 0.0
+  out = DotInteraction(self_interaction=self_interaction).forward_stacked(x)
+  out.backward(dy)
+  feats = [_np(x.detach()[:, j, :]) for j in range(f)]
+  dref = o_fi.dot_interaction_grad(feats, _np(dy), self_interaction, False)
+  _, yb = o_fi.dot_interaction_yardsticks(feats, _np(dy), self_interaction, False)
+  assert torch.isfinite(x.grad).all()
+  assert float(x.grad[3].abs().max()) == 0.0 and float(x.grad[5].abs().max()) == 0.0
+  float_gate(f"dot_h16.f{f}.bwd", _np(x.grad), dref, yb, GATE_DOT_C4["bwd"])
+
+
 @pytest.mark.parametrize("f", [122, 123, 128])
 def test_dot_interaction_forward_concat_envelope_edge(f):
   """F = 123..128 at D = 32 are inside the strided forward's envelope but outside the strided
@@ -664,13 +697,15 @@ def _dot_c4_samples(b):
   return np.unique(np.clip(np.r_[spread, edge, extra], 0, b - 1))
 
 
-@pytest.mark.parametrize("variant", ["default", "strided", "dense_bwd", "staged_fwd", "f32_fwd"])
+@pytest.mark.parametrize("variant", ["default", "strided", "pc_bwd", "dense_bwd", "staged_fwd", "f32_fwd"])
 @pytest.mark.parametrize("self_interaction", [False, True])
 def test_dot_interaction_config5_vs_float64(self_interaction, variant, monkeypatch):
   from oracle import feature_interaction as o_fi
   from recommenders_amd.layers.feature_interaction import DotInteraction
   b, f, d = 131072, 101, 32
-  if variant == "dense_bwd":
+  if variant == "pc_bwd":
+    monkeypatch.setenv("TFRS_DOT_BWD", "pc")          # the f32 producer / consumer backward kernel (round 2)
+  elif variant == "dense_bwd":
     monkeypatch.setenv("TFRS_DOT_BWD", "d")           # the single-role dense-S backward kernel
   elif variant == "staged_fwd":
     monkeypatch.setenv("TFRS_DOT_FWD", "staged")      # LDS-staged split-fp16 forward

@@ -44,8 +44,8 @@ for kern in ("direct", "staged", "f32"):   # "direct" = the default (split-fp16 
   emit(op="dot_interaction_fwd", kernel=kern, ms=t * 1e3, gbps=byts / t / 1e9, frac_hbm_peak=byts / t / HBM_PEAK,
        algorithmic_bytes=byts)
 os.environ.pop("TFRS_DOT_FWD")
-for mode in ("pc", "dense", "gather"):
-  os.environ["TFRS_DOT_BWD"] = mode   # "pc" (default kernel): any value not starting with d / g
+for mode in ("h16", "pc", "dense", "gather"):
+  os.environ["TFRS_DOT_BWD"] = mode   # "h16" = the default (split-fp16 MFMA on the packed gradient)
   t = timeit(lambda: _lib.check(lib.tfrs_dot_interaction_bwd(_lib.ptr(x), _lib.ptr(dout), B, F, D, 0, 0, _lib.ptr(dx), st)),
              iters=6)
   byts = (2 * B * F * D + B * od) * 4
@@ -53,6 +53,8 @@ for mode in ("pc", "dense", "gather"):
        algorithmic_bytes=byts)
 os.environ.pop("TFRS_DOT_BWD")
 del x, out, dout, dx
+if len(sys.argv) > 1 and sys.argv[1] == "dot":
+  sys.exit(0)
 
 # ---- Cross ----
 Bc, dc = (65536, 3456) if not small else (8192, 1024)
