@@ -1172,40 +1172,60 @@ __global__ void __launch_bounds__(512) dot_interaction_bwd_h16_kernel(
   if (wave >= 4) {
     // ---------------------------------- producers ----------------------------------
     const int ptid = tid & 255;
-    const int tail_e = (out_dim & 3) ? ((out_dim >> 2) >> 8) : -1;   // the chunk that straddles the end of the row
     f32x4 ry[NSET][NEY], rx[NSET][NEX];
+    // Every thread ALWAYS issues its NEY + NEX 16-byte loads, at addresses clamped into the row, and
+    // repairs the clamped chunks with selects afterwards: gfx950 counts outstanding loads in order
+    // (vmcnt), so a load inside a branch makes the count unknown to the compiler, which then waits
+    // for ALL loads (vmcnt(0)) wherever it needs one -- the first version of this kernel guarded its
+    // loads with `if (p < out_dim)` and had no prefetch at all (every wait in its ISA was vmcnt(0)).
+    // A clamped chunk holds elements [q, q + 4), q = min(p0, n - 4); element p0 + c is lane value c + (p0 - q).
+    auto shifted = [](f32x4 v, int sft) __attribute__((always_inline)) -> f32x4 {
+      f32x4 o;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = c; k < 4; ++k) t = (sft == k - c) ? v[k] : t;
+        o[c] = t;
+      }
+      return o;
+    };
+    const int ey_fix = (((out_dim - 4) >> 2) + 1) >> 8;   // first e with chunks that are clamped (uniform)
+    const int ex_fix = (xn >> 2) >> 8;
     auto load_sample = [&](f32x4 (&gy)[NEY], f32x4 (&gx)[NEX], int64_t b) __attribute__((always_inline)) {
-      const bool live = b < batch;                                   // uniform
-      const float *dy = dout + (live ? b : 0) * dout_stride;         // (rows of a wider matrix: _bwd_strided)
-      const float *xb = x + (live ? b : 0) * (int64_t)xn;
+      const int64_t bl = b < batch ? b : batch - 1;                  // past the end: reload the last sample (unused)
+      const float *dy = dout + bl * dout_stride;                     // (rows of a wider matrix: _bwd_strided)
+      const float *xb = x + bl * (int64_t)xn;
 #pragma unroll
       for (int e = 0; e < NEY; ++e) {
         const int p0 = 4 * (ptid + 256 * e);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (live) {
-          if (e == tail_e) {                                         // uniform: no read past the row's end
-            if (p0 + 3 < out_dim) {
-              v = __builtin_nontemporal_load(reinterpret_cast<const f4u *>(dy + p0));
-            } else {
-#pragma unroll
-              for (int c = 0; c < 4; ++c)
-                if (p0 + c < out_dim) v[c] = dy[p0 + c];
-            }
-          } else if (p0 < out_dim) {
-            v = __builtin_nontemporal_load(reinterpret_cast<const f4u *>(dy + p0));
-          }
-        }
-        gy[e] = v;
+        gy[e] = __builtin_nontemporal_load(reinterpret_cast<const f4u *>(dy + min(p0, out_dim - 4)));
       }
 #pragma unroll
       for (int e = 0; e < NEX; ++e) {
         const int p0 = 4 * (ptid + 256 * e);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (live && p0 < xn) v = *reinterpret_cast<const f4u *>(xb + p0);
-        gx[e] = v;
+        gx[e] = *reinterpret_cast<const f4u *>(xb + min(p0, xn - 4));
       }
     };
-    auto max_sample = [&](const f32x4 (&gy)[NEY], const f32x4 (&gx)[NEX], int slot) __attribute__((always_inline)) {
+    // after the loads have landed: chunks cut by (or beyond) the row's end
+    auto repair_sample = [&](f32x4 (&gy)[NEY], f32x4 (&gx)[NEX]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int e = 0; e < NEY; ++e) {
+        if (e >= ey_fix) {                                           // uniform
+          const int p0 = 4 * (ptid + 256 * e);
+          gy[e] = shifted(gy[e], p0 - min(p0, out_dim - 4));
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < NEX; ++e) {
+        if (e >= ex_fix) {
+          const int p0 = 4 * (ptid + 256 * e);
+          gx[e] = shifted(gx[e], p0 - min(p0, xn - 4));
+        }
+      }
+    };
+    auto max_sample = [&](f32x4 (&gy)[NEY], f32x4 (&gx)[NEX], int slot) __attribute__((always_inline)) {
+      repair_sample(gy, gx);
       float my = 0.0f, mx = 0.0f;
 #pragma unroll
       for (int e = 0; e < NEY; ++e)
@@ -1238,12 +1258,12 @@ __global__ void __launch_bounds__(512) dot_interaction_bwd_h16_kernel(
       const float sx = __uint_as_float((uint32_t)(127 + pow2_exponent(slots[2 * slot + 1])) << 23);
 #pragma unroll
       for (int e = 0; e < NEY; ++e) {
-        const int p0 = 4 * (ptid + 256 * e);
-        if (p0 < out_dim) {
+        const int w0 = 4 * (ptid + 256 * e);   // elements beyond the row's end are 0 (repair_sample)
+        if (w0 < out_dim) {
           u32x4 w;
 #pragma unroll
           for (int c = 0; c < 4; ++c) w[c] = split_word(gy[e][c] * sy);
-          *reinterpret_cast<u32x4 *>(buf + p0) = w;
+          *reinterpret_cast<u32x4 *>(buf + w0) = w;
         }
       }
 #pragma unroll
@@ -1265,26 +1285,33 @@ __global__ void __launch_bounds__(512) dot_interaction_bwd_h16_kernel(
     load_sample(ry[0], rx[0], b0 + NSET * stride);
     max_sample(ry[1 % NSET], rx[1 % NSET], 1);
     lds_barrier();
-    for (int64_t n = 0;; n += NSET) {
-      bool done = false;
-#pragma unroll
-      for (int u = 0; u < NSET; ++u) {
-        const int64_t bn = b0 + (n + u) * stride;
-        if (bn >= batch) {
-          done = true;
-          break;
-        }
-        const int sl = (int)((n + u) & 3);
-        convert_sample(ry[(u + 1) % NSET], rx[(u + 1) % NSET], (sl + 1) & 3, w_lds + ((n + u + 1) & 1) * bufw);
-        load_sample(ry[(u + 1) % NSET], rx[(u + 1) % NSET], bn + (NSET + 1) * stride);
-        max_sample(ry[(u + 2) % NSET], rx[(u + 2) % NSET], (sl + 2) & 3);
-        if (ptid == 0) {                       // the slot of sample n + 3: last read two iterations ago
-          slots[2 * ((sl + 3) & 3)] = 0u;
-          slots[2 * ((sl + 3) & 3) + 1] = 0u;
-        }
-        lds_barrier();
+    // iteration n = n0 + U of the steady state; U is a compile-time constant so that the register sets
+    // rotate by NAME (no copies) and every load has a fixed position in the vmcnt order
+    auto iteration = [&](auto uc, int64_t n0) __attribute__((always_inline)) {
+      constexpr int U = decltype(uc)::value;
+      const int64_t n = n0 + U;
+      const int sl = (int)(n & 3);
+      convert_sample(ry[(U + 1) % NSET], rx[(U + 1) % NSET], (sl + 1) & 3, w_lds + ((n + 1) & 1) * bufw);
+      load_sample(ry[(U + 1) % NSET], rx[(U + 1) % NSET], b0 + (n + NSET + 1) * stride);
+      max_sample(ry[(U + 2) % NSET], rx[(U + 2) % NSET], (sl + 2) & 3);
+      if (ptid == 0) {                         // the slot of sample n + 3: last read two iterations ago
+        slots[2 * ((sl + 3) & 3)] = 0u;
+        slots[2 * ((sl + 3) & 3) + 1] = 0u;
       }
-      if (done) break;
+      lds_barrier();
+    };
+    const int64_t total = (batch - b0 + stride - 1) / stride;   // samples of this workgroup (>= 1)
+    int64_t n = 0;
+    for (; n + NSET <= total; n += NSET) {
+      iteration(std::integral_constant<int, 0>{}, n);
+      iteration(std::integral_constant<int, 1>{}, n);
+      iteration(std::integral_constant<int, 2>{}, n);
+      if constexpr (NSET == 4) iteration(std::integral_constant<int, 3>{}, n);
+    }
+    if (n < total) iteration(std::integral_constant<int, 0>{}, n);
+    if (n + 1 < total) iteration(std::integral_constant<int, 1>{}, n);
+    if constexpr (NSET == 4) {
+      if (n + 2 < total) iteration(std::integral_constant<int, 2>{}, n);
     }
     return;
   }
@@ -1320,64 +1347,86 @@ __global__ void __launch_bounds__(512) dot_interaction_bwd_h16_kernel(
     *hi = a.v;
     *lo = b.v;
   };
-  auto consume = [&](auto rbc, const uint32_t *buf, int slot, int64_t b) __attribute__((always_inline)) {
+  auto consume = [&](auto rbc, const uint32_t *xbuf, int slot, int64_t b) __attribute__((always_inline)) {
     constexpr int RB = decltype(rbc)::value;
+    const uint32_t *buf = xbuf;
     const int k = pow2_exponent(slots[2 * slot]) + pow2_exponent(slots[2 * slot + 1]);
     const float inv = __uint_as_float((uint32_t)(127 - k) << 23);
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-#pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
-      uint32_t w[8], xw[8];
+    // the words of step s: X[16 s + P + u][r] and S[i][16 s + P + u]
+    auto fetch = [&](auto sc, uint32_t (&w)[8], uint32_t (&xw)[8]) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc)::value;
 #pragma unroll
       for (int u = 0; u < 8; ++u) xw[u] = buf[xa + 32 * (16 * s + u)];
-      {
-        if (s < 2 * RB) {                      // below the diagonal block: 8 consecutive words of row i
+      if constexpr (s < 2 * RB) {              // below the diagonal block: 8 consecutive words of row i
 #pragma unroll
-          for (int u = 0; u < 8; ++u) w[u] = buf[ra + 16 * s + u];
-        } else if (s < 2 * RB + 2) {           // on it: row part + column part (the diagonal from both)
+        for (int u = 0; u < 8; ++u) w[u] = buf[ra + 16 * s + u];
+      } else if constexpr (s < 2 * RB + 2) {   // on it: row part + column part (the diagonal from both)
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int m = 16 * s + u;
-            union {
-              uint32_t u32;
-              h16x2 h2;
-            } lo_w, up_w, sum;
-            lo_w.u32 = buf[ra + m] & mlo[s - 2 * RB][u];
-            up_w.u32 = buf[ca + __mul24(m, cb) + m * (m - 1) / 2] & mup[s - 2 * RB][u];
-            sum.h2 = lo_w.h2 + up_w.h2;
-            w[u] = sum.u32;
-          }
-        } else {                               // right of it: 8 words of column i of L (rows 16 s + P + u)
+        for (int u = 0; u < 8; ++u) {
+          constexpr int ss = s - 2 * RB;
+          const int m = 16 * s + u;
+          union {
+            uint32_t u32;
+            h16x2 h2;
+          } lo_w, up_w, sum;
+          lo_w.u32 = buf[ra + m] & mlo[ss][u];
+          up_w.u32 = buf[ca + __mul24(m, cb) + m * (m - 1) / 2] & mup[ss][u];
+          sum.h2 = lo_w.h2 + up_w.h2;
+          w[u] = sum.u32;
+        }
+      } else {                                 // right of it: 8 words of column i of L (rows 16 s + P + u)
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int m = 16 * s + u;
-            w[u] = buf[ca + __mul24(m, cb) + m * (m - 1) / 2];
-          }
+        for (int u = 0; u < 8; ++u) {
+          const int m = 16 * s + u;
+          w[u] = buf[ca + __mul24(m, cb) + m * (m - 1) / 2];
         }
       }
+    };
+    // one step ahead: the LDS reads of step s + 1 are issued before the permutes and MFMAs of step s
+    uint32_t w[2][8], xw[2][8];
+    fetch(std::integral_constant<int, 0>{}, w[0], xw[0]);
+    auto step = [&](auto sc) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc)::value;
+      if constexpr (s + 1 < NSTEP) fetch(std::integral_constant<int, s + 1>{}, w[(s + 1) & 1], xw[(s + 1) & 1]);
       h16x8 ah, al, xh, xl;
-      halves(w, &ah, &al);
-      halves(xw, &xh, &xl);
+      halves(w[s & 1], &ah, &al);
+      halves(xw[s & 1], &xh, &xl);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc, 0, 0, 0);
-    }
+    };
+    step(std::integral_constant<int, 0>{});
+    if constexpr (NSTEP > 1) step(std::integral_constant<int, 1>{});
+    if constexpr (NSTEP > 2) step(std::integral_constant<int, 2>{});
+    if constexpr (NSTEP > 3) step(std::integral_constant<int, 3>{});
+    if constexpr (NSTEP > 4) step(std::integral_constant<int, 4>{});
+    if constexpr (NSTEP > 5) step(std::integral_constant<int, 5>{});
+    if constexpr (NSTEP > 6) step(std::integral_constant<int, 6>{});
+    if constexpr (NSTEP > 7) step(std::integral_constant<int, 7>{});
+    // lane = dim, register q = row: a store instruction writes two whole 128-byte rows.  (The transposed
+    // product X^T S would leave four 16-byte stores per wave instead of sixteen 4-byte ones, but each
+    // of them touches 32 rows 32 bytes at a time: measured 1.31 against 1.11 ms.)
     float *db = dx + b * (int64_t)xn;
+    if (RB * 32 + 32 <= f) {                   // uniform: a whole row block
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int orow = RB * 32 + tile_row_of_reg(q, h);
-      if (orow < f) db[orow * D + r] = acc[q] * inv;
+      for (int q = 0; q < 16; ++q) db[(RB * 32 + tile_row_of_reg(q, h)) * D + r] = acc[q] * inv;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int orow = RB * 32 + tile_row_of_reg(q, h);
+        if (orow < f) db[orow * D + r] = acc[q] * inv;
+      }
     }
   };
   auto consumer_loop = [&](auto rbc) __attribute__((always_inline)) {
     lds_barrier();
     lds_barrier();
-    for (int64_t n = 0;; ++n) {
-      const int64_t bn = b0 + n * stride;
-      if (bn >= batch) break;
-      if (active) consume(rbc, w_lds + (n & 1) * bufw, (int)(n & 3), bn);
+    const int64_t total = (batch - b0 + stride - 1) / stride;
+    for (int64_t n = 0; n < total; ++n) {
+      if (active) consume(rbc, w_lds + (n & 1) * bufw, (int)(n & 3), b0 + n * stride);
       lds_barrier();
     }
   };
@@ -1411,6 +1460,7 @@ static bool launch_dot_bwd_h16(const float *x, const float *dout, int64_t batch,
                                float *dx, hipStream_t s, int64_t dout_stride, bool probe_only = false) {
   if (d != 32 || f < 2 || f > 128 || batch < 512) return false;
   const int out_dim = self ? f * (f + 1) / 2 : f * (f - 1) / 2;
+  if (out_dim < 4) return false;               // (a 16-byte load must fit inside a packed row)
   const int nstep = (f + 15) / 16, ney = ((out_dim + 3) / 4 + 255) / 256;
   if (ney > 8) return false;                   // f = 128 with self interaction: 8256 pairs
   if (probe_only) return true;
