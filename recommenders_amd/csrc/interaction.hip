@@ -690,6 +690,292 @@ __global__ void __launch_bounds__(256, BLOCKS) dot_interaction_f16x3_direct_kern
   }
 }
 
+// Forward, producer / consumer form (d == 32, default): the split-fp16 products of the kernel above with
+// the loads and the stores on DIFFERENT waves.  In the direct kernel every wave loads its sample, waits,
+// multiplies and stores: gfx950 has ONE in-order counter (vmcnt) for a wave's loads and stores, and loads
+// and stores complete out of order with respect to each other, so a wave that has stores in flight
+// cannot wait for a prefetched load without waiting for all of its stores -- the direct kernel has no
+// prefetch for that reason and each of its 12 waves per CU pays the HBM round trip of its sample with
+// nothing else to do (0.50-0.54 of HBM).  Here (the structure of dot_interaction_bwd_h16_kernel): waves 4-7
+// only load -- NSET samples in registers, 16-byte loads that are never awaited for two iterations --
+// convert sample n + 1 to {hi, lo} fp16 with ONE power-of-two scale per sample (wave max by DPP, one
+// ds_max per wave, reduced one iteration earlier) and write it to LDS as operand fragments; waves 0-3
+// only multiply and store: they read ready 16-byte fragments (row r: eight 16-byte pieces, 4 hi + 4 lo,
+// piece p stored at slot p ^ ((r >> 1) & 7) so that the 16 lanes of a ds_read_b128 group hit 16 different
+// bank groups), run the 32 x 32 blocks of the lower triangle (block k = tri(bi) + bj on wave k mod 4) and
+// store from the accumulators exactly as the direct kernel does.
+template <int NB, int NSET>
+__global__ void __launch_bounds__(512, 4) dot_interaction_fwd_pc_kernel(const float *__restrict__ x, int64_t batch,
+                                                                        int f, int self, float *__restrict__ out,
+                                                                        int64_t out_stride) {
+  extern __shared__ __attribute__((aligned(16))) char f_lds[];
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  constexpr int D = 32;
+  constexpr int NEX = (NB * 32 * D / 4 + 255) / 256;   // 16-byte chunks of X per producer thread
+  constexpr int BUFB = NB * 32 * 128;                  // bytes per buffer: 128 per row (hi plane, lo plane)
+  const int stage_bytes = ((((self ? f * (f + 1) / 2 : f * (f - 1) / 2) * 4) + 15) & ~15) + 1024;   // row image + dummy words
+  uint32_t *const slots = reinterpret_cast<uint32_t *>(f_lds + 2 * BUFB);   // bits of max |x| of samples n % 4
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xn = f * D;
+  const int64_t stride = gridDim.x;
+  const int64_t b0 = blockIdx.x;
+  for (int e = tid; e < (2 * BUFB + 16) / 4; e += 512) reinterpret_cast<uint32_t *>(f_lds)[e] = 0u;   // (the row images need no init)
+  __syncthreads();
+  auto lds_barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  auto pow2_exponent = [](uint32_t mbits) __attribute__((always_inline)) -> int {
+    int k = 139 - (int)(mbits >> 23);          // max * 2^k in [2^12, 2^13)
+    return (mbits > 0u && mbits < 0x7F800000u) ? min(max(k, -60), 60) : 0;
+  };
+  const int64_t total = (batch - b0 + stride - 1) / stride;   // samples of this workgroup (>= 1)
+
+  if (wave >= 4) {
+    // ---------------------------------- producers ----------------------------------
+    const int ptid = tid & 255;
+    f32x4 rx[NSET][NEX];
+    // loads are unconditional (clamped into the sample) so that the compiler can count them: see
+    // dot_interaction_bwd_h16_kernel
+    auto load_sample = [&](f32x4 (&gx)[NEX], int64_t b) __attribute__((always_inline)) {
+      const float *xb = x + (b < batch ? b : batch - 1) * (int64_t)xn;
+#pragma unroll
+      for (int e = 0; e < NEX; ++e) {
+        const int p0 = 4 * (ptid + 256 * e);
+        gx[e] = *reinterpret_cast<const f4u *>(xb + min(p0, xn - 4));
+      }
+    };
+    auto max_sample = [&](f32x4 (&gx)[NEX], int slot) __attribute__((always_inline)) {
+      float mx = 0.0f;
+#pragma unroll
+      for (int e = 0; e < NEX; ++e) {
+        if (4 * (ptid + 256 * e) >= xn) gx[e] = f32x4{0.f, 0.f, 0.f, 0.f};   // chunks beyond the sample
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mx = fmaxf(mx, __builtin_fabsf(gx[e][c]));
+      }
+      mx = wave_max_nonneg(mx);
+      if (lane == 0) atomicMax(&slots[slot], __float_as_uint(mx));
+    };
+    // chunk c = ptid + 256 e is row c >> 3, dims 4 (c & 7) ..+3: 8 bytes of the hi plane and 8 of the lo plane
+    const int d0 = (ptid & 7) * 4, sw = (ptid >> 4) & 7;   // (row >> 1) & 7 does not depend on e: rows advance by 32
+    const int wr_hi = (ptid >> 3) * 128 + ((((d0 >> 3)) ^ sw) << 4) + ((d0 >> 2) & 1) * 8;
+    const int wr_lo = (ptid >> 3) * 128 + (((4 + (d0 >> 3)) ^ sw) << 4) + ((d0 >> 2) & 1) * 8;
+    auto convert_sample = [&](const f32x4 (&gx)[NEX], int slot, char *buf) __attribute__((always_inline)) {
+      const float sx = __uint_as_float((uint32_t)(127 + pow2_exponent(slots[slot])) << 23);
+#pragma unroll
+      for (int e = 0; e < NEX; ++e) {
+        if (4 * (ptid + 256 * e) < xn) {
+          float a[4];
+          _Float16 hh[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            a[c] = gx[e][c] * sx;
+            hh[c] = (_Float16)a[c];
+          }
+          u32x2 vh, vl;
+          union {
+            h16x2 h;
+            uint32_t u;
+          } q0, q1;
+          q0.h[0] = hh[0];
+          q0.h[1] = hh[1];
+          q1.h[0] = hh[2];
+          q1.h[1] = hh[3];
+          vh[0] = q0.u;
+          vh[1] = q1.u;
+          vl[0] = pack_h2(a[0] - (float)hh[0], a[1] - (float)hh[1]);
+          vl[1] = pack_h2(a[2] - (float)hh[2], a[3] - (float)hh[3]);
+          *reinterpret_cast<u32x2 *>(buf + wr_hi + e * 32 * 128) = vh;
+          *reinterpret_cast<u32x2 *>(buf + wr_lo + e * 32 * 128) = vl;
+        }
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < NSET; ++s) load_sample(rx[s], b0 + s * stride);
+    max_sample(rx[0], 0);
+    lds_barrier();
+    convert_sample(rx[0], 0, f_lds);
+    load_sample(rx[0], b0 + NSET * stride);
+    max_sample(rx[1 % NSET], 1);
+    lds_barrier();
+    auto iteration = [&](auto uc, int64_t n0) __attribute__((always_inline)) {
+      constexpr int U = decltype(uc)::value;
+      const int64_t n = n0 + U;
+      const int sl = (int)(n & 3);
+      convert_sample(rx[(U + 1) % NSET], (sl + 1) & 3, f_lds + ((n + 1) & 1) * BUFB);
+      load_sample(rx[(U + 1) % NSET], b0 + (n + NSET + 1) * stride);
+      max_sample(rx[(U + 2) % NSET], (sl + 2) & 3);
+      if (ptid == 0) slots[(sl + 3) & 3] = 0u;     // the slot of sample n + 3: last read two iterations ago
+      lds_barrier();
+    };
+    int64_t n = 0;
+    for (; n + NSET <= total; n += NSET) {
+      iteration(std::integral_constant<int, 0>{}, n);
+      iteration(std::integral_constant<int, 1>{}, n);
+      iteration(std::integral_constant<int, 2>{}, n);
+      if constexpr (NSET == 4) iteration(std::integral_constant<int, 3>{}, n);
+    }
+    if (n < total) iteration(std::integral_constant<int, 0>{}, n);
+    if (n + 1 < total) iteration(std::integral_constant<int, 1>{}, n);
+    if constexpr (NSET == 4) {
+      if (n + 2 < total) iteration(std::integral_constant<int, 2>{}, n);
+    }
+    return;
+  }
+
+  // ---------------------------------- consumers ----------------------------------
+  const int r = lane & 31, h = lane >> 5;
+  const int rsw = (r >> 1) & 7;
+  int frag_off[2][2];                            // [k step t][hi, lo]: byte offset of the lane's 16-byte piece in its row
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    frag_off[t][0] = r * 128 + (((2 * t + h) ^ rsw) << 4);
+    frag_off[t][1] = r * 128 + (((4 + 2 * t + h) ^ rsw) << 4);
+  }
+  // The packed row of a sample leaves through LDS.  A 64-lane 4-byte store moves 256 bytes for the same
+  // address work as a 16-byte store that moves 1 KiB, and the 160 4-byte stores per sample of the direct
+  // kernel cost about as much as everything else together (measured on this kernel: 1.22 ms with them,
+  // 0.74 without).  The accumulators are written into an LDS image of the row (lanes are consecutive
+  // columns: conflict-free 128-byte runs; a lane whose element does not exist -- above the diagonal, rows
+  // >= f -- writes to a per-lane dummy word, so there is no exec masking), and at the NEXT iteration the
+  // four waves stream the finished image out with 16-byte stores, 1 KiB per instruction.  The per-lane LDS
+  // offsets of a wave's blocks do not depend on the sample and are computed once.
+  constexpr int NBLK = NB * (NB + 1) / 2, MB = (NBLK + 3) / 4;
+  const int out_dim = self ? f * (f + 1) / 2 : f * (f - 1) / 2;
+  const int n4 = out_dim >> 2;                   // whole 16-byte chunks of a packed row
+  char *const stage0 = f_lds + 2 * BUFB + 16;
+  auto consumer_loop = [&](auto wc) __attribute__((always_inline)) {
+    constexpr int W = decltype(wc)::value;
+    int soff[MB][16];                            // byte offset of acc[q] of the wave's idx-th block in the row image
+    uint32_t anyv[MB];                           // bit q: some lane stores acc[q]
+    {
+      int idx = 0;
+#pragma unroll
+      for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+        for (int bj = 0; bj <= bi; ++bj) {
+          if (((bi * (bi + 1) / 2 + bj) & 3) != W) continue;
+          const int row0 = bi * 32 + 4 * h;
+          const int tri0 = self ? row0 * (row0 + 1) / 2 : row0 * (row0 - 1) / 2;
+          uint32_t any = 0u;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int dr = (q & 3) + 8 * (q >> 2);
+            const int i = row0 + dr, j = bj * 32 + r;
+            const bool keep = i < f && (self ? j <= i : j < i);
+            // tri(row0 + dr) - tri(row0) = dr * row0 + dr (dr -+ 1) / 2
+            soff[idx][q] = keep ? 4 * (tri0 + j + dr * row0 + (self ? dr * (dr + 1) / 2 : dr * (dr - 1) / 2))
+                                : stage_bytes - 1024 + 4 * (W * 64 + lane);
+            any |= (__ballot(keep) != 0ull ? 1u : 0u) << q;
+          }
+          anyv[idx] = any;
+          ++idx;
+        }
+    }
+    // sample m's finished image -> global: chunk c = 256 e + 64 W + lane
+    // sample m's finished image -> global, in rounds of three 16-byte chunks per lane (chunk c = 768 k + 256 e +
+    // 64 W + lane): a round's LDS reads are issued before a block's fragment reads and its stores after
+    // the block's MFMAs, so that the store queue never holds up the products
+    auto copy_reads = [&](const char *stage, int k, f32x4 (&v)[3]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int e = 0; e < 3; ++e)
+        v[e] = *reinterpret_cast<const f32x4 *>(stage + 16 * min(768 * k + 256 * e + 64 * W + lane, n4 - 1));
+    };
+    auto copy_stores = [&](float *ob, int k, const f32x4 (&v)[3]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int c = 768 * k + 256 * e + 64 * W + lane;
+        if (c < n4) *reinterpret_cast<f4u *>(ob + 4 * c) = v[e];
+      }
+    };
+    auto copy_tail = [&](const char *stage, float *ob) __attribute__((always_inline)) {
+      if ((out_dim & 3) != 0 && W == ((n4 >> 6) & 3)) {   // the last 1-3 elements: one lane
+        if (lane == (n4 & 63)) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            if (4 * n4 + c < out_dim) ob[4 * n4 + c] = *reinterpret_cast<const float *>(stage + 16 * n4 + 4 * c);
+        }
+      }
+    };
+    auto copy_out = [&](const char *stage, int64_t m) __attribute__((always_inline)) {
+      float *ob = out + (b0 + m * stride) * out_stride;
+      for (int k = 0; 768 * k < n4; ++k) {
+        f32x4 v[3];
+        copy_reads(stage, k, v);
+        copy_stores(ob, k, v);
+      }
+      copy_tail(stage, ob);
+    };
+    auto body = [&](auto pc, int64_t n) __attribute__((always_inline)) {
+      constexpr int PAR = decltype(pc)::value;
+      const char *buf = f_lds + PAR * BUFB;
+      char *stage = stage0 + PAR * stage_bytes;
+      // (spreading the copy rounds between the blocks -- reads before a block's fragments, stores after its
+      // MFMAs -- was measured 30 % slower than copying first)
+      if (n > 0) copy_out(stage0 + (1 - PAR) * stage_bytes, n - 1);
+      const int k2 = 2 * pow2_exponent(slots[n & 3]);
+      const float unscale = __uint_as_float((uint32_t)(127 - k2) << 23);
+      int idx = 0;
+#pragma unroll
+      for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+        for (int bj = 0; bj <= bi; ++bj) {
+          if (((bi * (bi + 1) / 2 + bj) & 3) != W) continue;   // compile time: this wave's blocks
+          const uint32_t any = anyv[idx];
+          if (any != 0u) {                                     // uniform (row blocks >= f have nothing to store)
+            h16x8 fa[2][2], fb[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int pl = 0; pl < 2; ++pl) {
+                fa[t][pl] = *reinterpret_cast<const h16x8 *>(buf + bi * 32 * 128 + frag_off[t][pl]);
+                fb[t][pl] = *reinterpret_cast<const h16x8 *>(buf + bj * 32 * 128 + frag_off[t][pl]);
+              }
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t][0], fb[t][0], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t][0], fb[t][1], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t][1], fb[t][0], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              if (any & (1u << q)) *reinterpret_cast<float *>(stage + soff[idx][q]) = acc[q] * unscale;
+          }
+          ++idx;
+        }
+      lds_barrier();
+    };
+    lds_barrier();
+    lds_barrier();
+    for (int64_t n = 0; n < total; n += 2) {
+      body(std::integral_constant<int, 0>{}, n);
+      if (n + 1 < total) body(std::integral_constant<int, 1>{}, n + 1);
+    }
+    copy_out(stage0 + ((total - 1) & 1) * stage_bytes, total - 1);
+  };
+  switch (wave) {
+    case 0: consumer_loop(std::integral_constant<int, 0>{}); break;
+    case 1: consumer_loop(std::integral_constant<int, 1>{}); break;
+    case 2: consumer_loop(std::integral_constant<int, 2>{}); break;
+    default: consumer_loop(std::integral_constant<int, 3>{}); break;
+  }
+}
+
+template <int NB>
+static void launch_dot_fwd_pc(const float *x, int64_t batch, int f, int self, float *out, hipStream_t s,
+                              int64_t out_stride) {
+  const int out_dim_ = self ? f * (f + 1) / 2 : f * (f - 1) / 2;
+  const size_t lds = (size_t)2 * NB * 32 * 128 + 16 + (size_t)2 * (((out_dim_ * 4 + 15) & ~15) + 1024);
+  (void)ensure_dynamic_lds(reinterpret_cast<const void *>(&dot_interaction_fwd_pc_kernel<NB, 4>), 80 * 1024);
+  const char *gv = option("TFRS_DOT_FWD_GRID");
+  const dim3 grid((unsigned)std::min<int64_t>(batch, gv ? atoi(gv) : 512));   // two workgroups per CU
+  hipLaunchKernelGGL((dot_interaction_fwd_pc_kernel<NB, 4>), grid, dim3(512), lds, s, x, batch, f, self, out, out_stride);
+}
+
 template <int DP, int NB>
 static bool launch_dot_mfma_nb(const float *x, int64_t batch, int f, int d, int self, int skip,
                                float *out, hipStream_t s, int64_t out_stride) {
@@ -707,7 +993,16 @@ static bool launch_dot_mfma_nb(const float *x, int64_t batch, int f, int d, int 
     // TFRS_DOT_FWD=f32 keeps the exact-f32 MFMA chain (measurement / comparison switch)
     const char *fv = option("TFRS_DOT_FWD");
     if constexpr (DP % 16 == 0 && NB * (DP / 2) <= 96) {   // (beyond that the raw + hi + lo operands spill)
-      if (!(fv && (fv[0] == 'f' || fv[0] == 's'))) {   // default: direct stores
+      if constexpr (DP == 32) {
+        // default at d == 32: loads and stores on different waves; TFRS_DOT_FWD=direct / staged / f32 select
+        // the earlier generations (measurement switches)
+        // (one row block, F <= 32, would leave three of the four product waves idle: 0.205 against 0.141 ms at F = 27)
+        if (!fv && d == 32 && NB >= 2 && batch >= 512) {
+          launch_dot_fwd_pc<NB>(x, batch, f, self, out, s, strided ? out_stride : (int64_t)out_dim);
+          return true;
+        }
+      }
+      if (!(fv && (fv[0] == 'f' || fv[0] == 's'))) {   // direct stores
         const dim3 gd((unsigned)std::min<int64_t>((batch + 3) / 4, 256 * 8));
         // three workgroups per CU: 142 VGPRs, no scratch (four would spill 16 registers: 1.18 vs 1.06 ms)
         hipLaunchKernelGGL((dot_interaction_f16x3_direct_kernel<DP, NB, 3>), gd, dim3(256), 0, s, x, batch, f, d, self, out,

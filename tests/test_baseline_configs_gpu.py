@@ -570,9 +570,9 @@ def test_dot_interaction_forward_concat_equals_cat(self_interaction):
 @pytest.mark.parametrize("f,self_interaction", [(2, False), (3, True), (17, True), (32, False), (33, True), (64, True),
                                                 (65, False), (96, True), (97, False), (101, True), (112, False),
                                                 (113, True), (127, True), (128, False)])
-def test_dot_backward_packed_fp16_kernel_shapes(f, self_interaction):
-  """`dot_interaction_bwd_h16_kernel` (the default backward at D = 32, batch >= 512) at every
-  instantiation and at the edges of its tiling -- feature counts around the 16-wide k steps and the
+def test_dot_producer_consumer_kernels_shapes(f, self_interaction):
+  """`dot_interaction_fwd_pc_kernel` and `dot_interaction_bwd_h16_kernel` (the defaults at D = 32, batch >= 512) at every
+  instantiation and at the edges of their tilings -- feature counts around the 16-wide k steps and the
   32-row blocks, the last chunk of a packed row cut at 1, 2 and 3 elements, a batch that is neither a
   multiple of the grid nor of the register-set rotation -- against the float64 oracle on EVERY sample
   (`layers/feature_interaction/dot_interaction.py:53-104` differentiated).  Samples span eight
@@ -594,7 +594,10 @@ def test_dot_backward_packed_fp16_kernel_shapes(f, self_interaction):
   out.backward(dy)
   feats = [_np(x.detach()[:, j, :]) for j in range(f)]
   dref = o_fi.dot_interaction_grad(feats, _np(dy), self_interaction, False)
-  _, yb = o_fi.dot_interaction_yardsticks(feats, _np(dy), self_interaction, False)
+  yf, yb = o_fi.dot_interaction_yardsticks(feats, _np(dy), self_interaction, False)
+  assert torch.isfinite(out).all() and float(out[5].abs().max()) == 0.0
+  float_gate(f"dot_pc.f{f}.fwd", _np(out.detach()), o_fi.dot_interaction(feats, self_interaction, False), yf,
+             GATE_DOT_C4["fwd"])
   assert torch.isfinite(x.grad).all()
   assert float(x.grad[3].abs().max()) == 0.0 and float(x.grad[5].abs().max()) == 0.0
   float_gate(f"dot_h16.f{f}.bwd", _np(x.grad), dref, yb, GATE_DOT_C4["bwd"])
@@ -697,7 +700,7 @@ def _dot_c4_samples(b):
   return np.unique(np.clip(np.r_[spread, edge, extra], 0, b - 1))
 
 
-@pytest.mark.parametrize("variant", ["default", "strided", "pc_bwd", "dense_bwd", "staged_fwd", "f32_fwd"])
+@pytest.mark.parametrize("variant", ["default", "strided", "pc_bwd", "dense_bwd", "direct_fwd", "staged_fwd", "f32_fwd"])
 @pytest.mark.parametrize("self_interaction", [False, True])
 def test_dot_interaction_config5_vs_float64(self_interaction, variant, monkeypatch):
   from oracle import feature_interaction as o_fi
@@ -707,6 +710,8 @@ def test_dot_interaction_config5_vs_float64(self_interaction, variant, monkeypat
     monkeypatch.setenv("TFRS_DOT_BWD", "pc")          # the f32 producer / consumer backward kernel (round 2)
   elif variant == "dense_bwd":
     monkeypatch.setenv("TFRS_DOT_BWD", "d")           # the single-role dense-S backward kernel
+  elif variant == "direct_fwd":
+    monkeypatch.setenv("TFRS_DOT_FWD", "direct")      # split-fp16 forward, every wave loads and stores (round 2)
   elif variant == "staged_fwd":
     monkeypatch.setenv("TFRS_DOT_FWD", "staged")      # LDS-staged split-fp16 forward
   elif variant == "f32_fwd":

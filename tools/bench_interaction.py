@@ -37,8 +37,11 @@ out = torch.empty((B, od), device=dev)
 dout = torch.randn((B, od), generator=g, device=dev)
 dx = torch.empty_like(x)
 st = _lib.current_stream()
-for kern in ("direct", "staged", "f32"):   # "direct" = the default (split-fp16 MFMA, stores from the accumulators)
-  os.environ["TFRS_DOT_FWD"] = kern
+for kern in ("pc", "direct", "staged", "f32"):   # "pc" = the default (loads and stores on different waves)
+  if kern == "pc":
+    os.environ.pop("TFRS_DOT_FWD", None)
+  else:
+    os.environ["TFRS_DOT_FWD"] = kern
   t = timeit(lambda: _lib.check(lib.tfrs_dot_interaction_fwd(_lib.ptr(x), B, F, D, 0, 0, _lib.ptr(out), st)))
   byts = (B * F * D + B * od) * 4
   emit(op="dot_interaction_fwd", kernel=kern, ms=t * 1e3, gbps=byts / t / 1e9, frac_hbm_peak=byts / t / HBM_PEAK,
