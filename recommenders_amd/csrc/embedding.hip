@@ -738,25 +738,45 @@ __global__ void __launch_bounds__(256) scatter_add_u32_kernel(
        t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = t / per_row;
     const int c = (int)(t - i * per_row);
+    // everything the common case (a run of one) needs goes out in TWO rounds of independent loads:
+    // {id, its neighbours, the position} then {gradient piece, weights, accumulator}
     const uint32_t id = sorted_ids[i];
+    const uint32_t id_prev = i > 0 ? sorted_ids[i - 1] : 0u;
+    const uint32_t id_next = i + 1 < n ? sorted_ids[i + 1] : 0u;
+    const int64_t src0 = perm[i];
     if (id >= vocab) continue;                       // invalid / padding id
-    if (i > 0 && sorted_ids[i - 1] == id) continue;  // not the start of a run
+    if (i > 0 && id_prev == id) continue;            // not the start of a run
     float g[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) g[v] = 0.f;
+    float4 a_pre = make_float4(0.f, 0.f, 0.f, 0.f), w_pre = a_pre;
+    if (VEC == 4 && adagrad) {
+      const int64_t o4 = (int64_t)id * per_row + c;
+      a_pre = reinterpret_cast<const float4 *>(accum)[o4];
+      w_pre = reinterpret_cast<const float4 *>(dst)[o4];
+    }
+    if (VEC == 4) {
+      const float4 e = reinterpret_cast<const float4 *>(grad_out)[src0 * per_row + c];
+      g[0] = 0.f + e.x;          // (0 + x, not x: the sum of a run starts from +0 like the oracle's, -0 gradients included)
+      g[1 % VEC] = 0.f + e.y;
+      g[2 % VEC] = 0.f + e.z;
+      g[3 % VEC] = 0.f + e.w;
+    } else {
+      g[0] = 0.f + grad_out[src0 * per_row + c];
+    }
     // the run's first piece: up to the first multiple of `piece` that is >= i + piece ...
-    int64_t p = i;
+    int64_t p = i + 1;
     const int64_t first_end = ((i + piece - 1) / piece + 1) * (int64_t)piece;
-    for (; p < n && p < first_end && sorted_ids[p] == id; ++p) {
-      const int64_t src = perm[p];
-      if (VEC == 4) {
-        const float4 e = reinterpret_cast<const float4 *>(grad_out)[src * per_row + c];
-        g[0] += e.x;
-        g[1 % VEC] += e.y;
-        g[2 % VEC] += e.z;
-        g[3 % VEC] += e.w;
-      } else {
-        g[0] += grad_out[src * per_row + c];
+    if (p < n && id_next == id) {
+      for (; p < n && p < first_end && sorted_ids[p] == id; ++p) {
+        const int64_t src = perm[p];
+        if (VEC == 4) {
+          const float4 e = reinterpret_cast<const float4 *>(grad_out)[src * per_row + c];
+          g[0] += e.x;
+          g[1 % VEC] += e.y;
+          g[2 % VEC] += e.z;
+          g[3 % VEC] += e.w;
+        } else {
+          g[0] += grad_out[src * per_row + c];
+        }
       }
     }
     // ... then the partial sums of the pieces that continue it (scatter_add_pieces_kernel)
@@ -771,7 +791,7 @@ __global__ void __launch_bounds__(256) scatter_add_u32_kernel(
       float4 *d4 = reinterpret_cast<float4 *>(dst) + o4;
       if (adagrad) {
         float4 *a4 = reinterpret_cast<float4 *>(accum) + o4;
-        float4 a = *a4, w = *d4;
+        float4 a = a_pre, w = w_pre;
         a.x += g[0] * g[0]; a.y += g[1 % VEC] * g[1 % VEC]; a.z += g[2 % VEC] * g[2 % VEC]; a.w += g[3 % VEC] * g[3 % VEC];
         w.x -= lr * g[0] / sqrtf(a.x + eps); w.y -= lr * g[1 % VEC] / sqrtf(a.y + eps);
         w.z -= lr * g[2 % VEC] / sqrtf(a.z + eps); w.w -= lr * g[3 % VEC] / sqrtf(a.w + eps);
