@@ -192,6 +192,99 @@ __global__ void __launch_bounds__(256) g16_prep_rows_ksm_kernel(const float *__r
   }
 }
 
+// Single-pass form of the kernel above for kp <= 4096: the four waves of a workgroup share FOUR rows, wave w
+// holding K blocks [w nq4, (w + 1) nq4) of them in registers (lane roles as above: 4 blocks x 4 rows x 4
+// parts per step, <= 16 steps), so a row is read ONCE -- the two-pass kernel reads it for the maximum and
+// again for the conversion, and at 55 KB per wave the second read comes from HBM (0.51 ms for a
+// 65536 x 3456 activation, 0.88 with the fused multiplier; both operands twice).  The row maxima meet in
+// LDS.  Same scale, same conversion, same image as the two-pass kernel, bit for bit.
+template <int STEPS>
+__global__ void __launch_bounds__(256) g16_prep_rows_ksm1_kernel(const float *__restrict__ x,
+                                                                 const float *__restrict__ mul, int64_t m,
+                                                                 int k, int kp, _Float16 *__restrict__ hi,
+                                                                 _Float16 *__restrict__ lo,
+                                                                 float *__restrict__ inv, int64_t rows_p) {
+  __shared__ float s_mx[4][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // lane roles per step: 8 K blocks x 4 rows x 2 halves of a block (8 floats in, one 16-byte store per image out)
+  const int part = lane & 1, rr = (lane >> 1) & 3, qi = lane >> 3;
+  const int64_t row = (int64_t)blockIdx.x * 4 + rr;
+  const bool valid = row < m;
+  const int64_t rowc = valid ? row : m - 1;     // (loads are unconditional: clamped, zeroed afterwards)
+  const float *xr = x + rowc * (int64_t)k;
+  const float *mr = mul ? mul + rowc * (int64_t)k : nullptr;
+  const bool vec = (k % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                   (!mul || (reinterpret_cast<uintptr_t>(mul) & 15) == 0);
+  const int nq = kp / 16, nq4 = (nq + 3) / 4;   // K blocks of a row, per wave
+  const int q_base = wave * nq4;
+  float v[STEPS][8];
+  float mx = 0.0f;
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) {
+    const int q = q_base + 8 * st + qi;
+    const bool in = 8 * st + qi < nq4 && q < nq && valid;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int c = q * 16 + part * 8 + hf * 4;
+      if (vec) {
+        const int cl = c + 3 < k ? c : (k >= 4 ? k - 4 : 0);
+        f32x4 t = *reinterpret_cast<const f32x4 *>(xr + cl);
+        if (mr) t = t * *reinterpret_cast<const f32x4 *>(mr + cl);
+        const bool ok = in && c + 3 < k;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[st][hf * 4 + u] = ok ? t[u] : 0.0f;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          v[st][hf * 4 + u] = (in && c + u < k) ? (mr ? xr[c + u] * mr[c + u] : xr[c + u]) : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mx = fmaxf(mx, fabsf(v[st][u]));
+  }
+  // lanes of one row: same rr (bits 1, 2) -> reduce over the half bit (1) and the block bits (8, 16, 32)
+  mx = fmaxf(mx, __shfl_xor(mx, 1));
+  mx = fmaxf(mx, __shfl_xor(mx, 8));
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  if (part == 0 && qi == 0) s_mx[wave][rr] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_mx[0][rr], s_mx[1][rr]), fmaxf(s_mx[2][rr], s_mx[3][rr]));
+  float s, iv;
+  g16_scale_of(mx, &s, &iv);
+  if (wave == 0 && part == 0 && qi == 0 && row < rows_p) inv[row] = iv;
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) {
+    const int q = q_base + 8 * st + qi;
+    if (8 * st + qi >= nq4 || q >= nq || row >= rows_p) continue;
+    g16h8 h8, l8;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float sv = v[st][u] * s;
+      h8[u] = (_Float16)sv;
+      l8[u] = (_Float16)(sv - (float)h8[u]);
+    }
+    const int64_t io = ((int64_t)q * rows_p + row) * 16 + part * 8;
+    *reinterpret_cast<g16h8 *>(hi + io) = h8;
+    *reinterpret_cast<g16h8 *>(lo + io) = l8;
+  }
+}
+
+static void g16_launch_prep_rows_ksm(const float *x, const float *mul, int64_t m, int k, int kp, _Float16 *hi,
+                                     _Float16 *lo, float *inv, int64_t rows_p, hipStream_t s) {
+  const int nq4 = (kp / 16 + 3) / 4, steps = (nq4 + 7) / 8;
+  const dim3 grid1((unsigned)(rows_p / 4));
+  if (steps <= 2)
+    hipLaunchKernelGGL(g16_prep_rows_ksm1_kernel<2>, grid1, dim3(256), 0, s, x, mul, m, k, kp, hi, lo, inv, rows_p);
+  else if (steps <= 4)
+    hipLaunchKernelGGL(g16_prep_rows_ksm1_kernel<4>, grid1, dim3(256), 0, s, x, mul, m, k, kp, hi, lo, inv, rows_p);
+  else if (steps <= 8)
+    hipLaunchKernelGGL(g16_prep_rows_ksm1_kernel<8>, grid1, dim3(256), 0, s, x, mul, m, k, kp, hi, lo, inv, rows_p);
+  else
+    hipLaunchKernelGGL(g16_prep_rows_ksm_kernel, dim3((unsigned)(rows_p / 16)), dim3(256), 0, s, x, mul, m, k, kp, hi,
+                       lo, inv, rows_p);
+}
+
 // ---- prep: columns of B (transposed images) ------------------------------------------------
 // B can be as large as A (dW = x^T dz: both operands are [batch, d] activations), so both passes
 // are parallel over K as well: (1) column maxima of 64-column x 1024-row slabs, combined with
@@ -214,11 +307,24 @@ __global__ void __launch_bounds__(256) g16_colmax_kernel(const float *__restrict
   float mx = 0.0f, sum = 0.0f;
   if (n0 + c < n) {
     const int k1 = k0 + kG16Slab < k ? k0 + kG16Slab : k;
-    for (int r = k0 + rg; r < k1; r += 4) {
-      const int64_t o = (int64_t)r * n + n0 + c;
-      const float v = mul ? b[o] * mul[o] : b[o];
-      mx = fmaxf(mx, fabsf(v));
-      sum += v;
+    // eight rows per round, their loads issued together (a loop of one load + one add per iteration is one
+    // memory round trip per iteration: 109 us for the 48 MB weight matrix, 290-380 us for a 906 MB activation);
+    // rows past the slab are clamped for the load and skipped in the sum, whose order is unchanged
+    for (int r0 = k0 + rg; r0 < k1; r0 += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + 4 * u < k1 ? r0 + 4 * u : k1 - 1;
+        const int64_t o = (int64_t)r * n + n0 + c;
+        v[u] = mul ? b[o] * mul[o] : b[o];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (r0 + 4 * u < k1) {
+          mx = fmaxf(mx, fabsf(v[u]));
+          sum += v[u];
+        }
+      }
     }
   }
   red[rg][c] = mx;
@@ -280,14 +386,35 @@ __global__ void __launch_bounds__(256) g16_prep_cols_kernel(const float *__restr
     s_scale[tid] = s;
     if (blockIdx.y == 0) inv[n0 + tid] = iv;
   }
-  for (int e = tid; e < 64 * 64; e += 256) {
-    const int r = e >> 6, cc = e & 63;
-    float v = 0.0f;
-    if (k0 + r < k && n0 + cc < n) {
-      const int64_t o = (int64_t)(k0 + r) * n + n0 + cc;
-      v = mul ? b[o] * mul[o] : b[o];
+  const bool vec = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0) &&
+                   (!mul || (reinterpret_cast<uintptr_t>(mul) & 15) == 0);
+  if (vec) {   // 16 threads x 16 bytes per row, 16 rows per pass: the four passes' loads go out together
+    const int cc = (tid & 15) * 4, rr = tid >> 4;
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = k0 + rr + 16 * u < k ? k0 + rr + 16 * u : k - 1;          // clamped: the load is unconditional
+      const int c4 = n0 + cc < n ? n0 + cc : n - 4;
+      const int64_t o = (int64_t)r * n + c4;
+      v[u] = *reinterpret_cast<const f32x4 *>(b + o);
+      if (mul) v[u] = v[u] * *reinterpret_cast<const f32x4 *>(mul + o);
     }
-    tile[r][cc] = v;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = k0 + rr + 16 * u < k && n0 + cc < n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tile[rr + 16 * u][cc + e] = ok ? v[u][e] : 0.0f;
+    }
+  } else {
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int r = e >> 6, cc = e & 63;
+      float v = 0.0f;
+      if (k0 + r < k && n0 + cc < n) {
+        const int64_t o = (int64_t)(k0 + r) * n + n0 + cc;
+        v = mul ? b[o] * mul[o] : b[o];
+      }
+      tile[r][cc] = v;
+    }
   }
   __syncthreads();
   const int col = tid >> 2, seg = (tid & 3) * 16;   // 16 consecutive k of one output column
@@ -729,8 +856,7 @@ int gemm16_run_ex(const G16Operand &a, const G16Operand &b, int64_t m, int n, in
   hipLaunchKernelGGL(g16_zero_kernel, dim3((unsigned)((L.np + L.mp + 255) / 256)), dim3(256), 0, s,
                      colmax, (int)(L.np + L.mp));   // colmax and colmax_a are adjacent
   if (!a.t && kb == kB16K) {
-    hipLaunchKernelGGL(g16_prep_rows_ksm_kernel, dim3((unsigned)(L.mp / 16)), dim3(256), 0, s, a.p, a.mul, m, k,
-                       L.kp, ah, al, inva, L.mp);
+    g16_launch_prep_rows_ksm(a.p, a.mul, m, k, L.kp, ah, al, inva, L.mp, s);
   } else if (!a.t) {
     hipLaunchKernelGGL(g16_prep_rows_kernel, dim3((unsigned)(L.mp / 4)), dim3(256), 0, s, a.p, a.mul, m, k,
                        L.kp, ah, al, inva, colmax, 0, kb, L.mp);
@@ -749,8 +875,7 @@ int gemm16_run_ex(const G16Operand &a, const G16Operand &b, int64_t m, int n, in
       hipLaunchKernelGGL(g16_colsum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, psum,
                          (int)nslab, n, colsum);
   } else if (kb == kB16K) {   // b.p is [N, K]: already one row per output column
-    hipLaunchKernelGGL(g16_prep_rows_ksm_kernel, dim3((unsigned)(L.np / 16)), dim3(256), 0, s, b.p, b.mul,
-                       (int64_t)n, k, L.kp, bh, bl, invb, L.np);
+    g16_launch_prep_rows_ksm(b.p, b.mul, (int64_t)n, k, L.kp, bh, bl, invb, L.np, s);
   } else {
     hipLaunchKernelGGL(g16_prep_rows_kernel, dim3((unsigned)(L.np / 4)), dim3(256), 0, s, b.p, b.mul,
                        (int64_t)n, k, L.kp, bh, bl, invb, colmax, 0, kb, L.np);
