@@ -342,7 +342,8 @@ __global__ void __launch_bounds__(256) g16_colsum_kernel(const float *__restrict
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= n) return;
   float s = 0.0f;
-  for (int i = 0; i < nslab; ++i) s += psum[(int64_t)i * n + c];
+#pragma unroll 8
+  for (int i = 0; i < nslab; ++i) s += psum[(int64_t)i * n + c];   // (eight loads in flight; the sum order is unchanged)
   out[c] = s;
 }
 
@@ -353,6 +354,7 @@ __global__ void __launch_bounds__(256) g16_splitk_reduce_kernel(const float *__r
   if (i >= count) return;
   if (i + 3 < count) {
     f32x4 acc = *reinterpret_cast<const f32x4 *>(part + i);
+#pragma unroll 4
     for (int s = 1; s < nsplit; ++s) acc = acc + *reinterpret_cast<const f32x4 *>(part + (int64_t)s * count + i);
     *reinterpret_cast<f32x4 *>(out + i) = acc;
   } else {
@@ -460,6 +462,23 @@ __device__ __forceinline__ float g16_epilogue(float v, const float *e0, const fl
     const float dyv = e0[o];
     return v + dyv + diag * dyv * e1[o];
   }
+  return v;
+}
+
+// The same epilogues on VALUES already in registers (e0v = e0[o], e1v = e1[o]); *u receives v + diag * x.
+// The kernels' epilogues first issue ALL the loads of a 32 x 32 accumulator tile (unconditional, at
+// clamped coordinates) and then compute and store: with `if (row >= m) continue; ... = e0[o] ...` inside
+// the loop every load sat in a branch, the compiler could not count the loads in flight and waited for
+// each one (vmcnt(0)) before the next -- 128 serial memory round trips per thread and tile, 1.3 ms of the
+// 5.8 ms Cross forward product at configs[3] (the bias-only product of the same size: 4.45 ms).
+template <int EPI>
+__device__ __forceinline__ float g16_epilogue_v(float v, float e0v, float e1v, float diag, float *u) {
+  if (EPI == kG16EpiCross) {
+    *u = v + diag * e1v;
+    return e0v * *u + e1v;
+  }
+  if (EPI == kG16EpiCrossDx0) return e0v * (v + diag * e1v);
+  if (EPI == kG16EpiCrossDx) return v + e0v + diag * e0v * e1v;
   return v;
 }
 
@@ -585,16 +604,30 @@ __global__ void __launch_bounds__(256, 2) gemm16_kernel(const Gemm16Args g) {
 #pragma unroll
     for (int jn = 0; jn < 2; ++jn) {
       const int col = bn + wn * 64 + jn * 32 + j;
-      if (col >= g.n) continue;
-      const float cs = g.invb[col];
-      const float bias = g.bias ? g.bias[col] : 0.0f;
+      const int colc = col < g.n ? col : g.n - 1;
+      const float cs = g.invb[colc];
+      const float bias = g.bias ? g.bias[colc] : 0.0f;
+      float ra[16], e0v[16], e1v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = bm + wm * 64 + i * 32 + tile_row_of_reg(r, h);
-        if (row >= g.m) continue;
-        const float v = acc[i][jn][r] * (g.inva[row] * cs) + bias;
-        const int64_t o = row * g.n + col;
-        g.out[o] = g16_epilogue<EPI>(v, g.x0, g.x, g.diag, o, g.aux);
+        const int64_t rowc = row < g.m ? row : g.m - 1;
+        const int64_t o = rowc * g.n + colc;
+        ra[r] = g.inva[rowc];
+        e0v[r] = EPI != kG16EpiBias ? g.x0[o] : 0.0f;
+        e1v[r] = EPI != kG16EpiBias ? g.x[o] : 0.0f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = bm + wm * 64 + i * 32 + tile_row_of_reg(r, h);
+        const float v = acc[i][jn][r] * (ra[r] * cs) + bias;
+        float u = 0.0f;
+        const float res = g16_epilogue_v<EPI>(v, e0v[r], e1v[r], g.diag, &u);
+        if (row < g.m && col < g.n) {
+          const int64_t o = row * g.n + col;
+          g.out[o] = res;
+          if (EPI == kG16EpiCross && g.aux) g.aux[o] = u;
+        }
       }
     }
 }
@@ -737,16 +770,30 @@ __global__ void __launch_bounds__(512) gemm16_big_kernel(const Gemm16Args g) {
 #pragma unroll
     for (int jn = 0; jn < 4; ++jn) {
       const int col = bn + wn * 128 + jn * 32 + j;
-      if (col >= g.n) continue;
-      const float cs = g.invb[col];
-      const float bias = g.bias ? g.bias[col] : 0.0f;
+      const int colc = col < g.n ? col : g.n - 1;
+      const float cs = g.invb[colc];
+      const float bias = g.bias ? g.bias[colc] : 0.0f;
+      float ra[16], e0v[16], e1v[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int64_t row = bm + wm * 64 + i * 32 + tile_row_of_reg(q, h);
-        if (row >= g.m) continue;
-        const float v = acc[i][jn][q] * (g.inva[row] * cs) + bias;
-        const int64_t o = row * g.n + col;
-        outp[o] = g16_epilogue<EPI>(v, g.x0, g.x, g.diag, o, g.aux);
+        const int64_t rowc = row < g.m ? row : g.m - 1;
+        const int64_t o = rowc * g.n + colc;
+        ra[q] = g.inva[rowc];
+        e0v[q] = EPI != kG16EpiBias ? g.x0[o] : 0.0f;
+        e1v[q] = EPI != kG16EpiBias ? g.x[o] : 0.0f;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int64_t row = bm + wm * 64 + i * 32 + tile_row_of_reg(q, h);
+        const float v = acc[i][jn][q] * (ra[q] * cs) + bias;
+        float u = 0.0f;
+        const float res = g16_epilogue_v<EPI>(v, e0v[q], e1v[q], g.diag, &u);
+        if (row < g.m && col < g.n) {
+          const int64_t o = row * g.n + col;
+          outp[o] = res;
+          if (EPI == kG16EpiCross && g.aux) g.aux[o] = u;
+        }
       }
     }
 }

@@ -1916,7 +1916,8 @@ __global__ void __launch_bounds__(256) splitk_sum_kernel(const float *__restrict
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
        i += (int64_t)gridDim.x * blockDim.x) {
     float v = bias ? bias[i % n] : 0.0f;
-    for (int z = 0; z < slices; ++z) v += part[(int64_t)z * count + i];
+#pragma unroll 8
+    for (int z = 0; z < slices; ++z) v += part[(int64_t)z * count + i];   // (eight loads in flight; fixed order)
     out[i] = v;
   }
 }
@@ -2028,6 +2029,7 @@ __global__ void __launch_bounds__(256) colsum_reduce_kernel(const float *__restr
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= n) return;
   float s = 0.0f;
+#pragma unroll 8
   for (int i = 0; i < nslab; ++i) s += part[(int64_t)i * n + c];
   out[c] = s;
 }
