@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -129,44 +130,58 @@ __global__ void __launch_bounds__(256) segment_reduce_kernel(
     // then their row pieces as a second batch, then they are added IN ORDER (the float32 sum order
     // stays the id order).  The entry-at-a-time loop it replaces paid two dependent memory round
     // trips per entry (0.61 of HBM at bags of 8).
+    // Every load of a round is UNCONDITIONAL (entries past the segment's end re-read its last entry, bad ids
+    // read row 0; both are discarded by selects afterwards): a load inside a branch -- `in ? ids[p] : -1`,
+    // `if (ok) x = row` -- makes the number of loads in flight unknown to the compiler, which then waits for
+    // every load before issuing the next (vmcnt(0)), and the round is eight serial round trips again.
     constexpr int kU = 8;
-    for (int64_t p0 = lo; p0 < hi; p0 += kU) {
-      int64_t idv[kU];
-      float wv[kU];
+    auto rounds = [&](auto has_w) __attribute__((always_inline)) {
+      for (int64_t p0 = lo; p0 < hi; p0 += kU) {
+        int64_t idv[kU];
+        float wv[kU];
 #pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        const bool in = p0 + u < hi;
-        idv[u] = in ? load_id<IdT>(ids, p0 + u) : (int64_t)-1;
-        wv[u] = in ? (weights ? weights[p0 + u] : 1.0f) : 0.0f;
-      }
-      float ev[kU][VEC];
-#pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        const bool ok = idv[u] >= 0 && idv[u] < vocab;
-        if (VEC == 4) {
-          typedef float f4 __attribute__((ext_vector_type(4)));
-          f4 x = {0.f, 0.f, 0.f, 0.f};
-          if (ok) x = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(table) + (idv[u] * per_row + c));
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) ev[u][v] = x[v];
-        } else {
-          ev[u][0] = ok ? table[idv[u] * per_row + c] : 0.0f;
+        for (int u = 0; u < kU; ++u) {
+          const int64_t p = p0 + u < hi ? p0 + u : hi - 1;
+          idv[u] = load_id<IdT>(ids, p);
+          wv[u] = decltype(has_w)::value ? weights[p] : 1.0f;
         }
-      }
 #pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        if (p0 + u < hi) {
-          wsum += wv[u];
-          wsq = __builtin_fmaf(wv[u], wv[u], wsq);
-          if (idv[u] < 0 || idv[u] >= vocab) {
-            if (err_flag) *err_flag = 1;
+        for (int u = 0; u < kU; ++u) {
+          if (!(p0 + u < hi)) {
+            idv[u] = -1;
+            wv[u] = 0.0f;
+          }
+        }
+        float ev[kU][VEC];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          const bool ok = idv[u] >= 0 && idv[u] < vocab;
+          const int64_t src = (ok ? idv[u] : 0) * per_row + c;
+          if (VEC == 4) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4 x = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(table) + src);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) ev[u][v] = x[v];
           } else {
+            ev[u][0] = table[src];
+          }
+        }
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[v] += wv[u] * ev[u][v];
+        for (int u = 0; u < kU; ++u) {
+          if (p0 + u < hi) {
+            wsum += wv[u];
+            wsq = __builtin_fmaf(wv[u], wv[u], wsq);
+            if (idv[u] < 0 || idv[u] >= vocab) {
+              if (err_flag) *err_flag = 1;
+            } else {
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) acc[v] += wv[u] * ev[u][v];
+            }
           }
         }
       }
-    }
+    };
+    if (weights) rounds(std::true_type{}); else rounds(std::false_type{});
     float scale = 1.0f;
     if (hi > lo) {
       if (combiner == 1) scale = 1.0f / wsum;
@@ -741,8 +756,8 @@ __global__ void __launch_bounds__(256) scatter_add_u32_kernel(
     // everything the common case (a run of one) needs goes out in TWO rounds of independent loads:
     // {id, its neighbours, the position} then {gradient piece, weights, accumulator}
     const uint32_t id = sorted_ids[i];
-    const uint32_t id_prev = i > 0 ? sorted_ids[i - 1] : 0u;
-    const uint32_t id_next = i + 1 < n ? sorted_ids[i + 1] : 0u;
+    const uint32_t id_prev = sorted_ids[i > 0 ? i - 1 : 0];          // (clamped: the loads are unconditional)
+    const uint32_t id_next = sorted_ids[i + 1 < n ? i + 1 : n - 1];
     const int64_t src0 = perm[i];
     if (id >= vocab) continue;                       // invalid / padding id
     if (i > 0 && id_prev == id) continue;            // not the start of a run

@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(256) g16_prep_rows_ksm_kernel(const float *__r
 // again for the conversion, and at 55 KB per wave the second read comes from HBM (0.51 ms for a
 // 65536 x 3456 activation, 0.88 with the fused multiplier; both operands twice).  The row maxima meet in
 // LDS.  Same scale, same conversion, same image as the two-pass kernel, bit for bit.
-template <int STEPS>
+template <int STEPS, bool MUL>
 __global__ void __launch_bounds__(256) g16_prep_rows_ksm1_kernel(const float *__restrict__ x,
                                                                  const float *__restrict__ mul, int64_t m,
                                                                  int k, int kp, _Float16 *__restrict__ hi,
@@ -212,9 +212,7 @@ __global__ void __launch_bounds__(256) g16_prep_rows_ksm1_kernel(const float *__
   const bool valid = row < m;
   const int64_t rowc = valid ? row : m - 1;     // (loads are unconditional: clamped, zeroed afterwards)
   const float *xr = x + rowc * (int64_t)k;
-  const float *mr = mul ? mul + rowc * (int64_t)k : nullptr;
-  const bool vec = (k % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
-                   (!mul || (reinterpret_cast<uintptr_t>(mul) & 15) == 0);
+  const float *mr = MUL ? mul + rowc * (int64_t)k : nullptr;   // (launched only for k % 4 == 0 and 16-byte aligned operands)
   const int nq = kp / 16, nq4 = (nq + 3) / 4;   // K blocks of a row, per wave
   const int q_base = wave * nq4;
   float v[STEPS][8];
@@ -226,18 +224,12 @@ __global__ void __launch_bounds__(256) g16_prep_rows_ksm1_kernel(const float *__
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       const int c = q * 16 + part * 8 + hf * 4;
-      if (vec) {
-        const int cl = c + 3 < k ? c : (k >= 4 ? k - 4 : 0);
-        f32x4 t = *reinterpret_cast<const f32x4 *>(xr + cl);
-        if (mr) t = t * *reinterpret_cast<const f32x4 *>(mr + cl);
-        const bool ok = in && c + 3 < k;
+      const int cl = c + 3 < k ? c : k - 4;   // clamped: every load is issued, nothing waits before the last one
+      f32x4 t = *reinterpret_cast<const f32x4 *>(xr + cl);
+      if (MUL) t = t * *reinterpret_cast<const f32x4 *>(mr + cl);
+      const bool ok = in && c + 3 < k;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[st][hf * 4 + u] = ok ? t[u] : 0.0f;
-      } else {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          v[st][hf * 4 + u] = (in && c + u < k) ? (mr ? xr[c + u] * mr[c + u] : xr[c + u]) : 0.0f;
-      }
+      for (int u = 0; u < 4; ++u) v[st][hf * 4 + u] = ok ? t[u] : 0.0f;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) mx = fmaxf(mx, fabsf(v[st][u]));
@@ -274,12 +266,14 @@ static void g16_launch_prep_rows_ksm(const float *x, const float *mul, int64_t m
                                      _Float16 *lo, float *inv, int64_t rows_p, hipStream_t s) {
   const int nq4 = (kp / 16 + 3) / 4, steps = (nq4 + 7) / 8;
   const dim3 grid1((unsigned)(rows_p / 4));
-  if (steps <= 2)
-    hipLaunchKernelGGL(g16_prep_rows_ksm1_kernel<2>, grid1, dim3(256), 0, s, x, mul, m, k, kp, hi, lo, inv, rows_p);
-  else if (steps <= 4)
-    hipLaunchKernelGGL(g16_prep_rows_ksm1_kernel<4>, grid1, dim3(256), 0, s, x, mul, m, k, kp, hi, lo, inv, rows_p);
-  else if (steps <= 8)
-    hipLaunchKernelGGL(g16_prep_rows_ksm1_kernel<8>, grid1, dim3(256), 0, s, x, mul, m, k, kp, hi, lo, inv, rows_p);
+  const bool vec = (k % 4 == 0) && k >= 4 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                   (!mul || (reinterpret_cast<uintptr_t>(mul) & 15) == 0);
+#define TFRS_KSM1(S, M) \
+  hipLaunchKernelGGL((g16_prep_rows_ksm1_kernel<S, M>), grid1, dim3(256), 0, s, x, mul, m, k, kp, hi, lo, inv, rows_p)
+  if (vec && steps <= 2) { if (mul) TFRS_KSM1(2, true); else TFRS_KSM1(2, false); }
+  else if (vec && steps <= 4) { if (mul) TFRS_KSM1(4, true); else TFRS_KSM1(4, false); }
+  else if (vec && steps <= 8) { if (mul) TFRS_KSM1(8, true); else TFRS_KSM1(8, false); }
+#undef TFRS_KSM1
   else
     hipLaunchKernelGGL(g16_prep_rows_ksm_kernel, dim3((unsigned)(rows_p / 16)), dim3(256), 0, s, x, mul, m, k, kp, hi,
                        lo, inv, rows_p);
