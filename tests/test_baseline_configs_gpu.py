@@ -603,6 +603,32 @@ def test_dot_producer_consumer_kernels_shapes(f, self_interaction):
   float_gate(f"dot_h16.f{f}.bwd", _np(x.grad), dref, yb, GATE_DOT_C4["bwd"])
 
 
+@pytest.mark.parametrize("b", [512, 513, 600, 767, 1024, 1025, 1290, 1537])
+def test_dot_producer_consumer_kernels_pipeline_tails(b):
+  """The software pipelines of the two default DotInteraction kernels rotate four register sets and two
+  LDS buffers by name; a workgroup that owns 2, 3, 4, 5, 6 or 7 samples leaves the unrolled loop through
+  a different remainder path each time (256 workgroups for the backward, 512 for the forward).  Every
+  sample of each batch size against the float64 oracle, F = 101, D = 32, both triangle variants."""
+  from oracle import feature_interaction as o_fi
+  from recommenders_amd.layers.feature_interaction import DotInteraction
+  f, d = 101, 32
+  for self_interaction in (False, True):
+    g = torch.Generator(device="cuda").manual_seed(b + int(self_interaction))
+    x = torch.randn((b, f, d), generator=g, device="cuda")
+    x *= torch.exp(torch.randn((b, 1, 1), generator=g, device="cuda"))
+    x.requires_grad_(True)
+    pairs = f * (f + 1) // 2 if self_interaction else f * (f - 1) // 2
+    dy = torch.randn((b, pairs), generator=g, device="cuda")
+    out = DotInteraction(self_interaction=self_interaction).forward_stacked(x)
+    out.backward(dy)
+    feats = [_np(x.detach()[:, j, :]) for j in range(f)]
+    yf, yb = o_fi.dot_interaction_yardsticks(feats, _np(dy), self_interaction, False)
+    float_gate("dot_tails.fwd", _np(out.detach()), o_fi.dot_interaction(feats, self_interaction, False), yf,
+               GATE_DOT_C4["fwd"])
+    float_gate("dot_tails.bwd", _np(x.grad), o_fi.dot_interaction_grad(feats, _np(dy), self_interaction, False), yb,
+               GATE_DOT_C4["bwd"])
+
+
 @pytest.mark.parametrize("f", [122, 123, 128])
 def test_dot_interaction_forward_concat_envelope_edge(f):
   """F = 123..128 at D = 32 are inside the strided forward's envelope but outside the strided
