@@ -22,6 +22,8 @@
 // workgroup).
 #include <algorithm>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace tfrs {
@@ -81,14 +83,22 @@ __device__ __forceinline__ void hits_fold(const HitsArgs &a, float (*part_s)[17]
   for (int64_t q0 = 0; q0 < a.nq; q0 += kB * NT) {       // trip covers 4096 queries at NT = 256
     uint32_t cv[kB];
     float wv[kB];
+    auto fetch = [&](auto has_w) __attribute__((always_inline)) {   // unconditional loads (clamped), see rank_count_kernel
 #pragma unroll
-    for (int u = 0; u < kB; ++u) {
-      const int64_t q = q0 + u * NT + tid;
-      cv[u] = 0u;
-      if (q < a.nq)
-        cv[u] = a.counts[q];
-      wv[u] = q < a.nq ? (a.weight ? a.weight[q] : 1.0f) : 0.0f;
-    }
+      for (int u = 0; u < kB; ++u) {
+        const int64_t q = q0 + u * NT + tid;
+        const int64_t qc = q < a.nq ? q : a.nq - 1;
+        cv[u] = a.counts[qc];
+        wv[u] = decltype(has_w)::value ? a.weight[qc] : 1.0f;
+      }
+    };
+    if (a.weight) fetch(std::true_type{}); else fetch(std::false_type{});
+#pragma unroll
+    for (int u = 0; u < kB; ++u)
+      if (!(q0 + u * NT + tid < a.nq)) {
+        cv[u] = 0u;
+        wv[u] = 0.0f;
+      }
 #pragma unroll
     for (int u = 0; u < kB; ++u) {
       const int64_t q = q0 + u * NT + tid;
@@ -171,24 +181,34 @@ __global__ void __launch_bounds__(256, 1) rank_count_kernel(const RankCountArgs 
   if ((d & 3) == 0) {
     constexpr int kIter = (G::kMaxTiles * 32 * (DP / 4) + 255) / 256;   // (7 tiles: not a multiple of 256 at DP <= 16)
     const int cpr = d >> 2;                             // float4 chunks per row
+    // Every load is UNCONDITIONAL (dead slots re-read row c0 / table row 0 and are zeroed by selects):
+    // a load inside `if (r < rows ...)` makes the number of loads in flight unknown to the compiler,
+    // which then waits for each one (vmcnt(0)) before the next -- the "two round trips" above were 37.
     int64_t src[kIter];
+    auto load_ids = [&](auto mode) __attribute__((always_inline)) {   // 0: no indirection, 1: int64 ids, 2: int32 ids
 #pragma unroll
-    for (int i = 0; i < kIter; ++i) {
-      const int e = tid + i * 256;
-      const int r = e / (DP / 4), c = e - r * (DP / 4);
-      src[i] = -1;
-      if (r < rows && c < cpr) {
-        const int64_t row = c0 + r;
-        src[i] = !a.ids ? row : (a.ids_i64 ? ((const int64_t *)a.ids)[row] : (int64_t)((const int32_t *)a.ids)[row]);
+      for (int i = 0; i < kIter; ++i) {
+        const int e = tid + i * 256;
+        const int r = e / (DP / 4), c = e - r * (DP / 4);
+        const bool live = r < rows && c < cpr;
+        const int64_t row = c0 + (live ? r : 0);
+        int64_t id = row;
+        if (decltype(mode)::value == 1) id = ((const int64_t *)a.ids)[row];
+        if (decltype(mode)::value == 2) id = (int64_t)((const int32_t *)a.ids)[row];
+        src[i] = (live && id >= 0 && id < a.vocab) ? id : -1;
       }
-    }
+    };
+    if (!a.ids) load_ids(std::integral_constant<int, 0>{});
+    else if (a.ids_i64) load_ids(std::integral_constant<int, 1>{});
+    else load_ids(std::integral_constant<int, 2>{});
     f32x4 v[kIter];
 #pragma unroll
     for (int i = 0; i < kIter; ++i) {
       const int e = tid + i * 256;
       const int c = e % (DP / 4);
-      v[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      if (src[i] >= 0 && src[i] < a.vocab) v[i] = *reinterpret_cast<const f32x4 *>(a.cand + src[i] * d + 4 * c);
+      const bool ok = src[i] >= 0;
+      const f32x4 t = *reinterpret_cast<const f32x4 *>(a.cand + (ok ? src[i] : 0) * d + 4 * (ok ? c : 0));
+      v[i] = ok ? t : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
 #pragma unroll
     for (int i = 0; i < kIter; ++i) {
@@ -231,33 +251,31 @@ __global__ void __launch_bounds__(256, 1) rank_count_kernel(const RankCountArgs 
   // alongside -- instead of one or two per phase; the price is registers, which are free at one
   // workgroup per CU)
   // ---- positives ----------------------------------------------------------------------------------
-  if (tid < 128) {
+  {
     // the d-ordered fma chain from +0 of the scoring kernels (oracle/c/oracle_core.c), so that the
     // positive ties exactly with its own copy among the candidates.  All loads are issued before
-    // the chain (one memory round trip, not d dependent ones); padded features add +0 * 0.
-    const int64_t r = (int64_t)qt * 128 + tid;
+    // the chain and unconditionally (threads 128-255 repeat the work of 0-127: a branch around the
+    // loads would cost the batching); padded features add +0 * 0.
+    const int64_t r = (int64_t)qt * 128 + (tid & 127);
+    const int64_t rc = r < a.nq ? r : a.nq - 1;
     float p = 0.0f;
-    if (r < a.nq) {
-      const float *qr = a.q + r * d, *cr = a.true_c + r * d;
+    {
+      const float *qr = a.q + rc * d, *cr = a.true_c + rc * d;
       if ((d & 3) == 0) {
-        constexpr int kPer = DP / 4;     // every load of both rows in flight at once
+        f32x4 qv[DP / 4], cv[DP / 4];
 #pragma unroll
-        for (int c0 = 0; c0 < DP / 4; c0 += kPer) {
-          f32x4 qv[kPer], cv[kPer];
+        for (int c = 0; c < DP / 4; ++c) {
+          const int off = 4 * c < d ? 4 * c : d - 4;
+          qv[c] = *reinterpret_cast<const f32x4 *>(qr + off);
+          cv[c] = *reinterpret_cast<const f32x4 *>(cr + off);
+        }
 #pragma unroll
-          for (int c = 0; c < kPer; ++c) {
-            const bool in = 4 * (c0 + c) < d;
-            qv[c] = in ? *reinterpret_cast<const f32x4 *>(qr + 4 * (c0 + c)) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            cv[c] = in ? *reinterpret_cast<const f32x4 *>(cr + 4 * (c0 + c)) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-          }
-#pragma unroll
-          for (int c = 0; c < kPer; ++c) {
-            if (4 * (c0 + c) < d) {
-              p = __builtin_fmaf(qv[c][0], cv[c][0], p);
-              p = __builtin_fmaf(qv[c][1], cv[c][1], p);
-              p = __builtin_fmaf(qv[c][2], cv[c][2], p);
-              p = __builtin_fmaf(qv[c][3], cv[c][3], p);
-            }
+        for (int c = 0; c < DP / 4; ++c) {
+          if (4 * c < d) {
+            p = __builtin_fmaf(qv[c][0], cv[c][0], p);
+            p = __builtin_fmaf(qv[c][1], cv[c][1], p);
+            p = __builtin_fmaf(qv[c][2], cv[c][2], p);
+            p = __builtin_fmaf(qv[c][3], cv[c][3], p);
           }
         }
       } else {
@@ -268,8 +286,9 @@ __global__ void __launch_bounds__(256, 1) rank_count_kernel(const RankCountArgs 
           float qv[kChunk], cv[kChunk];
 #pragma unroll
           for (int k = 0; k < kChunk; ++k) {
-            qv[k] = k0 + k < d ? qr[k0 + k] : 0.0f;
-            cv[k] = k0 + k < d ? cr[k0 + k] : 0.0f;
+            const int kc = k0 + k < d ? k0 + k : d - 1;
+            qv[k] = qr[kc];
+            cv[k] = cr[kc];
           }
 #pragma unroll
           for (int k = 0; k < kChunk; ++k)
@@ -277,7 +296,7 @@ __global__ void __launch_bounds__(256, 1) rank_count_kernel(const RankCountArgs 
         }
       }
     }
-    pos_s[tid] = p;
+    if (tid < 128) pos_s[tid] = p;
   }
 
   // ---- this wave's 32 queries -> MFMA B operand ---------------------------------------
@@ -287,8 +306,8 @@ __global__ void __launch_bounds__(256, 1) rank_count_kernel(const RankCountArgs 
   if ((d & 3) == 0) {
 #pragma unroll
     for (int c = 0; c < DP / 4; ++c) {
-      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (qvalid && 4 * c < d) v = *reinterpret_cast<const f32x4 *>(a.q + qrow * d + 4 * c);
+      f32x4 v = *reinterpret_cast<const f32x4 *>(a.q + (qvalid ? qrow : a.nq - 1) * d + (4 * c < d ? 4 * c : d - 4));
+      if (!(qvalid && 4 * c < d)) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       bq[2 * c] = h ? v[1] : v[0];
       bq[2 * c + 1] = h ? v[3] : v[2];
     }

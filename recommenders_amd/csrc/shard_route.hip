@@ -57,7 +57,9 @@ __global__ void __launch_bounds__(256) shard_count_kernel(const void *ids, int64
   for (int u = 0; u < kRouteTile / 256; ++u) {
     const int64_t i = base + u * 256 + threadIdx.x;
     int64_t local;
-    own[u] = i < n ? owner_of<IdT>(ids, i, input_dim, rows_per_rank, &local) : -1;
+    // (the load is unconditional, at a clamped index: inside `i < n ? ... : -1` each of the 16 loads was awaited on its own)
+    const int o = owner_of<IdT>(ids, i < n ? i : n - 1, input_dim, rows_per_rank, &local);
+    own[u] = i < n ? o : -1;
   }
 #pragma unroll
   for (int u = 0; u < kRouteTile / 256; ++u)
@@ -122,8 +124,9 @@ __global__ void __launch_bounds__(256) shard_place_kernel(const void *ids, int64
 #pragma unroll
   for (int u = 0; u < kRouteTile / 256; ++u) {
     const int64_t i = base + (u * 4 + wave) * 64 + lane;
-    loc[u] = -1;
-    own[u] = i < n ? owner_of<IdT>(ids, i, input_dim, rows_per_rank, &loc[u]) : -1;
+    const int o = owner_of<IdT>(ids, i < n ? i : n - 1, input_dim, rows_per_rank, &loc[u]);
+    own[u] = i < n ? o : -1;
+    if (!(i < n)) loc[u] = -1;
   }
 #pragma unroll
   for (int u = 0; u < kRouteTile / 256; ++u) {

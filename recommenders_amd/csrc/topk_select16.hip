@@ -61,6 +61,19 @@ __global__ void __launch_bounds__(kSel16Waves * 64) bin_threshold_kernel(
   if (row >= nq) return;
   const float *src = binmax + row * ld;
   uint32_t key[kSlots];
+  if (group == 1) {
+    // one bin per lane and slot (up to 1024 bins: configs[1] has 355): the slots' loads are issued together,
+    // unconditionally at a clamped index -- guarded by `if (b < n_bins)` each was awaited on its own
+    // (vmcnt(0)): 16 serial round trips, 24 us for a kernel that reads 11 MB
+    float v[kSlots];
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+      const int b = s * 64 + lane;
+      v[s] = src[b < n_bins ? b : n_bins - 1];
+    }
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) key[s] = (s * 64 + lane < n_bins) ? f32_orderable(v[s]) : 0u;
+  } else
 #pragma unroll
   for (int s = 0; s < kSlots; ++s) {
     const int b0 = (s * 64 + lane) * group;
