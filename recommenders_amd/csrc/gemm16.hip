@@ -759,34 +759,49 @@ __global__ void __launch_bounds__(512) gemm16_big_kernel(const Gemm16Args g) {
     if (kt + 1 < nk) half(kt + 1, fb, fa);
   }
 
+  // Epilogue addressing: one 64-bit base per array for the tile (uniform) + 32-bit per-lane offsets (a 256-row
+  // tile spans < 2^31 elements for n < 2^23, checked by the launcher): sixteen 64-bit addresses per batch next
+  // to the 128 accumulators spilled.
+  const int64_t tile0 = bm * (int64_t)g.n + bn;
+  const float *const x0b = EPI != kG16EpiBias ? g.x0 + tile0 : nullptr;
+  const float *const xb = EPI != kG16EpiBias ? g.x + tile0 : nullptr;
+  float *const outb = outp + tile0;
+  float *const auxb = (EPI == kG16EpiCross && g.aux) ? g.aux + tile0 : nullptr;
+  const int rows_here = (int)(g.m - bm < kB16M ? g.m - bm : kB16M);   // >= 1
+  const int cols_here = g.n - bn < kB16N ? g.n - bn : kB16N;           // >= 1
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int jn = 0; jn < 4; ++jn) {
-      const int col = bn + wn * 128 + jn * 32 + j;
-      const int colc = col < g.n ? col : g.n - 1;
-      const float cs = g.invb[colc];
-      const float bias = g.bias ? g.bias[colc] : 0.0f;
-      float ra[16], e0v[16], e1v[16];
+      const int lc = wn * 128 + jn * 32 + j;                           // column within the tile
+      const int lcc = lc < cols_here ? lc : cols_here - 1;
+      const float cs = g.invb[bn + lcc];
+      const float bias = g.bias ? g.bias[bn + lcc] : 0.0f;
+      // (four batches of four rows: sixteen at once -- 48 values + 16 addresses next to the 128 accumulators --
+      // spilled 50 registers in the Cross instantiation, eight at once 22)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int64_t row = bm + wm * 64 + i * 32 + tile_row_of_reg(q, h);
-        const int64_t rowc = row < g.m ? row : g.m - 1;
-        const int64_t o = rowc * g.n + colc;
-        ra[q] = g.inva[rowc];
-        e0v[q] = EPI != kG16EpiBias ? g.x0[o] : 0.0f;
-        e1v[q] = EPI != kG16EpiBias ? g.x[o] : 0.0f;
-      }
+      for (int q0 = 0; q0 < 16; q0 += 4) {
+        float ra[4], e0v[4], e1v[4];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int64_t row = bm + wm * 64 + i * 32 + tile_row_of_reg(q, h);
-        const float v = acc[i][jn][q] * (ra[q] * cs) + bias;
-        float u = 0.0f;
-        const float res = g16_epilogue_v<EPI>(v, e0v[q], e1v[q], g.diag, &u);
-        if (row < g.m && col < g.n) {
-          const int64_t o = row * g.n + col;
-          outp[o] = res;
-          if (EPI == kG16EpiCross && g.aux) g.aux[o] = u;
+        for (int q = 0; q < 4; ++q) {
+          const int lr = wm * 64 + i * 32 + tile_row_of_reg(q0 + q, h);
+          const int lrc = lr < rows_here ? lr : rows_here - 1;
+          const uint32_t o = (uint32_t)lrc * (uint32_t)g.n + (uint32_t)lcc;
+          ra[q] = g.inva[bm + lrc];
+          e0v[q] = EPI != kG16EpiBias ? x0b[o] : 0.0f;
+          e1v[q] = EPI != kG16EpiBias ? xb[o] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int lr = wm * 64 + i * 32 + tile_row_of_reg(q0 + q, h);
+          const float v = acc[i][jn][q0 + q] * (ra[q] * cs) + bias;
+          float u = 0.0f;
+          const float res = g16_epilogue_v<EPI>(v, e0v[q], e1v[q], g.diag, &u);
+          if (lr < rows_here && lc < cols_here) {
+            const uint32_t o = (uint32_t)lr * (uint32_t)g.n + (uint32_t)lc;
+            outb[o] = res;
+            if (EPI == kG16EpiCross && auxb) auxb[o] = u;
+          }
         }
       }
     }
@@ -887,7 +902,7 @@ int gemm16_run_ex(const G16Operand &a, const G16Operand &b, int64_t m, int n, in
   const int forced = (tv && *tv) ? atoi(tv) : 0;
   const int64_t big_tiles = (L.mp / kB16M) * (L.np / kB16N);
   const bool splitk = L.nsplit > 1 && epi == kG16EpiBias && !bias && forced != 128;
-  const bool big = forced == 256 || (forced != 128 && big_tiles >= 512) || splitk;
+  const bool big = (forced == 256 || (forced != 128 && big_tiles >= 512) || splitk) && n < (1 << 23);   // (32-bit tile offsets in its epilogue)
   // the 256 x 256 kernel reads K-step-major images (kb = 16 halves): the operand tile of one K
   // step is 256 rows x 32 bytes CONTIGUOUS, so every direct-to-LDS copy instruction moves eight
   // full 128-byte lines instead of 32 quarter lines 2 * kp bytes apart
