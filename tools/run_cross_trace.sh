@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/cross_trace
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d "$OUT" -o t -- python $ROOT/tools/exp_cross_trace.py > "$OUT/log.txt" 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT" -o t -- python $ROOT/tools/exp_cross_trace.py > "$OUT/log.txt" 2>&1
 cd "$ROOT"
 python - <<PY
 import csv, glob
