@@ -192,9 +192,9 @@ __global__ void __launch_bounds__(256) g16_prep_rows_ksm_kernel(const float *__r
   }
 }
 
-// Single-pass form of the kernel above for kp <= 4096: the four waves of a workgroup share FOUR rows, wave w
+// Single-pass form of the kernel above for kp <= 8192: the four waves of a workgroup share FOUR rows, wave w
 // holding K blocks [w nq4, (w + 1) nq4) of them in registers (lane roles as above: 4 blocks x 4 rows x 4
-// parts per step, <= 16 steps), so a row is read ONCE -- the two-pass kernel reads it for the maximum and
+// parts per step, <= 16 steps of 8 floats), so a row is read ONCE -- the two-pass kernel reads it for the maximum and
 // again for the conversion, and at 55 KB per wave the second read comes from HBM (0.51 ms for a
 // 65536 x 3456 activation, 0.88 with the fused multiplier; both operands twice).  The row maxima meet in
 // LDS.  Same scale, same conversion, same image as the two-pass kernel, bit for bit.
@@ -273,6 +273,7 @@ static void g16_launch_prep_rows_ksm(const float *x, const float *mul, int64_t m
   if (vec && steps <= 2) { if (mul) TFRS_KSM1(2, true); else TFRS_KSM1(2, false); }
   else if (vec && steps <= 4) { if (mul) TFRS_KSM1(4, true); else TFRS_KSM1(4, false); }
   else if (vec && steps <= 8) { if (mul) TFRS_KSM1(8, true); else TFRS_KSM1(8, false); }
+  else if (vec && steps <= 16) { if (mul) TFRS_KSM1(16, true); else TFRS_KSM1(16, false); }   // kp <= 8192 (DLRM top MLP: 5082)
 #undef TFRS_KSM1
   else
     hipLaunchKernelGGL(g16_prep_rows_ksm_kernel, dim3((unsigned)(rows_p / 16)), dim3(256), 0, s, x, mul, m, k, kp, hi,
@@ -281,11 +282,11 @@ static void g16_launch_prep_rows_ksm(const float *x, const float *mul, int64_t m
 
 // ---- prep: columns of B (transposed images) ------------------------------------------------
 // B can be as large as A (dW = x^T dz: both operands are [batch, d] activations), so both passes
-// are parallel over K as well: (1) column maxima of 64-column x 1024-row slabs, combined with
+// are parallel over K as well: (1) column maxima of 64-column x 256-row slabs, combined with
 // atomicMax on the bit patterns of the non-negative maxima (order-independent, hence
 // reproducible; colmax is zeroed by the row-prep kernel that runs first), (2) 64 x 64 tiles
 // scaled, split and transposed through LDS.
-constexpr int kG16Slab = 1024;
+constexpr int kG16Slab = 256;   // (1024 left a 5082 x 1024 weight matrix with 80 workgroups of 32 serial rounds: 95 us)
 
 // `psum` (optional): psum[slab, n] = column sums of the slab's rows (b * mul), combined
 // afterwards in slab order by g16_colsum_kernel -- a deterministic db = sum_rows dz.
