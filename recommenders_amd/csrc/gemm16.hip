@@ -778,13 +778,13 @@ __global__ void __launch_bounds__(512) gemm16_big_kernel(const Gemm16Args g) {
       const int lcc = lc < cols_here ? lc : cols_here - 1;
       const float cs = g.invb[bn + lcc];
       const float bias = g.bias ? g.bias[bn + lcc] : 0.0f;
-      // (four batches of four rows: sixteen at once -- 48 values + 16 addresses next to the 128 accumulators --
-      // spilled 50 registers in the Cross instantiation, eight at once 22)
+      // (two batches of eight rows; sixteen at once -- 48 values + 16 offsets next to the 128 accumulators -- spill
+      // 9-11 registers in the Cross instantiations even with 32-bit offsets, 50 with 64-bit addresses)
 #pragma unroll
-      for (int q0 = 0; q0 < 16; q0 += 4) {
-        float ra[4], e0v[4], e1v[4];
+      for (int q0 = 0; q0 < 16; q0 += 8) {
+        float ra[8], e0v[8], e1v[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
           const int lr = wm * 64 + i * 32 + tile_row_of_reg(q0 + q, h);
           const int lrc = lr < rows_here ? lr : rows_here - 1;
           const uint32_t o = (uint32_t)lrc * (uint32_t)g.n + (uint32_t)lcc;
@@ -793,7 +793,7 @@ __global__ void __launch_bounds__(512) gemm16_big_kernel(const Gemm16Args g) {
           e1v[q] = EPI != kG16EpiBias ? xb[o] : 0.0f;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
           const int lr = wm * 64 + i * 32 + tile_row_of_reg(q0 + q, h);
           const float v = acc[i][jn][q0 + q] * (ra[q] * cs) + bias;
           float u = 0.0f;

@@ -669,8 +669,8 @@ def test_hot_kernel_register_budgets(source, patterns, max_vgprs):
     # producers: convert n + 1, load n + 5, reduce n + 2 -- three samples of 9 loads stay in flight
     ("interaction.hip", "dot_interaction_bwd_h16_kernelILi7ELi5ELi4E", 27),
     ("interaction.hip", "dot_interaction_fwd_pc_kernelILi4ELi4E", 12),
-    # the Cross epilogue issues the 12 loads of four rows of an accumulator tile before it waits
-    ("gemm16.hip", "gemm16_big_kernelILi1E", 8),
+    # the Cross epilogue issues the 24 loads of eight rows of an accumulator tile before it waits
+    ("gemm16.hip", "gemm16_big_kernelILi1E", 16),
     # single-pass row images: a wave's share of four rows (14 + 14 16-byte loads) in flight
     ("gemm16.hip", "g16_prep_rows_ksm1_kernelILi8ELb0E", 8),
 ])
