@@ -606,10 +606,15 @@ __global__ void __launch_bounds__(256) sort_hist_kernel(const uint32_t *__restri
   for (int e = tid; e < 1024; e += 256) (&h[0][0])[e] = 0u;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * kSortTile + wave * 1024;
-  for (int r = 0; r < 16; ++r) {
+  uint32_t kv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {   // unconditional, at a clamped index: 16 loads in flight (guarded, each was awaited)
     const int64_t i = base + r * 64 + lane;
-    if (i < n) atomicAdd(&h[wave][(keys[i] >> shift) & 255u], 1u);
+    kv[r] = keys[i < n ? i : n - 1];
   }
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if (base + r * 64 + lane < n) atomicAdd(&h[wave][(kv[r] >> shift) & 255u], 1u);
   __syncthreads();
   for (int e = tid; e < 1024; e += 256) hist[(int64_t)blockIdx.x * 1024 + e] = (&h[0][0])[e];
 }
@@ -671,11 +676,22 @@ __global__ void __launch_bounds__(256) sort_scatter_kernel(const uint32_t *__res
   __builtin_amdgcn_wave_barrier();
   const int64_t base = (int64_t)blockIdx.x * kSortTile + wave * 1024;
   const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // the wave's 1024 keys and values: 32 unconditional loads (clamped index) issued up front -- loaded round by
+  // round behind `i < n ? ... : 0`, each round paid its own memory round trip between two LDS synchronisations
+  // (28 us per pass for 1.7 M keys)
+  uint32_t kk[16], vv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    kk[r] = keys_in[i < n ? i : n - 1];
+    vv[r] = vals_in[i < n ? i : n - 1];
+  }
+#pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int64_t i = base + r * 64 + lane;
     const bool ok = i < n;
-    const uint32_t key = ok ? keys_in[i] : 0u;
-    const uint32_t val = ok ? vals_in[i] : 0u;
+    const uint32_t key = ok ? kk[r] : 0u;
+    const uint32_t val = ok ? vv[r] : 0u;
     // inactive tail lanes get a digit of their own class so that they never rank among real keys
     const uint32_t digit = (key >> shift) & 255u;
     const uint64_t act = __ballot(ok);

@@ -30,10 +30,9 @@ namespace tfrs {
 constexpr int kRouteTile = 4096;     // ids per workgroup
 constexpr int kRouteMaxWorld = 64;
 
-template <typename IdT>
-__device__ __forceinline__ int owner_of(const void *ids, int64_t i, int64_t input_dim, int64_t rows_per_rank,
-                                        int64_t *local) {
-  const int64_t id = (int64_t) reinterpret_cast<const IdT *>(ids)[i];
+// (takes the id VALUE: the callers load all their ids first -- the 64-bit division below expands into
+// branches, and a load that sits behind them is awaited before the next one is issued)
+__device__ __forceinline__ int owner_of(int64_t id, int64_t input_dim, int64_t rows_per_rank, int64_t *local) {
   if (id < 0 || id >= input_dim) {
     *local = -1;
     return 0;
@@ -53,12 +52,17 @@ __global__ void __launch_bounds__(256) shard_count_kernel(const void *ids, int64
   const int64_t base = (int64_t)blockIdx.x * kRouteTile;
   // every thread's 16 id loads are independent: one memory round trip per tile
   int own[kRouteTile / 256];
+  int64_t idv[kRouteTile / 256];
+#pragma unroll
+  for (int u = 0; u < kRouteTile / 256; ++u) {   // unconditional, at a clamped index: 16 loads in flight
+    const int64_t i = base + u * 256 + threadIdx.x;
+    idv[u] = (int64_t) reinterpret_cast<const IdT *>(ids)[i < n ? i : n - 1];
+  }
 #pragma unroll
   for (int u = 0; u < kRouteTile / 256; ++u) {
     const int64_t i = base + u * 256 + threadIdx.x;
     int64_t local;
-    // (the load is unconditional, at a clamped index: inside `i < n ? ... : -1` each of the 16 loads was awaited on its own)
-    const int o = owner_of<IdT>(ids, i < n ? i : n - 1, input_dim, rows_per_rank, &local);
+    const int o = owner_of(idv[u], input_dim, rows_per_rank, &local);
     own[u] = i < n ? o : -1;
   }
 #pragma unroll
@@ -121,10 +125,16 @@ __global__ void __launch_bounds__(256) shard_place_kernel(const void *ids, int64
   const int64_t base = (int64_t)blockIdx.x * kRouteTile;
   int own[kRouteTile / 256];
   int64_t loc[kRouteTile / 256];
+  int64_t idv[kRouteTile / 256];
 #pragma unroll
   for (int u = 0; u < kRouteTile / 256; ++u) {
     const int64_t i = base + (u * 4 + wave) * 64 + lane;
-    const int o = owner_of<IdT>(ids, i < n ? i : n - 1, input_dim, rows_per_rank, &loc[u]);
+    idv[u] = (int64_t) reinterpret_cast<const IdT *>(ids)[i < n ? i : n - 1];
+  }
+#pragma unroll
+  for (int u = 0; u < kRouteTile / 256; ++u) {
+    const int64_t i = base + (u * 4 + wave) * 64 + lane;
+    const int o = owner_of(idv[u], input_dim, rows_per_rank, &loc[u]);
     own[u] = i < n ? o : -1;
     if (!(i < n)) loc[u] = -1;
   }
