@@ -685,3 +685,16 @@ def test_pipelined_kernels_keep_loads_in_flight(source, pattern, min_in_flight):
   assert m, pattern
   waits = [int(v) for v in re.findall(r"s_waitcnt[^\n]*vmcnt\((\d+)\)", m.group(2))]
   assert waits and max(waits) >= min_in_flight, (pattern, sorted(set(waits))[-5:])
+
+
+def test_every_library_switch_is_documented():
+  """The `TFRS_*` switches read by the library (tfrs::option / env_int; settable through
+  tfrs_set_option) form its configuration plane: each one appears in INTEGRATION.md's table."""
+  import glob
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  names = set()
+  for f in glob.glob(os.path.join(root, "recommenders_amd", "csrc", "*")):
+    if f.endswith((".hip", ".cpp", ".h")):
+      names.update(re.findall(r'"(TFRS_[A-Z0-9_]+)"', open(f).read()))
+  doc = open(os.path.join(root, "INTEGRATION.md")).read()
+  assert names and not [n for n in sorted(names) if n not in doc]
