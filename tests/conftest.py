@@ -13,6 +13,21 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+@pytest.fixture(autouse=True)
+def _seed_global_rng(request):
+  """Layers initialise their weights from torch's GLOBAL generator; the float gates are 4 x the error observed
+  for THIS quantity, so the inputs of a test must not change from run to run (unseeded, the observed error of the
+  low-rank Cross gradients moved by 1.5 x between two runs).  Seeded per test from its node id."""
+  import zlib
+  try:
+    import torch
+  except ImportError:      # pragma: no cover
+    yield
+    return
+  torch.manual_seed(zlib.crc32(request.node.nodeid.encode()) & 0x7FFFFFFF)
+  yield
+
+
 def pytest_configure(config):
   config.addinivalue_line(
       "markers", "gpu: needs a real MI355X (run with `pytest -m gpu` via gpurun)")

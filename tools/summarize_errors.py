@@ -15,9 +15,12 @@ if "--gates" in sys.argv:      # regenerate tests/golden/float_gates.json: 4 x o
     e = math.floor(math.log10(v))
     return math.ceil(v / 10 ** (e - 1)) * 10 ** (e - 1)
   out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "float_gates.json")
-  json.dump({"_comment": "limit per float gate = 4 x the largest error observed on MI355X, rounded up to two digits; "
+  # "largest error observed" is over ALL recorded runs: a gate only widens with new evidence unless --reset is
+  # given (some products sum split-K partials whose rounding depends on the run's inputs by a factor of ~1.5)
+  previous = {} if "--reset" in sys.argv or not os.path.exists(out) else json.load(open(out)).get("gates", {})
+  json.dump({"_comment": "limit per float gate = 4 x the largest error observed on MI355X over the recorded runs, rounded up to two digits; "
                          "regenerate with tools/summarize_errors.py --gates after a full `pytest -m gpu` run",
-             "gates": {g: float(f"{up(v):.2g}") for g, v in sorted(worst.items()) if v > 0.0}},   # (an exact result keeps its family's ceiling)
+             "gates": {g: max(float(f"{up(v):.2g}"), previous.get(g, 0.0)) for g, v in sorted(worst.items()) if v > 0.0}},   # (an exact result keeps its family's ceiling)
             open(out, "w"), indent=1)
   print("wrote", out)
   sys.exit(0)
