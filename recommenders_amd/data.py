@@ -77,7 +77,12 @@ class Dataset:
     ``None``."""
     from recommenders_amd.layers.embedding import Embedding
     fn, ids = self.map_fn, self.source
-    if not isinstance(fn, Embedding) or self.batch_size is None:
+    # exactly the base layer: the fused consumer reads `fn.embeddings` and bypasses `fn.forward`, so a
+    # subclass with its own forward (normalisation, scaling), forward (pre-)hooks or id validation
+    # (IndexError on bad ids) must be iterated like any other map function
+    if type(fn) is not Embedding or self.batch_size is None:
+      return None
+    if fn.validate_ids or fn._forward_hooks or fn._forward_pre_hooks:
       return None
     if not (isinstance(ids, torch.Tensor) and ids.is_cuda and ids.dim() == 1
             and ids.dtype in (torch.int32, torch.int64)):

@@ -823,6 +823,11 @@ class Streaming(TopK):
   def _cached_index(self, k: int) -> Optional["BruteForce"]:
     if not self._cache_blocks:
       return None
+    if torch.cuda.is_current_stream_capturing():
+      # a captured step (Model.fit / evaluate replay HIP graphs) runs no host code on replay, so the
+      # (object, storage, version) comparison below could never notice that a block changed: under
+      # capture the blocks are read in place, as the reference re-reads its dataset on every call
+      return None
     probe = self._block_keys()
     if probe is None:
       self._cache_key, self._cache, self._cache_alive = None, None, None

@@ -67,7 +67,13 @@ class Mean:
     if self._total is None:
       return torch.tensor(0.0)
     if self._result_fresh:
-      return self._result_view
+      # a FRESH tensor, as Keras returns: the view aliases the metric's shared device buffer, which the
+      # next update_state overwrites and reset_states zeroes (logs kept per step / epoch must not change
+      # afterwards).  Only under HIP-graph capture the view itself is handed out: the graphed step
+      # documents that its returned tensors are overwritten by the next replay.
+      if self._result_view.is_cuda and torch.cuda.is_current_stream_capturing():
+        return self._result_view
+      return self._result_view.clone()
     return torch.where(self._count > 0, self._total / self._count,
                        torch.zeros_like(self._total))
 
@@ -117,7 +123,7 @@ class FactorizedTopK(Factorized):
     self._top_k_metrics = [
         Mean(name=f"{self.name}/top_{x}_categorical_accuracy") for x in ks]   # :85-89
     self._fused_state = None          # (state[2 * nks], results[nks]) on the device
-    self._counts = None               # uint32 [nq] rank counts, zero between updates
+    self._counts = None               # {(nq, device): uint32 [nq] rank counts}, zero between updates
 
   @property
   def metrics(self) -> List[Mean]:
@@ -188,9 +194,16 @@ class FactorizedTopK(Factorized):
     if c.shape != q.shape:
       raise ValueError("true_candidate_embeddings must have the shape of query_embeddings")
     state, results = self._bound_state(q.device)
-    if self._counts is None or self._counts.numel() != nq or self._counts.device != q.device:
-      self._counts = torch.zeros((nq,), dtype=torch.int32, device=q.device)
-    counts = self._counts
+    # one scratch buffer per (batch size, device), kept for the life of the metric: a captured step
+    # (Model.fit replays one HIP graph per batch shape) holds the pointer of the buffer it was captured
+    # with, so a buffer must never be dropped -- and its memory handed to someone else -- when a batch of
+    # another size comes by (the ragged last batch of an epoch)
+    if self._counts is None:
+      self._counts = {}
+    key = (nq, q.device)
+    if key not in self._counts:
+      self._counts[key] = torch.zeros((nq,), dtype=torch.int32, device=q.device)
+    counts = self._counts[key]
     stream = _lib.current_stream()
     w = None
     if sample_weight is not None:
@@ -223,7 +236,7 @@ class FactorizedTopK(Factorized):
           _lib.ptr(counts), nq, ks_arr, len(self._ks), _lib.ptr(w), _lib.ptr(state),
           _lib.ptr(results), None, stream))
     except Exception:
-      self._counts = None               # a half-swept count buffer must not be reused
+      self._counts.pop(key, None)       # a half-swept count buffer must not be reused
       raise
     for metric in self._top_k_metrics:
       metric._result_fresh = True

@@ -199,16 +199,45 @@ class Model(torch.nn.Module):
     Contract: every batch must have the shapes/dtypes of ``example_inputs``; the step must be
     free of host synchronisation (``compute_metrics=False`` or tensor-only metrics; no
     ``validate_ids``); the returned dict holds static tensors that the next replay overwrites.
-    Parameters and optimizer state are left exactly as they were before the call (the warm-up
-    iterations needed for capture are rolled back) -- except with an optimizer whose state is
-    created lazily and that has no ``reset_state_`` (plain ``torch.optim``): then the warm-up
-    iterations stay applied as ordinary training steps on ``example_inputs``."""
+    Parameters, optimizer state and metric state are left exactly as they were before the call
+    (the warm-up iterations needed for capture are rolled back, also when the capture fails) --
+    except with an optimizer whose state is created lazily and that has no ``reset_state_``
+    (plain ``torch.optim``): then the warm-up iterations stay applied as ordinary training steps
+    on ``example_inputs``.  ``fit`` uses this by default (see there)."""
     if self.optimizer is None:
       raise RuntimeError("Call `compile(optimizer=...)` before training.")
     if self._sync_world() > 1:
       raise RuntimeError("make_graphed_train_step does not capture the gradient exchange; use "
                          "train_step under data parallelism (or compile(sync_gradients=False)).")
+    return self._make_graphed_step(self.train_step, example_inputs, warmup, training=True)
 
+  def make_graphed_test_step(self, example_inputs, warmup: int = 1):
+    """``test_step`` captured in a HIP graph (same contract as ``make_graphed_train_step``;
+    nothing but the metric state is written, and that is rolled back after the capture)."""
+    return self._make_graphed_step(self.test_step, example_inputs, warmup, training=False)
+
+  def _metric_state_tensors(self) -> List[torch.Tensor]:
+    """Every device tensor the metrics keep between updates (running totals, fused state buffers,
+    rank-count scratch), deduplicated by storage + offset: what a capture's warm-up steps change
+    besides parameters and optimizer state."""
+    seen, out = set(), []
+    stack = list(self.metrics)
+    for module in self.modules():
+      if module is not self and callable(getattr(module, "update_state", None)):
+        stack.append(module)
+    for obj in stack:
+      for value in vars(obj).values():
+        items = (value if isinstance(value, (tuple, list)) else
+                 tuple(value.values()) if isinstance(value, dict) else (value,))
+        for t in items:
+          if isinstance(t, torch.Tensor) and not isinstance(t, torch.nn.Parameter):
+            key = (t.data_ptr(), tuple(t.shape), t.dtype)
+            if t.numel() and key not in seen:
+              seen.add(key)
+              out.append(t)
+    return out
+
+  def _make_graphed_step(self, step_fn, example_inputs, warmup: int, training: bool):
     def map_tensors(x, fn):
       if isinstance(x, torch.Tensor):
         return fn(x)
@@ -221,7 +250,7 @@ class Model(torch.nn.Module):
     def copy_into(dst, src):
       if isinstance(dst, torch.Tensor):
         if dst.shape != src.shape or dst.dtype != src.dtype:
-          raise ValueError(f"graphed train step was captured for {tuple(dst.shape)} "
+          raise ValueError(f"graphed step was captured for {tuple(dst.shape)} "
                            f"{dst.dtype}; got {tuple(src.shape)} {src.dtype}")
         dst.copy_(src, non_blocking=True)
       elif isinstance(dst, dict):
@@ -231,32 +260,50 @@ class Model(torch.nn.Module):
         for d, s_ in zip(dst, src):
           copy_into(d, s_)
 
-    static_inputs = map_tensors(example_inputs, lambda t: t.detach().clone())
+    device = next(self.parameters()).device
+    static_inputs = map_tensors(example_inputs, lambda t: t.detach().to(device).clone())
     params = [p for p in self.parameters()]
-    saved_params = [p.detach().clone() for p in params]
+    saved_params = [p.detach().clone() for p in params] if training else []
     # optimizer state that already exists is snapshotted; lazily created state is re-initialised
     # through the optimizer's own ``reset_state_`` (recommenders_amd.optimizers) after capture
-    had_state = [(t, t.detach().clone()) for st in self.optimizer.state.values()
-                 for t in st.values() if isinstance(t, torch.Tensor)]
+    had_state = []
+    if training:
+      had_state = [(t, t.detach().clone()) for st in self.optimizer.state.values()
+                   for t in st.values() if isinstance(t, torch.Tensor)]
     can_roll_back = bool(had_state) or callable(getattr(self.optimizer, "reset_state_", None))
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-      for _ in range(max(warmup, 1)):
-        self.train_step(static_inputs)
-    torch.cuda.current_stream().wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-      logs = self.train_step(static_inputs)
-    if can_roll_back:
+    metric_before = [(t, t.detach().clone()) for t in self._metric_state_tensors()]
+    known = {(t.data_ptr(), tuple(t.shape), t.dtype) for t, _ in metric_before}
+
+    def roll_back():
       with torch.no_grad():
-        for p, v in zip(params, saved_params):
-          p.copy_(v)
-        if had_state:
-          for t, v in had_state:
-            t.copy_(v)
-        else:
-          self.optimizer.reset_state_()
+        if training and can_roll_back:
+          for p, v in zip(params, saved_params):
+            p.copy_(v)
+          if had_state:
+            for t, v in had_state:
+              t.copy_(v)
+          else:
+            self.optimizer.reset_state_()
+        for t, v in metric_before:
+          t.copy_(v)
+        # metric state created BY the warm-up (lazily allocated totals): back to zero, in place --
+        # the captured graph accumulates into this very storage
+        for t in self._metric_state_tensors():
+          if (t.data_ptr(), tuple(t.shape), t.dtype) not in known:
+            t.zero_()
+
+    graph = torch.cuda.CUDAGraph()
+    try:
+      side = torch.cuda.Stream()
+      side.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(side):
+        for _ in range(max(warmup, 1)):
+          step_fn(static_inputs)
+      torch.cuda.current_stream().wait_stream(side)
+      with torch.cuda.graph(graph):
+        logs = step_fn(static_inputs)
+    finally:
+      roll_back()
 
     def flat_tensors(x, out):
       if isinstance(x, torch.Tensor):
@@ -270,6 +317,7 @@ class Model(torch.nn.Module):
       return out
 
     static_flat = flat_tensors(static_inputs, [])
+    bump = getattr(self.optimizer, "bump_table_versions", None) if training else None
 
     def step(inputs):
       src_flat = flat_tensors(inputs, [])
@@ -281,6 +329,8 @@ class Model(torch.nn.Module):
       else:
         copy_into(static_inputs, inputs)                 # (also raises on a shape mismatch)
       graph.replay()
+      if bump is not None:
+        bump()       # the replay wrote the tables through raw pointers and ran no host code
       return logs
 
     step.graph = graph
@@ -295,23 +345,105 @@ class Model(torch.nn.Module):
       total = loss if reg is None else loss + reg
     return self._metrics_dict(loss, self._constant(0.0, loss) if reg is None else reg, total)
 
-  def fit(self, dataset: Iterable, epochs: int = 1) -> Dict[str, List[Any]]:
+  # -- fit / evaluate: a captured step is the default, as Keras compiles train_step ------------
+  @staticmethod
+  def _batch_key(batch):
+    """Shape key of a batch (tensors by position / dict key); ``None`` when it holds anything
+    but tensors (then the step stays eager)."""
+    out = []
+
+    def walk(x, path):
+      if isinstance(x, torch.Tensor):
+        out.append((path, tuple(x.shape), x.dtype))
+        return True
+      if isinstance(x, dict):
+        return all(walk(x[k], path + (str(k),)) for k in sorted(x, key=str))
+      if isinstance(x, (list, tuple)):
+        return all(walk(v, path + (i,)) for i, v in enumerate(x))
+      return False
+
+    return tuple(out) if walk(batch, ()) and out else None
+
+  def _graph_steps_allowed(self, graph: Optional[bool], training: bool) -> bool:
+    """``graph=None`` (default): replay captured steps when that is known to be safe -- a ROCm device,
+    no gradient exchange (a collective inside a capture is not supported here), and for training an
+    optimizer whose step has no host-side state that changes from step to step: this package's
+    ``Adagrad``, or a ``torch.optim`` optimizer built with ``capturable=True`` (a host-side step
+    counter or learning-rate schedule would be frozen into the graph at capture time).
+    ``graph=True`` forces it, ``graph=False`` / ``TFRS_FIT_GRAPH=0`` keeps every step eager."""
+    import os
+    if graph is False or os.environ.get("TFRS_FIT_GRAPH", "1") == "0":
+      return False
+    if not torch.cuda.is_available():
+      return False
+    first = next(self.parameters(), None)
+    if first is None or not first.is_cuda:
+      return False
+    if training and self._sync_world() > 1:
+      return False
+    if graph is True or not training:
+      return True
+    from recommenders_amd import optimizers as own
+    opt = self.optimizer
+    if isinstance(opt, own.Adagrad):
+      return True
+    return bool(opt.param_groups) and all(g.get("capturable", False) for g in opt.param_groups)
+
+  def _run_epoch(self, dataset: Iterable, eager_step, make_graphed, cache: dict, allowed: bool):
+    """One pass over ``dataset``.  A batch shape seen for the SECOND time is captured
+    (``make_graphed``) and replayed from then on; first sightings -- among them the ragged last
+    batch of an epoch, 19 x 4096 + 2176 at the MovieLens shapes -- run the eager step.  A step that
+    cannot be captured (host synchronisation inside it: ``validate_ids``, host-side identifiers)
+    is remembered as eager-only; the failed capture's warm-up is rolled back."""
+    logs = {}
+    for batch in dataset:
+      key = self._batch_key(batch) if allowed else None
+      entry = cache.get(key) if key is not None else "eager"
+      if entry is None:
+        cache[key] = "seen"
+        logs = eager_step(batch)
+      elif entry == "seen":
+        try:
+          cache[key] = make_graphed(batch)
+          logs = cache[key](batch)
+        except (RuntimeError, ValueError) as e:
+          cache[key] = "eager"
+          cache.setdefault("_errors", []).append(repr(e))
+          torch.cuda.synchronize()
+          logs = eager_step(batch)
+      elif entry == "eager":
+        logs = eager_step(batch)
+      else:
+        logs = entry(batch)
+    return logs
+
+  def fit(self, dataset: Iterable, epochs: int = 1, graph: Optional[bool] = None) -> Dict[str, List[Any]]:
+    """Keras ``Model.fit`` over a re-iterable of batches (``models/base.py:64-85`` runs under
+    ``Model.fit``, which COMPILES ``train_step`` by default; ``README.md:84-98``).  Here the
+    compiled form is a HIP graph per batch shape (``_run_epoch``): same kernels, order and
+    arithmetic as the eager ``train_step``, bit-identical parameters and logs
+    (``tests/test_ops_gpu.py::test_fit_replays_captured_steps_and_matches_eager``)."""
     history: Dict[str, List[Any]] = {}
+    if self.optimizer is None:
+      raise RuntimeError("Call `compile(optimizer=...)` before training.")
+    allowed = self._graph_steps_allowed(graph, training=True)
+    cache = self.__dict__.setdefault("_fit_graphs", {})
+    if self.__dict__.get("_fit_graphs_optimizer") is not self.optimizer:
+      cache.clear()                      # captured steps belong to the optimizer they were captured with
+      self.__dict__["_fit_graphs_optimizer"] = self.optimizer
     for _ in range(epochs):
       for m in self.metrics:
         m.reset_states()
-      logs = {}
-      for batch in dataset:
-        logs = self.train_step(batch)
+      logs = self._run_epoch(dataset, self.train_step, self.make_graphed_train_step, cache, allowed)
       for k, v in logs.items():
         history.setdefault(k, []).append(float(v))
     return history
 
-  def evaluate(self, dataset: Iterable, return_dict: bool = True):
+  def evaluate(self, dataset: Iterable, return_dict: bool = True, graph: Optional[bool] = None):
     for m in self.metrics:
       m.reset_states()
-    logs = {}
-    for batch in dataset:
-      logs = self.test_step(batch)
+    allowed = self._graph_steps_allowed(graph, training=False)
+    cache = self.__dict__.setdefault("_eval_graphs", {})
+    logs = self._run_epoch(dataset, self.test_step, self.make_graphed_test_step, cache, allowed)
     logs = {k: float(v) for k, v in logs.items()}
     return logs if return_dict else list(logs.values())

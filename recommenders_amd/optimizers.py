@@ -85,6 +85,16 @@ class Adagrad(torch.optim.Optimizer):
         if acc is not None:
           acc.fill_(group["initial_accumulator_value"])
 
+  def bump_table_versions(self) -> None:
+    """Version counters of every table this optimizer updates through raw pointers.  ``step()`` does it
+    for the tables it touched; a HIP-graph REPLAY of a captured step runs no host code, so
+    ``Model.make_graphed_train_step`` calls this after every replay -- anything keyed on the counters
+    (Streaming's packed-block cache over detached views of a trained table) then sees the change."""
+    for group in self.param_groups:
+      for p in group["params"]:
+        if getattr(p, "_tfrs_sparse_grad", False):
+          torch.autograd.graph.increment_version(p)
+
   def zero_grad(self, set_to_none: bool = True) -> None:
     super().zero_grad(set_to_none=set_to_none)
     for group in self.param_groups:

@@ -64,9 +64,15 @@ except (OSError, ValueError, KeyError):      # pragma: no cover
 
 
 def _gate_limit(name, fallback):
+  """(hard, soft): the family ceiling the test passes is the CONTRACT and the only limit that fails
+  a test; the per-gate entry of float_gates.json (4 x the error observed for this quantity in
+  round 3, FROZEN: never regenerated together with a kernel change) is an early-warning tier --
+  exceeding it emits a warning and is recorded, because a max-statistic with a 4 x margin moves
+  with the inputs (a renamed test reseeds them), the compiler and the reduction order
+  (ADVICE round 3)."""
   import re
   key = re.sub(r"\.d(biases|u_kernels|v_kernels)\.\d", ".dparam", name)
-  return min(_GATES.get(key, fallback), fallback)
+  return fallback, min(_GATES.get(key, fallback), fallback)
 
 
 def _record_error(name, err, limit):
@@ -81,15 +87,15 @@ def _record_error(name, err, limit):
 
 def float_gate(name, got, ref, yardstick, limit, floor=1e-30, floor_rel=0.0):
   """Asserts max |got - ref| / max(yardstick, floor) <= limit and records the observed value.
-  `limit` is the family's ceiling; the limit in force is the per-gate entry of
-  tests/golden/float_gates.json when that is tighter (4 x the error observed for THIS quantity).
+  `limit` is the family's ceiling and the limit in force; the per-gate entry of
+  tests/golden/float_gates.json (4 x the error observed for THIS quantity, frozen) only warns.
   Accepts numpy arrays or torch tensors (torch: evaluated on the tensors' device in float64);
   `yardstick` broadcasts against `ref`.  `floor_rel` > 0 adds floor_rel * max(yardstick) to every
   entry's yardstick: the error model of a product whose operands share ONE power-of-two scale per
   tile (split-fp16 with a common scale: absolute error 2^-22 of the tile's largest term, so an
   entry whose own terms are all tiny is accurate relative to its neighbours' terms, not to its
   own) -- used only where the docstring of the test says why."""
-  limit = _gate_limit(name, limit)
+  limit, soft = _gate_limit(name, limit)
   try:
     import torch
   except ImportError:      # pragma: no cover
@@ -112,5 +118,9 @@ def float_gate(name, got, ref, yardstick, limit, floor=1e-30, floor_rel=0.0):
     y = np.maximum(y, floor)
     err = float(np.max(np.abs(g - r) / y)) if g.size else 0.0
   _record_error(name, err, limit)
+  if err > soft:
+    import warnings
+    warnings.warn(f"{name}: observed {err:.3e} above the frozen round-3 tier {soft:.3e} "
+                  f"(ceiling {limit:.3e})")
   assert err <= limit, f"{name}: observed {err:.3e} > gate {limit:.3e} (relative to the sum of |terms|)"
   return err

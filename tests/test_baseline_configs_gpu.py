@@ -778,3 +778,179 @@ def test_dot_interaction_config5_vs_float64(self_interaction, variant, monkeypat
   rhs = 2.0 * (dy.double() * out.detach().double()).sum(dim=1)
   yard = (x.grad.double().abs() * x.detach().double().abs()).sum(dim=(1, 2)) + 1e-30
   assert float(((lhs - rhs).abs() / yard).max()) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# Embedding path at the TABLE sizes of BASELINE configs[3] / configs[4]:
+# byte offsets beyond 2^32, the last row, int32 and int64 ids.  The table is synthetic with a closed
+# form -- value(r, j) is an integer hash of (r, j) scaled by a power of two, exact in float32 -- so
+# the host regenerates any row without ever holding the 13 GB table.
+# ------------------------------------------------------------------------------------------------
+def _synthetic_rows_host(rows, d, salt=0):
+  r = np.asarray(rows, dtype=np.int64)[:, None]
+  j = np.arange(d, dtype=np.int64)[None, :]
+  h = (r * 2654435761 + j * 40503 + 12345 + salt * 7919) & 0x3FFFFF          # 22 bits: exact in f32
+  return (h.astype(np.float32) - np.float32(2097152.0)) * np.float32(2.0 ** -26)   # [-1/32, 1/32)
+
+
+def _synthetic_table_device(rows, d, salt=0, chunk=1 << 20):
+  table = torch.empty((rows, d), dtype=torch.float32, device="cuda")
+  j = torch.arange(d, dtype=torch.int64, device="cuda")[None, :] * 40503 + 12345 + salt * 7919
+  for lo in range(0, rows, chunk):
+    hi = min(rows, lo + chunk)
+    r = torch.arange(lo, hi, dtype=torch.int64, device="cuda")[:, None] * 2654435761
+    h = (r + j) & 0x3FFFFF
+    table[lo:hi] = (h.to(torch.float32) - 2097152.0) * (2.0 ** -26)
+  return table
+
+
+def _compact(ids, d, salt=0):
+  """(sub-table of the distinct ids, ids remapped into it): the oracle then works on a table of
+  a few thousand rows; the ORDER of the ids (hence of every float32 sum) is unchanged."""
+  uniq, inv = np.unique(np.asarray(ids, dtype=np.int64), return_inverse=True)
+  return _synthetic_rows_host(uniq, d, salt), inv.astype(np.int64), uniq
+
+
+@pytest.mark.parametrize("rows,d,n", [(26_000_000, 128, 65536 * 26), (100_000_000, 32, 131072 * 13)])
+def test_embedding_path_at_config_table_sizes(rows, d, n):
+  """configs[3]: 26 x 1M-row tables of dim 128 held as one 26M x 128 store (13.3 GB); configs[4]: one
+  GPU's 100M-row share of the dim-32 tables (12.8 GB).  Gather (what bench.py's `gather` leg times),
+  weighted segment-sum with the three combiners and the fused sparse Adagrad, each on ids that
+  include row 0, the last row and rows on both sides of the 2^32-byte offset, against the oracle
+  (`oracle/embedding.py`; reference layers/embedding/tpu_embedding_layer.py:913-919) on sampled /
+  touched rows: gather and the Adagrad-untouched rows bit for bit."""
+  from recommenders_amd.layers import embedding as emb
+  from oracle import embedding as o_emb
+  rng = np.random.default_rng(rows % 1000 + d)
+  table = _synthetic_table_device(rows, d)
+  edge = (1 << 32) // (d * 4)                     # first row whose byte offset is >= 2^32
+  special = np.array([0, 1, rows - 1, rows - 2, edge - 1, edge, edge + 1, 2 * edge, rows // 2], dtype=np.int64)
+  assert special.max() < rows and rows * d * 4 > (1 << 33)
+
+  # ---- gather: the bench's shape, int64 and int32 ids
+  ids = rng.integers(0, rows, size=n)
+  ids[:special.size] = special
+  ids[-special.size:] = special[::-1]
+  sample = np.unique(np.r_[0:special.size, n - special.size:n, rng.integers(0, n, size=4096)])
+  sub, remap, _ = _compact(ids[sample], d)
+  want = o_emb.gather(sub, remap)
+  for dtype in (np.int64, np.int32):
+    out = emb.gather_rows(table, torch.as_tensor(ids.astype(dtype)).cuda())
+    np.testing.assert_array_equal(_np(out[torch.as_tensor(sample).cuda()]), want)
+    # ... and every output row against the table through an independent route (torch indexing)
+    assert torch.equal(out, table[torch.as_tensor(ids).cuda()])
+    del out
+
+  # ---- weighted segment-sum: ragged rows of 0..8 ids
+  nseg = 200_000
+  lens = rng.integers(0, 9, size=nseg)
+  splits = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+  sids = rng.integers(0, rows, size=int(splits[-1]))
+  sids[:special.size] = special
+  wts = rng.uniform(0.5, 2.0, size=sids.size).astype(np.float32)
+  seg_sample = np.unique(np.r_[0:8, rng.integers(0, nseg, size=4096)])
+  # the sampled segments as their own small CSR problem for the oracle
+  pieces = [np.arange(splits[b], splits[b + 1]) for b in seg_sample]
+  take = np.concatenate(pieces) if pieces else np.zeros((0,), np.int64)
+  sub, remap, _ = _compact(sids[take], d)
+  sub_splits = np.concatenate([[0], np.cumsum([p.size for p in pieces])]).astype(np.int64)
+  for comb in ("sum", "mean", "sqrtn"):
+    for w in (None, wts):
+      out = emb.embedding_lookup_sparse(table, torch.as_tensor(sids).cuda(), torch.as_tensor(splits).cuda(),
+                                        None if w is None else torch.as_tensor(w).cuda(), combiner=comb)
+      ref = o_emb.lookup_sparse(sub, remap, sub_splits, None if w is None else w[take], comb)
+      np.testing.assert_allclose(_np(out[torch.as_tensor(seg_sample).cuda()]), ref, rtol=2e-6, atol=2e-7)   # fma contraction only
+      del out
+
+  # ---- fused sparse Adagrad on the full-size table + accumulator (a guard row behind both)
+  del table
+  torch.cuda.empty_cache()
+  backing = torch.empty((rows + 1, d), dtype=torch.float32, device="cuda")
+  backing[:rows] = _synthetic_table_device(rows, d)
+  backing[rows] = 0.0
+  acc_backing = torch.full((rows + 1, d), 0.1, dtype=torch.float32, device="cuda")
+  tab, accum = backing[:rows], acc_backing[:rows]
+  m = 300_000
+  # half of the gradient rows go to ~20 000 hot ids: runs of ~8 duplicates, all shorter than the kernel's
+  # `piece` (32 positions), so every sum is ONE thread's occurrence-order chain = the oracle's, bit for bit
+  hot = np.concatenate([special, rng.integers(0, rows, size=20_000)])
+  gids = np.where(rng.random(m) < 0.5, hot[rng.integers(0, hot.size, size=m)], rng.integers(0, rows, size=m))
+  gids[:special.size] = special
+  g = rng.normal(size=(m, d)).astype(np.float32)
+  untouched = np.setdiff1d(np.r_[rng.integers(0, rows, size=4096), (special + 3) % rows], gids)
+  for dtype in (np.int64, np.int32):
+    emb.adagrad_sparse_update_(tab, accum, torch.as_tensor(g).cuda(), torch.as_tensor(gids.astype(dtype)).cuda(),
+                               lr=0.5)
+  sub, remap, uniq = _compact(gids, d)
+  t_ref, a_ref = sub, np.full_like(sub, 0.1)
+  for _ in range(2):                                                   # the two updates above, in order
+    t_ref, a_ref = o_emb.adagrad_sparse_update(t_ref, a_ref, g, remap, lr=0.5)
+  touched = torch.as_tensor(uniq).cuda()
+  np.testing.assert_allclose(_np(accum[touched]), a_ref, rtol=1e-6)
+  np.testing.assert_allclose(_np(tab[touched]), t_ref, rtol=1e-5, atol=1e-7)
+  np.testing.assert_array_equal(_np(tab[torch.as_tensor(untouched).cuda()]), _synthetic_rows_host(untouched, d))
+  assert float((accum[torch.as_tensor(untouched).cuda()] - 0.1).abs().max()) == 0.0
+  assert float(backing[rows].abs().max()) == 0.0 and float((acc_backing[rows] - 0.1).abs().max()) == 0.0
+  # the scatter-add alone (dense gradient of the gather), bit-exact occurrence-order sums on the touched rows
+  del backing, acc_backing, tab, accum
+  torch.cuda.empty_cache()
+  dense = emb.scatter_add_rows(torch.as_tensor(g).cuda(), torch.as_tensor(gids).cuda(), rows)
+  ref = o_emb.scatter_add_grad(g, remap, uniq.size)
+  np.testing.assert_array_equal(_np(dense[touched]), ref)
+  assert float(dense[torch.as_tensor(untouched).cuda()].abs().max()) == 0.0
+  # very hot rows (runs of 4000 >> piece: summed as partial sums of pieces, csrc/embedding.hip): float64
+  # reference, gate relative to the sum of |terms|
+  del dense
+  vh = np.array([rows - 1, edge, 5], dtype=np.int64)
+  vids = np.repeat(vh[None, :], 4000, axis=0).reshape(-1)
+  vg = rng.normal(size=(vids.size, d)).astype(np.float32)
+  dense = emb.scatter_add_rows(torch.as_tensor(vg).cuda(), torch.as_tensor(vids).cuda(), rows)
+  got = _np(dense[torch.as_tensor(vh).cuda()])
+  for j in range(3):
+    terms = vg[j::3].astype(np.float64)
+    float_gate("scatter.long_runs", got[j], terms.sum(axis=0), np.abs(terms).sum(axis=0), 4e-6)
+
+
+def test_scale_workload_100m_x_64_search_vs_oracle():
+  """The 100M x 64 single-GPU search that bench.py's `scale_workload` times (the N = 1 point of the
+  strong-scaling configuration): same row generator (1M-row blocks from seeds 1000 + b), batch 8192,
+  top-100; 16 sampled queries against the oracle's Streaming fold (layers/factorized_top_k.py:404-509,
+  which equals BruteForce.call :586-607 on the concatenation) over the same blocks downloaded to the
+  host, bit for bit; no query may need the exact redo."""
+  ftk = _ftk()
+  n, d, nq, k, blk = 100_000_000, 64, 8192, 100, 1_000_000
+
+  def block(b):
+    g = torch.Generator(device="cuda").manual_seed(1000 + b)
+    return torch.randn((blk, d), generator=g, device="cuda", dtype=torch.float32) / (d ** 0.5)
+
+  class Blocks:
+    def __iter__(self):
+      for b in range(n // blk):
+        yield block(b)
+
+  g = torch.Generator(device="cuda").manual_seed(7)
+  q = torch.randn((nq, d), generator=g, device="cuda", dtype=torch.float32) / (d ** 0.5)
+  bf = ftk.BruteForce(k=k).index_from_dataset(Blocks(), total_rows=n)
+  s, i = bf(q)
+  assert bf.last_redo_count() == 0, bf.last_redo_reasons()
+  sample = np.r_[0:6, 4000:4004, nq - 6:nq]
+  qs = q[sample].cpu().numpy()
+  es = np.zeros((sample.size, 0), np.float32)
+  ei = np.zeros((sample.size, 0), np.int64)
+  for b in range(n // blk):
+    # Streaming.call's fold: per-block top-k with global row numbers, concat([state, new]) -> top_k
+    # (ties -> left-most column = lower global row), reference :424-472
+    bs, bi = o_topk.brute_force(qs, block(b).cpu().numpy(), k)
+    joined_s, joined_i = np.concatenate([es, bs], axis=1), np.concatenate([ei, bi.astype(np.int64) + b * blk], axis=1)
+    es, order = o_topk.top_k(joined_s, k)
+    ei = o_topk.take_along_axis(joined_i, order)
+  np.testing.assert_array_equal(_np(i)[sample], ei)
+  np.testing.assert_array_equal(_np(s)[sample], es)
+  # size-independent properties on the whole batch: sorted (score desc, row asc), rows distinct and in range
+  sv, iv = _np(s), _np(i).astype(np.int64)
+  assert (sv[:, :-1] >= sv[:, 1:]).all()
+  tie = sv[:, :-1] == sv[:, 1:]
+  assert (iv[:, :-1][tie] < iv[:, 1:][tie]).all()
+  assert iv.min() >= 0 and iv.max() < n
+  assert (np.sort(iv, axis=1)[:, 1:] != np.sort(iv, axis=1)[:, :-1]).all()

@@ -590,6 +590,136 @@ def test_graphed_train_step_matches_eager():
     step({"user_id": batches[0]["user_id"][:10], "movie_id": batches[0]["movie_id"][:10]})
 
 
+def _quickstart_model(tfrs, with_metrics=True, validate_ids=False, seed=5):
+  """The README quickstart model (README.md:58-82) at the MovieLens-100K shapes."""
+
+  class TwoTower(tfrs.Model):
+    def __init__(self):
+      super().__init__()
+      self.user_model = tfrs.layers.embedding.Embedding(943, 64, validate_ids=validate_ids)
+      self.item_model = tfrs.layers.embedding.Embedding(1682, 64)
+      if with_metrics:
+        movies = tfrs.data.Dataset.from_tensor_slices(torch.arange(1682, device="cuda"))
+        self.task = tfrs.tasks.Retrieval(metrics=tfrs.metrics.FactorizedTopK(
+            candidates=movies.batch(128).map(self.item_model)))
+      else:
+        self.task = tfrs.tasks.Retrieval()
+
+    def compute_loss(self, features, training=False):
+      return self.task(self.user_model(features["user_id"]), self.item_model(features["movie_id"]),
+                       compute_metrics=with_metrics)
+
+  torch.manual_seed(seed)
+  m = TwoTower()
+  m.compile(optimizer=tfrs.optimizers.Adagrad(m.parameters(), learning_rate=0.5))
+  return m
+
+
+def _epoch_batches(rng, sizes):
+  return [{"user_id": _t(rng.integers(0, 943, size=n)), "movie_id": _t(rng.integers(0, 1682, size=n))}
+          for n in sizes]
+
+
+def test_fit_replays_captured_steps_and_matches_eager():
+  """`Model.fit` / `evaluate` (models/base.py:64-104 under Keras' compiled Model.fit): by default a
+  batch shape seen for the second time is captured in a HIP graph and replayed; the ragged last
+  batch runs eager in the first epoch.  Parameters, Adagrad accumulators, the per-epoch history
+  (loss + the five FactorizedTopK accuracies, compute_metrics=True as the quickstart runs it) and
+  the evaluate() dict must be bit-identical to the all-eager loop."""
+  import recommenders_amd as tfrs
+  rng = np.random.default_rng(8)
+  batches = _epoch_batches(rng, [1024] * 5 + [600])
+  test_batches = _epoch_batches(rng, [1024] * 3 + [100])
+  eager, graphed = _quickstart_model(tfrs), _quickstart_model(tfrs)
+  he = eager.fit(batches, epochs=3, graph=False)
+  hg = graphed.fit(batches, epochs=3)
+  cache = graphed.__dict__["_fit_graphs"]
+  assert sum(callable(v) for v in cache.values()) == 2, cache           # both shapes captured by epoch 2
+  assert "_errors" not in cache
+  assert not eager.__dict__.get("_fit_graphs")
+  assert set(he) == set(hg) and len(hg["loss"]) == 3
+  for key in he:
+    assert he[key] == hg[key], (key, he[key], hg[key])
+  for a, b in zip(eager.parameters(), graphed.parameters()):
+    np.testing.assert_array_equal(_np(a), _np(b))
+  for pa, pb in zip(eager.parameters(), graphed.parameters()):
+    np.testing.assert_array_equal(_np(eager.optimizer.state[pa]["accumulator"]),
+                                  _np(graphed.optimizer.state[pb]["accumulator"]))
+  ee = eager.evaluate(test_batches, graph=False)
+  eg = graphed.evaluate(test_batches)
+  eg2 = graphed.evaluate(test_batches)            # second pass: the 1024-row shape is replayed
+  assert ee == eg == eg2
+  assert any(callable(v) for v in graphed.__dict__["_eval_graphs"].values())
+  assert 0.0 < eg["factorized_top_k/top_100_categorical_accuracy"] <= 1.0
+  # one more training epoch after the evaluation: still the eager trajectory
+  he2 = eager.fit(batches, epochs=1, graph=False)
+  hg2 = graphed.fit(batches, epochs=1)
+  assert he2 == hg2
+  for a, b in zip(eager.parameters(), graphed.parameters()):
+    np.testing.assert_array_equal(_np(a), _np(b))
+
+
+def test_fit_keeps_uncapturable_steps_eager():
+  """A step with a host synchronisation inside it (`validate_ids=True` reads an error flag back)
+  cannot be captured: fit() remembers the shape as eager-only, rolls the failed capture's warm-up
+  back and walks the eager trajectory; a plain torch optimizer with host-side step state is never
+  captured by default."""
+  import recommenders_amd as tfrs
+  rng = np.random.default_rng(9)
+  batches = _epoch_batches(rng, [512] * 4)
+  eager = _quickstart_model(tfrs, with_metrics=False, validate_ids=True)
+  auto = _quickstart_model(tfrs, with_metrics=False, validate_ids=True)
+  he = eager.fit(batches, epochs=2, graph=False)
+  ha = auto.fit(batches, epochs=2)
+  assert he == ha
+  cache = auto.__dict__["_fit_graphs"]
+  assert "eager" in cache.values() and cache.get("_errors"), cache
+  for a, b in zip(eager.parameters(), auto.parameters()):
+    np.testing.assert_array_equal(_np(a), _np(b))
+  plain = _quickstart_model(tfrs, with_metrics=False)
+  plain.optimizer.close()            # tables back to dense gradients for the torch optimizer
+  plain.compile(optimizer=torch.optim.Adam(plain.parameters(), lr=0.01))
+  plain.fit(batches, epochs=2)
+  assert not any(callable(v) for v in plain.__dict__["_fit_graphs"].values())
+
+
+def test_metric_results_are_fresh_tensors_and_graphed_steps_bump_versions():
+  """(medium) `Mean.result()` after a fused FactorizedTopK update is a fresh tensor:
+  logs kept from one step do not change when the metric is updated or reset afterwards; (low) a
+  replayed graphed step bumps the version counters of the tables it trains, so a Streaming layer
+  over detached views of a trained table rebuilds its packed-block cache."""
+  import recommenders_amd as tfrs
+  from recommenders_amd.layers import factorized_top_k as ftk
+  from oracle import topk as o_topk
+  rng = np.random.default_rng(10)
+  model = _quickstart_model(tfrs)
+  b1, b2 = _epoch_batches(rng, [2048, 2048])
+  logs1 = model.train_step(b1)
+  kept = {k: float(v) for k, v in logs1.items()}
+  logs2 = model.train_step(b2)
+  for m in model.metrics:
+    m.reset_states()
+  assert {k: float(v) for k, v in logs1.items()} == kept          # not overwritten, not zeroed
+  assert any(float(logs2[k]) != kept[k] for k in kept)
+  # graphed replay -> version bump -> Streaming's cache over views of the item table is rebuilt
+  table = model.item_model.embeddings
+  views = [table.detach()[lo:lo + 512] for lo in range(0, 1682, 512)]
+  layer = ftk.Streaming(k=10).index_from_dataset(views)
+  q = _t((rng.normal(size=(32, 64)) / 8).astype(np.float32))
+  layer(q)
+  first = layer._cache
+  assert first is not None
+  step = model.make_graphed_train_step(b1)
+  layer(q)
+  second = layer._cache              # (the capture's eager warm-up steps bumped the versions themselves)
+  step(b2)
+  s, i = layer(q)
+  assert layer._cache is not second
+  es, ei = o_topk.brute_force(_np(q), _np(table.detach()), 10)
+  np.testing.assert_array_equal(_np(i), ei)
+  np.testing.assert_array_equal(_np(s), es)
+
+
 def test_adagrad_optimizer_sparse_slices_match_dense_formula():
   """optimizers.Adagrad: embedding tables are updated from (ids, rows) slices by the fused
   kernel (no dense gradient), dense parameters element-wise; both follow
