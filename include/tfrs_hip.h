@@ -179,6 +179,29 @@ int tfrs_streaming_topk_update(const float *queries, int64_t nq, int d,
                                size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------- *
+ * Streaming.call over a GROUP of consecutive candidate blocks read in place
+ * (layers/factorized_top_k.py:404-509; the layer keeps only a reference to its dataset and
+ * re-reads it on every call, :384-390,:496-507).  blocks_h[nblocks] are DEVICE pointers to
+ * row-major float32 [block_rows_h[b], d] blocks (the arrays themselves live on the host), whose
+ * rows carry the global row numbers base_row, base_row + 1, ... in block order (:474-480);
+ * seen_rows = candidates already folded into the state by earlier calls.  One call replaces
+ * nblocks calls of tfrs_streaming_topk_update with identical results: no packed copy of the
+ * blocks is built -- small query batches are scored exactly from the blocks by an HBM-bound
+ * f32-MFMA kernel, large ones through one fp16 prefilter image of the group with exact re-scoring
+ * from the blocks (csrc/topk_raw.hip).  Requirements: d in {8, 16, 32, 64, 128}, 16-byte aligned
+ * block pointers, nblocks <= 192 (TFRS_EINVAL otherwise: use the per-block entry point); the blocks
+ * must stay valid until the work enqueued on `stream` has run.  Workspace from
+ * tfrs_streaming_topk_blocks_workspace_bytes(nq, total rows of the group, d, k).
+ * ------------------------------------------------------------------------- */
+size_t tfrs_streaming_topk_blocks_workspace_bytes(int64_t nq, int64_t total_rows, int d, int k);
+int tfrs_streaming_topk_update_blocks(const float *queries, int64_t nq, int d,
+                                      const float *const *blocks_h, const int64_t *block_rows_h,
+                                      int nblocks, int64_t base_row, int64_t seen_rows, int k,
+                                      float *state_scores, int32_t *state_idx, int32_t state_len,
+                                      int32_t *new_len_h, void *workspace, size_t workspace_bytes,
+                                      void *stream);
+
+/* ------------------------------------------------------------------------- *
  * Embedding dims above TFRS_MAX_DIM (the fused scan kernels keep a row in registers): the same
  * result through materialised score blocks.
  *   tfrs_compute_scores: scores[nq, nc] = q @ c^T (TopK._compute_score,

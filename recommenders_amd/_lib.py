@@ -49,6 +49,9 @@ SIGNATURES = {
     "tfrs_streaming_topk_workspace_bytes": (c_size_t, [c_i64, c_i64, c_int, c_int]),
     "tfrs_streaming_topk_update": (c_int, [P, c_i64, c_int, P, c_i64, c_i64, c_int, P, P,
                                            ctypes.c_int32, P, P, c_size_t, P]),
+    "tfrs_streaming_topk_blocks_workspace_bytes": (c_size_t, [c_i64, c_i64, c_int, c_int]),
+    "tfrs_streaming_topk_update_blocks": (c_int, [P, c_i64, c_int, P, P, c_int, c_i64, c_i64, c_int, P, P,
+                                                  ctypes.c_int32, P, P, c_size_t, P]),
     "tfrs_compute_scores": (c_int, [P, P, c_i64, c_int, c_int, P, c_int, P, c_size_t, P]),
     "tfrs_topk_update_from_scores": (c_int, [P, c_i64, c_i64, c_i64, c_i64, c_int, P, P, ctypes.c_int32,
                                              P, P]),

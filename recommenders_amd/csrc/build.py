@@ -26,6 +26,7 @@ SOURCES = [
     "topk_scan16.hip",
     "topk_select.hip",
     "topk_select16.hip",
+    "topk_raw.hip",
     "topk_api.hip",
     "metric_fused.hip",
     "dedup.hip",

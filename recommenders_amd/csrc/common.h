@@ -145,6 +145,95 @@ __device__ inline uint64_t make_key(float s, int32_t idx) {
 __device__ inline float key_score(uint64_t k) { return f32_from_orderable((uint32_t)(k >> 32)); }
 __device__ inline int32_t key_index(uint64_t k) { return (int32_t)(~(uint32_t)k); }
 
+// ---- row-major candidate blocks read in place (Streaming over a dataset) ------------------------
+// Streaming.call (layers/factorized_top_k.py:404-509) re-reads its candidate dataset on every call
+// (:384-390: "index_from_dataset" only keeps the dataset).  The blocks of ONE group of consecutive
+// dataset elements -- device pointers to row-major f32 [rows, d] -- are described by a RawTable
+// in device memory; image-local row r of the group is row r - row_start[b] of block b.  The kernels
+// that need a candidate's f32 features (the raw scan, the fp16 packer, the exact re-scoring of
+// survivors and the exact-recompute fallback) fetch them through it, so no packed f32 image of
+// the stream is ever built.  Requirements of this path: d in {8, 16, 32, 64, 128} (a row is a whole
+// number of 16-byte pieces, d == padded_dim(d)) and 16-byte aligned block pointers.
+constexpr int kRawMaxBlocks = 192;   // descriptor table by value: 16 + 193 * 8 + 192 * 8 = 3096 bytes < 4 KiB of kernel arguments
+struct RawTable {
+  int32_t n_blocks;
+  int32_t uniform_rows;   // > 0: every block but the last holds exactly this many rows (block = row / uniform_rows)
+  int64_t total_rows;
+  int64_t row_start[kRawMaxBlocks + 1];
+  const float *ptr[kRawMaxBlocks];
+};
+__device__ inline int raw_find_block(const RawTable *t, int64_t row) {
+  const int nb = t->n_blocks;
+  if (t->uniform_rows > 0) {
+    const int64_t b = row / t->uniform_rows;
+    return b < nb ? (int)b : nb - 1;
+  }
+  int lo = 0, hi = nb - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (t->row_start[mid] <= row) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+__device__ inline const float *raw_row_ptr(const RawTable *t, int64_t row, int d) {
+  const int b = raw_find_block(t, row);
+  return t->ptr[b] + (row - t->row_start[b]) * d;
+}
+// Exact score of one candidate read from its block: the d-ordered fma chain of the MFMA f32 path
+// (`qs`: the query in LDS, read as broadcast float4; d is a multiple of 8).
+__device__ __forceinline__ float raw_score(const RawTable *t, int64_t row, int d, const float *qs) {
+  const float4 *c4 = reinterpret_cast<const float4 *>(raw_row_ptr(t, row, d));
+  const float4 *q4 = reinterpret_cast<const float4 *>(qs);
+  float acc = 0.0f;
+#pragma unroll 4
+  for (int m = 0; m < d / 4; ++m) {
+    const float4 c = c4[m], q = q4[m];
+    acc = __builtin_fmaf(c.x, q.x, acc);
+    acc = __builtin_fmaf(c.y, q.y, acc);
+    acc = __builtin_fmaf(c.z, q.z, acc);
+    acc = __builtin_fmaf(c.w, q.w, acc);
+  }
+  return acc;
+}
+// Copies a table passed BY VALUE (kernel arguments) to device memory: no host-to-device copy, no
+// synchronisation, capturable in a HIP graph.
+int launch_raw_table_write(const RawTable &table_h, RawTable *table_dev, hipStream_t stream);
+
+// Raw scan (topk_raw.hip): exact f32 scores (v_mfma_f32_32x32x2_f32, the d-ordered fma chain) of the
+// group's rows [c_begin, c_end) read straight from the row-major blocks, for small query batches
+// (HBM-bound: every candidate byte is read once from HBM and never written back).
+//   grid      = n_splits x n_qtiles workgroups of 256 threads; a query tile = qg groups of 32 queries
+//               (qg = 1 or 2), resident in ALL four waves as MFMA B operands; wave w scores 32 of a
+//               stage's 128 rows against them.
+//   FILTER      scores > thr[q] are appended to the (query, split) segment of the survivor list,
+//               slot taken from a workgroup-shared LDS counter:
+//               buf[(q * cap_l + e) * nseg + split], cnt[q * nseg + split]  (nseg == n_splits;
+//               counts beyond cap_l: entries were dropped, the query is recomputed exactly)
+//   MATERIALIZE dense[q * ld_dense + (row - c_begin)]
+struct RawScanArgs {
+  const float *q;
+  int64_t nq;
+  int d;
+  const RawTable *table;
+  int64_t c_begin, c_end;   // c_begin: a multiple of kTileN
+  int64_t split_len;        // rows per split (a multiple of kTileN)
+  int n_splits;
+  int n_qtiles;             // ceil(nq / (32 * qg))
+  int qg;                   // 1 or 2
+  const float *thr;
+  uint32_t *cnt;
+  uint2 *buf;
+  uint32_t cap_l;
+  int nseg;
+  float *dense;
+  int64_t ld_dense;
+};
+int launch_rawscan(const RawScanArgs &a, bool materialize, hipStream_t stream);
+// fp16 prefilter image (+ StageMeta, global max row norm) of the group's rows [0, table.total_rows),
+// zero rows up to the next stage boundary, straight from the row-major blocks
+int launch_pack16_raw(const RawTable *table, int64_t n_rows, int d, char *packed16, StageMeta *meta,
+                      float *norm_max, hipStream_t stream);
+
 // ---- top-K internals shared between translation units -------------------------
 struct ScanArgs {
   const float *q;        // [nq, d] row-major
@@ -289,6 +378,9 @@ struct SelectArgs {
   // launch_recompute only: only_flagged != NULL restricts the work to the listed queries,
   // only_flagged[0] = count, only_flagged[1 + s] = query index of slot s.
   const uint32_t *only_flagged;
+  // raw != NULL: exact scores are computed from the row-major blocks of the table (rc_begin / rc_end
+  // and the list's row numbers are group-local rows) instead of the packed f32 image
+  const RawTable *raw;
 };
 
 int launch_select(const SelectArgs &a, hipStream_t stream);
@@ -336,6 +428,6 @@ int launch_list_topk16(const float *q, int64_t nq, int d, const char *packed, co
                        const float *norm_max, float *out_scores, int32_t *out_idx, uint32_t *redo,
                        int64_t idx_base, const uint32_t *ovf_cnt, const uint2 *ovf_buf,
                        uint32_t ovf_cap, const int32_t *rowmap, const float *verify_raw,
-                       uint32_t *redo_reason, hipStream_t stream);
+                       uint32_t *redo_reason, hipStream_t stream, const RawTable *raw = nullptr);
 
 }  // namespace tfrs

@@ -250,11 +250,11 @@ struct RoundWs {
   char *end;
 };
 
-static size_t round_ws_bytes(int64_t nq, int64_t n, int k, const TopkTuning &t) {
+static size_t round_ws_bytes(int64_t nq, int64_t n, int k, const TopkTuning &t, int64_t ld_dense = 0) {
   size_t b = 0;
   b += 2 * align_up((size_t)nq * 4);                                    // thr, thr_raw
   b += align_up((size_t)nq * 2 * max_splits(nq, t) * 4);                 // cnt[nq, nseg]
-  b += align_up((size_t)nq * dense_rows(n, k, t) * 4);                   // dense
+  b += align_up((size_t)nq * (ld_dense > 0 ? ld_dense : dense_rows(n, k, t)) * 4);   // dense
   b += align_up((size_t)nq * list_entries_per_query(nq, k, t) * 8);      // buf
   b += 2 * align_up((size_t)nq * 4) + align_up((size_t)(nq + 5) * 4);    // qk, qscale, redo
   b += align_up((size_t)nq * kRecomputeChunks * k * 8);                  // part_keys
@@ -262,7 +262,8 @@ static size_t round_ws_bytes(int64_t nq, int64_t n, int k, const TopkTuning &t) 
   return b;
 }
 
-static RoundWs carve_round_ws(char *p, int64_t nq, int64_t n, int k, const TopkTuning &t) {
+static RoundWs carve_round_ws(char *p, int64_t nq, int64_t n, int k, const TopkTuning &t,
+                              int64_t ld_dense = 0) {
   RoundWs w;
   w.thr = reinterpret_cast<float *>(p);
   p += align_up((size_t)nq * 4);
@@ -270,7 +271,7 @@ static RoundWs carve_round_ws(char *p, int64_t nq, int64_t n, int k, const TopkT
   p += align_up((size_t)nq * 4);
   w.cnt = reinterpret_cast<uint32_t *>(p);
   p += align_up((size_t)nq * 2 * max_splits(nq, t) * 4);
-  w.ld_dense = dense_rows(n, k, t);
+  w.ld_dense = ld_dense > 0 ? ld_dense : dense_rows(n, k, t);
   w.dense = reinterpret_cast<float *>(p);
   p += align_up((size_t)nq * w.ld_dense * 4);
   w.entries = list_entries_per_query(nq, k, t);
@@ -434,11 +435,16 @@ static void plan_stage_splits(int64_t n_stages, int n_qtiles, const TopkTuning &
 
 // lower_preset: w.thr already holds a proven lower bound per query (Streaming: the carried
 // state's exact K-th score) -> the threshold pass is skipped.
+// row_lo (a multiple of kTileN) / n: the rows [row_lo, row_lo + n) of the image are searched (survivor
+// row numbers stay image-absolute; sp must have been planned for n rows).  raw != NULL: exact scores come
+// from the row-major blocks of the table (Streaming groups, topk_raw.hip) and `packed` is unused.
 static int run_f16(const float *q, int64_t nq, int d, const char *packed, const F16Image &img,
                    int64_t n, int64_t idx_base, int k, const SamplePlan &sp, bool lower_preset,
                    float *out_scores, int32_t *out_idx, const RoundWs &w, const TopkTuning &t,
-                   hipStream_t stream, const int32_t *rowmap = nullptr) {
+                   hipStream_t stream, const int32_t *rowmap = nullptr, int64_t row_lo = 0,
+                   const RawTable *raw = nullptr) {
   const int n_qtiles = (int)((nq + kScan16QueriesPerWg - 1) / kScan16QueriesPerWg);
+  const int64_t stage_lo = row_lo / kTileN;
   int rc;
   // (the per-query overflow counters are re-armed here whether or not the filter pass uses them)
   if ((rc = launch_query_kappa(q, nq, d, w.qk, w.qscale, w.ovf_cnt, stream)) != TFRS_OK) return rc;
@@ -452,11 +458,11 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
   s16.n_qtiles = n_qtiles;
   s16.qk = w.qk;
   s16.qscale = w.qscale;
-  s16.row_limit = n;
+  s16.row_limit = row_lo + n;
+  s16.stage0 = stage_lo;
 
   // threshold pass
   if (!lower_preset) {
-  s16.stage0 = 0;
   s16.n_stages = (int)sp.n_stages;
   s16.stage_stride = (int)sp.stride;
   plan_stage_splits(sp.n_stages, n_qtiles, t, &s16.stages_per_split, &s16.n_splits);
@@ -506,7 +512,7 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
   if ((rc = launch_list_topk16(q, nq, d, packed, w.buf, w.cnt, s16.cap_l, s16.nseg, k, w.qk,
                                img.norm_max, out_scores, out_idx, w.redo, idx_base, s16.ovf_cnt, w.ovf_buf,
                                kOvfCap, rowmap, (sp.stat && !lower_preset) ? w.thr_raw : nullptr,
-                               w.redo + 1 + nq, stream)) != TFRS_OK)
+                               w.redo + 1 + nq, stream, raw)) != TFRS_OK)
     return rc;
   SelectArgs se = {};
   se.nq = nq;
@@ -519,8 +525,9 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
   se.part_keys = w.part_keys;
   se.rowmap = rowmap;
   se.idx_base = idx_base;
-  se.rc_begin = 0;
-  se.rc_end = n;
+  se.rc_begin = row_lo;
+  se.rc_end = row_lo + n;
+  se.raw = raw;
   se.out_scores = out_scores;
   se.out_idx = out_idx;
   return launch_recompute(se, stream);
@@ -976,6 +983,312 @@ extern "C" int tfrs_streaming_topk_update(const float *queries, int64_t nq, int 
                   state_scores, state_idx, state_len, w, t, (hipStream_t)stream, &new_len);
   if (new_len_h) *new_len_h = new_len;
   return rc;
+}
+
+// ----------------------------------------------------------------------------------------
+// Streaming.call, a GROUP of candidate blocks read in place (topk_raw.hip)
+// ----------------------------------------------------------------------------------------
+// The per-block entry point above costs a pack + pack16 + ~6 search launches per block and writes
+// every candidate byte back to HBM twice (f32 image, fp16 image) before reading it again: over a
+// dataset of 191 blocks of 65536 x 128 that is launch-bound at small query batches (18 ms at
+// B = 1: 0.045 of the HBM rate) and 2x BruteForce at B = 8192.  Here the blocks of a group are
+// described once (RawTable) and searched where they lie:
+//   * nq <= raw_max_nq (TFRS_STREAM_RAW_MAX_NQ, default 128): all-f32 rounds with the raw scan
+//     kernel -- dense round over the first rows while the state is not full, then geometric
+//     filtered rounds (rho = 8) with the threshold of the running state; every candidate byte is
+//     read from HBM once per 64 queries;
+//   * larger batches: ONE fp16 image of the group built straight from the blocks, then
+//     geometric fp16-prefiltered rounds (rho = TFRS_STREAM_RHO16, default 4) whose bound is the
+//     running state's exact K-th score (the first range takes it from its own bin maxima);
+//     survivors are re-scored exactly from the blocks.
+// Identical results to the per-block path and to the oracle's Streaming fold: every round is exact.
+namespace tfrs {
+
+static int64_t stream_raw_max_nq() { return std::max<int64_t>(0, env_i64("TFRS_STREAM_RAW_MAX_NQ", 128)); }
+static int64_t stream_rho16() { return std::max<int64_t>(2, env_i64("TFRS_STREAM_RHO16", 4)); }
+constexpr int64_t kStreamFirstRange = 262144;   // rows of the first fp16 range (threshold pass of its own)
+
+static bool group_uses_f16(int64_t nq, int64_t n, int k, const TopkTuning &t) {
+  if (!(t.f16_filter && k <= kMaxKF16) || nq <= stream_raw_max_nq()) return false;
+  // the first range must be able to take its bound from bin maxima
+  return plan_sample(std::min<int64_t>(n, kStreamFirstRange), k, t, false).n_stages > 0;
+}
+static int raw_qg(int64_t nq) { return nq <= 32 ? 1 : 2; }
+static int64_t group_ld_dense(int64_t n, int k, const TopkTuning &t) {
+  return std::max(dense_rows(n, k, t), dense_rows(std::min<int64_t>(n, kStreamFirstRange), k, t));
+}
+// survivor-list entries per query of a raw round: nseg = n_splits segments of segment_cap each
+static int raw_max_splits(int64_t nq, const TopkTuning &t) {
+  const int64_t n_qtiles = (nq + 32 * raw_qg(nq) - 1) / (32 * raw_qg(nq));
+  return (int)std::max<int64_t>(1, (t.target_wgs + n_qtiles - 1) / n_qtiles);
+}
+static int64_t raw_list_entries(int64_t nq, int k, const TopkTuning &t) {
+  const int nseg = raw_max_splits(nq, t);
+  int64_t worst = 0;
+  for (int sg = 1; sg <= nseg; sg *= 2) worst = std::max<int64_t>(worst, (int64_t)sg * ((int64_t)segment_cap(k, sg, t) + 1));
+  return std::max<int64_t>(worst, (int64_t)nseg * ((int64_t)segment_cap(k, nseg, t) + 1));
+}
+
+struct GroupWs {
+  RawTable *table;
+  RoundWs w;
+  char *packed16;        // fp16 path only
+  StageMeta *meta;
+  float *norm_max;
+  float *blk_scores;
+  int32_t *blk_idx;
+};
+
+static size_t group_ws_bytes(int64_t nq, int64_t n, int d, int k, const TopkTuning &t) {
+  size_t b = align_up(sizeof(RawTable));
+  b += round_ws_bytes(nq, n, k, t, group_ld_dense(n, k, t));
+  b += align_up((size_t)nq * raw_list_entries(nq, k, t) * 8) + align_up((size_t)nq * raw_max_splits(nq, t) * 4);
+  if (group_uses_f16(nq, n, k, t)) {
+    b += align_up((size_t)padded_rows(n) * row_bytes16(padded_dim16(d)));
+    b += align_up((size_t)(padded_rows(n) / kTileN + 1) * sizeof(StageMeta));
+    b += 2 * align_up((size_t)nq * k * 4);
+  }
+  return b;
+}
+
+// All-f32 rounds over the group's rows [0, n) through the raw scan kernel (same round structure as
+// run_rounds).  raw_buf / raw_cnt: the survivor lists of the raw geometry (one segment per split).
+static int run_rounds_raw(const float *q, int64_t nq, int d, const RawTable *table, int64_t n,
+                          int64_t idx_base, int64_t seen, int k, float *state_scores, int32_t *state_idx,
+                          int state_len, const RoundWs &w, uint2 *raw_buf, uint32_t *raw_cnt,
+                          int64_t raw_entries, const TopkTuning &t, hipStream_t stream, int *new_len) {
+  int len = state_len;
+  if (n <= 0 || nq <= 0) {
+    *new_len = len;
+    return TFRS_OK;
+  }
+  const int qg = raw_qg(nq);
+  const int n_qtiles = (int)((nq + 32 * qg - 1) / (32 * qg));
+  int rc;
+  RawScanArgs sa = {};
+  sa.q = q;
+  sa.nq = nq;
+  sa.d = d;
+  sa.table = table;
+  sa.n_qtiles = n_qtiles;
+  sa.qg = qg;
+  sa.thr = w.thr;
+  sa.cnt = raw_cnt;
+  sa.buf = raw_buf;
+  sa.dense = w.dense;
+  sa.ld_dense = w.ld_dense;
+
+  SelectArgs se = {};
+  se.nq = nq;
+  se.k = k;
+  se.state_scores = state_scores;
+  se.state_idx = state_idx;
+  se.q = q;
+  se.d = d;
+  se.raw = table;
+  se.idx_base = idx_base;
+  se.out_scores = state_scores;
+  se.out_idx = state_idx;
+  se.out_thr = w.thr;
+
+  int64_t lo = 0;
+  if (len < k) {
+    const int64_t n0 = std::min<int64_t>(n, w.ld_dense);
+    sa.c_begin = 0;
+    sa.c_end = n0;
+    plan_splits(n0, n_qtiles, t, &sa.split_len, &sa.n_splits);
+    if ((rc = launch_rawscan(sa, /*materialize=*/true, stream)) != TFRS_OK) return rc;
+    se.state_len = len;
+    se.source = kSrcDense;
+    se.dense = w.dense;
+    se.ld_dense = w.ld_dense;
+    se.n_dense = n0;
+    if ((rc = launch_select(se, stream)) != TFRS_OK) return rc;
+    len = (int)std::min<int64_t>(k, (int64_t)len + n0);
+    seen += n0;
+    lo = n0;
+  } else {
+    hipLaunchKernelGGL(thr_from_state_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream,
+                       state_scores, nq, k, w.thr);
+    TFRS_LAUNCH_CHECK();
+  }
+  while (lo < n) {   // the state is full here (len == k), w.thr is current
+    int64_t span = std::max<int64_t>((t.rho - 1) * std::max<int64_t>(seen, 1), kTileN);
+    span = padded_rows(span);
+    const int64_t hi = (n - lo <= span) ? n : lo + span;
+    sa.c_begin = lo;
+    sa.c_end = hi;
+    plan_splits(hi - lo, n_qtiles, t, &sa.split_len, &sa.n_splits);
+    sa.nseg = sa.n_splits;
+    sa.cap_l = segment_cap(k, sa.nseg, t);
+    if ((int64_t)sa.nseg * sa.cap_l > raw_entries) {
+      set_error("streaming blocks: survivor workspace too small (%d segments x %u)", sa.nseg, sa.cap_l);
+      return TFRS_ENOMEM;
+    }
+    if ((rc = launch_rawscan(sa, /*materialize=*/false, stream)) != TFRS_OK) return rc;
+    se.state_len = len;
+    se.source = kSrcList;
+    se.buf = raw_buf;
+    se.cnt = raw_cnt;
+    se.cap_l = sa.cap_l;
+    se.nseg = sa.nseg;
+    se.rc_begin = lo;
+    se.rc_end = hi;
+    if ((rc = launch_select(se, stream)) != TFRS_OK) return rc;
+    seen += hi - lo;
+    lo = hi;
+  }
+  *new_len = len;
+  return TFRS_OK;
+}
+
+}  // namespace tfrs
+
+extern "C" size_t tfrs_streaming_topk_blocks_workspace_bytes(int64_t nq, int64_t total_rows, int d, int k) {
+  if (nq <= 0 || total_rows <= 0 || k <= 0 || d <= 0 || d > TFRS_MAX_DIM) return 256;
+  return group_ws_bytes(nq, total_rows, d, k, tuning());
+}
+
+extern "C" int tfrs_streaming_topk_update_blocks(const float *queries, int64_t nq, int d,
+                                                 const float *const *blocks_h, const int64_t *block_rows_h,
+                                                 int nblocks, int64_t base_row, int64_t seen_rows, int k,
+                                                 float *state_scores, int32_t *state_idx, int32_t state_len,
+                                                 int32_t *new_len_h, void *workspace, size_t workspace_bytes,
+                                                 void *stream) {
+  TFRS_CHECK_ARG(nq >= 0 && d >= 1 && nblocks >= 0, "streaming_topk_update_blocks: bad shape");
+  TFRS_CHECK_ARG(d == padded_dim(d) && d <= TFRS_MAX_DIM,
+                 "streaming_topk_update_blocks: dim %d is not one of 8, 16, 32, 64, 128 (use the per-block entry point)", d);
+  TFRS_CHECK_ARG(nblocks <= kRawMaxBlocks, "streaming_topk_update_blocks: %d blocks > %d per call", nblocks,
+                 kRawMaxBlocks);
+  TFRS_CHECK_ARG(k >= 1 && k <= TFRS_MAX_K, "streaming_topk_update_blocks: k=%d outside [1, %d]", k, TFRS_MAX_K);
+  TFRS_CHECK_ARG(state_len >= 0 && state_len <= k, "streaming_topk_update_blocks: bad state_len");
+  TFRS_CHECK_ARG(seen_rows >= 0 && base_row >= 0, "streaming_topk_update_blocks: negative row counters");
+  if (new_len_h) *new_len_h = state_len;
+  if (nblocks == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(blocks_h && block_rows_h, "streaming_topk_update_blocks: NULL block list");
+  RawTable table;
+  table.n_blocks = 0;
+  table.uniform_rows = 0;
+  int64_t total = 0;
+  bool uniform = true;
+  int64_t first_rows = -1;
+  for (int b = 0; b < nblocks; ++b) {
+    const int64_t nb = block_rows_h[b];
+    TFRS_CHECK_ARG(nb >= 0, "streaming_topk_update_blocks: block %d has %lld rows", b, (long long)nb);
+    if (nb == 0) continue;   // empty dataset elements contribute nothing
+    TFRS_CHECK_ARG(blocks_h[b] != nullptr && (reinterpret_cast<uintptr_t>(blocks_h[b]) & 15) == 0,
+                   "streaming_topk_update_blocks: block %d is NULL or not 16-byte aligned", b);
+    const int i = table.n_blocks++;
+    table.ptr[i] = blocks_h[b];
+    table.row_start[i] = total;
+    // uniform: every block BEFORE the last one has the rows of the first
+    if (first_rows < 0) first_rows = nb;
+    else if (table.row_start[i] != (int64_t)i * first_rows) uniform = false;
+    total += nb;
+  }
+  table.row_start[table.n_blocks] = total;
+  for (int i = table.n_blocks + 1; i <= kRawMaxBlocks; ++i) table.row_start[i] = total;
+  for (int i = table.n_blocks; i < kRawMaxBlocks; ++i) table.ptr[i] = nullptr;
+  if (uniform && first_rows > 0 && first_rows <= 0x7FFFFFFF) {
+    // (the last block may be shorter, never longer: a longer one would hold rows of "block n")
+    const int64_t last = total - table.row_start[table.n_blocks > 0 ? table.n_blocks - 1 : 0];
+    if (table.n_blocks <= 1 || last <= first_rows) table.uniform_rows = (int32_t)first_rows;
+  }
+  table.total_rows = total;
+  TFRS_CHECK_ARG(base_row + total <= 0x7FFFFFFFll, "streaming_topk_update_blocks: row numbers exceed int32");
+  if (nq == 0 || total == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(queries && state_scores && state_idx && workspace, "streaming_topk_update_blocks: NULL pointer");
+  const TopkTuning t = tuning();
+  const size_t need = group_ws_bytes(nq, total, d, k, t);
+  if (workspace_bytes < need) {
+    set_error("streaming_topk_update_blocks: workspace %zu < required %zu", workspace_bytes, need);
+    return TFRS_ENOMEM;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  char *p = static_cast<char *>(workspace);
+  RawTable *table_dev = reinterpret_cast<RawTable *>(p);
+  p += align_up(sizeof(RawTable));
+  const RoundWs w = carve_round_ws(p, nq, total, k, t, group_ld_dense(total, k, t));
+  p = w.end;
+  uint2 *raw_buf = reinterpret_cast<uint2 *>(p);
+  const int64_t raw_entries = raw_list_entries(nq, k, t);
+  p += align_up((size_t)nq * raw_entries * 8);
+  uint32_t *raw_cnt = reinterpret_cast<uint32_t *>(p);
+  p += align_up((size_t)nq * raw_max_splits(nq, t) * 4);
+  int rc = launch_raw_table_write(table, table_dev, st);
+  if (rc != TFRS_OK) return rc;
+  int new_len = state_len;
+
+  if (!group_uses_f16(nq, total, k, t)) {
+    rc = run_rounds_raw(queries, nq, d, table_dev, total, base_row, seen_rows, k, state_scores, state_idx,
+                        state_len, w, raw_buf, raw_cnt, raw_entries, t, st, &new_len);
+    if (new_len_h) *new_len_h = new_len;
+    return rc;
+  }
+
+  // ---- fp16-prefiltered rounds over ONE image of the group ---------------------------------------
+  char *packed16 = p;
+  p += align_up((size_t)padded_rows(total) * row_bytes16(padded_dim16(d)));
+  StageMeta *meta = reinterpret_cast<StageMeta *>(p);
+  const size_t nstages = (size_t)(padded_rows(total) / kTileN);
+  float *norm_max = reinterpret_cast<float *>(meta + nstages);
+  p += align_up((nstages + 1) * sizeof(StageMeta));
+  float *blk_scores = reinterpret_cast<float *>(p);
+  p += align_up((size_t)nq * k * 4);
+  int32_t *blk_idx = reinterpret_cast<int32_t *>(p);
+  TFRS_HIP(hipMemsetAsync(norm_max, 0, sizeof(float), st));
+  if ((rc = launch_pack16_raw(table_dev, total, d, packed16, meta, norm_max, st)) != TFRS_OK) return rc;
+  const F16Image img = {packed16, meta, norm_max};
+  const int64_t rho = stream_rho16();
+  int64_t lo = 0, seen = seen_rows;
+  while (lo < total) {
+    const bool preset = (new_len == k);
+    int64_t hi;
+    SamplePlan sp = {1, 0, 1, k, false};
+    if (preset) {
+      int64_t span = std::max<int64_t>((rho - 1) * std::max<int64_t>(seen, 1), 16 * kTileN);
+      span = padded_rows(span);
+      hi = (total - lo <= span) ? total : lo + span;
+      // a short tail (fewer than 16 stages) is not worth a round of its own
+      if (total - hi < 16 * kTileN) hi = total;
+      hipLaunchKernelGGL(thr_from_state_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st,
+                         state_scores, nq, k, w.thr);
+      TFRS_LAUNCH_CHECK();
+    } else {
+      // the state is not full: this range's own bin maxima give the bound (guaranteed plan).  Only the
+      // FIRST range of a stream gets here (it fills the state: >= 8 * K bins means >= K rows).
+      hi = std::min<int64_t>(total, lo + kStreamFirstRange);
+      if (total - hi < 16 * kTileN) hi = total;
+      sp = plan_sample(hi - lo, k, t, false);
+      if (sp.n_stages <= 0) {
+        set_error("streaming_topk_update_blocks: internal: no threshold plan for %lld rows", (long long)(hi - lo));
+        return TFRS_ESTATE;
+      }
+    }
+    if ((rc = run_f16(queries, nq, d, /*packed=*/nullptr, img, hi - lo, base_row, k, sp, preset, blk_scores,
+                      blk_idx, w, t, st, /*rowmap=*/nullptr, lo, table_dev)) != TFRS_OK)
+      return rc;
+    SelectArgs se = {};
+    se.nq = nq;
+    se.k = k;
+    se.state_scores = state_scores;
+    se.state_idx = state_idx;
+    se.state_len = new_len;
+    se.source = kSrcParts;
+    se.part_scores = blk_scores;
+    se.part_idx = blk_idx;
+    se.nparts = 1;
+    se.k_in = k;
+    se.d = 8;
+    se.out_scores = state_scores;
+    se.out_idx = state_idx;
+    if ((rc = launch_select(se, st)) != TFRS_OK) return rc;
+    new_len = (int)std::min<int64_t>(k, (int64_t)new_len + (hi - lo));
+    seen += hi - lo;
+    lo = hi;
+  }
+  if (new_len_h) *new_len_h = new_len;
+  return TFRS_OK;
 }
 
 // ----------------------------------------------------------------------------------------

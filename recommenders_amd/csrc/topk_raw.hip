@@ -1,0 +1,403 @@
+// topk_raw.hip -- Streaming.call over candidate blocks that are read IN PLACE.
+//
+// The reference's Streaming layer keeps only a reference to its candidate dataset and re-reads it
+// on every call (layers/factorized_top_k.py:384-390, :496-507): per block tf.matmul + tf.math.top_k
+// (:424-438) and a concat + top_k fold (:440-472).  Here the blocks of a group of consecutive
+// dataset elements (row-major f32 [rows, d] in HBM, described by a RawTable, common.h) are scored
+// where they lie:
+//
+//   rawscan_kernel     small query batches (HBM-bound): exact f32 scores on the f32 matrix cores
+//                      (v_mfma_f32_32x32x2_f32 == the d-ordered fma chain of oracle/c/oracle_core.c)
+//                      with the top-K filter fused behind them.  A candidate byte is read from HBM
+//                      once and nothing is written but the survivors.
+//   pack16_raw_kernel  large query batches (MFMA-bound): the fp16 prefilter image of the group
+//                      (topk_scan16.hip consumes it) is built straight from the blocks -- the f32
+//                      packed image of the BruteForce index is never written; survivors are
+//                      re-scored exactly from the blocks (raw_score, common.h).
+//
+// Layout of a raw stage in LDS.  A stage is 128 consecutive rows = DP/2 KiB; the copy is
+// global_load_lds_dwordx4 (LDS address = wave-uniform base + lane * 16, so one instruction lands
+// 1 KiB of consecutive rows contiguously: a "chunk" of 256 / DP rows).  Chunks are placed 1040 bytes
+// apart (one 16-byte pad): consecutive chunks then start in consecutive 16-byte bank groups, and
+// the lane -> row assignment of the MFMA A operand walks the CHUNKS first,
+//     t = 32 * wave + j  ->  row (t % chunks) * rows_per_chunk + t / chunks,
+// so the 16 lanes of a ds_read_b128 quarter hit 16 different bank groups (DP >= 32).  Any
+// assignment is exact: a score's value does not depend on which MFMA row computes it, and the
+// survivor carries its row number.
+// A row keeps its natural feature order.  v_mfma_f32_32x32x2_f32 wants feature 2s from lanes
+// 0-31 and 2s+1 from lanes 32-63 at step s: lane half h reads the 16-byte piece 2m + h
+// (features 8m + 4h ..) and two v_permlane32_swap turn the four registers into the steps
+// 4m .. 4m+3 = features (8m, 8m+1), (8m+2, 8m+3), (8m+4, 8m+5), (8m+6, 8m+7).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace tfrs {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRawWaves = 4;
+constexpr int kRawThreads = kRawWaves * 64;
+constexpr int kRawChunkB = 1040;   // 1 KiB of rows + 16 bytes of padding
+
+template <int DP>
+struct RawGeom {
+  static constexpr int kRowB = DP * 4;
+  static constexpr int kRowsPerChunk = 1024 / kRowB;          // 2 (DP = 128) .. 32 (DP = 8)
+  static constexpr int kChunks = kTileN / kRowsPerChunk;      // DP / 2
+  static constexpr int kCopies = kChunks / kRawWaves;         // copy instructions per wave and stage
+  static constexpr int kStageB = kChunks * kRawChunkB;
+  static constexpr int kCntOff = 2 * kStageB;                 // uint32 [64] workgroup survivor counters
+  static constexpr int kLdsBytes = 2 * kStageB + 64 * 4;
+  static_assert(kChunks % kRawWaves == 0, "every wave issues the same number of stage copies");
+};
+
+// Direct-to-LDS copy of 16 bytes per lane, issued from inline assembly so that the prefetch of the
+// next stage stays in flight under the MFMAs of the current one (see topk_scan16.hip); completion
+// is awaited by hand (raw_wait_dma) before the barrier that ends a stage.
+__device__ __forceinline__ void raw_glds_copy16(const char *gsrc_lane, const char *lds_wave_base) {
+  const uint32_t m0v = (uint32_t)(uintptr_t)(
+      __attribute__((address_space(3))) const char *)lds_wave_base;
+  uint32_t m0_saved;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(m0_saved)
+               : "v"(gsrc_lane), "s"(m0v)
+               : "memory");
+}
+__device__ __forceinline__ void raw_wait_dma() {   // s_waitcnt vmcnt(0), other counters untouched
+  __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8) | (0 << 14));
+}
+
+__device__ __forceinline__ float raw_max16(const f32x16 &c) {
+  const float a = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3]));
+  const float b = fmaxf(fmaxf(c[4], c[5]), fmaxf(c[6], c[7]));
+  const float d = fmaxf(fmaxf(c[8], c[9]), fmaxf(c[10], c[11]));
+  const float e = fmaxf(fmaxf(c[12], c[13]), fmaxf(c[14], c[15]));
+  return fmaxf(fmaxf(a, b), fmaxf(d, e));
+}
+
+__global__ void raw_table_write_kernel(const RawTable t, RawTable *dst) {
+  // (word-wise copy of the by-value argument; 3096 bytes)
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(&t);
+  uint32_t *out = reinterpret_cast<uint32_t *>(dst);
+  for (int i = threadIdx.x; i < (int)(sizeof(RawTable) / 4); i += blockDim.x) out[i] = src[i];
+}
+
+int launch_raw_table_write(const RawTable &table_h, RawTable *table_dev, hipStream_t stream) {
+  hipLaunchKernelGGL(raw_table_write_kernel, dim3(1), dim3(256), 0, stream, table_h, table_dev);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+template <int DP, int QG, bool MATERIALIZE>
+__global__ void __launch_bounds__(kRawThreads) rawscan_kernel(const RawScanArgs a) {
+  using G = RawGeom<DP>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t *wg_cnt = reinterpret_cast<uint32_t *>(smem + G::kCntOff);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31;   // query column of this lane / A-tile row it supplies
+  const int h = lane >> 5;   // feature half of the MFMA step / upper candidate half of the C layout
+
+  // ---- XCD-aware workgroup remap (bijective for any grid size), as in topk_scan.hip ------------
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int xcd = bid & 7, pos = bid >> 3;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + pos;
+  const int split = logical / a.n_qtiles;
+  const int qt = logical - split * a.n_qtiles;
+
+  const int64_t c0 = a.c_begin + (int64_t)split * a.split_len;
+  int64_t c1 = c0 + a.split_len;
+  if (c1 > a.c_end) c1 = a.c_end;
+  const int nstages = c0 < c1 ? (int)((c1 - c0 + kTileN - 1) / kTileN) : 0;
+
+  // ---- the tile's queries -> MFMA B operands, resident in every wave for the whole kernel ------
+  float bq[QG][DP / 2];
+  float thr[QG];
+  int64_t qrow[QG];
+#pragma unroll
+  for (int g = 0; g < QG; ++g) {
+    qrow[g] = ((int64_t)qt * QG + g) * 32 + j;
+    const bool qvalid = qrow[g] < a.nq;
+    // unconditional 16-byte loads at a clamped row, selected afterwards: a load under `if (qvalid)` is
+    // awaited on its own (one memory round trip per feature pair)
+    const f32x4 *q4 = reinterpret_cast<const f32x4 *>(a.q + (qvalid ? qrow[g] : 0) * DP);
+#pragma unroll
+    for (int u = 0; u < DP / 4; ++u) {
+      const f32x4 v = q4[u];   // features 4u .. 4u+3; step 2u takes (4u | 4u+1), step 2u+1 takes (4u+2 | 4u+3)
+      bq[g][2 * u] = qvalid ? (h ? v[1] : v[0]) : 0.0f;
+      bq[g][2 * u + 1] = qvalid ? (h ? v[3] : v[2]) : 0.0f;
+    }
+    thr[g] = __builtin_inff();
+    if (!MATERIALIZE) {
+      const float tv = a.thr[qvalid ? qrow[g] : 0];
+      thr[g] = qvalid ? tv : __builtin_inff();
+    }
+  }
+  if (tid < 64) wg_cnt[tid] = 0u;
+
+  // ---- block cursor (wave-uniform): the block that holds the stage's first row -----------------
+  const RawTable *T = a.table;
+  const int nblk = T->n_blocks;
+  int blk = nstages > 0 ? __builtin_amdgcn_readfirstlane(raw_find_block(T, c0)) : 0;
+  int64_t blk_lo = T->row_start[blk], blk_hi = T->row_start[blk + 1];
+  const char *blk_ptr = reinterpret_cast<const char *>(T->ptr[blk]);
+
+  auto issue_stage = [&](int st, char *lds) {
+    const int64_t v0 = c0 + (int64_t)st * kTileN;
+    while (v0 >= blk_hi && blk + 1 < nblk) {
+      ++blk;
+      blk_lo = blk_hi;
+      blk_hi = T->row_start[blk + 1];
+      blk_ptr = reinterpret_cast<const char *>(T->ptr[blk]);
+    }
+    if (v0 + kTileN <= blk_hi && v0 + kTileN <= c1) {
+      // the whole stage lies in one block: a linear copy
+      const char *src = blk_ptr + (v0 - blk_lo) * (int64_t)G::kRowB + lane * 16;
+#pragma unroll
+      for (int i = 0; i < G::kCopies; ++i) {
+        const int ch = wave + kRawWaves * i;
+        raw_glds_copy16(src + ch * 1024, lds + ch * kRawChunkB);
+      }
+    } else {
+      // block boundary or the last, partly filled stage: every lane looks its row up; rows at or
+      // beyond c1 re-read the last valid row (their scores are never used)
+#pragma unroll
+      for (int i = 0; i < G::kCopies; ++i) {
+        const int ch = wave + kRawWaves * i;
+        const int byte = ch * 1024 + lane * 16;
+        const int r = byte / G::kRowB;
+        int64_t row = v0 + r;
+        if (row > c1 - 1) row = c1 - 1;
+        const char *p = reinterpret_cast<const char *>(raw_row_ptr(T, row, DP)) + (byte - r * G::kRowB);
+        raw_glds_copy16(p, lds + ch * kRawChunkB);
+      }
+    }
+  };
+
+  if (nstages > 0) issue_stage(0, smem);
+  raw_wait_dma();
+  __syncthreads();
+
+  // this lane's A-tile row: stage row of t = 32 * wave + j
+  const int t_row = 32 * wave + j;
+  const int a_off = (t_row % G::kChunks) * kRawChunkB + (t_row / G::kChunks) * G::kRowB + h * 16;
+
+  for (int st = 0; st < nstages; ++st) {
+    const char *tile = smem + (st & 1) * G::kStageB;
+    const bool more = st + 1 < nstages;
+    if (more) issue_stage(st + 1, smem + ((st + 1) & 1) * G::kStageB);
+    const int64_t stage_c = c0 + (int64_t)st * kTileN;
+
+    f32x16 acc[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][r] = 0.0f;
+    const char *ap = tile + a_off;
+#pragma unroll
+    for (int m = 0; m < DP / 8; ++m) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(ap + m * 32);
+      // (lo | hi) lanes: v = (d0|d4, d1|d5, d2|d6, d3|d7) -> steps (d0|d1), (d2|d3), (d4|d5), (d6|d7)
+      const auto s01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);
+      const auto s23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2]), __float_as_uint(v[3]), false, false);
+      const float a0 = __uint_as_float(s01[0]), a2 = __uint_as_float(s01[1]);
+      const float a1 = __uint_as_float(s23[0]), a3 = __uint_as_float(s23[1]);
+#pragma unroll
+      for (int g = 0; g < QG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq[g][4 * m + 0], acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < QG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq[g][4 * m + 1], acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < QG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bq[g][4 * m + 2], acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < QG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, bq[g][4 * m + 3], acc[g], 0, 0, 0);
+    }
+    // acc[g][r] = score(query qrow[g], stage row of t = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h)
+
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+      if (MATERIALIZE) {
+        if (qrow[g] < a.nq) {
+          float *drow = a.dense + qrow[g] * a.ld_dense + (stage_c - a.c_begin);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int t = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int srow = (t % G::kChunks) * G::kRowsPerChunk + t / G::kChunks;
+            if (stage_c + srow < c1) drow[srow] = acc[g][r];
+          }
+        }
+      } else {
+        const float m0 = raw_max16(acc[g]);
+        if (__ballot(m0 > thr[g]) != 0ull) {   // rare once the threshold is warm
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int t = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int srow = (t % G::kChunks) * G::kRowsPerChunk + t / G::kChunks;
+            if (acc[g][r] > thr[g] && stage_c + srow < c1) {
+              const uint32_t e = atomicAdd(&wg_cnt[g * 32 + j], 1u);
+              if (e < a.cap_l)
+                a.buf[(qrow[g] * (int64_t)a.cap_l + e) * a.nseg + split] =
+                    make_uint2(__float_as_uint(acc[g][r]), (uint32_t)(stage_c + srow));
+            }
+          }
+        }
+      }
+    }
+    if (more) raw_wait_dma();
+    __syncthreads();
+  }
+
+  // every (query, split) count is written: no memset needed
+  if (!MATERIALIZE && tid < QG * 32) {
+    const int64_t qr = ((int64_t)qt * QG + (tid >> 5)) * 32 + (tid & 31);
+    if (qr < a.nq) a.cnt[qr * a.nseg + split] = wg_cnt[tid];
+  }
+}
+
+template <int DP, int QG, bool MAT>
+static int launch_rawscan_variant(const RawScanArgs &a, hipStream_t stream) {
+  using G = RawGeom<DP>;
+  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&rawscan_kernel<DP, QG, MAT>), G::kLdsBytes));
+  const dim3 grid((unsigned)(a.n_qtiles * a.n_splits));
+  hipLaunchKernelGGL((rawscan_kernel<DP, QG, MAT>), grid, dim3(kRawThreads), G::kLdsBytes, stream, a);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+template <int DP>
+static int launch_rawscan_dp(const RawScanArgs &a, bool materialize, hipStream_t stream) {
+  if (a.qg == 1)
+    return materialize ? launch_rawscan_variant<DP, 1, true>(a, stream)
+                       : launch_rawscan_variant<DP, 1, false>(a, stream);
+  return materialize ? launch_rawscan_variant<DP, 2, true>(a, stream)
+                     : launch_rawscan_variant<DP, 2, false>(a, stream);
+}
+
+int launch_rawscan(const RawScanArgs &a, bool materialize, hipStream_t stream) {
+  if (a.nq <= 0 || a.c_end <= a.c_begin) return TFRS_OK;
+  TFRS_CHECK_ARG(a.c_begin % kTileN == 0 && a.split_len % kTileN == 0 && a.split_len > 0,
+                 "rawscan: c_begin/split_len must be multiples of %d", kTileN);
+  TFRS_CHECK_ARG(a.qg == 1 || a.qg == 2, "rawscan: qg must be 1 or 2");
+  TFRS_CHECK_ARG(materialize || a.nseg == a.n_splits, "rawscan: nseg must equal n_splits");
+  TFRS_CHECK_ARG(a.d == padded_dim(a.d), "rawscan: dim %d is not one of 8, 16, 32, 64, 128", a.d);
+  switch (a.d) {
+    case 8: return launch_rawscan_dp<8>(a, materialize, stream);
+    case 16: return launch_rawscan_dp<16>(a, materialize, stream);
+    case 32: return launch_rawscan_dp<32>(a, materialize, stream);
+    case 64: return launch_rawscan_dp<64>(a, materialize, stream);
+    case 128: return launch_rawscan_dp<128>(a, materialize, stream);
+  }
+  set_error("rawscan: unsupported dim %d", a.d);
+  return TFRS_ENOTIMPL;
+}
+
+// ---- fp16 prefilter image straight from the blocks ----------------------------------------------
+typedef _Float16 rf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t raw_pack_f16x2(float lo, float hi) {
+  union {
+    rf16x2_t h;
+    uint32_t u;
+  } v;
+  v.h[0] = (_Float16)lo;   // v_cvt_pk_f16_f32, round to nearest even
+  v.h[1] = (_Float16)hi;
+  return v.u;
+}
+
+// One workgroup (256 threads) per stage of kTileN rows (same contract as pack16_stage_kernel,
+// topk_pack.hip: x / scale with scale = 2^ceil(log2 max |x|), StageMeta, global max row norm):
+//   pass 1: two threads per row (one per half of the features) -> row norm, row max |x|;
+//   pass 2: every thread converts 16-byte slots (8 halves, natural feature order).
+// Rows at or beyond n_rows are written as zeros.
+__global__ void __launch_bounds__(256) pack16_raw_kernel(const RawTable *__restrict__ T, int64_t n_rows, int d,
+                                                         int dp16, char *__restrict__ packed16,
+                                                         StageMeta *__restrict__ meta,
+                                                         float *__restrict__ norm_max) {
+  __shared__ float s_norm[kTileN], s_amax[kTileN];
+  __shared__ const float *s_row[kTileN];
+  __shared__ float s_scale;
+  const int64_t stage = blockIdx.x;
+  const int64_t row0 = stage * kTileN;
+  const int tid = threadIdx.x;
+  {
+    const int r = tid >> 1, pl = tid & 1;
+    const int64_t row = row0 + r;
+    float ssq = 0.0f, amax = 0.0f;
+    const float *rp = nullptr;
+    if (row < n_rows) {
+      rp = raw_row_ptr(T, row, d);
+      const float4 *p4 = reinterpret_cast<const float4 *>(rp) + pl * (d / 8);
+      for (int m = 0; m < d / 8; ++m) {
+        const float4 v = p4[m];
+        ssq = __builtin_fmaf(v.x, v.x, ssq);
+        ssq = __builtin_fmaf(v.y, v.y, ssq);
+        ssq = __builtin_fmaf(v.z, v.z, ssq);
+        ssq = __builtin_fmaf(v.w, v.w, ssq);
+        amax = fmaxf(fmaxf(amax, fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y))),
+                     fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
+      }
+    }
+    ssq += __shfl_xor(ssq, 1);
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    if (pl == 0) {
+      s_norm[r] = __builtin_sqrtf(ssq) * kNormSlack;
+      s_amax[r] = amax;
+      s_row[r] = rp;
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float nm = fmaxf(s_norm[tid], s_norm[tid + 64]);
+    float am = fmaxf(s_amax[tid], s_amax[tid + 64]);
+    for (int off = 32; off > 0; off >>= 1) {
+      nm = fmaxf(nm, __shfl_xor(nm, off));
+      am = fmaxf(am, __shfl_xor(am, off));
+    }
+    if (tid == 0) {
+      const float sc = pow2_ceil(am);
+      s_scale = sc;
+      meta[stage].norm = nm;
+      meta[stage].scale = sc;
+      meta[stage].inv_scale = 1.0f / sc;
+      meta[stage].pad_ = 0.0f;
+      atomicMax(reinterpret_cast<uint32_t *>(norm_max), __float_as_uint(nm));   // nm >= 0
+    }
+  }
+  __syncthreads();
+  const float inv = 1.0f / s_scale;   // exact: power of two
+  const int slots = dp16 / 8 + 1;
+  for (int t = tid; t < kTileN * slots; t += 256) {
+    const int r = t / slots;
+    const int s = t - r * slots;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    const float *rp = s_row[r];
+    if (rp != nullptr && 8 * s < d) {
+      const float4 lo = reinterpret_cast<const float4 *>(rp)[2 * s];
+      const float4 hi = reinterpret_cast<const float4 *>(rp)[2 * s + 1];
+      w[0] = raw_pack_f16x2(lo.x * inv, lo.y * inv);
+      w[1] = raw_pack_f16x2(lo.z * inv, lo.w * inv);
+      w[2] = raw_pack_f16x2(hi.x * inv, hi.y * inv);
+      w[3] = raw_pack_f16x2(hi.z * inv, hi.w * inv);
+    }
+    *reinterpret_cast<uint4 *>(packed16 + (row0 + r) * (int64_t)row_bytes16(dp16) + (int64_t)s * 16) =
+        make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+int launch_pack16_raw(const RawTable *table, int64_t n_rows, int d, char *packed16, StageMeta *meta,
+                      float *norm_max, hipStream_t stream) {
+  if (n_rows <= 0) return TFRS_OK;
+  TFRS_CHECK_ARG(d == padded_dim(d), "pack16_raw: dim %d is not one of 8, 16, 32, 64, 128", d);
+  const int64_t stages = (n_rows + kTileN - 1) / kTileN;
+  hipLaunchKernelGGL(pack16_raw_kernel, dim3((unsigned)stages), dim3(256), 0, stream, table, n_rows, d,
+                     padded_dim16(d), packed16, meta, norm_max);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+}  // namespace tfrs

@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
       uint64_t key = 0ull;
       if (e < m) {
         const int64_t crow = a.rc_begin + e;
-        key = make_key(packed_score(a.packed, crow, dp, qs),
+        key = make_key(a.raw ? raw_score(a.raw, crow, a.d, qs) : packed_score(a.packed, crow, dp, qs),
                        (int32_t)((a.rowmap ? (int64_t)a.rowmap[crow] : crow) + a.idx_base));
       }
       consume(key);
@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(NW * 64) recompute_kernel(const SelectArgs a) 
     uint64_t key = 0ull;
     if (e < hi) {
       const int64_t crow = a.rc_begin + e;
-      key = make_key(packed_score(a.packed, crow, dp, qs),
+      key = make_key(a.raw ? raw_score(a.raw, crow, a.d, qs) : packed_score(a.packed, crow, dp, qs),
                        (int32_t)((a.rowmap ? (int64_t)a.rowmap[crow] : crow) + a.idx_base));
     }
     consume(key);

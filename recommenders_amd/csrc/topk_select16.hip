@@ -196,6 +196,9 @@ struct List16Args {
   // 1: the statistical bound did not hold, 2: the retained set did not fit}; [3]: the longest
   // survivor list of the call if one exceeded 3/4 of the capacity 64 * kSlots (else 0)
   uint32_t *redo_reason;
+  // raw != NULL: survivors are re-scored from the row-major blocks of the table (their row numbers are
+  // group-local rows) instead of the packed f32 image
+  const RawTable *raw;
 };
 
 // KP: slots for the retained set (>= K + band); the list itself may hold up to 64 * kSlots.
@@ -376,7 +379,7 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
     for (int u = 0; u < kSlots; ++u) {
       uint64_t kk = 0ull;
       if (u * 64 + lane < m)
-        kk = make_key(packed_score16(a.packed, (int64_t)kall[u], dp, qs),
+        kk = make_key(a.raw ? raw_score(a.raw, (int64_t)kall[u], a.d, qs) : packed_score16(a.packed, (int64_t)kall[u], dp, qs),
                       (int32_t)((a.rowmap ? (int64_t)a.rowmap[kall[u]] : (int64_t)kall[u]) + a.idx_base));
       ex[u * 64 + lane] = kk;
     }
@@ -400,7 +403,7 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
     if (u * 64 < m) {  // wave-uniform
       uint64_t kk = 0ull;
       if (u * 64 + lane < m)
-        kk = make_key(packed_score16(a.packed, (int64_t)kid[u], dp, qs),
+        kk = make_key(a.raw ? raw_score(a.raw, (int64_t)kid[u], a.d, qs) : packed_score16(a.packed, (int64_t)kid[u], dp, qs),
                       (int32_t)((a.rowmap ? (int64_t)a.rowmap[kid[u]] : (int64_t)kid[u]) + a.idx_base));
       ex[u * 64 + lane] = kk;
     }
@@ -430,9 +433,10 @@ int launch_list_topk16(const float *q, int64_t nq, int d, const char *packed, co
                        const float *norm_max, float *out_scores, int32_t *out_idx, uint32_t *redo,
                        int64_t idx_base, const uint32_t *ovf_cnt, const uint2 *ovf_buf,
                        uint32_t ovf_cap, const int32_t *rowmap, const float *verify_raw,
-                       uint32_t *redo_reason, hipStream_t stream) {
+                       uint32_t *redo_reason, hipStream_t stream, const RawTable *raw) {
   if (nq <= 0) return TFRS_OK;
   List16Args a;
+  a.raw = raw;
   a.idx_base = idx_base;
   a.nq = nq;
   a.k = k;

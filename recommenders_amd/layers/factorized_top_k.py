@@ -63,6 +63,8 @@ def _workspace(nbytes: int) -> Tensor:
   return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=_device())
 
 
+_RAW_DIMS = (8, 16, 32, 64, 128)   # dims whose row-major rows the grouped Streaming path reads in place
+_RAW_MAX_BLOCKS = 192              # blocks per tfrs_streaming_topk_update_blocks call (kRawMaxBlocks)
 MAX_FUSED_DIM = 128    # TFRS_MAX_DIM: embedding dims the fused scan kernels keep in registers
 MAX_FUSED_K = 1024     # TFRS_MAX_K: results per query the selection kernels hold in one pass
 _WIDE_BLOCK = 32768    # candidate rows per materialised score block on the wide-dim path
@@ -728,13 +730,21 @@ class Streaming(TopK):
   def __init__(self, query_model: Optional[Callable] = None, k: int = 10,
                handle_incomplete_batches: bool = True,
                num_parallel_calls: Optional[int] = None, sorted_order: bool = True,
-               cache_packed_blocks: bool = True, cache_max_bytes: int = 64 << 30) -> None:
+               cache_packed_blocks: bool = True, cache_max_bytes: int = 64 << 30,
+               group_max_bytes: int = 8 << 30) -> None:
     super().__init__(k=k)
     self.query_model = query_model
     self._candidates = None
     self._handle_incomplete_batches = handle_incomplete_batches
-    self._num_parallel_calls = num_parallel_calls  # accepted for API parity; unused
-    self._sorted = sorted_order                    # results are always sorted
+    # `num_parallel_calls` / `sorted_order` (reference :343-350, :503: tf.data's parallel map and the
+    # `sorted=` flag of tf.math.top_k) are accepted for API parity and have no effect here: the
+    # blocks of a group are scored by one launch, and results always come back sorted
+    self._num_parallel_calls = num_parallel_calls
+    self._sorted = sorted_order
+    # candidate bytes (float32 rows) searched per library call on the block-by-block path: the
+    # blocks of a group are read IN PLACE (tfrs_streaming_topk_update_blocks), so this bounds how
+    # many lazily produced blocks are alive at once plus the fp16 image of the group
+    self._group_max_bytes = max(int(group_max_bytes), 1)
     self._last_ids: Optional[_Identifiers] = None
     self._cache_blocks = cache_packed_blocks
     self._cache_max_bytes = int(cache_max_bytes)
@@ -881,12 +891,39 @@ class Streaming(TopK):
     has_ids = False
     new_len = ctypes.c_int32(0)
     ws = None
+    # Groups of consecutive blocks are searched where they lie (no packed copy) when the row
+    # layout allows it: one launch chain per group instead of one per block.
+    grouped = d in _RAW_DIMS and k <= MAX_FUSED_K
+    group: list = []
+    group_rows = 0
+    group_base = counter
+
+    def flush_group():
+      nonlocal group, group_rows, group_base, state_len, ws
+      if not group:
+        return
+      n = len(group)
+      ptrs = (ctypes.c_void_p * n)(*[b.data_ptr() for b in group])
+      rows = (ctypes.c_int64 * n)(*[b.shape[0] for b in group])
+      need = lib.tfrs_streaming_topk_blocks_workspace_bytes(nq, group_rows, d, k)
+      if ws is None or ws.numel() < need:
+        ws = None
+        ws = _workspace(need)
+      _lib.check(lib.tfrs_streaming_topk_update_blocks(
+          _lib.ptr(q), nq, d, ptrs, rows, n, group_base, group_base - self._base_row, k,
+          _lib.ptr(state_scores), _lib.ptr(state_rows), state_len, ctypes.byref(new_len),
+          _lib.ptr(ws), ws.numel(), _lib.current_stream()))            # :424-472 for every block of the group
+      state_len = int(new_len.value)
+      # (the blocks were only referenced by the enqueued kernels: the caching allocator reuses their
+      # memory in stream order, so dropping them here is safe)
+      group, group_rows = [], 0
+
     for element in self._candidates:
       if isinstance(element, (tuple, list)):
         block_ids, block = element
         has_ids = True
-        ids.append(block_ids.cpu().numpy() if isinstance(block_ids, torch.Tensor)
-                   else np.asarray(block_ids))
+        # (device identifiers stay on the device: a `.cpu()` here would synchronise once per block)
+        ids.append(block_ids if isinstance(block_ids, torch.Tensor) else np.asarray(block_ids))
       else:
         block = element
       block = _as_f32_matrix(block, "candidates")
@@ -901,6 +938,16 @@ class Streaming(TopK):
         state_len = _wide_topk_update(q, block, counter, k, state_scores, state_rows, state_len)
         counter += nb
         continue
+      if grouped and nb > 0 and block.data_ptr() % 16 == 0:
+        if not group:
+          group_base = counter
+        group.append(block)
+        group_rows += nb
+        counter += nb
+        if len(group) == _RAW_MAX_BLOCKS or group_rows * d * 4 >= self._group_max_bytes:
+          flush_group()
+        continue
+      flush_group()          # (a block the grouped path cannot take: keep the stream order)
       need = lib.tfrs_streaming_topk_workspace_bytes(nq, nb, d, k)
       if ws is None or ws.numel() < need:
         ws = _workspace(need)
@@ -910,8 +957,14 @@ class Streaming(TopK):
           ws.numel(), _lib.current_stream()))                          # :424-472
       state_len = int(new_len.value)
       counter += nb                                                     # :477-478
-    self._last_ids = _Identifiers(np.concatenate(ids, axis=0) if has_ids else None,
-                                  counter - self._base_row)
+    flush_group()
+    all_ids = None
+    if has_ids:
+      if all(isinstance(i, torch.Tensor) for i in ids):
+        all_ids = torch.cat([i.reshape(-1) for i in ids])
+      else:
+        all_ids = np.concatenate([i.cpu().numpy() if isinstance(i, torch.Tensor) else i for i in ids], axis=0)
+    self._last_ids = _Identifiers(all_ids, counter - self._base_row)
     return state_scores[:, :state_len], state_rows[:, :state_len]
 
   def _ids_of_rows(self, rows: Tensor):

@@ -220,6 +220,107 @@ def test_streaming_f16_blocks(d, k, bs):
   np.testing.assert_array_equal(_np(s), es)
 
 
+class _LazyBlocks:
+  """A lazily produced dataset: every pass yields FRESH device tensors (like
+  `candidates.map(item_model)`), optionally with identifiers, in blocks of the given sizes."""
+
+  def __init__(self, c, sizes, ids=None, device_ids=True):
+    self.c, self.sizes, self.ids, self.device_ids = c, sizes, ids, device_ids
+
+  def __iter__(self):
+    lo = 0
+    for nb in self.sizes:
+      blk = torch.as_tensor(self.c[lo:lo + nb]).cuda()
+      if self.ids is None:
+        yield blk
+      else:
+        i = self.ids[lo:lo + nb]
+        yield (torch.as_tensor(i).cuda() if self.device_ids else i, blk)
+      lo += nb
+
+
+def _ragged_sizes(rng, n, typical):
+  sizes, left = [], n
+  while left > 0:
+    nb = int(min(left, max(1, rng.integers(1, 2 * typical))))
+    if rng.random() < 0.15:
+      nb = int(min(left, rng.integers(1, 40)))          # a few tiny blocks
+    sizes.append(nb)
+    left -= nb
+  return sizes
+
+
+@pytest.mark.parametrize("regime", ["raw", "f16"])
+@pytest.mark.parametrize("d", [8, 16, 32, 64, 128])
+def test_streaming_groups_read_blocks_in_place(d, regime, monkeypatch):
+  """Streaming over a lazily produced dataset: groups of blocks are searched
+  where they lie (tfrs_streaming_topk_update_blocks): the raw f32-MFMA scan for small query batches
+  and the fp16 image built straight from the blocks for large ones (forced here for every batch size
+  with TFRS_STREAM_RAW_MAX_NQ=0).  Ragged and uniform block sizes, several groups with a carried state
+  (small group_max_bytes), 1 / 20 / 64 / 100 queries, k = 1 / 10 / 100, integer identifiers kept on the
+  device, a row offset: bit for bit the oracle's Streaming fold (layers/factorized_top_k.py:404-509)."""
+  ftk = _layers()
+  if regime == "f16":
+    monkeypatch.setenv("TFRS_STREAM_RAW_MAX_NQ", "0")
+    monkeypatch.setenv("TFRS_STREAM_RHO16", "2")       # more rounds than the default
+  rng = np.random.default_rng(100 + d)
+  n = 330_000 if regime == "f16" else 90_000
+  c = (rng.normal(size=(n, d)) * np.exp(0.25 * rng.normal(size=(n, 1))) / np.sqrt(d)).astype(np.float32)
+  qall = (rng.normal(size=(100, d)) / np.sqrt(d)).astype(np.float32)
+  ids = (np.arange(n, dtype=np.int64) * 3 + 7)
+  for nq, k, sizes, group_bytes, with_ids in (
+      (1, 100, _ragged_sizes(rng, n, 3000), 8 << 30, False),
+      (20, 10, [8192] * (n // 8192) + ([n % 8192] if n % 8192 else []), 8 << 30, True),
+      (64, 100, _ragged_sizes(rng, n, 20000), n * d * 4 // 3, False),      # three groups
+      (100, 1, _ragged_sizes(rng, n, 700), 8 << 30, True)):                # > 192 blocks: several calls
+    q = qall[:nq]
+    key = (d, regime, nq, k)
+    if key not in _ORACLE_CACHE:
+      _ORACLE_CACHE[key] = o_topk.brute_force(q, c, k)
+    es, ei = _ORACLE_CACHE[key]
+    layer = ftk.Streaming(k=k, group_max_bytes=group_bytes).index_from_dataset(
+        _LazyBlocks(c, sizes, ids if with_ids else None))
+    s, got = layer(q)
+    assert layer._cache is None                          # never cached: read in place on every call
+    np.testing.assert_array_equal(_np(s), es)
+    np.testing.assert_array_equal(_np(got), ids[ei] if with_ids else ei)
+  # a row-sharded stream: global row numbers start at base_row
+  sh = ftk.ShardedStreaming(k=10).index_from_dataset(_LazyBlocks(c[:50_000], [4096] * 12 + [848]), base_row=1_000_000)
+  s, rows = sh(qall[:33])
+  es, ei = o_topk.brute_force(qall[:33], c[:50_000], 10)
+  np.testing.assert_array_equal(_np(s), es)
+  np.testing.assert_array_equal(_np(rows), ei + 1_000_000)
+
+
+def test_streaming_groups_edge_cases(monkeypatch):
+  """The grouped path on the edges: fewer candidates than k (short state), empty blocks, a block
+  that is not 16-byte aligned (falls back to the per-block entry point in stream order), ties
+  (integer-valued rows: lower row wins), handle_incomplete_batches=False."""
+  ftk = _layers()
+  rng = np.random.default_rng(5)
+  d = 16
+  c = rng.integers(-3, 4, size=(5000, d)).astype(np.float32)           # many exact ties
+  q = rng.integers(-3, 4, size=(40, d)).astype(np.float32)
+  dev = torch.as_tensor(c).cuda()
+  odd = torch.empty((1000 * d + 1,), dtype=torch.float32, device="cuda")[1:].view(1000, d)   # 4-byte aligned only
+  odd.copy_(dev[2000:3000])
+  blocks = [dev[:700], dev[700:700], dev[700:2000], odd, dev[3000:]]
+  assert odd.data_ptr() % 16 != 0
+  s, i = ftk.Streaming(k=50, cache_packed_blocks=False).index_from_dataset(blocks)(q)
+  es, ei = o_topk.streaming(q, [c[:700], c[700:2000], c[2000:3000], c[3000:]], 50)
+  np.testing.assert_array_equal(_np(i), ei)
+  np.testing.assert_array_equal(_np(s), es)
+  # fewer rows than k
+  s, i = ftk.Streaming(k=64, cache_packed_blocks=False).index_from_dataset([dev[:10], dev[10:37]])(q)
+  es, ei = o_topk.streaming(q, [c[:10], c[10:37]], 64)
+  assert _np(s).shape == (40, 37)
+  np.testing.assert_array_equal(_np(i), ei)
+  np.testing.assert_array_equal(_np(s), es)
+  with pytest.raises(ValueError, match="batch size is too small"):
+    ftk.Streaming(k=20, handle_incomplete_batches=False, cache_packed_blocks=False).index_from_dataset(
+        [dev[:100], dev[100:110]])(q)
+
+
 def test_streaming_incomplete_and_errors():
   ftk = _layers()
   c = np.random.default_rng(0).normal(size=(7, 4)).astype(np.float32)
