@@ -993,7 +993,7 @@ extern "C" int tfrs_streaming_topk_update(const float *queries, int64_t nq, int 
 // dataset of 191 blocks of 65536 x 128 that is launch-bound at small query batches (18 ms at
 // B = 1: 0.045 of the HBM rate) and 2x BruteForce at B = 8192.  Here the blocks of a group are
 // described once (RawTable) and searched where they lie:
-//   * nq <= raw_max_nq (TFRS_STREAM_RAW_MAX_NQ, default 128): all-f32 rounds with the raw scan
+//   * nq <= raw_max_nq (TFRS_STREAM_RAW_MAX_NQ, default 64): all-f32 rounds with the raw scan
 //     kernel -- dense round over the first rows while the state is not full, then geometric
 //     filtered rounds (rho = 8) with the threshold of the running state; every candidate byte is
 //     read from HBM once per 64 queries;
@@ -1004,7 +1004,7 @@ extern "C" int tfrs_streaming_topk_update(const float *queries, int64_t nq, int 
 // Identical results to the per-block path and to the oracle's Streaming fold: every round is exact.
 namespace tfrs {
 
-static int64_t stream_raw_max_nq() { return std::max<int64_t>(0, env_i64("TFRS_STREAM_RAW_MAX_NQ", 128)); }
+static int64_t stream_raw_max_nq() { return std::max<int64_t>(0, env_i64("TFRS_STREAM_RAW_MAX_NQ", 64)); }
 static int64_t stream_rho16() { return std::max<int64_t>(2, env_i64("TFRS_STREAM_RHO16", 4)); }
 constexpr int64_t kStreamFirstRange = 262144;   // rows of the first fp16 range (threshold pass of its own)
 

@@ -149,7 +149,12 @@ __global__ void __launch_bounds__(kRawThreads) rawscan_kernel(const RawScanArgs 
   int64_t blk_lo = T->row_start[blk], blk_hi = T->row_start[blk + 1];
   const char *blk_ptr = reinterpret_cast<const char *>(T->ptr[blk]);
 
-  auto issue_stage = [&](int st, char *lds) {
+  // Prefetch of stage `st` into `lds`.  The copies of a stage that lies in one block (the common case)
+  // are NOT issued here: the caller spreads them over its MFMA loop, one per feature step -- a wave that
+  // issues all of them back to back sits in the issue stage until the LDS-DMA queue has room, i.e. for
+  // most of a memory latency, before its first MFMA (measured: copy time + MFMA time per stage instead of
+  // their maximum).  Returns the lane's source address of chunk `wave` (NULL: the copies were issued here).
+  auto begin_stage = [&](int st, char *lds) -> const char * {
     const int64_t v0 = c0 + (int64_t)st * kTileN;
     while (v0 >= blk_hi && blk + 1 < nblk) {
       ++blk;
@@ -157,42 +162,44 @@ __global__ void __launch_bounds__(kRawThreads) rawscan_kernel(const RawScanArgs 
       blk_hi = T->row_start[blk + 1];
       blk_ptr = reinterpret_cast<const char *>(T->ptr[blk]);
     }
-    if (v0 + kTileN <= blk_hi && v0 + kTileN <= c1) {
-      // the whole stage lies in one block: a linear copy
-      const char *src = blk_ptr + (v0 - blk_lo) * (int64_t)G::kRowB + lane * 16;
-#pragma unroll
-      for (int i = 0; i < G::kCopies; ++i) {
-        const int ch = wave + kRawWaves * i;
-        raw_glds_copy16(src + ch * 1024, lds + ch * kRawChunkB);
-      }
-    } else {
-      // block boundary or the last, partly filled stage: every lane looks its row up; rows at or
-      // beyond c1 re-read the last valid row (their scores are never used)
-#pragma unroll
-      for (int i = 0; i < G::kCopies; ++i) {
-        const int ch = wave + kRawWaves * i;
-        const int byte = ch * 1024 + lane * 16;
-        const int r = byte / G::kRowB;
-        int64_t row = v0 + r;
-        if (row > c1 - 1) row = c1 - 1;
-        const char *p = reinterpret_cast<const char *>(raw_row_ptr(T, row, DP)) + (byte - r * G::kRowB);
-        raw_glds_copy16(p, lds + ch * kRawChunkB);
-      }
+    if (v0 + kTileN <= blk_hi && v0 + kTileN <= c1)   // the whole stage lies in one block: a linear copy
+      return blk_ptr + (v0 - blk_lo) * (int64_t)G::kRowB + wave * 1024 + lane * 16;
+    // block boundary or the last, partly filled stage: every lane looks its row up; rows at or
+    // beyond c1 re-read the last valid row (their scores are never used)
+#pragma unroll 1
+    for (int i = 0; i < G::kCopies; ++i) {
+      const int ch = wave + kRawWaves * i;
+      const int byte = ch * 1024 + lane * 16;
+      const int r = byte / G::kRowB;
+      int64_t row = v0 + r;
+      if (row > c1 - 1) row = c1 - 1;
+      const char *p = reinterpret_cast<const char *>(raw_row_ptr(T, row, DP)) + (byte - r * G::kRowB);
+      raw_glds_copy16(p, lds + ch * kRawChunkB);
     }
+    return nullptr;
   };
 
-  if (nstages > 0) issue_stage(0, smem);
+  if (nstages > 0) {
+    const char *src0 = begin_stage(0, smem);
+    if (src0 != nullptr) {
+#pragma unroll
+      for (int i = 0; i < G::kCopies; ++i)
+        raw_glds_copy16(src0 + i * (kRawWaves * 1024), smem + (wave + kRawWaves * i) * kRawChunkB);
+    }
+  }
   raw_wait_dma();
   __syncthreads();
 
   // this lane's A-tile row: stage row of t = 32 * wave + j
   const int t_row = 32 * wave + j;
   const int a_off = (t_row % G::kChunks) * kRawChunkB + (t_row / G::kChunks) * G::kRowB + h * 16;
+  static_assert(G::kCopies == DP / 8, "one stage copy per feature step of the MFMA loop");
 
   for (int st = 0; st < nstages; ++st) {
     const char *tile = smem + (st & 1) * G::kStageB;
     const bool more = st + 1 < nstages;
-    if (more) issue_stage(st + 1, smem + ((st + 1) & 1) * G::kStageB);
+    char *next_lds = smem + ((st + 1) & 1) * G::kStageB + wave * kRawChunkB;
+    const char *next_src = more ? begin_stage(st + 1, smem + ((st + 1) & 1) * G::kStageB) : nullptr;
     const int64_t stage_c = c0 + (int64_t)st * kTileN;
 
     f32x16 acc[QG];
@@ -203,6 +210,8 @@ __global__ void __launch_bounds__(kRawThreads) rawscan_kernel(const RawScanArgs 
     const char *ap = tile + a_off;
 #pragma unroll
     for (int m = 0; m < DP / 8; ++m) {
+      if (next_src != nullptr)   // (wave-uniform) chunk wave + 4 m of the next stage
+        raw_glds_copy16(next_src + m * (kRawWaves * 1024), next_lds + m * (kRawWaves * kRawChunkB));
       const f32x4 v = *reinterpret_cast<const f32x4 *>(ap + m * 32);
       // (lo | hi) lanes: v = (d0|d4, d1|d5, d2|d6, d3|d7) -> steps (d0|d1), (d2|d3), (d4|d5), (d6|d7)
       const auto s01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);
@@ -310,94 +319,124 @@ __device__ __forceinline__ uint32_t raw_pack_f16x2(float lo, float hi) {
 }
 
 // One workgroup (256 threads) per stage of kTileN rows (same contract as pack16_stage_kernel,
-// topk_pack.hip: x / scale with scale = 2^ceil(log2 max |x|), StageMeta, global max row norm):
-//   pass 1: two threads per row (one per half of the features) -> row norm, row max |x|;
-//   pass 2: every thread converts 16-byte slots (8 halves, natural feature order).
+// topk_pack.hip: x / scale with scale = 2^ceil(log2 max |x|), StageMeta, global max row norm).
+// Every candidate byte is read ONCE, coalesced: thread t holds the 16-byte pieces t, t + 256, ... of
+// the stage (DP / 8 of them, all loads in flight together); a row's pieces sit in DP / 4 neighbouring
+// lanes, so its norm and max |x| are xor-shuffle reductions; after the workgroup has agreed on the
+// scale each thread converts the pieces it holds and stores 8 bytes of the image.  (The first version
+// walked each row with two threads and re-read the stage for the conversion: 2.4 TB/s.)
 // Rows at or beyond n_rows are written as zeros.
-__global__ void __launch_bounds__(256) pack16_raw_kernel(const RawTable *__restrict__ T, int64_t n_rows, int d,
-                                                         int dp16, char *__restrict__ packed16,
+template <int DP>
+__global__ void __launch_bounds__(256) pack16_raw_kernel(const RawTable *__restrict__ T, int64_t n_rows,
+                                                         char *__restrict__ packed16,
                                                          StageMeta *__restrict__ meta,
                                                          float *__restrict__ norm_max) {
-  __shared__ float s_norm[kTileN], s_amax[kTileN];
+  constexpr int kPieces = DP / 8;          // 16-byte pieces per thread
+  constexpr int kRowPieces = DP / 4;       // 16-byte pieces per row
+  constexpr int kDp16 = DP < 16 ? 16 : DP; // padded_dim16
+  constexpr int kRowB16 = kDp16 * 2 + 16;
   __shared__ const float *s_row[kTileN];
+  __shared__ float s_red[2][4];
   __shared__ float s_scale;
   const int64_t stage = blockIdx.x;
   const int64_t row0 = stage * kTileN;
   const int tid = threadIdx.x;
-  {
-    const int r = tid >> 1, pl = tid & 1;
-    const int64_t row = row0 + r;
-    float ssq = 0.0f, amax = 0.0f;
-    const float *rp = nullptr;
-    if (row < n_rows) {
-      rp = raw_row_ptr(T, row, d);
-      const float4 *p4 = reinterpret_cast<const float4 *>(rp) + pl * (d / 8);
-      for (int m = 0; m < d / 8; ++m) {
-        const float4 v = p4[m];
-        ssq = __builtin_fmaf(v.x, v.x, ssq);
-        ssq = __builtin_fmaf(v.y, v.y, ssq);
-        ssq = __builtin_fmaf(v.z, v.z, ssq);
-        ssq = __builtin_fmaf(v.w, v.w, ssq);
-        amax = fmaxf(fmaxf(amax, fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y))),
-                     fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
-      }
-    }
-    ssq += __shfl_xor(ssq, 1);
-    amax = fmaxf(amax, __shfl_xor(amax, 1));
-    if (pl == 0) {
-      s_norm[r] = __builtin_sqrtf(ssq) * kNormSlack;
-      s_amax[r] = amax;
-      s_row[r] = rp;
-    }
+  if (tid < kTileN) {
+    // (rows past the end borrow the stage's first row -- always valid -- so that every load below is
+    // unconditional; their values are zeroed after the load)
+    const int64_t row = row0 + tid;
+    s_row[tid] = raw_row_ptr(T, row < n_rows ? row : row0, DP);
   }
   __syncthreads();
-  if (tid < 64) {
-    float nm = fmaxf(s_norm[tid], s_norm[tid + 64]);
-    float am = fmaxf(s_amax[tid], s_amax[tid + 64]);
-    for (int off = 32; off > 0; off >>= 1) {
-      nm = fmaxf(nm, __shfl_xor(nm, off));
-      am = fmaxf(am, __shfl_xor(am, off));
+  f32x4 v[kPieces];
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) {
+    const int x = i * 256 + tid;
+    const int r = x / kRowPieces, c4 = x - r * kRowPieces;
+    v[i] = reinterpret_cast<const f32x4 *>(s_row[r])[c4];
+  }
+  float nm2 = 0.0f, am = 0.0f;   // max over this thread's rows of (sum of squares, max |x|)
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) {
+    const int r = (i * 256 + tid) / kRowPieces;
+    if (row0 + r >= n_rows) v[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float ssq = 0.0f;
+    ssq = __builtin_fmaf(v[i][0], v[i][0], ssq);
+    ssq = __builtin_fmaf(v[i][1], v[i][1], ssq);
+    ssq = __builtin_fmaf(v[i][2], v[i][2], ssq);
+    ssq = __builtin_fmaf(v[i][3], v[i][3], ssq);
+    float amax = fmaxf(fmaxf(__builtin_fabsf(v[i][0]), __builtin_fabsf(v[i][1])),
+                       fmaxf(__builtin_fabsf(v[i][2]), __builtin_fabsf(v[i][3])));
+#pragma unroll
+    for (int off = 1; off < kRowPieces; off <<= 1) {   // the row's pieces: kRowPieces neighbouring lanes
+      ssq += __shfl_xor(ssq, off);
+      amax = fmaxf(amax, __shfl_xor(amax, off));
     }
-    if (tid == 0) {
-      const float sc = pow2_ceil(am);
-      s_scale = sc;
-      meta[stage].norm = nm;
-      meta[stage].scale = sc;
-      meta[stage].inv_scale = 1.0f / sc;
-      meta[stage].pad_ = 0.0f;
-      atomicMax(reinterpret_cast<uint32_t *>(norm_max), __float_as_uint(nm));   // nm >= 0
-    }
+    nm2 = fmaxf(nm2, ssq);
+    am = fmaxf(am, amax);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    nm2 = fmaxf(nm2, __shfl_xor(nm2, off));
+    am = fmaxf(am, __shfl_xor(am, off));
+  }
+  if ((tid & 63) == 0) {
+    s_red[0][tid >> 6] = nm2;
+    s_red[1][tid >> 6] = am;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float n2 = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
+    const float a_ = fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3]));
+    // (the sum of squares of a row is accumulated in a different order than pack16_stage_kernel does:
+    // kNormSlack covers the rounding of either; the norm only has to be an upper bound)
+    const float nm = __builtin_sqrtf(n2) * kNormSlack;
+    const float sc = pow2_ceil(a_);
+    s_scale = sc;
+    meta[stage].norm = nm;
+    meta[stage].scale = sc;
+    meta[stage].inv_scale = 1.0f / sc;
+    meta[stage].pad_ = 0.0f;
+    atomicMax(reinterpret_cast<uint32_t *>(norm_max), __float_as_uint(nm));   // nm >= 0
   }
   __syncthreads();
   const float inv = 1.0f / s_scale;   // exact: power of two
-  const int slots = dp16 / 8 + 1;
-  for (int t = tid; t < kTileN * slots; t += 256) {
-    const int r = t / slots;
-    const int s = t - r * slots;
-    uint32_t w[4] = {0u, 0u, 0u, 0u};
-    const float *rp = s_row[r];
-    if (rp != nullptr && 8 * s < d) {
-      const float4 lo = reinterpret_cast<const float4 *>(rp)[2 * s];
-      const float4 hi = reinterpret_cast<const float4 *>(rp)[2 * s + 1];
-      w[0] = raw_pack_f16x2(lo.x * inv, lo.y * inv);
-      w[1] = raw_pack_f16x2(lo.z * inv, lo.w * inv);
-      w[2] = raw_pack_f16x2(hi.x * inv, hi.y * inv);
-      w[3] = raw_pack_f16x2(hi.z * inv, hi.w * inv);
-    }
-    *reinterpret_cast<uint4 *>(packed16 + (row0 + r) * (int64_t)row_bytes16(dp16) + (int64_t)s * 16) =
-        make_uint4(w[0], w[1], w[2], w[3]);
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) {
+    const int x = i * 256 + tid;
+    const int r = x / kRowPieces, c4 = x - r * kRowPieces;
+    const uint2 w = make_uint2(raw_pack_f16x2(v[i][0] * inv, v[i][1] * inv), raw_pack_f16x2(v[i][2] * inv, v[i][3] * inv));
+    *reinterpret_cast<uint2 *>(packed16 + (row0 + r) * (int64_t)kRowB16 + c4 * 8) = w;
   }
+  if (tid < kTileN) {   // the zero tail of every row: padding features (DP = 8) and the 16-byte pad slot
+    char *tail = packed16 + (row0 + tid) * (int64_t)kRowB16 + DP * 2;
+#pragma unroll
+    for (int b = 0; b < kRowB16 - DP * 2; b += 16) *reinterpret_cast<uint4 *>(tail + b) = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
+template <int DP>
+static int launch_pack16_raw_dp(const RawTable *table, int64_t n_rows, char *packed16, StageMeta *meta,
+                                float *norm_max, hipStream_t stream) {
+  const int64_t stages = (n_rows + kTileN - 1) / kTileN;
+  hipLaunchKernelGGL((pack16_raw_kernel<DP>), dim3((unsigned)stages), dim3(256), 0, stream, table, n_rows,
+                     packed16, meta, norm_max);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
 }
 
 int launch_pack16_raw(const RawTable *table, int64_t n_rows, int d, char *packed16, StageMeta *meta,
                       float *norm_max, hipStream_t stream) {
   if (n_rows <= 0) return TFRS_OK;
-  TFRS_CHECK_ARG(d == padded_dim(d), "pack16_raw: dim %d is not one of 8, 16, 32, 64, 128", d);
-  const int64_t stages = (n_rows + kTileN - 1) / kTileN;
-  hipLaunchKernelGGL(pack16_raw_kernel, dim3((unsigned)stages), dim3(256), 0, stream, table, n_rows, d,
-                     padded_dim16(d), packed16, meta, norm_max);
-  TFRS_LAUNCH_CHECK();
-  return TFRS_OK;
+  switch (d) {
+    case 8: return launch_pack16_raw_dp<8>(table, n_rows, packed16, meta, norm_max, stream);
+    case 16: return launch_pack16_raw_dp<16>(table, n_rows, packed16, meta, norm_max, stream);
+    case 32: return launch_pack16_raw_dp<32>(table, n_rows, packed16, meta, norm_max, stream);
+    case 64: return launch_pack16_raw_dp<64>(table, n_rows, packed16, meta, norm_max, stream);
+    case 128: return launch_pack16_raw_dp<128>(table, n_rows, packed16, meta, norm_max, stream);
+  }
+  set_error("pack16_raw: dim %d is not one of 8, 16, 32, 64, 128", d);
+  return TFRS_EINVAL;
 }
 
 }  // namespace tfrs

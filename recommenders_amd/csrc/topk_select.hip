@@ -184,33 +184,85 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
   if (source == kSrcRecompute) {
     recompute_range();
   } else if (source == kSrcList) {
-    // a segment whose count exceeds its capacity lost entries: recompute the query exactly
+    // a segment whose count exceeds its capacity lost entries: recompute the query exactly.
+    // Counts are fetched kSegBatch x 64 at a time as one batch of independent loads (the raw scan of
+    // small query batches leaves up to 512 short segments per query: walked 64 at a time with a
+    // dependent count -> entry chain this kernel took 44 us per round at B = 1).
+    constexpr int kSegBatch = 8;
     bool ovf = false;
-    for (int sg = lane; sg < a.nseg; sg += 64) ovf = ovf || (a.cnt[row * a.nseg + sg] > a.cap_l);
+    for (int sb0 = 0; sb0 < a.nseg; sb0 += 64 * kSegBatch) {
+      uint32_t c[kSegBatch];
+#pragma unroll
+      for (int b = 0; b < kSegBatch; ++b) {
+        const int sg = sb0 + b * 64 + lane;
+        c[b] = a.cnt[row * a.nseg + (sg < a.nseg ? sg : a.nseg - 1)];
+      }
+#pragma unroll
+      for (int b = 0; b < kSegBatch; ++b) ovf = ovf || (sb0 + b * 64 + lane < a.nseg && c[b] > a.cap_l);
+    }
     if (__ballot(ovf) != 0ull) {
       recompute_range();
-    } else {
-      // lanes <-> segments, 64 at a time; entry e of 64 consecutive segments is one 512-B row
+    } else if (a.nseg <= 64) {
+      // large query batches: one segment per lane, ~K (rho - 1) / nseg entries each, 4 per round trip
       const uint2 *qbuf = a.buf + (row * (int64_t)a.cap_l) * a.nseg;
-      for (int sb = 0; sb < a.nseg; sb += 64) {
-        const int sg = sb + lane;
-        const uint32_t c = (sg < a.nseg) ? a.cnt[row * a.nseg + sg] : 0u;
-        uint32_t cmax = c;
+      const uint32_t c = (lane < a.nseg) ? a.cnt[row * a.nseg + lane] : 0u;
+      uint32_t cmax = c;
+      for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, off));
+      for (uint32_t e0 = 0; e0 < cmax; e0 += 4) {
+        uint2 ent[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          ent[u] = make_uint2(0u, 0u);
+          if (e0 + u < c) ent[u] = qbuf[(int64_t)(e0 + u) * a.nseg + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          uint64_t key = 0ull;
+          if (e0 + u < c)
+            key = make_key(__uint_as_float(ent[u].x),
+                           (int32_t)((a.rowmap ? (int64_t)a.rowmap[ent[u].y] : (int64_t)ent[u].y) + a.idx_base));
+          consume(key);
+        }
+      }
+    } else {
+      // lanes <-> segments; entry e of 64 consecutive segments is one 512-B row
+      const uint2 *qbuf = a.buf + (row * (int64_t)a.cap_l) * a.nseg;
+      for (int sb0 = 0; sb0 < a.nseg; sb0 += 64 * kSegBatch) {
+        uint32_t c[kSegBatch];
+#pragma unroll
+        for (int b = 0; b < kSegBatch; ++b) {
+          const int sg = sb0 + b * 64 + lane;
+          c[b] = a.cnt[row * a.nseg + (sg < a.nseg ? sg : a.nseg - 1)];
+        }
+        uint32_t cmax = 0u;
+#pragma unroll
+        for (int b = 0; b < kSegBatch; ++b) {
+          if (sb0 + b * 64 + lane >= a.nseg) c[b] = 0u;
+          cmax = max(cmax, c[b]);
+        }
         for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, off));
-        for (uint32_t e0 = 0; e0 < cmax; e0 += 4) {
-          uint2 ent[4];
+        for (uint32_t e0 = 0; e0 < cmax; e0 += 2) {
+          uint2 ent[kSegBatch][2];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            ent[u] = make_uint2(0u, 0u);
-            if (e0 + u < c) ent[u] = qbuf[(int64_t)(e0 + u) * a.nseg + sg];
-          }
+          for (int b = 0; b < kSegBatch; ++b)
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            uint64_t key = 0ull;
-            if (e0 + u < c)
-              key = make_key(__uint_as_float(ent[u].x),
-                             (int32_t)((a.rowmap ? (int64_t)a.rowmap[ent[u].y] : (int64_t)ent[u].y) + a.idx_base));
-            consume(key);
+            for (int u = 0; u < 2; ++u) {
+              // (clamped, unconditional loads: a load under `if` is awaited on its own)
+              const int sg = min(sb0 + b * 64 + lane, a.nseg - 1);
+              const uint32_t e = min(e0 + u, a.cap_l - 1);
+              ent[b][u] = qbuf[(int64_t)e * a.nseg + sg];
+            }
+#pragma unroll
+          for (int b = 0; b < kSegBatch; ++b) {
+            if (sb0 + b * 64 >= a.nseg) break;   // (uniform)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              uint64_t key = 0ull;
+              if (e0 + u < c[b])
+                key = make_key(__uint_as_float(ent[b][u].x),
+                               (int32_t)((a.rowmap ? (int64_t)a.rowmap[ent[b][u].y] : (int64_t)ent[b][u].y) + a.idx_base));
+              consume(key);
+            }
           }
         }
       }

@@ -344,7 +344,7 @@ def test_factorized_top_k_rank_count_paths_vs_oracle(d, id_dtype):
     metric.update_state(_t(q), _t(true_c), sample_weight=_t(w))
     got = [float(v) for v in metric.result()]
     np.testing.assert_allclose(got, want, rtol=2e-6, err_msg=name)
-    assert int(metric._counts.abs().max()) == 0                  # counts and ticket re-armed for the next update
+    assert all(int(c.abs().max()) == 0 for c in metric._counts.values())   # counts and ticket re-armed for the next update
     metric.update_state(_t(q), _t(true_c), sample_weight=_t(w))   # running mean of two equal updates
     np.testing.assert_allclose([float(v) for v in metric.result()], want, rtol=2e-6, err_msg=name)
     metric.reset_states()
