@@ -28,8 +28,9 @@ brackets each scan launch with HIP events on its stream (`tfrs_profile_enable`; 
 records per launch inside the timed region -- conservative for `value`): `roofline` is the
 kernel the step spends most time in, priced with its ALGORITHMIC flop 2*B*N*D against the
 dense 16-bit MFMA peak.  N = 1 only: `cpu_baseline` (oracle restatement on the host cores),
-`secondary` (train steps/sec with its own roofline + cpu_baseline) and `gather` (embedding
-gather GB/s at BASELINE configs[3] shapes).
+`secondary` (train steps/sec of `Model.fit` with its own roofline + cpu_baseline), `gather` (embedding
+gather GB/s at BASELINE configs[3] shapes) and `streaming` (Streaming over a dataset of blocks, one GPU's
+shard of configs[2]).  The CPU legs run after every GPU measurement.
 """
 
 import argparse
@@ -63,6 +64,7 @@ def parse_args():
   ap.add_argument("--no-gather", action="store_true")
   ap.add_argument("--no-scale-workload", action="store_true")
   ap.add_argument("--no-robustness", action="store_true")
+  ap.add_argument("--no-streaming", action="store_true")
   ap.add_argument("--no-single-gpu-reference", action="store_true")
   return ap.parse_args()
 
@@ -156,7 +158,24 @@ def event_times_ms(fn, iters: int, warmup: int):
   return [a.elapsed_time(b) for a, b in ev]
 
 
-def train_step_metric(dev, cpu_baseline: bool) -> dict:
+def train_step_cpu_baseline() -> dict:
+  """The secondary metric's `cpu_baseline` (run AFTER every GPU measurement of the line: the 128 host
+  threads of a torch-CPU leg keep spinning for a while after it returns and slow the host side of
+  whatever GPU work follows -- round 4 measured Model.fit at 0.37-0.52 ms per step right after the
+  CPU legs against 0.137 ms without them)."""
+  from oracle import cpu_path   # checker-side code: only this baseline leg uses it
+  B, D, V = 4096, 64, 2000
+  base = cpu_path.time_train_step(B, D, V, budget_s=4.0, with_metrics=True)
+  base_off = cpu_path.time_train_step(B, D, V, budget_s=2.0, with_metrics=False)
+  return {"value": base["value"], "unit": "steps/s", "cores": base["threads"], "kind": "port",
+          "sample": "%d steps in %.1f s; torch-CPU restatement of the quickstart train "
+                    "step WITH its FactorizedTopK update (lookup, sgemm logits, softmax CE, "
+                    "14 candidate blocks of sgemm + top-k folded Streaming-style, in_top_k, "
+                    "backward, Adagrad; not TensorFlow); without the metric update: %.1f "
+                    "steps/s" % (base["steps"], base["seconds"], base_off["value"])}
+
+
+def train_step_metric(dev) -> dict:
   """Second half of BASELINE.json's metric: train steps/sec of the in-batch-softmax two-tower
   step at the MovieLens-100K shapes of configs[0] (B=4096, D=64, 2k-row user/item tables), AS THE
   REFERENCE'S QUICKSTART RUNS IT (README.md:58-97): ``tfrs.Model.train_step`` of
@@ -290,17 +309,6 @@ def train_step_metric(dev, cpu_baseline: bool) -> dict:
                       "ms_p90": sm["p90"],
                       "note": "4096^2 x 64 is 6.4 GFLOP: the chain is launch/latency bound at this "
                               "batch (DESIGN.md 4.5); the fraction is reported for completeness"}}
-  if cpu_baseline:
-    from oracle import cpu_path   # checker-side code: only this baseline leg uses it
-    base = cpu_path.time_train_step(B, D, V, budget_s=4.0, with_metrics=True)
-    base_off = cpu_path.time_train_step(B, D, V, budget_s=2.0, with_metrics=False)
-    out["cpu_baseline"] = {"value": base["value"], "unit": "steps/s", "cores": base["threads"],
-                           "kind": "port",
-                           "sample": "%d steps in %.1f s; torch-CPU restatement of the quickstart train "
-                                     "step WITH its FactorizedTopK update (lookup, sgemm logits, softmax CE, "
-                                     "14 candidate blocks of sgemm + top-k folded Streaming-style, in_top_k, "
-                                     "backward, Adagrad; not TensorFlow); without the metric update: %.1f "
-                                     "steps/s" % (base["steps"], base["seconds"], base_off["value"])}
   return out
 
 
@@ -351,6 +359,63 @@ def gather_metric(dev) -> dict:
           "config": {"workload": c3["workload"], "rows": c3["rows"], "dim": c3["dim"]},
           "roofline": dict(c3["roofline"], **gather_traffic()),
           "configs4_rows_dim32": out["c4_rows"]}
+
+
+def streaming_metric(dev) -> dict:
+  """BASELINE.json configs[2], one GPU's shard: Streaming top-100 over a 12.5M x dim-128 candidate
+  stream in blocks of 65536 rows handed over by a re-iterable dataset object (the layer keeps only a
+  reference and re-reads it on every call, reference layers/factorized_top_k.py:384-390,:496-507; no
+  packed copy of the stream is cached), at B = 8192 (MFMA-bound: one fp16 image of the group built
+  straight from the blocks + fp16-prefiltered rounds, exact re-scoring from the blocks), B = 64 and
+  B = 1 (HBM-bound: raw f32-MFMA scan of the blocks, every candidate byte read once).  Beside each:
+  BruteForce over the same rows held as a resident index."""
+  from recommenders_amd.layers import factorized_top_k as ftk
+  n, d, k, bs = int(os.environ.get("TFRS_BENCH_STREAM_ROWS", 12_500_000)), 128, TOPK, 65536
+  g = torch.Generator(device=dev).manual_seed(5)
+  corpus = torch.randn((n, d), generator=g, device=dev) / (d ** 0.5)
+
+  class Blocks:                     # a dataset object: iterated afresh by every call
+    def __iter__(self):
+      for lo in range(0, n, bs):
+        yield corpus[lo:lo + bs]
+
+  st = ftk.Streaming(k=k).index_from_dataset(Blocks())
+  bf = ftk.BruteForce(k=k).index(corpus)
+  out = {}
+  for nq in (8192, 64, 1):
+    q = torch.randn((nq, d), generator=g, device=dev) / (d ** 0.5)
+    ts = percentiles(event_times_ms(lambda: st(q), 5, 2))
+    tb = percentiles(event_times_ms(lambda: bf(q), 5, 2))
+    a, b = st(q), bf(q)
+    same = bool(torch.equal(a[0], b[0]) and torch.equal(a[1].long(), b[1].long()))
+    if not same:
+      raise SystemExit("bench.py: Streaming and BruteForce disagree at B = %d" % nq)
+    ms = ts["median"]
+    flop = 2.0 * nq * n * d
+    if nq >= 1024:
+      roof = {"kernel": "tfrs::scan16f_kernel<128, 8, 2> over the group's fp16 image (+ tfrs::pack16_raw_kernel)",
+              "bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": F16_MFMA_PEAK_TFLOPS,
+              "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, "traffic": None,
+              "algorithmic_flop": flop, "note": "whole call (packer, rounds, re-scoring, merges), not one launch"}
+    else:
+      nbytes = float(n) * d * 4 + nq * d * 4 + nq * k * 8     # SURVEY 8(d): N*D*s + B*D*s + B*K*8
+      roof = {"kernel": "tfrs::rawscan_kernel<128, %d, false>" % (1 if nq <= 32 else 2), "bound": "hbm",
+              "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+              "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+              "algorithmic_bytes": nbytes, "note": "whole call (dense round + 4 filtered rounds + selects), not one launch"}
+    out["batch_%d" % nq] = {"value": nq / (ms * 1e-3), "unit": "queries/s", "ms_per_call": ms,
+                            "ms_p10": ts["p10"], "ms_p90": ts["p90"],
+                            "bruteforce_resident_index_ms": tb["median"], "vs_bruteforce": ms / tb["median"],
+                            "equals_bruteforce": same, "roofline": roof}
+  del st, bf, corpus
+  torch.cuda.empty_cache()
+  head = out["batch_8192"]
+  return {"metric": "Streaming top-100 over a dataset of candidate blocks", "value": head["value"],
+          "unit": "queries/s", "ms_per_call": head["ms_per_call"],
+          "config": {"workload": "Streaming top-100, 12.5M x dim-128 stream (one GPU's shard of BASELINE.json "
+                                 "configs[2]) in 65536-row blocks from a dataset object, batch 8192",
+                     "rows": n, "dim": d, "block_rows": bs, "k": k},
+          "roofline": head["roofline"], "batches": out}
 
 
 def robustness_block(dev, queries, ref_ms: float) -> dict:
@@ -586,27 +651,15 @@ def main() -> None:
         },
     }
     if world == 1 and workload == "headline":
-      if not args.no_cpu_baseline:
-        from oracle import cpu_path  # checker-side code: only this baseline leg uses it
-        corpus_host = index.candidates().cpu().numpy()
-        q_host = queries.cpu().numpy()
-        base = cpu_path.time_brute_force(corpus_host, q_host, TOPK, budget_s=args.cpu_budget)
-        # sanity: the timed CPU path agrees with the GPU result on its first block
-        v, i = cpu_path.brute_force_topk(q_host[:64], corpus_host, TOPK)
-        agree = float((i == out[1][:64].cpu().numpy()).mean())
-        del corpus_host
-        result["cpu_baseline"] = {
-            "value": base["value"], "unit": "queries/s", "cores": base["threads"],
-            "kind": "port",
-            "sample": "%d queries x full 1M x 64 corpus in blocks of 256, %.1f s; torch-CPU "
-                      "sgemm + topk restatement of BruteForce.call (not TensorFlow); index "
-                      "agreement with the GPU on 64 queries: %.4f"
-                      % (base["queries"], base["seconds"], agree),
-        }
+      cpu_inputs = None
+      if not args.no_cpu_baseline:   # (inputs of the CPU leg, which runs after every GPU measurement;
+        cpu_inputs = (index.candidates(), out[1][:64].clone())   # still on the device here)
       if not args.no_train_step:
-        result["secondary"] = train_step_metric(dev, cpu_baseline=not args.no_cpu_baseline)
+        result["secondary"] = train_step_metric(dev)
       if not args.no_gather:
         result["gather"] = gather_metric(dev)
+      if not args.no_streaming:
+        result["streaming"] = streaming_metric(dev)
       if not args.no_robustness:
         result["robustness"] = robustness_block(dev, queries, pct["median"])
       if not args.no_scale_workload:
@@ -625,6 +678,25 @@ def main() -> None:
             "step_ms_median": p["median"], "steps": 5, "warmup": 2,
             "filter_pass_tflops": kk[1][2] / max(kk[1][0] * 1e-3, 1e-12) / 1e12,
             "redo_queries_last_step": big.last_redo_count()}
+    if world == 1 and workload == "headline" and not args.no_cpu_baseline:
+      # the CPU legs come LAST: their host threads would disturb the GPU measurements above
+      from oracle import cpu_path  # checker-side code: only this baseline leg uses it
+      corpus_host, q_host, gpu_idx64 = cpu_inputs[0].cpu().numpy(), queries.cpu().numpy(), cpu_inputs[1].cpu().numpy()
+      base = cpu_path.time_brute_force(corpus_host, q_host, TOPK, budget_s=args.cpu_budget)
+      # sanity: the timed CPU path agrees with the GPU result on its first block
+      v, i = cpu_path.brute_force_topk(q_host[:64], corpus_host, TOPK)
+      agree = float((i == gpu_idx64).mean())
+      del corpus_host
+      result["cpu_baseline"] = {
+          "value": base["value"], "unit": "queries/s", "cores": base["threads"],
+          "kind": "port",
+          "sample": "%d queries x full 1M x 64 corpus in blocks of 256, %.1f s; torch-CPU "
+                    "sgemm + topk restatement of BruteForce.call (not TensorFlow); index "
+                    "agreement with the GPU on 64 queries: %.4f"
+                    % (base["queries"], base["seconds"], agree),
+      }
+      if "secondary" in result:
+        result["secondary"]["cpu_baseline"] = train_step_cpu_baseline()
     if world > 1 and not args.no_single_gpu_reference:
       # the SAME workload on one GPU, measured by rank 0 after the timed region (the other ranks
       # wait at the final barrier): makes the N > 1 line self-contained -- speedup = value / this --

@@ -67,7 +67,7 @@ struct Rec16 {
 
 struct Side16 {
   const char *rec;        // [np / 32] records
-  const uint32_t *bmax;   // [np / 32] per record: max biased exponent of (|w_r| *) inv_r
+  const uint32_t *bmax;   // [np / 32] per record: biased exponent of its largest |2^floor(log2|w|/2) * x| (0: zero record)
   int64_t n, np;
 };
 
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) sm16_prep_kernel(const PrepSide sq, const
                                                         uint32_t *__restrict__ ticket) {
   typedef Rec16<DP> RL;
   __shared__ float tile[32][DP + 1];
-  __shared__ float s_scale[32];
+  __shared__ float s_scale[32], s_xw[32], s_tw[32];
   __shared__ uint32_t s_exp[32];
   // first kernel of the chain: re-arms the finalize kernel's ticket (a hipMemsetAsync node is
   // not reliably ordered against kernel nodes when the step is replayed from a HIP graph)
@@ -149,17 +149,49 @@ __global__ void __launch_bounds__(256) sm16_prep_kernel(const PrepSide sq, const
       const float wr = (w && r0 + row < n) ? w[r0 + row] : 1.0f;
       reinterpret_cast<float *>(rec + RL::kInv)[row] = iv;
       reinterpret_cast<float *>(rec + RL::kLse)[row] = 0.0f;      // finalize overwrites (queries)
-      reinterpret_cast<float *>(rec + RL::kWq)[row] = wr * iv;
+      // Second-GEMM operands (the backward's out^T += X^T T, contraction over the STREAMED rows).
+      // A factor that varies along the contraction can live in either operand; each fp16 hi + lo
+      // pair is accurate to 2^-22 of its own value over ~23 binades only, so the weight is split
+      // between the two: X carries the power of two 2^floor(log2|w| / 2), T the rest (|tw| in
+      // [1, 4)) -- sample weights spanning 4 decades cost each operand 7 binades instead of one
+      // operand 13 -- and the transposed image takes ONE scale per record (below), so that T
+      // carries no per-row data magnitude at all.  (Round 3: T = p * w * 2^-a_row under one scale:
+      // an entry whose own terms were small was accurate only relative to its neighbours'.)
+      const uint32_t ewb = (f2u(wr) >> 23) & 0xffu;
+      float xw = 1.0f, tw = wr;
+      if (ewb >= 1u && ewb < 255u) {
+        const int hw = ((int)ewb - 127) >> 1;                     // floor(log2 |w| / 2)
+        xw = u2f((uint32_t)(hw + 127) << 23);
+        tw = wr * u2f((uint32_t)(127 - hw) << 23);
+      }
+      s_xw[row] = xw;
+      s_tw[row] = tw;
       uint32_t ev = 0u;
-      if (r0 + row < n) ev = (f2u(fabsf(wr) * iv) >> 23) & 0xffu;
+      if (r0 + row < n) ev = (f2u(xw * m) >> 23) & 0xffu;         // exponent of the row's largest |xw * x|
       s_exp[row] = ev;
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  {
+    // the record's exponent (wave-uniform work done by every thread: 32 LDS reads)
     uint32_t ev = 0u;
     for (int r = 0; r < 32; ++r) ev = s_exp[r] > ev ? s_exp[r] : ev;
-    sd.bmax[blk] = ev;
+    float srec = 0.0f, xs = 0.0f;     // records below 2^-100: zero image, no contribution
+    if (ev >= 27u && ev < 255u) {
+      srec = u2f((263u - ev) << 23);  // largest |xw * x| of the record -> [2^9, 2^10)
+      xs = u2f((ev - 9u) << 23);      // ... and its inverse
+    }
+    if (threadIdx.x == 0) sd.bmax[blk] = (ev >= 27u && ev < 255u) ? ev : 0u;
+    // per streamed row: the factor T takes = (rest of the weight) * (inverse image scale)
+    if (threadIdx.x < 32) reinterpret_cast<float *>(rec + RL::kWq)[threadIdx.x] = s_tw[threadIdx.x] * xs;
+    for (int idx = threadIdx.x; idx < 32 * DP; idx += 256) {
+      const int f = idx >> 5, p = idx & 31;
+      const int srow = xt_row_of_pos(p);
+      const float v = tile[srow][f] * (s_xw[srow] * srec);
+      const _Float16 vh = (_Float16)v;
+      reinterpret_cast<_Float16 *>(rec + RL::kXh + f * RL::kXtB)[p] = vh;
+      reinterpret_cast<_Float16 *>(rec + RL::kXl + f * RL::kXtB)[p] = (_Float16)(v - (float)vh);
+    }
   }
   for (int idx = threadIdx.x; idx < 32 * DP; idx += 256) {
     const int row = idx / DP, f = idx - row * DP;
@@ -167,14 +199,6 @@ __global__ void __launch_bounds__(256) sm16_prep_kernel(const PrepSide sq, const
     const _Float16 vh = (_Float16)v;
     reinterpret_cast<_Float16 *>(rec + RL::kHi + row * RL::kRowB)[f] = vh;
     reinterpret_cast<_Float16 *>(rec + RL::kLo + row * RL::kRowB)[f] = (_Float16)(v - (float)vh);
-  }
-  for (int idx = threadIdx.x; idx < 32 * DP; idx += 256) {
-    const int f = idx >> 5, p = idx & 31;
-    const int srow = xt_row_of_pos(p);
-    const float v = tile[srow][f] * s_scale[srow];
-    const _Float16 vh = (_Float16)v;
-    reinterpret_cast<_Float16 *>(rec + RL::kXh + f * RL::kXtB)[p] = vh;
-    reinterpret_cast<_Float16 *>(rec + RL::kXl + f * RL::kXtB)[p] = (_Float16)(v - (float)vh);
   }
 }
 
@@ -501,26 +525,21 @@ __device__ __forceinline__ void sm16_bwd_body(const Sm16Args &a, const int block
   h8 bh[DP / 16], bl[DP / 16];
   const float rowfac2 = load_owned<DP>(bh, bl, R, row, h) * a.inv_t * kLog2e;
 
-  // T = (softmax - onehot) * (streamed-row factor) is scaled by 2^G so that its largest
-  // possible magnitude is below 2^14: G from the streamed side's largest factor exponent.
-  {
-    uint32_t E = 0u;
-    const int64_t nblk = S.np >> 5;
-    for (int64_t b = tid; b < nblk; b += NW * 64) E = S.bmax[b] > E ? S.bmax[b] : E;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const uint32_t o = (uint32_t)__shfl_xor((int)E, off);
-      E = o > E ? o : E;
-    }
-    if (lane == 0) s_e[wave] = E;
-  }
+  // T = (softmax - onehot) * (streamed-row factor) goes to the second GEMM as fp16 hi + lo: accurate to
+  // 2^-22 of a value only while that value sits in the upper ~27 binades of the fp16 range.  The scale
+  // is therefore kept PER OWNED ROW (= per lane: a column of the T tile, a factor on the dimension that is
+  // not contracted, undone exactly in the epilogue) and follows the largest |T| this row has met so far,
+  // like the running maximum of an online softmax: when a tile brings a larger value the row's
+  // accumulators are rescaled by the power of two.  An owned row whose terms are ALL tiny -- a candidate
+  // no query likes: p ~ 1e-9 in every tile -- is then as accurate relative to its own terms as any
+  // other (round 3 used one scale per streamed side: such rows fell into the fp16 subnormals).
+  int gcur = 100;           // T is multiplied by 2^gcur (lowered as larger values arrive)
   float lse2_r = 0.0f, w_r = 1.0f;
   if (RQ && rvalid) {
     lse2_r = a.lse[row] * kLog2e;
     if (a.w) w_r = a.w[row];
   }
   const float gl = (a.gloss ? *a.gloss : 1.0f) * a.inv_t;
-  float tscale = 1.0f, coef_r = 0.0f;
   wait_vm<0>();   // prologue loads land outside the loop (see the forward kernel)
 
   f32x16 outacc[NFB];
@@ -533,15 +552,6 @@ __device__ __forceinline__ void sm16_bwd_body(const Sm16Args &a, const int block
     wait_tile<kInstr, NB - 2>(nt - 1 - t);
     if (t + NB - 1 < nt)
       stage_glds<RL::kBytes, NW>(src + (int64_t)(t + NB - 1) * RL::kBytes, pre, wave, lane);
-    if (t == 0) {           // the first barrier also published s_e
-      uint32_t Em = s_e[0];
-#pragma unroll
-      for (int k = 1; k < NW; ++k) Em = s_e[k] > Em ? s_e[k] : Em;
-      int G = Em ? 14 - ((int)Em - 126) : 0;
-      G = G > 120 ? 120 : (G < -120 ? -120 : G);
-      tscale = u2f((uint32_t)(G + 127) << 23);
-      coef_r = gl * u2f((uint32_t)(127 - G) << 23) * w_r;
-    }
     const int64_t s0 = s_lo + (int64_t)t * 32;
     const f32x16 acc = tile_dot16<DP>(cur, bh, bl, j, h);
     const float *fl = reinterpret_cast<const float *>(cur + RL::kInv);
@@ -567,20 +577,44 @@ __device__ __forceinline__ void sm16_bwd_body(const Sm16Args &a, const int block
       for (int r = 0; r < 16; ++r)
         if (s0 + tile_row_of_reg(r, h) >= s_hi) tp[r] = 0.0f;
     }
-    h8 th[2], tl[2];
+    // streamed-row factor (prep: rest of the weight of a streamed query, times the inverse scale of
+    // the record's transposed image)
+    float mx = 0.0f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      // streamed-row factor: 2^-a (RQ) or w * 2^-a (rows = candidates: the weight belongs to
-      // the streamed query), times the common 2^G
-      const f32x4 tf = *reinterpret_cast<const f32x4 *>(fl + (RQ ? 0 : 64) + 8 * g + 4 * h);
+      const f32x4 tf = *reinterpret_cast<const f32x4 *>(fl + 64 + 8 * g + 4 * h);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int r = 4 * g + k;
-        const float v = tp[r] * (tf[k] * tscale);
-        const _Float16 vh = (_Float16)v;
-        th[r >> 3][r & 7] = vh;
-        tl[r >> 3][r & 7] = (_Float16)(v - (float)vh);
+        tp[4 * g + k] *= tf[k];
+        mx = fmaxf(mx, __builtin_fabsf(tp[4 * g + k]));
       }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));               // the other 16 streamed rows of this owned row
+    {
+      // |T| < 2^(need + 1): the scale that keeps it below 2^14 is 2^(13 - need)
+      const int need = (int)((f2u(mx) >> 23) & 0xffu) - 127;
+      const bool lower = (13 - need) < gcur;
+      if (__ballot(lower) != 0ull) {                   // rare after the first tiles of a sweep
+        int gnew = 11 - need;                          // two binades of head-room: fewer rescales
+        gnew = gnew < -100 ? -100 : gnew;
+        // (a drop of more than 126 binades only happens from the initial scale, with nothing accumulated)
+        const int dg = gnew - gcur;
+        const float fac = lower ? (dg < -126 ? 0.0f : u2f((uint32_t)(dg + 127) << 23)) : 1.0f;
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) outacc[fb][r] *= fac;
+        gcur = lower ? gnew : gcur;
+      }
+    }
+    const float tsc = u2f((uint32_t)(gcur + 127) << 23);
+    h8 th[2], tl[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = tp[r] * tsc;
+      const _Float16 vh = (_Float16)v;
+      th[r >> 3][r & 7] = vh;
+      tl[r >> 3][r & 7] = (_Float16)(v - (float)vh);
     }
     // out^T[feature][owned row] += sum over the tile's streamed rows X'[srow][feature] T[srow][row]
 #pragma unroll
@@ -607,6 +641,9 @@ __device__ __forceinline__ void sm16_bwd_body(const Sm16Args &a, const int block
       if (t + 1 < nt) step(ring1, ring0, t + 1);
     }
   }
+
+  // undo the row's scale; upstream gradient / temperature; the owned query's weight
+  const float coef_r = gl * w_r * u2f((uint32_t)(127 - gcur) << 23);
 
   // Epilogue.  The accumulators hold out^T (lane = owned row, register = feature): written
   // directly that is one 4-byte store per lane with a row stride between lanes.  Each wave

@@ -129,6 +129,16 @@ class FactorizedTopK(Factorized):
   def metrics(self) -> List[Mean]:
     return self._top_k_metrics
 
+  def reset_states(self) -> None:
+    """Two launches when the metrics live in the fused state buffer (instead of three per k)."""
+    if self._fused_state is not None and all(m._result_view is not None for m in self._top_k_metrics):
+      self._fused_state[0].zero_()
+      self._fused_state[1].zero_()
+      return
+    super().reset_states()
+
+  reset_state = reset_states
+
   def update_state(self, query_embeddings, true_candidate_embeddings,
                    true_candidate_ids=None, sample_weight=None):
     if true_candidate_ids is None and not self._candidates.is_exact():   # :125-131

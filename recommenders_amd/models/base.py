@@ -152,6 +152,25 @@ class Model(torch.nn.Module):
           out.append(m)
     return out
 
+  def _reset_metrics(self) -> None:
+    """Start of an epoch (Keras resets every metric): metric CONTAINERS that keep the state of their
+    metrics in one buffer (``FactorizedTopK``: fused update kernel) reset it in two launches; everything
+    else is reset metric by metric."""
+    done = set()
+    for module in self.modules():
+      # (a task keeps its FactorizedTopK objects in a plain list: they are not registered sub-modules)
+      for holder in [module] + list(getattr(module, "_factorized_metrics", None) or []):
+        if holder is self or getattr(holder, "_fused_state", None) is None:
+          continue
+        fn = getattr(holder, "reset_states", None)
+        if callable(fn) and id(holder) not in done:
+          fn()
+          done.add(id(holder))
+          done.update(id(m) for m in holder.metrics)
+    for m in self.metrics:
+      if id(m) not in done:
+        m.reset_states()
+
   def _regularization_loss(self, like: torch.Tensor) -> Optional[torch.Tensor]:
     """Sum of the layers' regularisation losses (:71-73); ``None`` when there are none (the
     metrics dict then reports a cached zero and no add / fill kernels are launched)."""
@@ -432,18 +451,31 @@ class Model(torch.nn.Module):
       cache.clear()                      # captured steps belong to the optimizer they were captured with
       self.__dict__["_fit_graphs_optimizer"] = self.optimizer
     for _ in range(epochs):
-      for m in self.metrics:
-        m.reset_states()
+      self._reset_metrics()
       logs = self._run_epoch(dataset, self.train_step, self.make_graphed_train_step, cache, allowed)
-      for k, v in logs.items():
-        history.setdefault(k, []).append(float(v))
+      for k, v in self._logs_to_floats(logs).items():
+        history.setdefault(k, []).append(v)
     return history
 
+  @staticmethod
+  def _logs_to_floats(logs: Dict[str, Any]) -> Dict[str, float]:
+    """The epoch's log values as Python floats with ONE device synchronisation (a `float(v)` per
+    entry is a stream synchronisation + copy each: eight per epoch for the quickstart model)."""
+    keys = list(logs)
+    dev = [k for k in keys if isinstance(logs[k], torch.Tensor) and logs[k].is_cuda]
+    out = {k: None for k in keys}
+    if dev:
+      vals = torch.stack([logs[k].detach().to(torch.float32).reshape(()) for k in dev]).tolist()
+      out.update(zip(dev, vals))
+    for k in keys:
+      if out[k] is None:
+        out[k] = float(logs[k])
+    return out
+
   def evaluate(self, dataset: Iterable, return_dict: bool = True, graph: Optional[bool] = None):
-    for m in self.metrics:
-      m.reset_states()
+    self._reset_metrics()
     allowed = self._graph_steps_allowed(graph, training=False)
     cache = self.__dict__.setdefault("_eval_graphs", {})
     logs = self._run_epoch(dataset, self.test_step, self.make_graphed_test_step, cache, allowed)
-    logs = {k: float(v) for k, v in logs.items()}
+    logs = self._logs_to_floats(logs)
     return logs if return_dict else list(logs.values())
