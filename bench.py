@@ -57,7 +57,8 @@ def parse_args():
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=50)
   ap.add_argument("--warmup", type=int, default=10)
-  ap.add_argument("--workload", choices=("auto", "headline", "scale100m"), default="auto")
+  ap.add_argument("--workload", choices=("auto", "headline", "scale100m", "streaming128", "dlrm_embedding"),
+                  default="auto")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--cpu-budget", type=float, default=12.0)
   ap.add_argument("--no-train-step", action="store_true")
@@ -418,6 +419,171 @@ def streaming_metric(dev) -> dict:
           "roofline": head["roofline"], "batches": out}
 
 
+def timed_region(fn, steps: int, warmup: int, world: int, dev):
+  """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides,
+  maximum over ranks (the driver's contract); returns seconds."""
+  for _ in range(warmup):
+    fn()
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    fn()
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+  if world > 1:
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  return float(t.item())
+
+
+def run_streaming128(args, rank: int, world: int, dev, rccl_ranks: int):
+  """BASELINE.json configs[2]: "Synthetic 100M-item x dim-128 corpus, Streaming top-100 sharded over 8
+  MI355X via RCCL/xGMI".  STRONG scaling: the 100M x 128 stream is row-sharded over the N ranks (rank r
+  streams rows [r * per, (r + 1) * per) in 65536-row blocks from a dataset object that is re-read on
+  every call, reference layers/factorized_top_k.py:384-390,:404-509), every rank scores the same 8192
+  queries (`ShardedStreaming`), one all_gather of the per-shard (score, row)[8192, 100] lists + merge
+  inside the timed region; value = 8192 / t."""
+  from recommenders_amd.layers import factorized_top_k as ftk
+  total = int(os.environ.get("TFRS_BENCH_ROWS", SCALE_ROWS))
+  d, bs = 128, 65536
+  per = -(-total // world)
+  lo, hi = rank * per, min(total, (rank + 1) * per)
+  g = torch.Generator(device=dev).manual_seed(7)
+  queries = torch.randn((BATCH, d), generator=g, device=dev) / (d ** 0.5)
+
+  def shard_rows(a, b):
+    # block k of the GLOBAL stream comes from seed 2000 + k: a shard's rows do not depend on N
+    out = torch.empty((b - a, d), dtype=torch.float32, device=dev)
+    k = a // INGEST_BLOCK
+    pos = a
+    while pos < b:
+      gk = torch.Generator(device=dev).manual_seed(2000 + k)
+      blk = torch.randn((INGEST_BLOCK, d), generator=gk, device=dev) / (d ** 0.5)
+      end = min(b, (k + 1) * INGEST_BLOCK)
+      out[pos - a:end - a] = blk[pos - k * INGEST_BLOCK:end - k * INGEST_BLOCK]
+      pos, k = end, k + 1
+    return out
+
+  def dataset(rows):
+    class Blocks:                       # re-iterated by every call: nothing is cached between calls
+      def __iter__(self):
+        for o in range(0, rows.shape[0], bs):
+          yield rows[o:o + bs]
+    return Blocks()
+
+  rows = shard_rows(lo, hi)
+  layer = ftk.ShardedStreaming(k=TOPK).index_from_dataset(dataset(rows), base_row=lo)
+  elapsed = timed_region(lambda: layer(queries), args.steps, args.warmup, world, dev)
+  value = BATCH / (elapsed / args.steps)
+  if rank != 0:
+    return None
+  flop = 2.0 * BATCH * (hi - lo) * d
+  ms = elapsed / args.steps * 1e3
+  result = {"metric": "queries/sec streaming top-100", "value": value, "unit": "queries/s", "n_gpus": world,
+            "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "filter_dtype": "f16", "data": "synthetic",
+            "config": {"workload": "Streaming top-100, %dM-item x dim-128 stream row-sharded over %d GPU(s), "
+                                   "65536-row blocks from a dataset object, batch 8192 (BASELINE.json configs[2])"
+                                   % (total // 1_000_000, world),
+                       "rows_total": total, "rows_per_gpu": hi - lo, "dim": d, "batch": BATCH, "k": TOPK,
+                       "parallelism": ("single GPU" if world == 1 else
+                                       f"stream row-sharded x{world}, one RCCL all_gather of per-shard top-K "
+                                       "+ merge inside the timed region")},
+            "roofline": {"kernel": "tfrs::scan16f_kernel<128, 8, 2> over the fp16 image of each group of blocks "
+                                   "(+ tfrs::pack16_raw_kernel<128>)", "bound": "mfma",
+                         "achieved": flop / (ms * 1e-3) / 1e12, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flop / (ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "algorithmic_flop_per_step": flop, "note": "per-GPU flop over the whole call"},
+            "exchange_bytes_per_rank": 2 * BATCH * TOPK * 4}
+  if world > 1 and not args.no_single_gpu_reference:
+    del layer, rows
+    torch.cuda.empty_cache()
+    allrows = shard_rows(0, total)
+    single = ftk.Streaming(k=TOPK).index_from_dataset(dataset(allrows))
+    for _ in range(2):
+      single(queries)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+      single(queries)
+    torch.cuda.synchronize()
+    one = (time.perf_counter() - t0) / 3
+    result["single_gpu_same_workload"] = {"value": BATCH / one, "unit": "queries/s", "ms_per_step": one * 1e3,
+                                          "steps": 3, "warmup": 2, "measured_on": "rank 0, after the timed region"}
+    result["speedup_vs_single_gpu_same_workload"] = value / (BATCH / one)
+  return result
+
+
+def run_dlrm_embedding(args, rank: int, world: int, dev, rccl_ranks: int):
+  """BASELINE.json configs[4]: "100 tables x 10M rows x dim-32, batch 131072, embedding-table row-sharded
+  over 8 MI355X".  The 100 tables are held as ONE [10^9, 32] table whose rows are sharded over the N ranks
+  (`ShardedEmbedding`: rank r owns rows [r * V/N, (r+1) * V/N)); the global batch of 131072 samples x 100
+  features is split over the ranks (data parallel).  One step = lookup (owner bucketing on the device, two
+  all-to-alls over xGMI) + backward (one all-to-all of gradient rows) + fused sparse Adagrad on the shard,
+  with the split sizes of the NEXT batch staged while the current step runs (`ShardedEmbedding.stage`).
+  STRONG scaling; value = samples / s of the global batch."""
+  import recommenders_amd as tfrs
+  from recommenders_amd.layers.sharded_embedding import ShardedEmbedding
+  tables, per_table, d = 100, 10_000_000, 32
+  gbatch = int(os.environ.get("TFRS_BENCH_BATCH", 131072))     # (shrunk for dry runs only)
+  vocab = int(os.environ.get("TFRS_BENCH_TABLE_ROWS", tables * per_table))
+  lbatch = gbatch // world
+  layer = ShardedEmbedding(vocab, d, device=dev)
+  opt = tfrs.optimizers.Adagrad(layer.parameters(), learning_rate=0.01)
+  g = torch.Generator(device=dev).manual_seed(100 + rank)
+  n_ids = lbatch * tables
+  # feature f draws from table f's row range: ids = f * rows_per_table + uniform row
+  rpt = vocab // tables
+  offs = (torch.arange(tables, device=dev, dtype=torch.int64) * rpt)[None, :]
+  batches = [torch.randint(0, rpt, (lbatch, tables), generator=g, device=dev) + offs for _ in range(4)]
+  upstream = torch.randn((lbatch, tables, d), generator=g, device=dev)
+  state = {"i": 0}
+  layer.stage(batches[0])
+
+  def step():
+    ids = batches[state["i"] % len(batches)]
+    state["i"] += 1
+    opt.zero_grad(set_to_none=True)
+    out = layer(ids)
+    layer.stage(batches[state["i"] % len(batches)])      # the next batch's split sizes, one step ahead
+    out.backward(upstream)
+    opt.step()
+
+  elapsed = timed_region(step, args.steps, args.warmup, world, dev)
+  if rank != 0:
+    return None
+  ms = elapsed / args.steps * 1e3
+  remote = (world - 1) / world
+  # SURVEY 8(d): gather n * (D*4 read + D*4 write) + ids; scatter/Adagrad nnz*D*4 + 4*uniq*D*4 (uniq ~ nnz here)
+  hbm = n_ids * (2 * d * 4 + 8) + n_ids * d * 4 * 5
+  return {"metric": "DLRM embedding step (row-sharded lookup + backward + sparse Adagrad) samples/sec",
+          "value": gbatch / (elapsed / args.steps), "unit": "samples/s", "n_gpus": world, "rccl_ranks": rccl_ranks,
+          "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+          "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+          "config": {"workload": "100 tables x %d rows x dim-32 as one row-sharded table over %d GPU(s), global batch "
+                                 "%d x 100 ids (BASELINE.json configs[4]): lookup + backward + fused sparse Adagrad"
+                                 % (rpt, world, gbatch),
+                     "table_rows_total": vocab, "table_rows_per_gpu": layer.row_range[1] - layer.row_range[0],
+                     "dim": d, "global_batch": gbatch, "ids_per_gpu_per_step": n_ids,
+                     "parallelism": ("single GPU" if world == 1 else
+                                     f"rows sharded x{world}; per step and rank: all_to_all ids, all_to_all rows, "
+                                     "all_to_all gradient rows")},
+          "exchange_bytes_per_rank_per_step": int(n_ids * remote * (8 + 2 * d * 4)),
+          "exchange_bytes_per_link_per_step": int(n_ids * (8 + 2 * d * 4) / world) if world > 1 else 0,
+          "roofline": {"kernel": "tfrs::gather_kernel + tfrs::scatter_add_u32_kernel (fused Adagrad) on the shard",
+                       "bound": "hbm", "achieved": hbm / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": hbm / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                       "algorithmic_bytes_per_gpu_per_step": hbm,
+                       "note": "per-GPU HBM bytes of the local gather + scatter/Adagrad over the whole step "
+                               "(the exchange is xGMI-bound: 7 links x ~153 GB/s)"}}
+
+
 def robustness_block(dev, queries, ref_ms: float) -> dict:
   """The default (fp16-prefiltered) BruteForce path is data dependent: its thresholds come from
   sampled stages and its error margin from row norms.  Same shapes as the headline (1M x 64,
@@ -491,7 +657,14 @@ def main() -> None:
   torch.cuda.set_device(local_rank)
   dev = torch.device("cuda", local_rank)
   rccl_ranks = 1
-  if world > 1:
+  # TFRS_BENCH_FORCE_DIST=1 (validation aid, with TFRS_FORCE_EXCHANGE=1): a ONE-rank RCCL process group, so
+  # that a single-GPU box executes the nccl branch of the sharded layers (all_gather / all_to_all of one rank)
+  force_dist = world == 1 and os.environ.get("TFRS_BENCH_FORCE_DIST", "0") == "1"
+  if force_dist:
+    for key, val in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(29500 + os.getpid() % 2000)),
+                     ("RANK", "0"), ("WORLD_SIZE", "1")):
+      os.environ.setdefault(key, val)
+  if world > 1 or force_dist:
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if one_gpu:
       dist.init_process_group("gloo")
@@ -512,12 +685,27 @@ def main() -> None:
       rccl_ranks = int(ones.item())
       if rccl_ranks != world:
         raise SystemExit(f"bench.py: {rccl_ranks} RCCL ranks answered, expected {world}")
+      # librccl prints its version banner through C stdio at the first collective; when stdout is a pipe
+      # it would otherwise sit in the buffer until exit and land AFTER the JSON line
+      ctypes.CDLL(None).fflush(None)
 
   from recommenders_amd import _lib
   from recommenders_amd.layers import factorized_top_k as ftk
   lib = _lib.load()
 
   workload = args.workload
+  if workload in ("streaming128", "dlrm_embedding"):
+    fn = run_streaming128 if workload == "streaming128" else run_dlrm_embedding
+    result = fn(args, rank, world, dev, rccl_ranks)
+    if rank == 0:
+      print(json.dumps(result), flush=True)
+    if world > 1:
+      try:
+        dist.barrier()
+        dist.destroy_process_group()
+      except Exception as e:
+        print(f"bench.py: process-group teardown: {e}", file=sys.stderr, flush=True)
+    return
   if workload == "auto":
     workload = "headline" if world == 1 else "scale100m"
   if workload == "headline" and world > 1:

@@ -18,6 +18,7 @@ Deviations forced by the host framework (documented in DESIGN.md):
 
 import abc
 import ctypes
+import os
 from typing import Any, Callable, Dict, Iterable, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -989,7 +990,7 @@ def _exchange_and_merge(scores: Tensor, rows: Tensor, k: int, group, merge: Opti
   if not (dist.is_available() and dist.is_initialized()):
     return scores, rows
   world = dist.get_world_size(group)
-  if world == 1:
+  if world == 1 and os.environ.get("TFRS_FORCE_EXCHANGE", "0") != "1":
     return scores, rows
   nq = scores.shape[0]
   if scores.shape[1] < k:      # a shard with fewer than k rows: pad with empty slots (row -1)

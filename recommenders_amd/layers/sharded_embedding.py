@@ -11,7 +11,12 @@ classic two-exchange pattern, one process per GPU, ``torch.distributed`` backend
         inverse permutation (rows land in their final positions)
 
 with ONE small collective and ONE device->host copy per lookup for the split sizes of both
-all-to-alls (``torch.distributed`` needs them on the host).
+all-to-alls (``torch.distributed`` needs them on the host).  That copy is the only thing that can
+make the host wait for the device: ``stage(ids)`` moves it OFF the critical path -- called for the
+NEXT batch right after the current step has been enqueued, it routes the ids, exchanges the counts
+and starts their copy into pinned host memory without waiting; the lookup of that batch one step
+later finds the counts already on the host (the "input dist one batch ahead" pipelining of
+production recommenders).  Without ``stage`` the lookup does the same work inline and waits.
 
 and the backward mirrors it: gradient rows travel to the owners (one all_to_all), where they
 become ``(ids, rows)`` slices for ``optimizers.Adagrad`` (fused sparse update on the shard) or
@@ -35,6 +40,15 @@ def _world(group) -> int:
   return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
 
 
+def _single(group) -> bool:
+  """One rank: nothing to exchange -- unless TFRS_FORCE_EXCHANGE=1 asks for the collectives anyway
+  (a single-GPU box then executes the RCCL branch; results are unchanged)."""
+  if _world(group) != 1:
+    return False
+  import os
+  return not (os.environ.get("TFRS_FORCE_EXCHANGE", "0") == "1" and dist.is_available() and dist.is_initialized())
+
+
 def _rank(group) -> int:
   return dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
 
@@ -45,7 +59,7 @@ def all_to_all_v(send: torch.Tensor, send_counts: List[int], recv_counts: List[i
   every peer p, in peer order."""
   world = _world(group)
   out = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
-  if world == 1:
+  if _single(group):
     out.copy_(send)
     return out
   if dist.get_backend(group) == "nccl":
@@ -83,7 +97,9 @@ def _route_hip(flat: torch.Tensor, input_dim: int, rows_per_rank: int, world: in
 
 
 def _route_torch(flat: torch.Tensor, input_dim: int, rows_per_rank: int, world: int):
-  """The same routing with torch ops: host tensors only (the gloo tests on CPU boxes)."""
+  """The same routing with torch ops.  TEST DOUBLE ONLY: reached when the layer was built with injected
+  ``local_gather`` / ``local_scatter`` (the gloo tests of the exchange logic on boxes without a GPU);
+  a native layer routes on the device and has no fallback."""
   flat = flat.long()
   bad = (flat < 0) | (flat >= input_dim)
   owner = torch.div(flat, rows_per_rank, rounding_mode="floor")
@@ -96,12 +112,28 @@ def _route_torch(flat: torch.Tensor, input_dim: int, rows_per_rank: int, world: 
   return send_ids, perm.to(torch.int32), order.to(torch.int32), counts
 
 
+class _Staged:
+  """Routing of one batch of ids whose split sizes are (being) copied to the host."""
+
+  __slots__ = ("ids", "version", "send_ids", "perm", "order", "host", "event", "lists")
+
+  def counts(self, group):
+    """``(send_counts, recv_counts)``; waits only for the copy started by ``stage`` (long finished
+    when staged a step ahead)."""
+    if self.lists is None:
+      self.event.synchronize()
+      world, me = _world(group), _rank(group)
+      m = self.host.view(world, world).tolist()
+      self.lists = ([int(v) for v in m[me]], [int(m[p][me]) for p in range(world)])
+    return self.lists
+
+
 def _exchange_counts(counts: torch.Tensor, group):
   """Split sizes of both all-to-alls from ONE collective and ONE device->host copy: every rank
   contributes its ``counts[world]`` row to the ``[world, world]`` matrix (round 2 paid two host
   synchronisations and a separate all-to-all of the counts per lookup)."""
   world, me = _world(group), _rank(group)
-  if world == 1:
+  if _single(group):
     return None, None                           # nothing to exchange: no synchronisation at all
   if dist.get_backend(group) == "nccl":
     matrix = torch.empty((world * world,), dtype=torch.int64, device=counts.device)
@@ -126,15 +158,22 @@ class _ShardedLookup(torch.autograd.Function):
     # ids outside [0, input_dim) read as a zero row and receive no gradient, like the plain
     # gather kernel; they are routed to rank 0 as row -1 so that every rank's split sizes stay
     # consistent (an unchecked owner >= world would desynchronise the all_to_all and hang)
-    route = _route_hip if (flat.is_cuda and layer._native) else _route_torch
-    send_ids, perm, order, counts = route(flat, layer.input_dim, layer.rows_per_rank, world)
-    send_counts, recv_counts = _exchange_counts(counts, group)
-    if world == 1:
+    staged = layer._take_staged(ids)
+    if staged is not None:
+      send_ids, perm, order = staged.send_ids, staged.perm, staged.order
+      send_counts, recv_counts = staged.counts(group)
+    else:
+      # (the torch routing only exists for layers built with injected local_gather / local_scatter
+      # doubles -- the gloo tests on boxes without a GPU; a native layer always routes on the device)
+      route = _route_hip if layer._native else _route_torch
+      send_ids, perm, order, counts = route(flat, layer.input_dim, layer.rows_per_rank, world)
+      send_counts, recv_counts = _exchange_counts(counts, group)
+    if send_counts is None:
       recv_ids = send_ids
     else:
       recv_ids = all_to_all_v(send_ids, send_counts, recv_counts, group)   # shard-local rows I serve
     rows = layer._gather(shard, recv_ids)                             # HIP gather on the owner
-    back = rows if world == 1 else all_to_all_v(rows, recv_counts, send_counts, group)
+    back = rows if send_counts is None else all_to_all_v(rows, recv_counts, send_counts, group)
     # rows arrive in send-slot order; lookup i sits in slot perm[i]: one gather through perm puts
     # every row in its final position (no argsort, no index_put)
     out = layer._gather(back, perm)
@@ -188,7 +227,48 @@ class ShardedEmbedding(torch.nn.Module):
     self._gather = local_gather if local_gather is not None else emb.gather_rows
     self._scatter = local_scatter if local_scatter is not None else emb.scatter_add_rows
 
+  # -- split sizes one batch ahead -----------------------------------------------------------------
+  def stage(self, ids: torch.Tensor) -> None:
+    """Routes ``ids`` (a batch that will be looked up LATER, typically the next one) and starts the
+    exchange + device->host copy of the all-to-all split sizes without waiting for them.  The lookup
+    of the same tensor object then takes the staged routing; staging is dropped when the tensor has
+    been written to in between (version counter) or another batch is staged.  World size 1: no-op."""
+    group, world = self._group, _world(self._group)
+    self._staged = None
+    if _single(group) or not isinstance(ids, torch.Tensor) or ids.device != self.embeddings.device:
+      return
+    flat = ids.reshape(-1)
+    if flat.dtype not in (torch.int32, torch.int64):
+      return
+    flat = flat.contiguous()
+    st = _Staged()
+    st.ids, st.version, st.lists = ids, ids._version, None
+    route = _route_hip if self._native else _route_torch
+    st.send_ids, st.perm, st.order, counts = route(flat, self.input_dim, self.rows_per_rank, world)
+    if dist.get_backend(group) == "nccl":
+      matrix = torch.empty((world * world,), dtype=torch.int64, device=counts.device)
+      dist.all_gather_into_tensor(matrix, counts.contiguous(), group=group)
+      st.host = torch.empty((world * world,), dtype=torch.int64, pin_memory=True)
+      st.host.copy_(matrix, non_blocking=True)
+      st.event = torch.cuda.Event()
+      st.event.record()
+    else:                                   # host-side collective (gloo): the counts are here already
+      rows = [None] * world
+      dist.all_gather_object(rows, counts.tolist(), group=group)
+      me = _rank(group)
+      st.host, st.event = None, None
+      st.lists = ([int(v) for v in rows[me]], [int(rows[p][me]) for p in range(world)])
+    self._staged = st
+
+  def _take_staged(self, ids) -> Optional[_Staged]:
+    st, self._staged = getattr(self, "_staged", None), None
+    if st is None or st.ids is not ids or ids._version != st.version:
+      return None
+    return st
+
   def forward(self, ids: torch.Tensor) -> torch.Tensor:
     if not isinstance(ids, torch.Tensor):
       ids = torch.as_tensor(ids)
-    return _ShardedLookup.apply(self.embeddings, ids.to(self.embeddings.device), self)
+    if ids.device != self.embeddings.device:
+      ids = ids.to(self.embeddings.device)
+    return _ShardedLookup.apply(self.embeddings, ids, self)

@@ -297,6 +297,22 @@ all_ids = [np.random.default_rng(100 + r).integers(0, V, size=(B,)) for r in ran
 all_w = [np.random.default_rng(200 + r).normal(size=(B, D)).astype(np.float32) for r in range(world)]
 ref = o_emb.scatter_add_grad(np.concatenate(all_w), np.concatenate(all_ids), V)[lo:hi]
 np.testing.assert_allclose(layer.embeddings.grad.numpy(), ref, rtol=1e-6, atol=1e-6)
+# split sizes one batch ahead: stage(next ids) now, look them up later -- same result; a batch that was
+# written to after staging, or another tensor, falls back to the inline routing
+nxt = torch.from_numpy(np.random.default_rng(300 + rank).integers(0, V, size=(B,)))
+layer.stage(nxt)
+assert layer._staged is not None and layer._staged.ids is nxt
+out2 = layer(nxt)
+assert layer._staged is None
+assert np.array_equal(out2.detach().numpy(), o_emb.gather(full, nxt.numpy())), "staged lookup differs"
+layer.stage(nxt)
+nxt[0] = (int(nxt[0]) + 1) % V                          # in-place write: the staged routing is stale
+out3 = layer(nxt)
+assert np.array_equal(out3.detach().numpy(), o_emb.gather(full, nxt.numpy())), "stale staging was used"
+layer.stage(nxt)
+other = nxt.clone()
+out4 = layer(other)                                    # not the staged object
+assert np.array_equal(out4.detach().numpy(), o_emb.gather(full, other.numpy()))
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
