@@ -208,11 +208,17 @@ __global__ void __launch_bounds__(kRawThreads) rawscan_kernel(const RawScanArgs 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[g][r] = 0.0f;
     const char *ap = tile + a_off;
+    // every A fragment of the wave's 32 rows is fetched before the first MFMA: the copies below are inline
+    // assembly with a memory clobber, which the compiler will not move an LDS read across -- read inside
+    // the loop, each fragment was awaited right where it was issued (one LDS latency per feature step)
+    f32x4 av[DP / 8];
+#pragma unroll
+    for (int m = 0; m < DP / 8; ++m) av[m] = *reinterpret_cast<const f32x4 *>(ap + m * 32);
 #pragma unroll
     for (int m = 0; m < DP / 8; ++m) {
       if (next_src != nullptr)   // (wave-uniform) chunk wave + 4 m of the next stage
         raw_glds_copy16(next_src + m * (kRawWaves * 1024), next_lds + m * (kRawWaves * kRawChunkB));
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(ap + m * 32);
+      const f32x4 v = av[m];
       // (lo | hi) lanes: v = (d0|d4, d1|d5, d2|d6, d3|d7) -> steps (d0|d1), (d2|d3), (d4|d5), (d6|d7)
       const auto s01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);
       const auto s23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2]), __float_as_uint(v[3]), false, false);

@@ -241,6 +241,33 @@ def test_inbatch_softmax_f16_path_sizes(nq, nc, d, scale, waves, monkeypatch):
     float_gate("softmax_f16.sizes.dc", _np(tc.grad) * 2.0, dc_ref, dc_y, GATE_SOFTMAX_MIXED)
 
 
+def test_retrieval_batch_metrics_without_the_logits_matrix():
+  """`batch_metrics` of unadjusted logits (tasks/retrieval.py:228-232) are updated from rank counts
+  (tfrs_rank_count_accumulate + tfrs_topk_hits_update), no [B, C] tensor: same values as the oracle's
+  in_top_k on the explicit logits and as the explicit-logits path (forced by a temperature of 1.0);
+  duplicated candidates tie with the positive and do not count against it."""
+  import recommenders_amd as tfrs
+  from recommenders_amd.tasks.retrieval import TopKCategoricalAccuracy
+  rng = np.random.default_rng(17)
+  nq, nc, d = 700, 1500, 48
+  q = (rng.normal(size=(nq, d)) / 4).astype(np.float32)
+  c = (rng.normal(size=(nc, d)) / 4).astype(np.float32)
+  c[900:1000] = c[:100]                                   # exact copies of 100 positives
+  w = rng.uniform(0.1, 3.0, size=nq).astype(np.float32)
+  logits = o_topk.scores(q, c)
+  labels = np.eye(nq, nc, dtype=np.float32)
+  for k in (1, 5, 50):
+    want = o_ret.batch_top_k_categorical_accuracy(labels, logits, k)
+    want_mean = float((want * w).sum() / w.sum())
+    fused = tfrs.tasks.Retrieval(batch_metrics=[TopKCategoricalAccuracy(k=k)])
+    matrix = tfrs.tasks.Retrieval(batch_metrics=[TopKCategoricalAccuracy(k=k)], temperature=1.0)
+    for task in (fused, matrix):
+      task(_t(q), _t(c), sample_weight=_t(w), compute_metrics=False)
+      task(_t(q), _t(c), sample_weight=_t(w), compute_metrics=False)          # running mean over two updates
+    assert float(fused.metrics[0].result()) == pytest.approx(want_mean, rel=1e-6)
+    assert float(matrix.metrics[0].result()) == pytest.approx(want_mean, rel=1e-6)
+
+
 def test_retrieval_hard_negatives_and_custom_paths():
   import recommenders_amd as tfrs
   rng = np.random.default_rng(4)
