@@ -382,6 +382,18 @@ int tfrs_unified_embedding_fwd(const void *ids, int ids_are_i64, const unsigned 
                                const uint64_t *salt1, int64_t num_bins, int d, float *out,
                                int64_t *buckets, void *stream);
 
+/* The same for EVERY dense integer feature of a UnifiedEmbedding layer in one launch
+ * (unified_embedding.py:186-215 loops over the features).  A unit u is one (feature, chunk):
+ *   outs[u][v, chunk_index[u]*d : (chunk_index[u]+1)*d] = tables[u][bucket(ids[u][v], salt0[u], salt1[u]), :]
+ * where outs[u] is the [n_values, feature_chunks[u] * d] output of the unit's feature (the units of one
+ * feature share it).  All host arrays have n_units entries; every ids[u] holds n_values ids of the same
+ * integer width.  buckets[n_values, n_units] (optional) keeps the buckets for the backward. */
+int tfrs_unified_embedding_fwd_multi(int n_units, const void *const *ids, int ids_are_i64,
+                                     int64_t n_values, const float *const *tables,
+                                     const uint64_t *salt0, const uint64_t *salt1, int64_t num_bins,
+                                     int d, float *const *outs, const int32_t *feature_chunks,
+                                     const int32_t *chunk_index, int64_t *buckets, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Retrieval.call loss (tasks/retrieval.py:172-210, layers/loss.py:114-158):
  * in-batch sampled softmax without materialising the [nq, nc] logits.

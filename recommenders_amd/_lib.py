@@ -73,6 +73,7 @@ SIGNATURES = {
     "tfrs_hash_bucket_strong_bytes": (c_int, [P, P, c_i64, c_i64, c_u64, c_u64, P, P]),
     "tfrs_unified_embedding_fwd": (c_int, [P, c_int, P, P, c_i64, c_int, P, P, P, c_i64, c_int, P,
                                            P, P]),
+    "tfrs_unified_embedding_fwd_multi": (c_int, [c_int, P, c_int, c_i64, P, P, P, c_i64, c_int, P, P, P, P, P]),
     "tfrs_embedding_scatter_add_bwd": (c_int, [P, P, P, c_i64, c_int, P, P, c_float, c_float,
                                                c_int, P]),
     "tfrs_embedding_scatter_add_workspace_bytes": (c_size_t, [c_i64]),

@@ -190,6 +190,65 @@ __global__ void __launch_bounds__(256) unified_lookup_kernel(
   }
 }
 
+// ---- every dense feature of a UnifiedEmbedding layer in ONE launch -----------------------------------
+// The per-feature kernel above is launched once per feature: 26 launches of ~22 us at the DCN-v2 shapes
+// (26 features x 65536 ids), launch-bound.  Here a "unit" is one (feature, chunk): lookup p = value * U + unit
+// hashes ids[unit][value] under the unit's salt and copies the table row into the unit's column block of ITS
+// feature's output (every feature keeps its own [n, chunks * D] tensor: the backward then receives one
+// gradient per feature, no slicing of a wide buffer).
+constexpr int kUnifiedMaxUnits = 64;    // 64 x 48 bytes of descriptors < 4 KiB of kernel arguments
+
+struct UnifiedUnits {
+  const void *ids[kUnifiedMaxUnits];
+  const float *table[kUnifiedMaxUnits];
+  float *out[kUnifiedMaxUnits];          // the unit's feature output [n, chunks * D]
+  uint64_t k0[kUnifiedMaxUnits], k1[kUnifiedMaxUnits];
+  int32_t chunks[kUnifiedMaxUnits];      // chunks of the unit's feature (row stride of `out` in units of D)
+  int32_t chunk[kUnifiedMaxUnits];       // the unit's chunk number inside its feature
+};
+
+template <typename IdT, int PER_ROW>
+__global__ void __launch_bounds__(256) unified_lookup_multi_kernel(
+    const UnifiedUnits un, int n_units, int64_t n_values, uint64_t num_bins, uint64_t recip,
+    int64_t *__restrict__ buckets, int64_t bucket_stride, int64_t bucket_col0) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  constexpr int kRowsPerIter = 64 / PER_ROW;
+  __shared__ const f4 *s_src[4][64];
+  __shared__ f4 *s_dst[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t total = n_values * n_units;
+  const int64_t wave_stride = (int64_t)gridDim.x * 4 * 64;
+  const int piece = lane % PER_ROW, sub = lane / PER_ROW;
+  for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 64; base < total; base += wave_stride) {
+    const int64_t p = base + lane;
+    const f4 *src = nullptr;
+    f4 *dst = nullptr;
+    if (p < total) {
+      const int64_t v = p / n_units;
+      const int u = (int)(p - v * n_units);
+      const int64_t id = (int64_t)static_cast<const IdT *>(un.ids[u])[v];
+      const uint64_t bucket = mod_barrett(sip_of_int(id, un.k0[u], un.k1[u]), num_bins, recip);
+      if (buckets) buckets[v * bucket_stride + bucket_col0 + u] = (int64_t)bucket;
+      src = reinterpret_cast<const f4 *>(un.table[u]) + bucket * PER_ROW;
+      dst = reinterpret_cast<f4 *>(un.out[u]) + (v * un.chunks[u] + un.chunk[u]) * PER_ROW;
+    }
+    s_src[wave][lane] = src;
+    s_dst[wave][lane] = dst;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+    for (int it = 0; it < PER_ROW; ++it) {
+      const int r = it * kRowsPerIter + sub;
+      const f4 *sp = s_src[wave][r];
+      f4 *dp = s_dst[wave][r];
+      if (sp != nullptr) {
+        const f4 x = __builtin_nontemporal_load(sp + piece);
+        __builtin_nontemporal_store(x, dp + piece);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace tfrs
 
 using namespace tfrs;
@@ -287,6 +346,68 @@ extern "C" int tfrs_unified_embedding_fwd(const void *ids, int ids_are_i64,
     }
 #undef TFRS_UE_DISPATCH
 #undef TFRS_UE_LAUNCH
+    TFRS_LAUNCH_CHECK();
+  }
+  return TFRS_OK;
+}
+
+extern "C" int tfrs_unified_embedding_fwd_multi(int n_units, const void *const *ids, int ids_are_i64,
+                                                int64_t n_values, const float *const *tables,
+                                                const uint64_t *salt0, const uint64_t *salt1,
+                                                int64_t num_bins, int d, float *const *outs,
+                                                const int32_t *feature_chunks, const int32_t *chunk_index,
+                                                int64_t *buckets, void *stream) {
+  TFRS_CHECK_ARG(n_units >= 1 && n_values >= 0 && d >= 4, "unified_embedding_fwd_multi: bad shape");
+  TFRS_CHECK_ARG(num_bins >= 1, "unified_embedding_fwd_multi: num_bins must be positive");
+  const int per_row = d / 4;
+  if (d % 4 != 0 || per_row > 64 || (per_row & (per_row - 1)) != 0) {
+    set_error("unified_embedding_fwd_multi: dim_per_table must be 4 * 2^k <= 256 (got %d); use the "
+              "unfused Hashing + lookup path", d);
+    return TFRS_ENOTIMPL;
+  }
+  if (n_values == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(ids && tables && salt0 && salt1 && outs && feature_chunks && chunk_index,
+                 "unified_embedding_fwd_multi: NULL pointer");
+  hipStream_t s = (hipStream_t)stream;
+  for (int u0 = 0; u0 < n_units; u0 += kUnifiedMaxUnits) {
+    const int ul = std::min(kUnifiedMaxUnits, n_units - u0);
+    UnifiedUnits un;
+    for (int u = 0; u < kUnifiedMaxUnits; ++u) {
+      const int uu = u < ul ? u0 + u : u0;
+      TFRS_CHECK_ARG(ids[uu] && tables[uu] && outs[uu] && ((uintptr_t)tables[uu]) % 16 == 0 &&
+                         ((uintptr_t)outs[uu]) % 16 == 0 && feature_chunks[uu] >= 1 &&
+                         chunk_index[uu] >= 0 && chunk_index[uu] < feature_chunks[uu],
+                     "unified_embedding_fwd_multi: unit %d: NULL / misaligned pointer or bad chunk index", uu);
+      un.ids[u] = ids[uu];
+      un.table[u] = tables[uu];
+      un.out[u] = outs[uu];
+      un.k0[u] = salt0[uu];
+      un.k1[u] = salt1[uu];
+      un.chunks[u] = feature_chunks[uu];
+      un.chunk[u] = chunk_index[uu];
+    }
+    const int64_t total = n_values * ul;
+    const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 256 * 16)));
+#define TFRS_UM_LAUNCH(IDT, PR)                                                                       \
+  hipLaunchKernelGGL((unified_lookup_multi_kernel<IDT, PR>), grid, dim3(256), 0, s, un, ul, n_values, \
+                     (uint64_t)num_bins, barrett_recip(num_bins), buckets, (int64_t)n_units, (int64_t)u0)
+#define TFRS_UM_DISPATCH(IDT)                                                                         \
+  switch (per_row) {                                                                                  \
+    case 1: TFRS_UM_LAUNCH(IDT, 1); break;                                                            \
+    case 2: TFRS_UM_LAUNCH(IDT, 2); break;                                                            \
+    case 4: TFRS_UM_LAUNCH(IDT, 4); break;                                                            \
+    case 8: TFRS_UM_LAUNCH(IDT, 8); break;                                                            \
+    case 16: TFRS_UM_LAUNCH(IDT, 16); break;                                                          \
+    case 32: TFRS_UM_LAUNCH(IDT, 32); break;                                                          \
+    default: TFRS_UM_LAUNCH(IDT, 64); break;                                                          \
+  }
+    if (ids_are_i64) {
+      TFRS_UM_DISPATCH(int64_t)
+    } else {
+      TFRS_UM_DISPATCH(int32_t)
+    }
+#undef TFRS_UM_DISPATCH
+#undef TFRS_UM_LAUNCH
     TFRS_LAUNCH_CHECK();
   }
   return TFRS_OK;

@@ -97,6 +97,72 @@ class _UnifiedLookupFn(torch.autograd.Function):
     return (None, None, None, None) + tuple(grads)
 
 
+class _UnifiedMultiFn(torch.autograd.Function):
+  """EVERY dense integer feature of the layer in one launch (``tfrs_unified_embedding_fwd_multi``): a
+  unit is one (feature, chunk); the kernel hashes the unit's feature ids under the unit's salt and copies
+  the table row into the unit's column block of its feature's own ``[n, chunks * d]`` output.  (One launch
+  per feature -- ``_UnifiedLookupFn`` -- was launch-bound at the DCN-v2 shapes: 26 x 22 us.)  ``meta`` =
+  (per feature: (chunk salts, table index of each chunk)), num_bins; the tensors that follow are the
+  features' id tensors, then the distinct tables."""
+
+  @staticmethod
+  def forward(ctx, meta, num_bins, n_features, *tensors):
+    id_tensors, tables = tensors[:n_features], tensors[n_features:]
+    dev = tables[0].device
+    d = tables[0].shape[1]
+    flats, shapes = [], []
+    for ids in id_tensors:
+      ids = ids.to(dev)
+      shapes.append(tuple(ids.shape))
+      flats.append(ids.reshape(-1).contiguous())
+    n = flats[0].numel()
+    i64 = flats[0].dtype == torch.int64
+    outs = [torch.empty((n, len(salts) * d), dtype=torch.float32, device=dev) for salts, _ in meta]
+    unit_ids, unit_tables, unit_outs, s0, s1, chunks, cidx = [], [], [], [], [], [], []
+    for f, (salts, index) in enumerate(meta):
+      for c, salt in enumerate(salts):
+        unit_ids.append(flats[f].data_ptr())
+        unit_tables.append(tables[index[c]].data_ptr())
+        unit_outs.append(outs[f].data_ptr())
+        s0.append(int(salt[0]) & _U64)
+        s1.append(int(salt[1]) & _U64)
+        chunks.append(len(salts))
+        cidx.append(c)
+    nu = len(unit_ids)
+    buckets = torch.empty((n, nu), dtype=torch.int64, device=dev)
+    vp, u64, i32 = ctypes.c_void_p * nu, ctypes.c_uint64 * nu, ctypes.c_int32 * nu
+    _lib.check(_lib.load().tfrs_unified_embedding_fwd_multi(
+        nu, vp(*unit_ids), 1 if i64 else 0, n, vp(*unit_tables), u64(*s0), u64(*s1), int(num_bins), d,
+        vp(*unit_outs), i32(*chunks), i32(*cidx), _lib.ptr(buckets), _lib.current_stream()))
+    ctx.save_for_backward(buckets)
+    ctx.meta, ctx.tables, ctx.d = meta, tables, d
+    ctx.n_features = n_features
+    return tuple(o.reshape(shape + (o.shape[1],)) for o, shape in zip(outs, shapes))
+
+  @staticmethod
+  def backward(ctx, *grads):
+    (buckets,) = ctx.saved_tensors
+    d = ctx.d
+    table_grads = [None] * len(ctx.tables)
+    u = 0
+    for f, (salts, index) in enumerate(ctx.meta):
+      g = grads[f]
+      nc = len(salts)
+      g = None if g is None else g.reshape(-1, nc, d)
+      for c in range(nc):
+        if g is not None:
+          table = ctx.tables[index[c]]
+          ids_c, rows_c = buckets[:, u].contiguous(), g[:, c, :].contiguous()
+          if getattr(table, "_tfrs_sparse_grad", False):
+            table._tfrs_slices.append((ids_c, rows_c))
+          else:
+            part = emb.scatter_add_rows(rows_c, ids_c, table.shape[0])
+            t = index[c]
+            table_grads[t] = part if table_grads[t] is None else table_grads[t] + part
+        u += 1
+    return (None, None, None) + (None,) * ctx.n_features + tuple(table_grads)
+
+
 class UnifiedEmbeddingConfig:
   """Describes the shared tables and the features multiplexed into them."""
 
@@ -162,6 +228,25 @@ class UnifiedEmbedding(torch.nn.Module):
   def embedding_layer(self) -> TPUEmbedding:
     return self._embedding_layer
 
+  def _multi_feature_groups(self, features) -> Dict[tuple, List[str]]:
+    """Features that one ``tfrs_unified_embedding_fwd_multi`` launch can take together: dense integer
+    tensors on the layer's device, no sequence features, a fusable table dim, grouped by (number of ids,
+    id width, buckets per table, dim); groups of one stay on the per-feature kernel."""
+    groups: Dict[tuple, List[str]] = {}
+    dev = next(iter(self._embedding_layer.embedding_tables.values())).device
+    for name, layers in self._hashing_layers.items():
+      value = features[name]
+      if not (isinstance(value, torch.Tensor) and value.dtype in (torch.int32, torch.int64)
+              and value.device == dev and value.numel() > 0):
+        continue
+      chunks = sorted(layers)
+      configs = [self._embed_config[name][c] for c in chunks]
+      if not (_fusable_dim(configs[0].table.dim) and all(f.max_sequence_length == 0 for f in configs)):
+        continue
+      key = (value.numel(), value.dtype, layers[chunks[0]].num_bins, configs[0].table.dim)
+      groups.setdefault(key, []).append(name)
+    return {k: v for k, v in groups.items() if len(v) > 1}
+
   def forward(self, features: Dict[str, object]) -> List[torch.Tensor]:
     """``features``: {feature name: ids/strings} holding at least every configured feature
     (extra keys are ignored).  Returns one ``[..., num_chunks * dim_per_table]`` tensor per
@@ -172,7 +257,26 @@ class UnifiedEmbedding(torch.nn.Module):
     tables = self._embedding_layer.embedding_tables
     outputs: Dict[str, torch.Tensor] = {}
     hashed, serving = {}, {}
+    # dense integer features with the same number of ids and the same id width go out in ONE launch
+    multi = self._multi_feature_groups(features) if self.fuse else {}
+    for names in multi.values():
+      distinct, meta = [], []
+      for name in names:
+        layers = self._hashing_layers[name]
+        chunks = sorted(layers)
+        configs = [self._embed_config[name][c] for c in chunks]
+        for f in configs:
+          if f.table not in distinct:
+            distinct.append(f.table)
+        meta.append((tuple(tuple(layers[c].salt) for c in chunks),
+                     tuple(distinct.index(f.table) for f in configs)))
+      num_bins = self._hashing_layers[names[0]][sorted(self._hashing_layers[names[0]])[0]].num_bins
+      outs = _UnifiedMultiFn.apply(tuple(meta), num_bins, len(names), *[features[n] for n in names],
+                                   *[tables[t] for t in distinct])
+      outputs.update(zip(names, outs))
     for name, layers in self._hashing_layers.items():
+      if name in outputs:
+        continue
       value = features[name]
       chunks = sorted(layers)                   # concatenation order of the reference (:209-211)
       configs = [self._embed_config[name][c] for c in chunks]

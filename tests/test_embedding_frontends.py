@@ -623,6 +623,56 @@ def test_unified_fused_backward(sparse_opt):
 
 
 @gpu
+@pytest.mark.parametrize("sparse_opt", [False, True])
+def test_unified_embedding_all_dense_features_in_one_launch(sparse_opt):
+  """Every dense integer feature of the layer goes out in ONE launch (tfrs_unified_embedding_fwd_multi;
+  round 3: one launch per feature, launch-bound at the DCN-v2 shapes): 26 features x 3 chunks = 78 units
+  (more than one launch descriptor holds: 64) over 5 shared tables, int64 and int32 id groups, a 2-D
+  feature; values bit for bit the per-feature kernel's (fuse=False path) and the oracle's; the backward
+  reaches every table as dense gradients or as IndexedSlices for the fused sparse Adagrad."""
+  rng = np.random.default_rng(33)
+  n, dim, bins, nf = 700, 16, 101, 26
+  cfg = UnifiedEmbeddingConfig(buckets_per_table=bins, dim_per_table=dim, num_tables=5, name="u")
+  for f in range(nf):
+    cfg.add_feature(f"f{f}", 3)
+  cfg.add_feature("two_d", 2)
+  cfg.add_feature("i32", 1)
+  cfg.add_feature("i32b", 2)
+  layer = UnifiedEmbedding(cfg, optimizer=None)
+  plain = UnifiedEmbedding(cfg, optimizer=None, fuse=False)
+  plain.load_state_dict(layer.state_dict())
+  feats = {f"f{f}": rng.integers(0, 10**9, size=(n,)) for f in range(nf)}
+  feats["two_d"] = rng.integers(0, 10**6, size=(n // 7, 7))            # same number of ids, other shape
+  feats["i32"] = rng.integers(0, 10**6, size=(n,)).astype(np.int32)
+  feats["i32b"] = rng.integers(0, 10**6, size=(n,)).astype(np.int32)
+  dev_feats = {k: _t(v) for k, v in feats.items()}
+  groups = layer._multi_feature_groups(dev_feats)
+  assert sorted(len(v) for v in groups.values()) == [2, nf + 1]         # int32 pair; 26 + the 2-D feature
+  opt = tfrs.optimizers.Adagrad(layer.parameters(), learning_rate=0.1) if sparse_opt else None
+  opt2 = tfrs.optimizers.Adagrad(plain.parameters(), learning_rate=0.1) if sparse_opt else None
+  outs, outs2 = layer(dev_feats), plain(dev_feats)
+  names = [f"f{f}" for f in range(nf)] + ["two_d", "i32", "i32b"]
+  assert tuple(outs[nf].shape) == (n // 7, 7, 2 * dim)
+  for name, o, o2 in zip(names, outs, outs2):
+    np.testing.assert_array_equal(_np(o), _np(o2))
+    np.testing.assert_array_equal(_np(o), _ue_reference(layer, cfg, name, feats[name]))
+  ws = [_t(rng.normal(size=tuple(o.shape)).astype(np.float32)) for o in outs]
+  sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+  sum((o * w).sum() for o, w in zip(outs2, ws)).backward()
+  ta, tb = layer.embedding_layer.embedding_tables, plain.embedding_layer.embedding_tables
+  if sparse_opt:
+    opt.step()
+    opt2.step()
+    # (a table receives the slices / partial gradients of ~16 units; the two paths add them in different
+    # orders: float32 sums of ~100 terms each, compared at a few ulps of the sum's magnitude)
+    for t in cfg._table_configs:
+      np.testing.assert_allclose(_np(ta[t]), _np(tb[t]), rtol=2e-5, atol=2e-6)
+  else:
+    for t in cfg._table_configs:
+      np.testing.assert_allclose(_np(ta[t].grad), _np(tb[t].grad), rtol=2e-5, atol=2e-5)
+
+
+@gpu
 def test_unified_embedding_trains_shared_tables():
   """Gradients of all chunks that share a table accumulate into that table; state_dict
   round-trips (the reference's save/load test, :149-168, needs SavedModel)."""
