@@ -105,6 +105,36 @@ def _wide_topk_update(q: Tensor, block: Tensor, base_row: int, k: int, state_sco
   return state_len
 
 
+def top_k_of_block(queries: Tensor, block: Tensor, k: int) -> Tuple[Tensor, Tensor]:
+  """Exact top-``k`` (scores, row numbers) of ``queries @ block.T`` for ONE resident candidate block, with
+  no index object, no host synchronisation and no ``[nq, n]`` matrix: the block is searched in place
+  (``tfrs_streaming_topk_update_blocks``) when its layout allows it, else through the per-block entry
+  point.  Used by ``tasks.Retrieval`` for hard-negative mining; capturable in a HIP graph."""
+  q = queries.contiguous()
+  block = block.contiguous()
+  nq, d = q.shape
+  n = block.shape[0]
+  if not (1 <= k <= min(n, MAX_FUSED_K)) or d > MAX_FUSED_DIM:
+    raise ValueError(f"top_k_of_block: k={k} / dim={d} outside the fused kernels' envelope")
+  lib = _lib.load()
+  scores = torch.zeros((nq, k), dtype=torch.float32, device=q.device)
+  rows = torch.zeros((nq, k), dtype=torch.int32, device=q.device)
+  new_len = ctypes.c_int32(0)
+  if d in _RAW_DIMS and block.data_ptr() % 16 == 0:
+    ws = _workspace(lib.tfrs_streaming_topk_blocks_workspace_bytes(nq, n, d, k))
+    ptrs = (ctypes.c_void_p * 1)(block.data_ptr())
+    counts = (ctypes.c_int64 * 1)(n)
+    _lib.check(lib.tfrs_streaming_topk_update_blocks(
+        _lib.ptr(q), nq, d, ptrs, counts, 1, 0, 0, k, _lib.ptr(scores), _lib.ptr(rows), 0,
+        ctypes.byref(new_len), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+  else:
+    ws = _workspace(lib.tfrs_streaming_topk_workspace_bytes(nq, n, d, k))
+    _lib.check(lib.tfrs_streaming_topk_update(
+        _lib.ptr(q), nq, d, _lib.ptr(block), n, 0, k, _lib.ptr(scores), _lib.ptr(rows), 0,
+        ctypes.byref(new_len), _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+  return scores, rows
+
+
 def _check_candidates_with_identifiers(candidates: Iterable) -> None:
   """Precondition of the dataset used for indexing (reference :118-137), checked on
   the first element: either blocks, or 2-tuples with equal leading dimensions."""

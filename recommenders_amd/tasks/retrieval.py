@@ -8,10 +8,14 @@ Mirror of ``tensorflow_recommenders/tasks/retrieval.py:29-235``: same constructo
 temperature (:187), sampling-probability correction (:190), accidental-hit removal
 (:194-200) and ``score_mask`` (:202) folded into the logit function.
 
-Paths that need the explicit logits matrix -- ``batch_metrics`` (:228-232), a
-user-supplied ``loss``, ``num_hard_negatives`` (:205-208) and multi-head (3-D) queries
-(:173-176) -- compute it with the HIP dense GEMM and then follow the reference's op
-sequence on that tensor.
+``batch_metrics`` (:228-232) of unadjusted logits are updated from rank counts
+(``TopKCategoricalAccuracy.update_from_embeddings``) and ``num_hard_negatives`` (:205-208) over
+plain dot-product logits from the fused top-K search (``hard_negative_softmax_loss``): neither
+builds the ``[num_queries, num_candidates]`` matrix.  What still needs the explicit matrix -- a
+user-supplied ``loss`` (its contract IS the matrix), multi-head (3-D) queries (:173-176), and
+batch metrics / hard negatives combined with a logit adjustment that can reorder a row
+(temperature for the metrics, sampling correction, accidental-hit removal, score mask) --
+computes it with the HIP dense GEMM and then follows the reference's op sequence on that tensor.
 """
 
 import os
@@ -89,6 +93,43 @@ def in_batch_softmax_loss(query_embeddings: torch.Tensor, candidate_embeddings: 
   mask = None if score_mask is None else score_mask.to(dev).to(torch.uint8).contiguous()
   return _InBatchSoftmaxFn.apply(query_embeddings.to(torch.float32),
                                  candidate_embeddings.to(torch.float32), w, inv_t, corr, ids, mask)
+
+
+def hard_negative_softmax_loss(query_embeddings: torch.Tensor, candidate_embeddings: torch.Tensor,
+                               num_hard_negatives: int, sample_weight: Optional[torch.Tensor] = None,
+                               temperature: Optional[float] = None) -> torch.Tensor:
+  """``HardNegativeMining`` + softmax cross-entropy (layers/loss.py:61-111, tasks/retrieval.py:205-210)
+  WITHOUT the ``[B, C]`` logits matrix, for logits that are plain (temperature-scaled) dot products: the
+  reference keeps, per row, the positive and the ``num_hard_negatives`` highest negatives
+  (``top_k(logits + labels * MAX_FLOAT, k + 1, sorted=False)``); here the fused top-K search of the batch's
+  candidates (``top_k_of_block``: exact f32 scores, no matrix) names those rows, the lookup kernel gathers
+  them (its backward is the deterministic scatter-add) and the cross-entropy runs on ``[B, k + 1]``
+  logits.  Boundary ties between equal negatives pick different but equally scored rows: same loss."""
+  from recommenders_amd.layers import embedding as emb_layers
+  from recommenders_amd.layers import factorized_top_k as ftk
+  q = query_embeddings.to(torch.float32)
+  c = candidate_embeddings.to(torch.float32)
+  nq, nc = q.shape[0], c.shape[0]
+  num_sampled = min(int(num_hard_negatives) + 1, nc)                    # loss.py:91
+  n_neg = num_sampled - 1
+  pos = (q * c[:nq]).sum(dim=1, keepdim=True)                            # [B, 1]
+  if n_neg > 0:
+    with torch.no_grad():
+      # the positive may or may not be among the best n_neg + 1 rows: search one more and drop it
+      _, rows = ftk.top_k_of_block(q.detach(), c.detach(), min(n_neg + 1, nc))
+      is_pos = (rows == torch.arange(nq, device=rows.device, dtype=rows.dtype)[:, None])
+      order = torch.sort(is_pos.to(torch.int8), dim=1, stable=True).indices[:, :n_neg]   # negatives first, by score
+      neg_rows = torch.gather(rows, 1, order).long()
+    neg = (emb_layers._GatherFn.apply(c, neg_rows) * q[:, None, :]).sum(dim=2)            # [B, n_neg]
+    logits = torch.cat([pos, neg], dim=1)
+  else:
+    logits = pos
+  if temperature is not None:
+    logits = logits / float(temperature)                                 # :187-188
+  per_row = torch.logsumexp(logits, dim=1) - logits[:, 0]                # CE with the label on column 0
+  if sample_weight is not None:
+    per_row = per_row * sample_weight.reshape(-1).to(per_row.device, torch.float32)
+  return per_row.sum()                                                   # Reduction.SUM (:86-87)
 
 
 class _CrossReplicaConcatFn(torch.autograd.Function):
@@ -294,8 +335,14 @@ class Retrieval(torch.nn.Module, base.Task):
         and candidate_sampling_probability is None and not self._remove_accidental_hits
         and score_mask is None
         and all(type(m) is TopKCategoricalAccuracy for m in self._batch_metrics))
+    # hard-negative mining over plain (temperature-scaled) dot products: the top-K search names the rows
+    fused_hard_negatives = (
+        self._num_hard_negatives is not None and self._loss is None and q.dim() == 2 and not wide
+        and candidate_sampling_probability is None and not self._remove_accidental_hits
+        and score_mask is None and int(self._num_hard_negatives) + 2 <= 1024
+        and not (compute_batch_metrics and len(self._batch_metrics) > 0))
     need_matrix = (q.dim() == 3 or self._loss is not None
-                   or self._num_hard_negatives is not None or wide
+                   or (self._num_hard_negatives is not None and not fused_hard_negatives) or wide
                    or (compute_batch_metrics and len(self._batch_metrics) > 0 and not fused_batch_metrics))
     scores = labels = None
     if need_matrix:
@@ -306,6 +353,8 @@ class Retrieval(torch.nn.Module, base.Task):
       loss = in_batch_softmax_loss(                                     # fused :172-210
           q, c, sample_weight, self._temperature, candidate_sampling_probability,
           candidate_ids if self._remove_accidental_hits else None, score_mask)
+    elif fused_hard_negatives:
+      loss = hard_negative_softmax_loss(q, c, self._num_hard_negatives, sample_weight, self._temperature)
     elif self._loss is None:
       # CategoricalCrossentropy(from_logits, SUM) on the explicit logits (:86-87, :210)
       per_row = -(labels * torch.log_softmax(scores, dim=1)).sum(dim=1)

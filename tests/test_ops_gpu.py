@@ -279,6 +279,32 @@ def test_retrieval_hard_negatives_and_custom_paths():
   np.testing.assert_allclose(float(loss), float(ref), rtol=1e-5)
 
 
+@pytest.mark.parametrize("nq,nc,d,k", [(300, 300, 64, 7), (512, 2000, 32, 50), (100, 4000, 20, 3), (64, 64, 16, 200)])
+def test_retrieval_hard_negatives_without_the_logits_matrix(nq, nc, d, k):
+  """`num_hard_negatives` over plain dot-product logits (layers/loss.py:61-111): the fused top-K search
+  names each row's hardest negatives, the cross-entropy runs on [B, k + 1] gathered logits -- no [B, C]
+  tensor.  Loss vs the oracle (1e-5 relative, north_star's tolerance); gradients vs the explicit-logits
+  path of the same task (forced by a score mask of ones), with sample weights and a temperature; k larger
+  than the number of candidates keeps every column (loss.py:91)."""
+  import recommenders_amd as tfrs
+  rng = np.random.default_rng(nq + k)
+  q = (rng.normal(size=(nq, d)) / np.sqrt(d)).astype(np.float32)
+  c = (rng.normal(size=(nc, d)) / np.sqrt(d)).astype(np.float32)
+  w = rng.uniform(0.2, 2.0, size=nq).astype(np.float32)
+  ref = o_ret.loss(q, c, num_hard_negatives=k, temperature=0.3, sample_weight=w)
+  grads = []
+  for force_matrix in (False, True):
+    tq, tc = _t(q).requires_grad_(True), _t(c).requires_grad_(True)
+    task = tfrs.tasks.Retrieval(num_hard_negatives=k, temperature=0.3)
+    loss = task(tq, tc, sample_weight=_t(w), compute_metrics=False,
+                score_mask=_t(np.ones((nq, nc), bool)) if force_matrix else None)
+    np.testing.assert_allclose(float(loss), float(ref), rtol=1e-5)
+    loss.backward()
+    grads.append((_np(tq.grad), _np(tc.grad)))
+  np.testing.assert_allclose(grads[0][0], grads[1][0], rtol=2e-4, atol=2e-6)
+  np.testing.assert_allclose(grads[0][1], grads[1][1], rtol=2e-4, atol=2e-6)
+
+
 # ---------------------------------------------------------------------------- metrics
 def test_factorized_top_k_metric_golden():
   """metrics/factorized_top_k_test.py:39-86 and :93-131."""
