@@ -1010,6 +1010,64 @@ class Streaming(TopK):
     return True
 
 
+_INT32_MAX = 0x7FFFFFFF
+
+
+def _exchange_and_merge_wide(scores: Tensor, local_rows: Tensor, k: int, group, merge: Optional[Callable],
+                             base_row: int):
+  """The same single exchange for corpora whose GLOBAL row numbers do not fit int32 ("ids
+  beyond 2^31 need i64"; 8 x 288 GB of dim-64 rows are 9 * 10^9 rows; the reference's counter is int32,
+  :380-382).  A shard always fits int32, so ranks exchange (score bits, LOCAL row) plus their int64 base
+  row (two extra words of the same all_gather); the parts are ordered by base row and merged on the
+  synthetic index ``part * k + position`` -- every part is already sorted (score desc, row asc), so part
+  order then position IS global-row order among equal scores, and the 64-bit merge keys need no wider
+  row field; ``base[part] + local[part, q, position]`` restores int64 global rows afterwards."""
+  import torch.distributed as dist
+  dev = scores.device
+  nq = scores.shape[0]
+  if scores.shape[1] < k:
+    pad = k - scores.shape[1]
+    scores = torch.cat([scores, scores.new_full((nq, pad), float("-inf"))], dim=1)
+    local_rows = torch.cat([local_rows, local_rows.new_full((nq, pad), -1)], dim=1)
+  world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+  words = 2 * nq * k + 2
+  mine = torch.empty((words,), dtype=torch.int32, device=dev)
+  mine[:nq * k].copy_(scores.contiguous().view(torch.int32).reshape(-1))
+  mine[nq * k:2 * nq * k].copy_(local_rows.to(torch.int32).reshape(-1))
+  mine[2 * nq * k:].copy_(torch.tensor([base_row & 0xFFFFFFFF, base_row >> 32], dtype=torch.int64).to(torch.int32))
+  gathered = torch.empty((world, words), dtype=torch.int32, device=dev)
+  if world > 1 or os.environ.get("TFRS_FORCE_EXCHANGE", "0") == "1":
+    dist.all_gather_into_tensor(gathered.view(-1), mine, group=group)
+  else:
+    gathered[0].copy_(mine)
+  tail = gathered[:, 2 * nq * k:].to(torch.int64)
+  bases = (tail[:, 0] & 0xFFFFFFFF) | (tail[:, 1] << 32)                  # [world] int64
+  order = torch.argsort(bases)                                            # parts in global-row order
+  parts = gathered.index_select(0, order)
+  bases = bases.index_select(0, order)
+  part_scores = parts[:, :nq * k].contiguous().view(torch.float32).reshape(world, nq, k)
+  part_rows = parts[:, nq * k:2 * nq * k].reshape(world, nq, k)
+  synth = (torch.arange(world, device=dev, dtype=torch.int32)[:, None, None] * k
+           + torch.arange(k, device=dev, dtype=torch.int32)[None, None, :]).expand(world, nq, k)
+  synth = torch.where(part_rows < 0, torch.full_like(part_rows, -1), synth).contiguous()
+  if merge is not None:
+    out_s, out_i = merge(part_scores, synth, k)
+    out_s, out_i = out_s.to(dev), out_i.to(dev)
+  else:
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    out_i = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().tfrs_topk_merge(
+        _lib.ptr(part_scores.contiguous()), _lib.ptr(synth), world, nq, k, k, _lib.ptr(out_s), _lib.ptr(out_i),
+        None, 0, _lib.current_stream()))
+  valid = out_i >= 0
+  idx = out_i.clamp_min(0).long()
+  part, pos = idx // k, idx % k
+  qidx = torch.arange(nq, device=dev)[:, None].expand(nq, k)
+  local = part_rows[part, qidx, pos].long()
+  rows64 = torch.where(valid, bases[part] + local, torch.full_like(local, -1))
+  return out_s, rows64
+
+
 def _exchange_and_merge(scores: Tensor, rows: Tensor, k: int, group, merge: Optional[Callable]):
   """The ONE exchange step of row-sharded top-K: this rank's (score bits, global row)[nq, k]
   lists go back to back into one int32 buffer [2, nq, k]; a single all_gather delivers
@@ -1059,10 +1117,21 @@ def _global_identifiers(rows: Tensor, local_ids: Optional[Tensor], base_row: int
 
 
 def _check_shard_rows(base_row: int, n_local: int) -> None:
-  if base_row < 0 or base_row + n_local > 0x7FFFFFFF:
-    raise ValueError(
-        f"sharded top-K returns int32 global row numbers (like the reference's int32 counter, "
-        f":380-382): base_row + rows = {base_row} + {n_local} does not fit")
+  if base_row < 0 or n_local > _INT32_MAX:
+    raise ValueError(f"a shard holds at most 2^31 - 1 rows and base_row must be >= 0 (got {n_local} rows "
+                     f"from row {base_row})")
+
+
+def _any_rank_beyond_int32(base_row: int, n_local: int, group) -> bool:
+  """True when some rank's global rows exceed int32 (decided once, at index time, with one small host
+  collective, so that every rank takes the same exchange path): results are then int64 row numbers."""
+  import torch.distributed as dist
+  mine = base_row + n_local > _INT32_MAX
+  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    return mine
+  flags = [None] * dist.get_world_size(group)
+  dist.all_gather_object(flags, bool(mine), group=group)
+  return any(flags)
 
 
 class ShardedBruteForce(TopK):
@@ -1114,6 +1183,7 @@ class ShardedBruteForce(TopK):
     _check_shard_rows(int(base_row), n_local)
     self._set_identifiers(identifiers, n_local)
     self._base_row, self._n_local = int(base_row), n_local
+    self._wide = _any_rank_beyond_int32(int(base_row), n_local, self._group)
     if self._local_search is None:
       self._local.index(candidates)
     else:
@@ -1130,6 +1200,7 @@ class ShardedBruteForce(TopK):
     self._set_identifiers(ids.device if ids.device is not None else
                           (None if ids.is_range else ids.host), self._local._n)
     self._base_row, self._n_local = int(base_row), self._local._n
+    self._wide = _any_rank_beyond_int32(int(base_row), self._local._n, self._group)
     return self
 
   def _identifier_table(self) -> _Identifiers:
@@ -1141,6 +1212,8 @@ class ShardedBruteForce(TopK):
       scores, rows = self._local._query_rows(self._embed(queries), kk)
     else:
       scores, rows = self._local_search(queries, self._cand, k)
+    if getattr(self, "_wide", False):       # global rows beyond int32: exchange local rows + int64 bases
+      return _exchange_and_merge_wide(scores, rows, k, self._group, self._merge, self._base_row)
     rows = rows + self._base_row
     return _exchange_and_merge(scores, rows, k, self._group, self._merge)
 
@@ -1170,14 +1243,22 @@ class ShardedStreaming(Streaming):
     self._group = process_group
     self._merge = merge
 
-  def index_from_dataset(self, candidates: Iterable, base_row: int = 0) -> "ShardedStreaming":
+  def index_from_dataset(self, candidates: Iterable, base_row: int = 0,
+                         total_rows: Optional[int] = None) -> "ShardedStreaming":
+    """``total_rows`` (the GLOBAL number of candidates, the same value on every rank): when it exceeds
+    int32 the layer streams with shard-local row numbers and returns int64 global rows; without it a
+    stream whose global rows pass 2^31 - 1 raises, as the int32 counter of the reference would wrap."""
     super().index_from_dataset(candidates)
     if base_row < 0:
       raise ValueError("base_row must be non-negative")
-    self._base_row = int(base_row)
+    self._wide = total_rows is not None and int(total_rows) > _INT32_MAX
+    self._global_base = int(base_row)
+    self._base_row = 0 if self._wide else int(base_row)
     return self
 
   def call(self, queries, k: Optional[int] = None):
     k = k if k is not None else self._k
-    scores, rows = self._query_rows(queries, k)       # local shard, global row numbers
+    scores, rows = self._query_rows(queries, k)       # local shard; global row numbers unless wide
+    if getattr(self, "_wide", False):
+      return _exchange_and_merge_wide(scores, rows, k, self._group, self._merge, self._global_base)
     return _exchange_and_merge(scores, rows, k, self._group, self._merge)

@@ -239,6 +239,19 @@ s, i = layer(qry)
 es, ei = o_topk.brute_force(qry, cand, k)
 assert np.array_equal(i.numpy(), ei), "sharded indices differ from the single-shard oracle"
 assert np.array_equal(s.numpy(), es)
+# global rows beyond int32 (SURVEY 8e): the shards sit at rows 5e9 + ..., rank order REVERSED with respect
+# to row order (rank 0 owns the higher rows): int64 rows, same scores, ties still by ascending global row
+big = 5_000_000_000
+base = big + (n - hi)                     # rank 0 -> the LAST rows of the corpus
+wide = ftk.ShardedBruteForce(k=k, local_search=local_search, merge=merge).index(cand[lo:hi], base_row=base)
+assert wide._wide
+s2, i2 = wide(qry)
+assert i2.dtype == torch.int64
+# the same corpus in global-row order: rank 1's rows first
+order = np.concatenate([np.arange(per * (world - 1 - r), n if r == 0 else per * (world - r)) for r in range(world)])
+es2, ei2 = o_topk.brute_force(qry, cand[order], k)
+assert np.array_equal(s2.numpy(), es2)
+assert np.array_equal(i2.numpy(), ei2.astype(np.int64) + big), "int64 global rows differ"
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")

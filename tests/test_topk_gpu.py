@@ -290,6 +290,18 @@ def test_streaming_groups_read_blocks_in_place(d, regime, monkeypatch):
   es, ei = o_topk.brute_force(qall[:33], c[:50_000], 10)
   np.testing.assert_array_equal(_np(s), es)
   np.testing.assert_array_equal(_np(rows), ei + 1_000_000)
+  # global rows beyond int32 (the reference's counter is int32, :380-382): shard-local rows are
+  # streamed, the exchange carries the int64 base, results are int64 (one rank here: the merge kernel and
+  # the row mapping run, the collective is a copy)
+  wide = ftk.ShardedStreaming(k=10).index_from_dataset(_LazyBlocks(c[:50_000], [4096] * 12 + [848]),
+                                                       base_row=5_000_000_000, total_rows=6_000_000_000)
+  s, rows = wide(qall[:33])
+  assert rows.dtype == torch.int64
+  np.testing.assert_array_equal(_np(s), es)
+  np.testing.assert_array_equal(_np(rows), ei.astype(np.int64) + 5_000_000_000)
+  with pytest.raises(ValueError, match="exceed int32"):
+    ftk.ShardedStreaming(k=10).index_from_dataset(_LazyBlocks(c[:50_000], [4096] * 12 + [848]),
+                                                  base_row=2_147_480_000)(qall[:4])
 
 
 def test_streaming_groups_edge_cases(monkeypatch):
