@@ -18,6 +18,14 @@ python tools/bench_ranking.py > "$O/ranking.jsonl" 2>&1
 python tools/bench_clustered.py > "$O/clustered.jsonl" 2>&1
 python tools/bench_ops.py > "$O/bench_ops.jsonl" 2>&1
 python tools/bench_batch_sweep.py > "$O/batch_sweep.jsonl" 2>&1
+python tools/bench_frontends.py > "$O/frontends.jsonl" 2>&1
+python tools/exp_fit.py > "$O/fit.txt" 2>&1
+# the N > 1 code paths on the one GPU of the box (two gloo ranks on cuda:0; one-rank RCCL group): NOT scaling numbers
+TFRS_BENCH_ONE_GPU=1 TFRS_BENCH_ROWS=4000000 python bench.py --gpus 2 --steps 3 --warmup 1 2>/dev/null | grep '^{' > "$O/two_rank.json"
+TFRS_BENCH_ONE_GPU=1 TFRS_BENCH_ROWS=4000000 python bench.py --gpus 2 --workload streaming128 --steps 3 --warmup 1 2>/dev/null | grep '^{' >> "$O/two_rank.json"
+TFRS_BENCH_ONE_GPU=1 TFRS_BENCH_TABLE_ROWS=20000000 TFRS_BENCH_BATCH=8192 python bench.py --gpus 2 --workload dlrm_embedding --steps 3 --warmup 1 2>/dev/null | grep '^{' >> "$O/two_rank.json"
+TFRS_BENCH_FORCE_DIST=1 TFRS_FORCE_EXCHANGE=1 TFRS_BENCH_ROWS=12500000 python bench.py --gpus 1 --workload streaming128 --steps 3 --warmup 1 2>/dev/null | grep '^{' > "$O/rccl_one_rank.json"
+TFRS_BENCH_FORCE_DIST=1 TFRS_FORCE_EXCHANGE=1 TFRS_BENCH_TABLE_ROWS=100000000 python bench.py --gpus 1 --workload dlrm_embedding --steps 5 --warmup 2 2>/dev/null | grep '^{' >> "$O/rccl_one_rank.json"
 python tools/exp_power.py > "$O/power.jsonl" 2>&1
 for m in random zeros; do ./tools/ubench/mfma_rate $m; done > "$O/mfma_rate.txt" 2>&1
 bash tools/pmc_generic.sh "$TAG/pmc_inter" tools/exp_interaction_prof.py > /dev/null 2>&1

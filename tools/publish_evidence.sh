@@ -20,6 +20,9 @@ grep '^{' "$S/batch_sweep.jsonl" > "${R}_batch_sweep.jsonl"
 grep '^{' "$S/power.jsonl" > "${R}_power.jsonl"
 cp "$S/mfma_rate.txt" "${R}_mfma_rate.txt"
 [ -f "$S/two_rank.json" ] && grep '^{' "$S/two_rank.json" > "${R}_two_rank_one_gpu_dryrun.json" || true
+[ -f "$S/rccl_one_rank.json" ] && grep '^{' "$S/rccl_one_rank.json" > "${R}_rccl_one_rank_dryrun.json" || true
+[ -f "$S/frontends.jsonl" ] && grep '^{' "$S/frontends.jsonl" > "${R}_frontends.jsonl" || true
+[ -f "$S/fit.txt" ] && grep -v "^ \|ncalls\|Ordered\|List reduced\|function calls\|amdgpu.ids" "$S/fit.txt" | grep -v '^$' > "${R}_fit.txt" || true
 {
   echo "# rocprofv3 summary: Cross (configs[3]) and DotInteraction (configs[4]) kernels"
   echo
