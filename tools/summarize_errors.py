@@ -5,7 +5,12 @@ import math, os
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 src = args[0] if args else "gpurun_out/observed_errors.jsonl"
 rows = [json.loads(l) for l in open(src)]
-if "--gates" in sys.argv:      # regenerate tests/golden/float_gates.json: 4 x observed, rounded up to 2 digits
+if "--gates" in sys.argv:
+  # FROZEN since round 4: tests/golden/float_gates.json is an
+  # early-warning tier, the family ceilings in the tests are the contract -- regenerating the file next to a
+  # kernel change could absorb a regression.  Kept only behind an explicit override.
+  if "--i-am-not-changing-a-kernel-in-this-commit" not in sys.argv:
+    raise SystemExit("tests/golden/float_gates.json is frozen; see tests/conftest.py::_gate_limit")
   worst = collections.defaultdict(float)
   for r in rows:
     g = re.sub(r"\.d(biases|u_kernels|v_kernels)\.\d", ".dparam", r["gate"])
@@ -31,7 +36,7 @@ for r in rows:
   count[g] += 1
   if g not in best or r["observed"] > best[g]["observed"]:
     best[g] = dict(r, gate=g)
-print("# Observed floating-point errors of the GPU parity tests (MI355X, round 3)\n")
+print("# Observed floating-point errors of the GPU parity tests (MI355X)\n")
 print("Every float comparison of a HIP kernel with the float64 oracle goes through `tests/conftest.py::float_gate`:")
 print("`max |got - ref| / yardstick <= limit`, the yardstick being the sum of the absolute values of the terms of")
 print("each entry (DESIGN.md section 2).  This table is the audit trail of the limits: largest observed value per")
