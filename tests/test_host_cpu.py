@@ -541,12 +541,15 @@ s, i = layer(qry)
 es, ei = o_topk.brute_force(qry, cand, k)
 assert np.array_equal(i.numpy(), ei) and np.array_equal(s.numpy(), es)
 
-# ShardedBruteForce: a shard whose rows would not fit int32 global row numbers is refused
+# ShardedBruteForce: global rows beyond int32 switch every rank to the int64 exchange (round 4; refused
+# before); a negative base row is still an error
+wide = ftk.ShardedBruteForce(k=5, local_search=lambda *a: None).index(cand[:10], base_row=2**31 - 5)
+assert wide._wide
 try:
-  ftk.ShardedBruteForce(k=5, local_search=lambda *a: None).index(cand[:10], base_row=2**31 - 5)
+  ftk.ShardedBruteForce(k=5, local_search=lambda *a: None).index(cand[:10], base_row=-1)
   raise SystemExit("expected ValueError")
 except ValueError as e:
-  assert "int32" in str(e)
+  assert "base_row" in str(e)
 # integer identifiers are resolved by their owners
 def local_search(q, c, kk):
   s_, i_ = o_topk.brute_force(np.asarray(q), np.asarray(c), kk)
