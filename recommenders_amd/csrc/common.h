@@ -227,8 +227,19 @@ struct RawScanArgs {
   int nseg;
   float *dense;
   int64_t ld_dense;
+  // rawscan16_kernel (fp16 prefilter straight from the blocks): thr[q] is a proven lower bound of the
+  // query's final K-th score; qk / qscale as launch_query_kappa writes them; norm_max: atomicMax (float
+  // bits) of the largest row norm met; zero_word / zero_aux: re-armed like Scan16Args' (topk_scan16.hip)
+  const float *qk;
+  const float *qscale;
+  float *norm_max;
+  uint32_t *zero_word;
+  uint32_t *zero_aux;
 };
 int launch_rawscan(const RawScanArgs &a, bool materialize, hipStream_t stream);
+// qg: 1, 2 or 4 groups of 32 queries per workgroup (n_qtiles = ceil(nq / (32 * qg))); survivors carry
+// PREFILTER scores (re-scored by launch_list_topk16 with the table), layout [nq, cap_l, nseg = n_splits]
+int launch_rawscan16(const RawScanArgs &a, hipStream_t stream);
 // fp16 prefilter image (+ StageMeta, global max row norm) of the group's rows [0, table.total_rows),
 // zero rows up to the next stage boundary, straight from the row-major blocks
 int launch_pack16_raw(const RawTable *table, int64_t n_rows, int d, char *packed16, StageMeta *meta,

@@ -312,7 +312,6 @@ int launch_rawscan(const RawScanArgs &a, bool materialize, hipStream_t stream) {
   return TFRS_ENOTIMPL;
 }
 
-// ---- fp16 prefilter image straight from the blocks ----------------------------------------------
 typedef _Float16 rf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t raw_pack_f16x2(float lo, float hi) {
   union {
@@ -323,6 +322,273 @@ __device__ __forceinline__ uint32_t raw_pack_f16x2(float lo, float hi) {
   v.h[1] = (_Float16)hi;
   return v.u;
 }
+
+// ---- fp16-PREFILTERED scan straight from the blocks (query batches up to 128) ---------------------
+//
+// The exact kernel above spends 64 matrix-core cycles per feature pair and group of 32 queries: at
+// D = 128 a workgroup needs 4096 cycles per stage for ONE group, about what the stage's 64 KiB take to
+// arrive from HBM -- and twice that for 64 queries.  Here the stage arrives the same way (row-major f32,
+// direct-to-LDS), every wave converts ITS 32 rows to fp16 in registers (x / s with s = 2^ceil(log2 max|x|)
+// of those 32 rows, the contract of the fp16 image of topk_pack.hip with a "stage" of 32 rows) and scores
+// them with v_mfma_f32_32x32x16_f16: 32 cycles per 16 features and group, so that up to four groups
+// (128 queries) cost less than the copy.  Nothing computed here is returned: a prefilter score only
+// decides whether a row can still reach a query's top-K under the bound of common.h,
+//     |s~ - s| <= ||q|| * N * kappa (+ tiny),   N = largest row norm of the wave's 32 rows,
+// against thr[q], a proven lower bound of the query's final K-th score (the carried state's exact K-th
+// score); survivors are re-scored exactly from the blocks by list_topk16_kernel (raw_score).
+typedef _Float16 f16x8r __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4r __attribute__((ext_vector_type(4)));
+
+template <int DP, int QG>
+__global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArgs a) {
+  using G = RawGeom<DP>;
+  constexpr int KS = DP >= 16 ? DP / 16 : 1;   // MFMA steps of 16 features
+  constexpr int NV = DP >= 16 ? DP / 8 : 2;    // 16-byte pieces a lane holds: half of its row (DP = 8: the row, lane half 0)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t *wg_cnt = reinterpret_cast<uint32_t *>(smem + G::kCntOff);
+  static_assert(QG * 32 <= 128, "wg_cnt holds 128 counters");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31;
+  const int h = lane >> 5;
+  if (a.zero_word && blockIdx.x == 0 && tid == 0) *a.zero_word = 0u;
+  if (a.zero_aux && blockIdx.x == 0 && tid < 4) a.zero_aux[tid] = 0u;
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int xcd = bid & 7, pos = bid >> 3;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + pos;
+  const int split = logical / a.n_qtiles;
+  const int qt = logical - split * a.n_qtiles;
+
+  const int64_t c0 = a.c_begin + (int64_t)split * a.split_len;
+  int64_t c1 = c0 + a.split_len;
+  if (c1 > a.c_end) c1 = a.c_end;
+  const int nstages = c0 < c1 ? (int)((c1 - c0 + kTileN - 1) / kTileN) : 0;
+
+  // ---- the tile's queries -> fp16 MFMA B operands (q / qscale), resident -------------------------
+  f16x8r bq[QG][KS];
+  float flo[QG], fqk[QG], qsc[QG];   // (lower - tiny) / qscale, qk / qscale, qscale
+  int64_t qrow[QG];
+#pragma unroll
+  for (int g = 0; g < QG; ++g) {
+    qrow[g] = ((int64_t)qt * QG + g) * 32 + j;
+    const bool qvalid = qrow[g] < a.nq;
+    const int64_t qr = qvalid ? qrow[g] : 0;
+    const float qs = qvalid ? a.qscale[qr] : 1.0f;
+    const float qinv = 1.0f / qs;   // exact: power of two
+    const f32x4 *q4 = reinterpret_cast<const f32x4 *>(a.q + qr * DP);
+#pragma unroll
+    for (int m = 0; m < KS; ++m) {
+      // features 16 m + 8 h .. + 7 (DP = 8: the whole row in lane half 0, zeros in half 1)
+      const int p0 = DP >= 16 ? 4 * m + 2 * h : 0;
+      const f32x4 lo = q4[p0], hi = q4[p0 + 1];
+      const bool on = qvalid && (DP >= 16 || h == 0);
+      u32x4r w;
+      w[0] = raw_pack_f16x2(on ? lo[0] * qinv : 0.0f, on ? lo[1] * qinv : 0.0f);
+      w[1] = raw_pack_f16x2(on ? lo[2] * qinv : 0.0f, on ? lo[3] * qinv : 0.0f);
+      w[2] = raw_pack_f16x2(on ? hi[0] * qinv : 0.0f, on ? hi[1] * qinv : 0.0f);
+      w[3] = raw_pack_f16x2(on ? hi[2] * qinv : 0.0f, on ? hi[3] * qinv : 0.0f);
+      bq[g][m] = __builtin_bit_cast(f16x8r, w);
+    }
+    flo[g] = qvalid ? (a.thr[qr] - kF16Tiny) * qinv : __builtin_inff();
+    fqk[g] = qvalid ? a.qk[qr] * qinv : 0.0f;
+    qsc[g] = qs;
+  }
+  if (tid < 128) wg_cnt[tid] = 0u;
+
+  // ---- block cursor and stage prefetch: as in rawscan_kernel ------------------------------------
+  const RawTable *T = a.table;
+  const int nblk = T->n_blocks;
+  int blk = nstages > 0 ? __builtin_amdgcn_readfirstlane(raw_find_block(T, c0)) : 0;
+  int64_t blk_lo = T->row_start[blk], blk_hi = T->row_start[blk + 1];
+  const char *blk_ptr = reinterpret_cast<const char *>(T->ptr[blk]);
+  // The copies of a stage that lies in one block (the common case) are NOT issued here: a wave that issues
+  // all of them back to back sits in the issue stage until the LDS-DMA queue has room, and its arithmetic
+  // starts only then (measured with four query groups: 382 us per 3.1 M rows against 272 us with one).
+  // The caller spreads them over the phases of the stage (copy_part).  Returns the lane's source address
+  // of chunk `wave` (NULL: the copies were issued here).
+  auto begin_stage = [&](int st, char *lds) -> const char * {
+    const int64_t v0 = c0 + (int64_t)st * kTileN;
+    while (v0 >= blk_hi && blk + 1 < nblk) {
+      ++blk;
+      blk_lo = blk_hi;
+      blk_hi = T->row_start[blk + 1];
+      blk_ptr = reinterpret_cast<const char *>(T->ptr[blk]);
+    }
+    if (v0 + kTileN <= blk_hi && v0 + kTileN <= c1)   // the whole stage lies in one block: a linear copy
+      return blk_ptr + (v0 - blk_lo) * (int64_t)G::kRowB + wave * 1024 + lane * 16;
+    // block boundary or the last, partly filled stage: every lane looks its row up; rows at or
+    // beyond c1 re-read the last valid row (their scores are never used)
+#pragma unroll 1
+    for (int i = 0; i < G::kCopies; ++i) {
+      const int ch = wave + kRawWaves * i;
+      const int byte = ch * 1024 + lane * 16;
+      const int r = byte / G::kRowB;
+      int64_t row = v0 + r;
+      if (row > c1 - 1) row = c1 - 1;
+      const char *p = reinterpret_cast<const char *>(raw_row_ptr(T, row, DP)) + (byte - r * G::kRowB);
+      raw_glds_copy16(p, lds + ch * kRawChunkB);
+    }
+    return nullptr;
+  };
+  // quarter `part` (0 .. 3) of the wave's copies of a stage
+  auto copy_part = [&](const char *src, char *lds_wave, int part) __attribute__((always_inline)) {
+    if (src == nullptr) return;   // (wave-uniform)
+    constexpr int kPer = (G::kCopies + 3) / 4;
+#pragma unroll
+    for (int i = part * kPer; i < (part + 1) * kPer && i < G::kCopies; ++i)
+      raw_glds_copy16(src + i * (kRawWaves * 1024), lds_wave + i * (kRawWaves * kRawChunkB));
+  };
+  if (nstages > 0) {
+    const char *src0 = begin_stage(0, smem);
+#pragma unroll
+    for (int part = 0; part < 4; ++part) copy_part(src0, smem + wave * kRawChunkB, part);
+  }
+  raw_wait_dma();
+  __syncthreads();
+
+  // this lane's A-tile row: stage row of t = 32 * wave + j; its half h of the row (32 bytes per step)
+  const int t_row = 32 * wave + j;
+  const int a_off = (t_row % G::kChunks) * kRawChunkB + (t_row / G::kChunks) * G::kRowB + (DP >= 16 ? h * 32 : 0);
+  float norm_run = 0.0f;   // largest row norm this wave has met
+
+  for (int st = 0; st < nstages; ++st) {
+    const char *tile = smem + (st & 1) * G::kStageB;
+    const bool more = st + 1 < nstages;
+    char *next_lds = smem + ((st + 1) & 1) * G::kStageB + wave * kRawChunkB;
+    const char *next_src = more ? begin_stage(st + 1, smem + ((st + 1) & 1) * G::kStageB) : nullptr;
+    const int64_t stage_c = c0 + (int64_t)st * kTileN;
+
+    // ---- the lane's half row; norm and max |x| of the wave's 32 rows ------------------------------
+    const char *ap = tile + a_off;
+    f32x4 av[NV];
+#pragma unroll
+    for (int m = 0; m < KS; ++m) {
+      av[2 * m] = *reinterpret_cast<const f32x4 *>(ap + m * 64);
+      av[2 * m + 1] = *reinterpret_cast<const f32x4 *>(ap + m * 64 + 16);
+    }
+    copy_part(next_src, next_lds, 0);
+    if (DP < 16 && h == 1) {
+      av[0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      av[1] = av[0];
+    }
+    float ss = 0.0f, am = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        ss = __builtin_fmaf(av[i][c], av[i][c], ss);
+        am = fmaxf(am, __builtin_fabsf(av[i][c]));
+      }
+    ss += __shfl_xor(ss, 32);   // the row's other half
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      if (off < 32) ss = fmaxf(ss, __shfl_xor(ss, off));
+      am = fmaxf(am, __shfl_xor(am, off));
+    }
+    const float nrm = __builtin_sqrtf(ss) * kNormSlack;   // (upper bound of the 32 row norms)
+    const float cs = pow2_ceil(am);
+    const float inv = 1.0f / cs;                          // exact: power of two
+    norm_run = fmaxf(norm_run, nrm);
+    copy_part(next_src, next_lds, 1);
+
+    f16x8r af[KS];
+#pragma unroll
+    for (int m = 0; m < KS; ++m) {
+      u32x4r w;
+      w[0] = raw_pack_f16x2(av[2 * m][0] * inv, av[2 * m][1] * inv);
+      w[1] = raw_pack_f16x2(av[2 * m][2] * inv, av[2 * m][3] * inv);
+      w[2] = raw_pack_f16x2(av[2 * m + 1][0] * inv, av[2 * m + 1][1] * inv);
+      w[3] = raw_pack_f16x2(av[2 * m + 1][2] * inv, av[2 * m + 1][3] * inv);
+      af[m] = __builtin_bit_cast(f16x8r, w);
+    }
+
+    copy_part(next_src, next_lds, 2);
+
+    // ---- prefilter scores and the filter ----------------------------------------------------------
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+      if (g == (QG > 1 ? 1 : 0)) copy_part(next_src, next_lds, 3);
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+      for (int m = 0; m < KS; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m], bq[g][m], acc, 0, 0, 0);
+      // acc[r] = prefilter score of (query qrow[g], stage row of t = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h),
+      // in units of qscale * cs.  keep s~ > lower - qk * N - tiny, the scales folded into the threshold
+      const float thr = __builtin_fmaf(-fqk[g], nrm, flo[g]) * inv;
+      const float m0 = raw_max16(acc);
+      if (__ballot(m0 > thr) != 0ull) {   // rare once the bound is warm
+        const float un = qsc[g] * cs;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int srow = (t % G::kChunks) * G::kRowsPerChunk + t / G::kChunks;
+          if (acc[r] > thr && stage_c + srow < c1) {
+            const uint32_t e = atomicAdd(&wg_cnt[g * 32 + j], 1u);
+            if (e < a.cap_l)
+              a.buf[(qrow[g] * (int64_t)a.cap_l + e) * a.nseg + split] =
+                  make_uint2(__float_as_uint(acc[r] * un), (uint32_t)(stage_c + srow));
+          }
+        }
+      }
+    }
+    if (more) raw_wait_dma();
+    __syncthreads();
+  }
+
+  // every (query, split) count is written: no memset needed (counts beyond cap_l flag the query for
+  // the exact redo, as the image-fed filter kernel does)
+  if (tid < QG * 32) {
+    const int64_t qr = ((int64_t)qt * QG + (tid >> 5)) * 32 + (tid & 31);
+    if (qr < a.nq) a.cnt[qr * a.nseg + split] = wg_cnt[tid];
+  }
+  if (nstages > 0 && lane == 0 && a.norm_max)
+    atomicMax(reinterpret_cast<uint32_t *>(a.norm_max), __float_as_uint(norm_run));   // >= 0
+}
+
+template <int DP, int QG>
+static int launch_rawscan16_variant(const RawScanArgs &a, hipStream_t stream) {
+  using G = RawGeom<DP>;
+  static_assert(G::kLdsBytes + 256 <= 160 * 1024, "two raw stages + the counters must fit the LDS");
+  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&rawscan16_kernel<DP, QG>), G::kLdsBytes + 256));
+  const dim3 grid((unsigned)(a.n_qtiles * a.n_splits));
+  hipLaunchKernelGGL((rawscan16_kernel<DP, QG>), grid, dim3(kRawThreads), G::kLdsBytes + 256, stream, a);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+template <int DP>
+static int launch_rawscan16_dp(const RawScanArgs &a, hipStream_t stream) {
+  switch (a.qg) {
+    case 1: return launch_rawscan16_variant<DP, 1>(a, stream);
+    case 2: return launch_rawscan16_variant<DP, 2>(a, stream);
+    case 4: return launch_rawscan16_variant<DP, 4>(a, stream);
+  }
+  set_error("rawscan16: %d query groups per workgroup (1, 2 or 4)", a.qg);
+  return TFRS_EINVAL;
+}
+
+int launch_rawscan16(const RawScanArgs &a, hipStream_t stream) {
+  if (a.nq <= 0 || a.c_end <= a.c_begin) return TFRS_OK;
+  TFRS_CHECK_ARG(a.d == padded_dim(a.d) && a.d >= 8 && a.d <= 128, "rawscan16: dim %d is not one of 8 .. 128", a.d);
+  TFRS_CHECK_ARG(a.split_len >= kTileN && a.split_len % kTileN == 0 && a.n_splits >= 1 && a.nseg == a.n_splits,
+                 "rawscan16: bad split");
+  TFRS_CHECK_ARG(a.thr && a.qk && a.qscale && a.cnt && a.buf, "rawscan16: NULL pointer");
+  switch (a.d) {
+    case 8: return launch_rawscan16_dp<8>(a, stream);
+    case 16: return launch_rawscan16_dp<16>(a, stream);
+    case 32: return launch_rawscan16_dp<32>(a, stream);
+    case 64: return launch_rawscan16_dp<64>(a, stream);
+    default: return launch_rawscan16_dp<128>(a, stream);
+  }
+}
+
+// ---- fp16 prefilter image straight from the blocks ----------------------------------------------
 
 // One workgroup (256 threads) per stage of kTileN rows (same contract as pack16_stage_kernel,
 // topk_pack.hip: x / scale with scale = 2^ceil(log2 max |x|), StageMeta, global max row norm).

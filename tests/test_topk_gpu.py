@@ -250,16 +250,20 @@ def _ragged_sizes(rng, n, typical):
   return sizes
 
 
-@pytest.mark.parametrize("regime", ["raw", "f16"])
+@pytest.mark.parametrize("regime", ["raw16", "raw", "f16"])
 @pytest.mark.parametrize("d", [8, 16, 32, 64, 128])
 def test_streaming_groups_read_blocks_in_place(d, regime, monkeypatch):
   """Streaming over a lazily produced dataset: groups of blocks are searched
-  where they lie (tfrs_streaming_topk_update_blocks): the raw f32-MFMA scan for small query batches
-  and the fp16 image built straight from the blocks for large ones (forced here for every batch size
-  with TFRS_STREAM_RAW_MAX_NQ=0).  Ragged and uniform block sizes, several groups with a carried state
+  where they lie (tfrs_streaming_topk_update_blocks): "raw16" = the default for up to 128 queries, the
+  fp16 filter fed by the f32 blocks themselves (rawscan16_kernel: 1, 2 and 4 query groups per workgroup
+  at 1 / 20, 64 and 100 queries); "raw" = the exact f32-MFMA scan (TFRS_STREAM_RAW16_MAX_NQ=0: up to 64
+  queries, the fp16 image above); "f16" = the fp16 image built straight from the blocks for every batch
+  size (TFRS_STREAM_RAW_MAX_NQ=0 as well).  Ragged and uniform block sizes, several groups with a carried state
   (small group_max_bytes), 1 / 20 / 64 / 100 queries, k = 1 / 10 / 100, integer identifiers kept on the
   device, a row offset: bit for bit the oracle's Streaming fold (layers/factorized_top_k.py:404-509)."""
   ftk = _layers()
+  if regime != "raw16":
+    monkeypatch.setenv("TFRS_STREAM_RAW16_MAX_NQ", "0")
   if regime == "f16":
     monkeypatch.setenv("TFRS_STREAM_RAW_MAX_NQ", "0")
     monkeypatch.setenv("TFRS_STREAM_RHO16", "2")       # more rounds than the default
@@ -302,6 +306,53 @@ def test_streaming_groups_read_blocks_in_place(d, regime, monkeypatch):
   with pytest.raises(ValueError, match="exceed int32"):
     ftk.ShardedStreaming(k=10).index_from_dataset(_LazyBlocks(c[:50_000], [4096] * 12 + [848]),
                                                   base_row=2_147_480_000)(qall[:4])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_streaming_block_fed_filter_awkward_data(seed):
+  """rawscan16_kernel (the default for up to 128 queries over a lazily produced dataset) on data that stresses
+  its per-32-row scales and norms: rows whose magnitudes span e^+-3, every row twice, a constant column,
+  all-negative scores, clustered rows ordered by cluster, blocks of zeros -- against the all-f32 scan of the
+  same rows (bit for bit, ties included), ragged blocks, 1 .. 128 queries, k up to 512."""
+  ftk = _layers()
+  from recommenders_amd import _lib
+  rng = np.random.default_rng(900 + seed)
+  dev = torch.device("cuda", 0)
+  for case in range(7):
+    d = int(rng.choice([8, 16, 32, 64, 128]))
+    k = int(rng.choice([1, 10, 100, 257, 512]))
+    nq = int(rng.choice([1, 31, 32, 33, 64, 65, 100, 128]))
+    n = int(rng.integers(40_000, 400_000))
+    kind = ["row_scales", "dups", "const_col", "negative", "clustered", "zero_blocks", "gauss"][(case + seed) % 7]
+    g = torch.Generator(device=dev).manual_seed(int(rng.integers(1 << 30)))
+    c = torch.randn((n, d), generator=g, device=dev) / d ** 0.5
+    q = torch.randn((nq, d), generator=g, device=dev) / d ** 0.5
+    if kind == "row_scales":
+      c *= torch.exp(3.0 * torch.randn((n, 1), generator=g, device=dev))
+    elif kind == "dups":
+      c[n // 2:] = c[: n - n // 2].clone()
+    elif kind == "const_col":
+      c[:, 0] = 3.0
+    elif kind == "negative":
+      c = -c.abs(); q = q.abs()
+    elif kind == "clustered":
+      cen = torch.randn((64, d), generator=g, device=dev) / d ** 0.5
+      c = cen[torch.arange(n, device=dev) * 64 // n] + 0.3 * c
+      q = cen[torch.randint(0, 64, (nq,), generator=g, device=dev)] + 0.3 * q
+    elif kind == "zero_blocks":
+      c[1000:9000] = 0.0
+      c[n // 2: n // 2 + 77] = 0.0
+    sizes = _ragged_sizes(rng, n, int(rng.choice([500, 4096, 30000])))
+    _lib.set_option("TFRS_TOPK_FILTER", "f32")
+    try:
+      es, ei = ftk.BruteForce(k=k).index(c)(q)
+    finally:
+      _lib.set_option("TFRS_TOPK_FILTER", None)
+    layer = ftk.Streaming(k=k, group_max_bytes=int(rng.choice([8 << 30, n * d * 4 // 2 + 4096]))).index_from_dataset(
+        _LazyBlocks(c.cpu().numpy(), sizes, None))
+    s, i = layer(q)
+    assert torch.equal(s, es), (case, kind, d, k, nq, n)
+    assert torch.equal(i.to(torch.int64), ei.to(torch.int64)), (case, kind, d, k, nq, n)
 
 
 def test_streaming_groups_edge_cases(monkeypatch):
