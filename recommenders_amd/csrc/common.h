@@ -232,12 +232,13 @@ struct RawScanArgs {
   // bits) of the largest row norm met; zero_word / zero_aux: re-armed like Scan16Args' (topk_scan16.hip)
   const float *qk;
   const float *qscale;
+  int64_t thr_stride;    // rawscan16: query q's bound is thr[q * thr_stride] (0 -> 1); lets the carried state's K-th column serve
   float *norm_max;
   uint32_t *zero_word;
   uint32_t *zero_aux;
 };
 int launch_rawscan(const RawScanArgs &a, bool materialize, hipStream_t stream);
-// qg: 1, 2 or 4 groups of 32 queries per workgroup (n_qtiles = ceil(nq / (32 * qg))); survivors carry
+// qg: 1, 2, 4 or 8 groups of 32 queries per workgroup (n_qtiles = ceil(nq / (32 * qg))); survivors carry
 // PREFILTER scores (re-scored by launch_list_topk16 with the table), layout [nq, cap_l, nseg = n_splits]
 int launch_rawscan16(const RawScanArgs &a, hipStream_t stream);
 // fp16 prefilter image (+ StageMeta, global max row norm) of the group's rows [0, table.total_rows),

@@ -433,6 +433,68 @@ static void plan_stage_splits(int64_t n_stages, int n_qtiles, const TopkTuning &
   *n_splits = (int)((n_stages + *per - 1) / *per);
 }
 
+// One range [row_lo, row_lo + n) of a group of blocks through the block-fed fp16 filter (rawscan16_kernel,
+// topk_raw.hip: the filter pass reads the f32 blocks themselves -- no image, hence no threshold pass over
+// one): bound[q * bound_stride] is a proven lower bound of query q's final K-th score (the carried state's
+// K-th column); w.qk / w.qscale hold launch_query_kappa's output; the range's exact top-K goes to out_*.
+static int run_raw16_range(const float *q, int64_t nq, int d, const RawTable *raw, float *norm_max,
+                           int64_t row_lo, int64_t n, int64_t idx_base, int k, const float *bound,
+                           int64_t bound_stride, int qg, float *out_scores, int32_t *out_idx, const RoundWs &w,
+                           const TopkTuning &t, hipStream_t stream) {
+  int rc;
+  RawScanArgs sa = {};
+  sa.q = q;
+  sa.nq = nq;
+  sa.d = d;
+  sa.table = raw;
+  sa.c_begin = row_lo;
+  sa.c_end = row_lo + n;
+  sa.qg = qg;
+  sa.n_qtiles = (int)((nq + 32 * qg - 1) / (32 * qg));
+  plan_splits(n, sa.n_qtiles, t, &sa.split_len, &sa.n_splits);
+  sa.nseg = sa.n_splits;
+  sa.cap_l = segment_cap(k, sa.nseg, t);
+  if ((int64_t)sa.nseg * sa.cap_l > w.entries || sa.nseg > 2 * max_splits(nq, t)) {
+    set_error("topk: survivor workspace too small (%d segments x %u)", sa.nseg, sa.cap_l);
+    return TFRS_ENOMEM;
+  }
+  sa.thr = bound;
+  sa.thr_stride = bound_stride;
+  sa.cnt = w.cnt;
+  sa.buf = w.buf;
+  sa.qk = w.qk;
+  sa.qscale = w.qscale;
+  sa.norm_max = norm_max;
+  sa.zero_word = reinterpret_cast<uint32_t *>(w.redo);
+  sa.zero_aux = w.redo + 1 + nq;
+  int slot = -1;
+  const bool timed = prof_begin(stream, 2.0 * (double)nq * (double)n * d, 1, &slot);
+  rc = launch_rawscan16(sa, stream);
+  if (timed) prof_end(stream, slot);
+  if (rc != TFRS_OK) return rc;
+  // prefilter top-K + exact re-scoring from the blocks; flagged queries (list overflow, retained set too
+  // large) are answered by the exact recompute path of the generic select kernel
+  if ((rc = launch_list_topk16(q, nq, d, /*packed=*/nullptr, w.buf, w.cnt, sa.cap_l, sa.nseg, k, w.qk, norm_max,
+                               out_scores, out_idx, w.redo, idx_base, /*ovf_cnt=*/nullptr, w.ovf_buf, kOvfCap,
+                               /*rowmap=*/nullptr, /*thr_raw=*/nullptr, w.redo + 1 + nq, stream, raw)) != TFRS_OK)
+    return rc;
+  SelectArgs se = {};
+  se.nq = nq;
+  se.k = k;
+  se.q = q;
+  se.d = d;
+  se.source = kSrcRecompute;
+  se.only_flagged = w.redo;
+  se.part_keys = w.part_keys;
+  se.idx_base = idx_base;
+  se.rc_begin = row_lo;
+  se.rc_end = row_lo + n;
+  se.raw = raw;
+  se.out_scores = out_scores;
+  se.out_idx = out_idx;
+  return launch_recompute(se, stream);
+}
+
 // lower_preset: w.thr already holds a proven lower bound per query (Streaming: the carried
 // state's exact K-th score) -> the threshold pass is skipped.
 // row_lo (a multiple of kTileN) / n: the rows [row_lo, row_lo + n) of the image are searched (survivor
@@ -442,67 +504,7 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
                    int64_t n, int64_t idx_base, int k, const SamplePlan &sp, bool lower_preset,
                    float *out_scores, int32_t *out_idx, const RoundWs &w, const TopkTuning &t,
                    hipStream_t stream, const int32_t *rowmap = nullptr, int64_t row_lo = 0,
-                   const RawTable *raw = nullptr, int raw16_qg = 0) {
-  if (raw16_qg > 0) {
-    // the filter pass reads the f32 blocks themselves (rawscan16_kernel, topk_raw.hip): no image, hence no
-    // threshold pass over one -- the caller's bound (the carried state's K-th score) is in w.thr
-    if (!raw || !lower_preset) {
-      set_error("topk: internal: the block-fed fp16 filter needs a table and a preset bound");
-      return TFRS_ESTATE;
-    }
-    int rc;
-    if ((rc = launch_query_kappa(q, nq, d, w.qk, w.qscale, w.ovf_cnt, stream)) != TFRS_OK) return rc;
-    RawScanArgs sa = {};
-    sa.q = q;
-    sa.nq = nq;
-    sa.d = d;
-    sa.table = raw;
-    sa.c_begin = row_lo;
-    sa.c_end = row_lo + n;
-    sa.qg = raw16_qg;
-    sa.n_qtiles = (int)((nq + 32 * raw16_qg - 1) / (32 * raw16_qg));
-    plan_splits(n, sa.n_qtiles, t, &sa.split_len, &sa.n_splits);
-    sa.nseg = sa.n_splits;
-    sa.cap_l = segment_cap(k, sa.nseg, t);
-    if ((int64_t)sa.nseg * sa.cap_l > w.entries || sa.nseg > 2 * max_splits(nq, t)) {
-      set_error("topk: survivor workspace too small (%d segments x %u)", sa.nseg, sa.cap_l);
-      return TFRS_ENOMEM;
-    }
-    sa.thr = w.thr;
-    sa.cnt = w.cnt;
-    sa.buf = w.buf;
-    sa.qk = w.qk;
-    sa.qscale = w.qscale;
-    sa.norm_max = const_cast<float *>(img.norm_max);   // (the group owns it: atomicMax of the row norms met)
-    sa.zero_word = reinterpret_cast<uint32_t *>(w.redo);
-    sa.zero_aux = w.redo + 1 + nq;
-    int slot = -1;
-    const bool timed = prof_begin(stream, 2.0 * (double)nq * (double)n * d, 1, &slot);
-    rc = launch_rawscan16(sa, stream);
-    if (timed) prof_end(stream, slot);
-    if (rc != TFRS_OK) return rc;
-    if ((rc = launch_list_topk16(q, nq, d, packed, w.buf, w.cnt, sa.cap_l, sa.nseg, k, w.qk, img.norm_max,
-                                 out_scores, out_idx, w.redo, idx_base, /*ovf_cnt=*/nullptr, w.ovf_buf, kOvfCap,
-                                 rowmap, /*thr_raw=*/nullptr, w.redo + 1 + nq, stream, raw)) != TFRS_OK)
-      return rc;
-    SelectArgs se = {};
-    se.nq = nq;
-    se.k = k;
-    se.q = q;
-    se.d = d;
-    se.packed = packed;
-    se.source = kSrcRecompute;
-    se.only_flagged = w.redo;
-    se.part_keys = w.part_keys;
-    se.rowmap = rowmap;
-    se.idx_base = idx_base;
-    se.rc_begin = row_lo;
-    se.rc_end = row_lo + n;
-    se.raw = raw;
-    se.out_scores = out_scores;
-    se.out_idx = out_idx;
-    return launch_recompute(se, stream);
-  }
+                   const RawTable *raw = nullptr) {
   const int n_qtiles = (int)((nq + kScan16QueriesPerWg - 1) / kScan16QueriesPerWg);
   const int64_t stage_lo = row_lo / kTileN;
   int rc;
@@ -1069,15 +1071,21 @@ static int64_t stream_rho16() { return std::max<int64_t>(2, env_i64("TFRS_STREAM
 constexpr int64_t kStreamFirstRange = 262144;   // rows of the first fp16 range (threshold pass of its own)
 
 // Query batches up to this size take the block-fed fp16 filter (rawscan16_kernel: one pass over the f32
-// blocks, <= 128 queries per workgroup); 0 sends them to the exact f32-MFMA scan (<= TFRS_STREAM_RAW_MAX_NQ
+// blocks, <= 256 queries per workgroup); 0 sends them to the exact f32-MFMA scan (<= TFRS_STREAM_RAW_MAX_NQ
 // queries) or the fp16 image (above)
-static int64_t stream_raw16_max_nq() { return std::max<int64_t>(0, env_i64("TFRS_STREAM_RAW16_MAX_NQ", 128)); }
-static bool group_uses_raw16(int64_t nq, int k, const TopkTuning &t) {
-  return t.f16_filter && k <= kMaxKF16 && nq <= stream_raw16_max_nq();
+static int64_t stream_raw16_max_nq() { return std::max<int64_t>(0, env_i64("TFRS_STREAM_RAW16_MAX_NQ", 256)); }
+// ... and, up to dim 64, from this size on: with one group of 32 queries the exact scan is copy-bound as well
+// there and needs half the launches per range (12.5 M x 64, one query: 0.89 against 1.00 ms); at dim 128 its
+// 64 matrix-core steps per row cost as much as the copy (one query 1.71 against 1.64 ms, 32: 1.88 against 1.70)
+static int64_t stream_raw16_min_nq() { return std::max<int64_t>(1, env_i64("TFRS_STREAM_RAW16_MIN_NQ", 33)); }
+static bool group_uses_raw16(int64_t nq, int d, int k, const TopkTuning &t) {
+  // one workgroup holds all queries: eight groups of 32 up to dim 64, four at dim 128 (register file)
+  return t.f16_filter && k <= kMaxKF16 && nq >= (d <= 64 ? stream_raw16_min_nq() : 1) &&
+         nq <= std::min<int64_t>(stream_raw16_max_nq(), d <= 64 ? 256 : 128);
 }
-static int raw16_qg(int64_t nq) { return nq <= 32 ? 1 : nq <= 64 ? 2 : 4; }
-static bool group_uses_f16(int64_t nq, int64_t n, int k, const TopkTuning &t) {
-  if (group_uses_raw16(nq, k, t)) return false;
+static int raw16_qg(int64_t nq) { return nq <= 32 ? 1 : nq <= 64 ? 2 : nq <= 128 ? 4 : 8; }
+static bool group_uses_f16(int64_t nq, int64_t n, int d, int k, const TopkTuning &t) {
+  if (group_uses_raw16(nq, d, k, t)) return false;
   if (!(t.f16_filter && k <= kMaxKF16) || nq <= stream_raw_max_nq()) return false;
   // the first range must be able to take its bound from bin maxima
   return plan_sample(std::min<int64_t>(n, kStreamFirstRange), k, t, false).n_stages > 0;
@@ -1112,12 +1120,12 @@ static size_t group_ws_bytes(int64_t nq, int64_t n, int d, int k, const TopkTuni
   size_t b = align_up(sizeof(RawTable));
   b += round_ws_bytes(nq, n, k, t, group_ld_dense(n, k, t));
   b += align_up((size_t)nq * raw_list_entries(nq, k, t) * 8) + align_up((size_t)nq * raw_max_splits(nq, t) * 4);
-  if (group_uses_f16(nq, n, k, t)) {
+  if (group_uses_f16(nq, n, d, k, t)) {
     b += align_up((size_t)padded_rows(n) * row_bytes16(padded_dim16(d)));
     b += align_up((size_t)(padded_rows(n) / kTileN + 1) * sizeof(StageMeta));
     b += 2 * align_up((size_t)nq * k * 4);
   }
-  if (group_uses_raw16(nq, k, t)) b += align_up(sizeof(float)) + 2 * align_up((size_t)nq * k * 4);   // norm_max, one round's top-K
+  if (group_uses_raw16(nq, d, k, t)) b += align_up(sizeof(float)) + 2 * align_up((size_t)nq * k * 4);   // norm_max, one round's top-K
   return b;
 }
 
@@ -1289,7 +1297,7 @@ extern "C" int tfrs_streaming_topk_update_blocks(const float *queries, int64_t n
   if (rc != TFRS_OK) return rc;
   int new_len = state_len;
 
-  if (group_uses_raw16(nq, k, t)) {
+  if (group_uses_raw16(nq, d, k, t)) {
     // ---- block-fed fp16 filter: an exact dense round fills the state (it is the bound of everything
     // after it), then geometrically growing ranges, each ONE pass over its f32 rows --------------------
     float *norm_max = reinterpret_cast<float *>(p);
@@ -1307,18 +1315,15 @@ extern "C" int tfrs_streaming_topk_update_blocks(const float *queries, int64_t n
       lo = n0;
       seen += n0;
     }
-    const F16Image img = {nullptr, nullptr, norm_max};
-    const SamplePlan sp = {1, 0, 1, k, false};
+    if (lo < total && (rc = launch_query_kappa(queries, nq, d, w.qk, w.qscale, nullptr, st)) != TFRS_OK) return rc;
     while (lo < total) {   // the state is full here: lo > 0 only after a dense round of >= k rows
       int64_t span = std::max<int64_t>((t.rho - 1) * std::max<int64_t>(seen, 1), 16 * kTileN);
       span = padded_rows(span);
       int64_t hi = (total - lo <= span) ? total : lo + span;
       if (total - hi < 16 * kTileN) hi = total;
-      hipLaunchKernelGGL(thr_from_state_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st,
-                         state_scores, nq, k, w.thr);
-      TFRS_LAUNCH_CHECK();
-      if ((rc = run_f16(queries, nq, d, /*packed=*/nullptr, img, hi - lo, base_row, k, sp, /*lower_preset=*/true,
-                        blk_scores, blk_idx, w, t, st, /*rowmap=*/nullptr, lo, table_dev, raw16_qg(nq))) != TFRS_OK)
+      // the bound of the range: the state's exact K-th score, read where it lies (column k - 1)
+      if ((rc = run_raw16_range(queries, nq, d, table_dev, norm_max, lo, hi - lo, base_row, k, state_scores + (k - 1),
+                                k, raw16_qg(nq), blk_scores, blk_idx, w, t, st)) != TFRS_OK)
         return rc;
       SelectArgs se = {};
       se.nq = nq;
@@ -1341,7 +1346,7 @@ extern "C" int tfrs_streaming_topk_update_blocks(const float *queries, int64_t n
     if (new_len_h) *new_len_h = new_len;
     return TFRS_OK;
   }
-  if (!group_uses_f16(nq, total, k, t)) {
+  if (!group_uses_f16(nq, total, d, k, t)) {
     rc = run_rounds_raw(queries, nq, d, table_dev, total, base_row, seen_rows, k, state_scores, state_idx,
                         state_len, w, raw_buf, raw_cnt, raw_entries, t, st, &new_len);
     if (new_len_h) *new_len_h = new_len;

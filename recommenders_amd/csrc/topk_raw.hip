@@ -323,15 +323,15 @@ __device__ __forceinline__ uint32_t raw_pack_f16x2(float lo, float hi) {
   return v.u;
 }
 
-// ---- fp16-PREFILTERED scan straight from the blocks (query batches up to 128) ---------------------
+// ---- fp16-PREFILTERED scan straight from the blocks (query batches up to 256) ---------------------
 //
 // The exact kernel above spends 64 matrix-core cycles per feature pair and group of 32 queries: at
 // D = 128 a workgroup needs 4096 cycles per stage for ONE group, about what the stage's 64 KiB take to
 // arrive from HBM -- and twice that for 64 queries.  Here the stage arrives the same way (row-major f32,
 // direct-to-LDS), every wave converts ITS 32 rows to fp16 in registers (x / s with s = 2^ceil(log2 max|x|)
 // of those 32 rows, the contract of the fp16 image of topk_pack.hip with a "stage" of 32 rows) and scores
-// them with v_mfma_f32_32x32x16_f16: 32 cycles per 16 features and group, so that up to four groups
-// (128 queries) cost less than the copy.  Nothing computed here is returned: a prefilter score only
+// them with v_mfma_f32_32x32x16_f16: 32 cycles per 16 features and group, so that four groups (128
+// queries) cost less than the copy and eight (256) about as much.  Nothing computed here is returned: a prefilter score only
 // decides whether a row can still reach a query's top-K under the bound of common.h,
 //     |s~ - s| <= ||q|| * N * kappa (+ tiny),   N = largest row norm of the wave's 32 rows,
 // against thr[q], a proven lower bound of the query's final K-th score (the carried state's exact K-th
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArg
   constexpr int NV = DP >= 16 ? DP / 8 : 2;    // 16-byte pieces a lane holds: half of its row (DP = 8: the row, lane half 0)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint32_t *wg_cnt = reinterpret_cast<uint32_t *>(smem + G::kCntOff);
-  static_assert(QG * 32 <= 128, "wg_cnt holds 128 counters");
+  static_assert(QG * 32 <= 256, "wg_cnt holds 256 counters");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -394,11 +394,11 @@ __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArg
       w[3] = raw_pack_f16x2(on ? hi[2] * qinv : 0.0f, on ? hi[3] * qinv : 0.0f);
       bq[g][m] = __builtin_bit_cast(f16x8r, w);
     }
-    flo[g] = qvalid ? (a.thr[qr] - kF16Tiny) * qinv : __builtin_inff();
+    flo[g] = qvalid ? (a.thr[qr * (a.thr_stride > 0 ? a.thr_stride : 1)] - kF16Tiny) * qinv : __builtin_inff();
     fqk[g] = qvalid ? a.qk[qr] * qinv : 0.0f;
     qsc[g] = qs;
   }
-  if (tid < 128) wg_cnt[tid] = 0u;
+  wg_cnt[tid] = 0u;   // 256 threads, 256 counters
 
   // ---- block cursor and stage prefetch: as in rawscan_kernel ------------------------------------
   const RawTable *T = a.table;
@@ -543,7 +543,7 @@ __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArg
 
   // every (query, split) count is written: no memset needed (counts beyond cap_l flag the query for
   // the exact redo, as the image-fed filter kernel does)
-  if (tid < QG * 32) {
+  if (tid < QG * 32) {   // (the stage loop ends with a barrier)
     const int64_t qr = ((int64_t)qt * QG + (tid >> 5)) * 32 + (tid & 31);
     if (qr < a.nq) a.cnt[qr * a.nseg + split] = wg_cnt[tid];
   }
@@ -554,10 +554,10 @@ __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArg
 template <int DP, int QG>
 static int launch_rawscan16_variant(const RawScanArgs &a, hipStream_t stream) {
   using G = RawGeom<DP>;
-  static_assert(G::kLdsBytes + 256 <= 160 * 1024, "two raw stages + the counters must fit the LDS");
-  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&rawscan16_kernel<DP, QG>), G::kLdsBytes + 256));
+  static_assert(G::kLdsBytes + 768 <= 160 * 1024, "two raw stages + the counters must fit the LDS");
+  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&rawscan16_kernel<DP, QG>), G::kLdsBytes + 768));
   const dim3 grid((unsigned)(a.n_qtiles * a.n_splits));
-  hipLaunchKernelGGL((rawscan16_kernel<DP, QG>), grid, dim3(kRawThreads), G::kLdsBytes + 256, stream, a);
+  hipLaunchKernelGGL((rawscan16_kernel<DP, QG>), grid, dim3(kRawThreads), G::kLdsBytes + 768, stream, a);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
 }
@@ -568,8 +568,11 @@ static int launch_rawscan16_dp(const RawScanArgs &a, hipStream_t stream) {
     case 1: return launch_rawscan16_variant<DP, 1>(a, stream);
     case 2: return launch_rawscan16_variant<DP, 2>(a, stream);
     case 4: return launch_rawscan16_variant<DP, 4>(a, stream);
+    case 8:   // (eight resident query groups of dim 128 do not fit the register file: 1.6 KB of scratch)
+      if constexpr (DP <= 64) return launch_rawscan16_variant<DP, 8>(a, stream);
+      break;
   }
-  set_error("rawscan16: %d query groups per workgroup (1, 2 or 4)", a.qg);
+  set_error("rawscan16: %d query groups per workgroup (1, 2, 4; 8 up to dim 64)", a.qg);
   return TFRS_EINVAL;
 }
 

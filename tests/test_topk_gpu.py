@@ -254,9 +254,9 @@ def _ragged_sizes(rng, n, typical):
 @pytest.mark.parametrize("d", [8, 16, 32, 64, 128])
 def test_streaming_groups_read_blocks_in_place(d, regime, monkeypatch):
   """Streaming over a lazily produced dataset: groups of blocks are searched
-  where they lie (tfrs_streaming_topk_update_blocks): "raw16" = the default for up to 128 queries, the
-  fp16 filter fed by the f32 blocks themselves (rawscan16_kernel: 1, 2 and 4 query groups per workgroup
-  at 1 / 20, 64 and 100 queries); "raw" = the exact f32-MFMA scan (TFRS_STREAM_RAW16_MAX_NQ=0: up to 64
+  where they lie (tfrs_streaming_topk_update_blocks): "raw16" = the fp16 filter fed by the f32 blocks
+  themselves (rawscan16_kernel, the default for 33 .. 256 queries -- 128 at dim 128 --, here from one query on:
+  1, 2 and 4 query groups per workgroup at 1 / 20, 64 and 100 queries); "raw" = the exact f32-MFMA scan (TFRS_STREAM_RAW16_MAX_NQ=0: up to 64
   queries, the fp16 image above); "f16" = the fp16 image built straight from the blocks for every batch
   size (TFRS_STREAM_RAW_MAX_NQ=0 as well).  Ragged and uniform block sizes, several groups with a carried state
   (small group_max_bytes), 1 / 20 / 64 / 100 queries, k = 1 / 10 / 100, integer identifiers kept on the
@@ -264,6 +264,8 @@ def test_streaming_groups_read_blocks_in_place(d, regime, monkeypatch):
   ftk = _layers()
   if regime != "raw16":
     monkeypatch.setenv("TFRS_STREAM_RAW16_MAX_NQ", "0")
+  else:
+    monkeypatch.setenv("TFRS_STREAM_RAW16_MIN_NQ", "1")    # (default 33: one query group stays on the exact scan)
   if regime == "f16":
     monkeypatch.setenv("TFRS_STREAM_RAW_MAX_NQ", "0")
     monkeypatch.setenv("TFRS_STREAM_RHO16", "2")       # more rounds than the default
@@ -308,20 +310,21 @@ def test_streaming_groups_read_blocks_in_place(d, regime, monkeypatch):
                                                   base_row=2_147_480_000)(qall[:4])
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2])
-def test_streaming_block_fed_filter_awkward_data(seed):
-  """rawscan16_kernel (the default for up to 128 queries over a lazily produced dataset) on data that stresses
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_streaming_block_fed_filter_awkward_data(seed, monkeypatch):
+  """rawscan16_kernel (the default for 33 .. 256 queries over a lazily produced dataset; from one query on here) on data that stresses
   its per-32-row scales and norms: rows whose magnitudes span e^+-3, every row twice, a constant column,
   all-negative scores, clustered rows ordered by cluster, blocks of zeros -- against the all-f32 scan of the
-  same rows (bit for bit, ties included), ragged blocks, 1 .. 128 queries, k up to 512."""
+  same rows (bit for bit, ties included), ragged blocks, 1 .. 256 queries, k up to 512."""
   ftk = _layers()
   from recommenders_amd import _lib
+  monkeypatch.setenv("TFRS_STREAM_RAW16_MIN_NQ", "1")
   rng = np.random.default_rng(900 + seed)
   dev = torch.device("cuda", 0)
   for case in range(7):
     d = int(rng.choice([8, 16, 32, 64, 128]))
     k = int(rng.choice([1, 10, 100, 257, 512]))
-    nq = int(rng.choice([1, 31, 32, 33, 64, 65, 100, 128]))
+    nq = int(rng.choice([1, 31, 32, 33, 64, 65, 100, 128, 129, 200, 256]))   # 1 / 2 / 4 / 8 query groups (8: dim <= 64)
     n = int(rng.integers(40_000, 400_000))
     kind = ["row_scales", "dups", "const_col", "negative", "clustered", "zero_blocks", "gauss"][(case + seed) % 7]
     g = torch.Generator(device=dev).manual_seed(int(rng.integers(1 << 30)))

@@ -8,7 +8,7 @@ mkdir -p "$O"
 cd "$ROOT"
 BATCHES=8192,1024,256,128,64,32,1 python tools/bench_streaming.py > "$O/stream.jsonl" 2> "$O/stream.err"
 cd /tmp && export TMPDIR=/tmp
-for B in 1 64 8192; do
+for B in 1 64 128 8192; do
   timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/b$B/trace" -o bench -- env BATCH=$B python $ROOT/tools/exp_streaming_prof.py > "$O/b$B.trace.log" 2>&1
   timeout 200 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$O/b$B/pmc_fetch" -o bench -- env BATCH=$B CALLS=3 python $ROOT/tools/exp_streaming_prof.py > "$O/b$B.fetch.log" 2>&1
   timeout 200 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$O/b$B/pmc_write" -o bench -- env BATCH=$B CALLS=3 python $ROOT/tools/exp_streaming_prof.py > "$O/b$B.write.log" 2>&1
