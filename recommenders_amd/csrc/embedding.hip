@@ -566,21 +566,23 @@ extern "C" int tfrs_embedding_scatter_add_bwd(const float *grad_out, const int64
 //   keys   uint32 ids; ids outside [0, vocab) -- the padding slots of sequence features and
 //          anything invalid -- become 0xFFFFFFFF: they sort last and the scatter skips them, so
 //          an out-of-range id can never write outside the table (the gather reads it as zeros)
-//   passes 8 bits each, ceil(bits(vocab) / 8) of them; every pass = tile histograms ->
+//   passes 8, 9 or 10 bits each (more than 8 when that saves a pass: 26 M rows need 26 bits = 3 x 9 instead
+//          of 4 x 8, 100 M rows 28 = 3 x 10; a pass is four launch-latency-bound kernels, 47 us at 1.7 M keys); every pass = tile histograms ->
 //          exclusive scan (digit-major) -> stable scatter
 //   tile   4096 keys per 256-thread workgroup; wave w owns keys [1024 w, 1024 w + 1024) of the
 //          tile and walks them 64 at a time IN ORDER: equal digits of one step are ranked with
-//          8 ballots (lanes with the same digit form a mask; rank = popcount below the lane), the
+//          8 .. 10 ballots (lanes with the same digit form a mask; rank = popcount below the lane), the
 //          wave's running per-digit offsets live in LDS.  Stable by construction.
 // Integer work, HBM-trivial (16 bytes per key and pass); launch-latency bound below ~1M keys.
 // ------------------------------------------------------------------------------------------------
 namespace tfrs {
 constexpr int kSortTile = 4096;
 
+template <int BITS>
 __device__ __forceinline__ uint64_t same_digit_mask(uint32_t digit) {
   uint64_t m = ~0ull;
 #pragma unroll
-  for (int bit = 0; bit < 8; ++bit) {
+  for (int bit = 0; bit < BITS; ++bit) {
     const uint64_t bal = __ballot((digit >> bit) & 1u);
     m &= ((digit >> bit) & 1u) ? bal : ~bal;
   }
@@ -599,11 +601,13 @@ __global__ void __launch_bounds__(256) sort_init_kernel(const void *__restrict__
 }
 
 // hist[tile][wave][digit]
+template <int BITS>
 __global__ void __launch_bounds__(256) sort_hist_kernel(const uint32_t *__restrict__ keys, int64_t n,
                                                         int shift, uint32_t *__restrict__ hist) {
-  __shared__ uint32_t h[4][256];
+  constexpr int NB = 1 << BITS;
+  __shared__ uint32_t h[4][NB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int e = tid; e < 1024; e += 256) (&h[0][0])[e] = 0u;
+  for (int e = tid; e < 4 * NB; e += 256) (&h[0][0])[e] = 0u;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * kSortTile + wave * 1024;
   uint32_t kv[16];
@@ -614,9 +618,9 @@ __global__ void __launch_bounds__(256) sort_hist_kernel(const uint32_t *__restri
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r)
-    if (base + r * 64 + lane < n) atomicAdd(&h[wave][(kv[r] >> shift) & 255u], 1u);
+    if (base + r * 64 + lane < n) atomicAdd(&h[wave][(kv[r] >> shift) & (uint32_t)(NB - 1)], 1u);
   __syncthreads();
-  for (int e = tid; e < 1024; e += 256) hist[(int64_t)blockIdx.x * 1024 + e] = (&h[0][0])[e];
+  for (int e = tid; e < 4 * NB; e += 256) hist[(int64_t)blockIdx.x * (4 * NB) + e] = (&h[0][0])[e];
 }
 
 // Exclusive scan of the segment histograms in digit-major order, two levels (thread = digit):
@@ -626,29 +630,33 @@ __global__ void __launch_bounds__(256) sort_hist_kernel(const uint32_t *__restri
 //          anywhere + keys with the same digit in earlier chunks.
 // The scatter kernel adds the two.
 constexpr int kScanChunk = 64;
-__global__ void __launch_bounds__(256) sort_scan1_kernel(const uint32_t *__restrict__ hist, int64_t nseg,
-                                                         uint32_t *__restrict__ offs,
-                                                         uint32_t *__restrict__ chunk_tot) {
+template <int BITS>
+__global__ void __launch_bounds__(1 << BITS) sort_scan1_kernel(const uint32_t *__restrict__ hist, int64_t nseg,
+                                                               uint32_t *__restrict__ offs,
+                                                               uint32_t *__restrict__ chunk_tot) {
+  constexpr int NB = 1 << BITS;
   const int dgt = threadIdx.x;
   const int64_t s0 = (int64_t)blockIdx.x * kScanChunk;
   const int64_t s1 = s0 + kScanChunk < nseg ? s0 + kScanChunk : nseg;
   uint32_t run = 0;
 #pragma unroll 8
   for (int64_t sgm = s0; sgm < s1; ++sgm) {
-    const uint32_t c = hist[sgm * 256 + dgt];
-    offs[sgm * 256 + dgt] = run;
+    const uint32_t c = hist[sgm * NB + dgt];
+    offs[sgm * NB + dgt] = run;
     run += c;
   }
-  chunk_tot[(int64_t)blockIdx.x * 256 + dgt] = run;
+  chunk_tot[(int64_t)blockIdx.x * NB + dgt] = run;
 }
-__global__ void __launch_bounds__(256) sort_scan2_kernel(uint32_t *__restrict__ chunk_tot, int64_t nchunk) {
-  __shared__ uint32_t tot[256];
+template <int BITS>
+__global__ void __launch_bounds__(1 << BITS) sort_scan2_kernel(uint32_t *__restrict__ chunk_tot, int64_t nchunk) {
+  constexpr int NB = 1 << BITS;
+  __shared__ uint32_t tot[NB];
   const int dgt = threadIdx.x;
   uint32_t run = 0;
 #pragma unroll 8
   for (int64_t c = 0; c < nchunk; ++c) {
-    const uint32_t v = chunk_tot[c * 256 + dgt];
-    chunk_tot[c * 256 + dgt] = run;
+    const uint32_t v = chunk_tot[c * NB + dgt];
+    chunk_tot[c * NB + dgt] = run;
     run += v;
   }
   tot[dgt] = run;
@@ -656,21 +664,23 @@ __global__ void __launch_bounds__(256) sort_scan2_kernel(uint32_t *__restrict__ 
   uint32_t before = 0;
   for (int e = 0; e < dgt; ++e) before += tot[e];
 #pragma unroll 8
-  for (int64_t c = 0; c < nchunk; ++c) chunk_tot[c * 256 + dgt] += before;
+  for (int64_t c = 0; c < nchunk; ++c) chunk_tot[c * NB + dgt] += before;
 }
 
+template <int BITS>
 __global__ void __launch_bounds__(256) sort_scatter_kernel(const uint32_t *__restrict__ keys_in,
                                                            const uint32_t *__restrict__ vals_in, int64_t n,
                                                            int shift, const uint32_t *__restrict__ offs,
                                                            const uint32_t *__restrict__ chunk_base,
                                                            uint32_t *__restrict__ keys_out,
                                                            uint32_t *__restrict__ vals_out) {
-  __shared__ uint32_t run[4][256];
+  constexpr int NB = 1 << BITS;
+  __shared__ uint32_t run[4][NB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   {
     const int64_t sgm = (int64_t)blockIdx.x * 4 + wave;
-    for (int e = lane; e < 256; e += 64)
-      run[wave][e] = offs[sgm * 256 + e] + chunk_base[(sgm / kScanChunk) * 256 + e];
+    for (int e = lane; e < NB; e += 64)
+      run[wave][e] = offs[sgm * NB + e] + chunk_base[(sgm / kScanChunk) * NB + e];
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -693,9 +703,9 @@ __global__ void __launch_bounds__(256) sort_scatter_kernel(const uint32_t *__res
     const uint32_t key = ok ? kk[r] : 0u;
     const uint32_t val = ok ? vv[r] : 0u;
     // inactive tail lanes get a digit of their own class so that they never rank among real keys
-    const uint32_t digit = (key >> shift) & 255u;
+    const uint32_t digit = (key >> shift) & (uint32_t)(NB - 1);
     const uint64_t act = __ballot(ok);
-    const uint64_t same = same_digit_mask(digit) & act;
+    const uint64_t same = same_digit_mask<BITS>(digit) & act;
     if (ok) {
       const uint32_t rank = (uint32_t)__builtin_popcountll(same & below);
       const uint32_t dst = run[wave][digit] + rank;
@@ -850,8 +860,9 @@ static inline size_t sort_al(size_t x) { return (x + 255) / 256 * 256; }
 extern "C" size_t tfrs_embedding_scatter_add_workspace_bytes(int64_t n) {
   if (n <= 0) return 256;
   const size_t tiles = (size_t)((n + tfrs::kSortTile - 1) / tfrs::kSortTile);
-  return 4 * tfrs::sort_al((size_t)n * 4) + 2 * tfrs::sort_al(tiles * 1024 * 4) +
-         tfrs::sort_al((tiles * 4 / tfrs::kScanChunk + 1) * 256 * 4);
+  // (histograms and offsets of 4 waves x 1024 digits per tile, chunk totals of 1024 digits: the 10-bit passes)
+  return 4 * tfrs::sort_al((size_t)n * 4) + 2 * tfrs::sort_al(tiles * 4096 * 4) +
+         tfrs::sort_al((tiles * 4 / tfrs::kScanChunk + 1) * 1024 * 4);
 }
 
 // Backward of gather from UNSORTED ids: own radix sort + the segmented scatter-add / fused
@@ -880,8 +891,8 @@ extern "C" int tfrs_embedding_scatter_add_unsorted(const float *grad_out, const 
   uint32_t *vals[2] = {reinterpret_cast<uint32_t *>(w + 2 * kb), reinterpret_cast<uint32_t *>(w + 3 * kb)};
   const int64_t tiles = (n + kSortTile - 1) / kSortTile;
   uint32_t *hist = reinterpret_cast<uint32_t *>(w + 4 * kb);
-  uint32_t *offs = reinterpret_cast<uint32_t *>(w + 4 * kb + sort_al((size_t)tiles * 1024 * 4));
-  uint32_t *chunk = reinterpret_cast<uint32_t *>(w + 4 * kb + 2 * sort_al((size_t)tiles * 1024 * 4));
+  uint32_t *offs = reinterpret_cast<uint32_t *>(w + 4 * kb + sort_al((size_t)tiles * 4096 * 4));
+  uint32_t *chunk = reinterpret_cast<uint32_t *>(w + 4 * kb + 2 * sort_al((size_t)tiles * 4096 * 4));
   const int64_t nseg = tiles * 4, nchunk = (nseg + kScanChunk - 1) / kScanChunk;
   hipLaunchKernelGGL(sort_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ids, ids_are_i64, n,
                      vocab, keys[0], vals[0]);
@@ -891,15 +902,28 @@ extern "C" int tfrs_embedding_scatter_add_unsorted(const float *grad_out, const 
   while (bits < 32 && (1ll << bits) <= vocab) ++bits;   // 2^bits > vocab: invalid keys have bit `bits`.. set
   int passes = (bits + 1 + 7) / 8;
   if (passes > 4) passes = 4;
+  // 9 or 10 bits per pass where that saves a whole pass (26 significant bits: 3 x 9; 28 .. 30: 3 x 10)
+  int digit_bits = 8;
+  for (int b = 9; b <= 10; ++b)
+    if ((bits + 1 + b - 1) / b < passes) {
+      passes = (bits + 1 + b - 1) / b;
+      digit_bits = b;
+    }
   int cur = 0;
-  for (int p = 0; p < passes; ++p) {
-    const int shift = 8 * p;
-    hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)tiles), dim3(256), 0, s, keys[cur], n, shift, hist);
-    hipLaunchKernelGGL(sort_scan1_kernel, dim3((unsigned)nchunk), dim3(256), 0, s, hist, nseg, offs, chunk);
-    hipLaunchKernelGGL(sort_scan2_kernel, dim3(1), dim3(256), 0, s, chunk, nchunk);
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3((unsigned)tiles), dim3(256), 0, s, keys[cur], vals[cur], n,
+  auto one_pass = [&](auto bc, int p) {
+    constexpr int B = decltype(bc)::value;
+    const int shift = B * p;
+    hipLaunchKernelGGL(sort_hist_kernel<B>, dim3((unsigned)tiles), dim3(256), 0, s, keys[cur], n, shift, hist);
+    hipLaunchKernelGGL(sort_scan1_kernel<B>, dim3((unsigned)nchunk), dim3(1 << B), 0, s, hist, nseg, offs, chunk);
+    hipLaunchKernelGGL(sort_scan2_kernel<B>, dim3(1), dim3(1 << B), 0, s, chunk, nchunk);
+    hipLaunchKernelGGL(sort_scatter_kernel<B>, dim3((unsigned)tiles), dim3(256), 0, s, keys[cur], vals[cur], n,
                        shift, offs, chunk, keys[cur ^ 1], vals[cur ^ 1]);
     cur ^= 1;
+  };
+  for (int p = 0; p < passes; ++p) {
+    if (digit_bits == 10) one_pass(std::integral_constant<int, 10>{}, p);
+    else if (digit_bits == 9) one_pass(std::integral_constant<int, 9>{}, p);
+    else one_pass(std::integral_constant<int, 8>{}, p);
   }
   TFRS_LAUNCH_CHECK();
   const bool vec = (d % 4 == 0) && (((uintptr_t)grad_out) % 16 == 0) &&
