@@ -186,7 +186,7 @@ int tfrs_streaming_topk_update(const float *queries, int64_t nq, int d,
  * rows carry the global row numbers base_row, base_row + 1, ... in block order (:474-480);
  * seen_rows = candidates already folded into the state by earlier calls.  One call replaces
  * nblocks calls of tfrs_streaming_topk_update with identical results: no packed copy of the
- * blocks is built -- query batches up to 256 (128 at d = 128) take ONE pass over the f32 blocks per
+ * blocks is built -- query batches up to 256 take ONE pass over the f32 blocks per
  * range: an fp16 filter fed by the blocks themselves, each wave converting its 32 rows of a stage in
  * registers, with exact re-scoring of the survivors from the blocks; up to 32 queries below d = 128 an
  * HBM-bound exact f32-MFMA scan; large batches one fp16 prefilter image of the group with exact

@@ -1079,11 +1079,18 @@ static int64_t stream_raw16_max_nq() { return std::max<int64_t>(0, env_i64("TFRS
 // 64 matrix-core steps per row cost as much as the copy (one query 1.71 against 1.64 ms, 32: 1.88 against 1.70)
 static int64_t stream_raw16_min_nq() { return std::max<int64_t>(1, env_i64("TFRS_STREAM_RAW16_MIN_NQ", 33)); }
 static bool group_uses_raw16(int64_t nq, int d, int k, const TopkTuning &t) {
-  // one workgroup holds all queries: eight groups of 32 up to dim 64, four at dim 128 (register file)
   return t.f16_filter && k <= kMaxKF16 && nq >= (d <= 64 ? stream_raw16_min_nq() : 1) &&
-         nq <= std::min<int64_t>(stream_raw16_max_nq(), d <= 64 ? 256 : 128);
+         nq <= stream_raw16_max_nq();
 }
-static int raw16_qg(int64_t nq) { return nq <= 32 ? 1 : nq <= 64 ? 2 : nq <= 128 ? 4 : 8; }
+// query groups of 32 per workgroup: eight up to dim 64, four at dim 128 (eight resident groups of dim 128 do
+// not fit the register file).  More queries than one workgroup holds make several query tiles per split of
+// the rows; the tiles of a split are neighbours in the XCD-aware workgroup order, so the second one reads the
+// rows from the XCD's L2
+static int raw16_qg(int64_t nq, int d) {
+  const int cap = d <= 64 ? 8 : 4;
+  const int want = nq <= 32 ? 1 : nq <= 64 ? 2 : nq <= 128 ? 4 : 8;
+  return std::min(want, cap);
+}
 static bool group_uses_f16(int64_t nq, int64_t n, int d, int k, const TopkTuning &t) {
   if (group_uses_raw16(nq, d, k, t)) return false;
   if (!(t.f16_filter && k <= kMaxKF16) || nq <= stream_raw_max_nq()) return false;
@@ -1323,7 +1330,7 @@ extern "C" int tfrs_streaming_topk_update_blocks(const float *queries, int64_t n
       if (total - hi < 16 * kTileN) hi = total;
       // the bound of the range: the state's exact K-th score, read where it lies (column k - 1)
       if ((rc = run_raw16_range(queries, nq, d, table_dev, norm_max, lo, hi - lo, base_row, k, state_scores + (k - 1),
-                                k, raw16_qg(nq), blk_scores, blk_idx, w, t, st)) != TFRS_OK)
+                                k, raw16_qg(nq, d), blk_scores, blk_idx, w, t, st)) != TFRS_OK)
         return rc;
       SelectArgs se = {};
       se.nq = nq;

@@ -255,7 +255,7 @@ def _ragged_sizes(rng, n, typical):
 def test_streaming_groups_read_blocks_in_place(d, regime, monkeypatch):
   """Streaming over a lazily produced dataset: groups of blocks are searched
   where they lie (tfrs_streaming_topk_update_blocks): "raw16" = the fp16 filter fed by the f32 blocks
-  themselves (rawscan16_kernel, the default for 33 .. 256 queries -- 128 at dim 128 --, here from one query on:
+  themselves (rawscan16_kernel, the default for 33 .. 256 queries -- at dim 128 from one --, here always from one:
   1, 2 and 4 query groups per workgroup at 1 / 20, 64 and 100 queries); "raw" = the exact f32-MFMA scan (TFRS_STREAM_RAW16_MAX_NQ=0: up to 64
   queries, the fp16 image above); "f16" = the fp16 image built straight from the blocks for every batch
   size (TFRS_STREAM_RAW_MAX_NQ=0 as well).  Ragged and uniform block sizes, several groups with a carried state
@@ -324,7 +324,7 @@ def test_streaming_block_fed_filter_awkward_data(seed, monkeypatch):
   for case in range(7):
     d = int(rng.choice([8, 16, 32, 64, 128]))
     k = int(rng.choice([1, 10, 100, 257, 512]))
-    nq = int(rng.choice([1, 31, 32, 33, 64, 65, 100, 128, 129, 200, 256]))   # 1 / 2 / 4 / 8 query groups (8: dim <= 64)
+    nq = int(rng.choice([1, 31, 32, 33, 64, 65, 100, 128, 129, 200, 256]))   # 1 / 2 / 4 / 8 query groups (dim 128: two tiles of 4)
     n = int(rng.integers(40_000, 400_000))
     kind = ["row_scales", "dups", "const_col", "negative", "clustered", "zero_blocks", "gauss"][(case + seed) % 7]
     g = torch.Generator(device=dev).manual_seed(int(rng.integers(1 << 30)))
