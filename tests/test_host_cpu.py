@@ -150,6 +150,38 @@ def test_options_are_addressable_through_the_c_abi(lib, monkeypatch):
     _lib.set_option("PATH", "x")
 
 
+def test_streaming_group_regimes_size_their_workspace(lib, monkeypatch):
+  """tfrs_streaming_topk_blocks_workspace_bytes follows the regime a group will take (topk_api.hip:
+  group_uses_raw16 / group_uses_f16): the block-fed fp16 filter needs one range's top-K + a norm word on top
+  of the round workspace, the fp16-image regime the image of the whole group; the switches move the
+  boundaries (host logic only -- nothing is launched)."""
+  from recommenders_amd import _lib
+  for name in ("TFRS_STREAM_RAW16_MIN_NQ", "TFRS_STREAM_RAW16_MAX_NQ", "TFRS_STREAM_RAW_MAX_NQ", "TFRS_TOPK_FILTER"):
+    monkeypatch.delenv(name, raising=False)
+  n, k = 12_500_000, 100
+  size = lambda nq, d: int(lib.tfrs_streaming_topk_blocks_workspace_bytes(nq, n, d, k))
+  image = n * (128 * 2 + 16)                                  # fp16 image of the group at dim 128
+  assert size(8192, 128) > image                              # large batches: the image regime
+  assert size(128, 128) < image and size(256, 128) < image    # block-fed filter up to 256 queries
+  assert size(512, 128) > image                               # ... and the image beyond
+  try:
+    _lib.set_option("TFRS_STREAM_RAW16_MAX_NQ", "0")          # off: 65+ queries go through the image
+    assert size(128, 128) > image and size(64, 128) < image
+    _lib.set_option("TFRS_STREAM_RAW16_MAX_NQ", None)
+    # one query group below dim 128 stays on the exact scan unless asked: the filter's extra buffers
+    # (one range's top-K: 2 * nq * k * 4 bytes, aligned, + the norm word) appear with the switch
+    base = size(8, 64)
+    _lib.set_option("TFRS_STREAM_RAW16_MIN_NQ", "1")
+    assert size(8, 64) > base
+    _lib.set_option("TFRS_STREAM_RAW16_MIN_NQ", None)
+    assert size(8, 128) > size(8, 64)                         # dim 128 takes the filter from one query on
+    _lib.set_option("TFRS_TOPK_FILTER", "f32")                # no fp16 anywhere: exact rounds for every batch
+    assert size(8192, 128) < image
+  finally:
+    for name in ("TFRS_STREAM_RAW16_MIN_NQ", "TFRS_STREAM_RAW16_MAX_NQ", "TFRS_TOPK_FILTER"):
+      _lib.set_option(name, None)
+
+
 def test_host_classes_reference_errors():
   import recommenders_amd as tfrs
   ftk = tfrs.layers.factorized_top_k
