@@ -6,10 +6,14 @@
 // dataset elements (row-major f32 [rows, d] in HBM, described by a RawTable, common.h) are scored
 // where they lie:
 //
-//   rawscan_kernel     small query batches (HBM-bound): exact f32 scores on the f32 matrix cores
-//                      (v_mfma_f32_32x32x2_f32 == the d-ordered fma chain of oracle/c/oracle_core.c)
-//                      with the top-K filter fused behind them.  A candidate byte is read from HBM
-//                      once and nothing is written but the survivors.
+//   rawscan_kernel     the first rows of every stream (dense round) and up to 32 queries below dim 128:
+//                      exact f32 scores on the f32 matrix cores (v_mfma_f32_32x32x2_f32 == the d-ordered
+//                      fma chain of oracle/c/oracle_core.c) with the top-K filter fused behind them.  A
+//                      candidate byte is read from HBM once and nothing is written but the survivors.
+//   rawscan16_kernel   up to 256 queries (HBM-bound, 0.73 of the spec): the same one pass over the f32
+//                      blocks, every wave converting its 32 rows of a stage to fp16 in registers and
+//                      scoring them on the 16-bit matrix cores; a prefilter under the bound of common.h,
+//                      survivors re-scored exactly from the blocks (list_topk16_kernel, raw_score).
 //   pack16_raw_kernel  large query batches (MFMA-bound): the fp16 prefilter image of the group
 //                      (topk_scan16.hip consumes it) is built straight from the blocks -- the f32
 //                      packed image of the BruteForce index is never written; survivors are
