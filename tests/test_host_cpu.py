@@ -702,17 +702,24 @@ def _device_asm(source):
   return _ASM_CACHE[source]
 
 
-@pytest.mark.parametrize("source,patterns,max_vgprs", [
+@pytest.mark.parametrize("source,patterns,max_vgprs,agpr_spills_ok", [
     # the fp16 filter kernel of the headline path: four waves per SIMD
-    ("topk_scan16.hip", ("scan16f_kernelILi64ELi8ELi2E", "scan16f_kernelILi32ELi8ELi2E"), 128),
+    ("topk_scan16.hip", ("scan16f_kernelILi64ELi8ELi2E", "scan16f_kernelILi32ELi8ELi2E"), 128, False),
     # the 256 x 256 split-fp16 GEMM (one 8-wave workgroup per CU: two waves per SIMD), all epilogues
     ("gemm16.hip", ("gemm16_big_kernelILi0E", "gemm16_big_kernelILi1E", "gemm16_big_kernelILi2E",
-                    "gemm16_big_kernelILi3E"), 256),
+                    "gemm16_big_kernelILi3E"), 256, False),
     # the DotInteraction producer / consumer kernels: backward one 8-wave workgroup per CU, forward two
-    ("interaction.hip", ("dot_interaction_bwd_h16_kernelILi7ELi5ELi4E", "dot_interaction_bwd_h16_kernelILi7ELi6ELi4E"), 256),
-    ("interaction.hip", ("dot_interaction_fwd_pc_kernelILi4ELi4E",), 128),
+    ("interaction.hip", ("dot_interaction_bwd_h16_kernelILi7ELi5ELi4E", "dot_interaction_bwd_h16_kernelILi7ELi6ELi4E"), 256, False),
+    ("interaction.hip", ("dot_interaction_fwd_pc_kernelILi4ELi4E",), 128, False),
+    # the block-fed fp16 filter of Streaming groups (one 4-wave workgroup per CU: one wave per SIMD): every
+    # instantiation the launcher can pick -- four resident query groups at dim 128, eight up to dim 64 (there
+    # 16 registers live in the accumulator file: no scratch memory, which is what the stage prefetch cares about)
+    ("topk_raw.hip", ("rawscan16_kernelILi128ELi1E", "rawscan16_kernelILi128ELi2E", "rawscan16_kernelILi128ELi4E",
+                      "rawscan16_kernelILi64ELi8E", "rawscan16_kernelILi32ELi8E", "rawscan16_kernelILi8ELi8E"), 512, True),
+    # the fp16 image packer that keeps a stage's parity planes in registers
+    ("topk_pack.hip", ("pack16_stage_regs_kernelILi128E", "pack16_stage_regs_kernelILi16E"), 128, False),
 ])
-def test_hot_kernel_register_budgets(source, patterns, max_vgprs):
+def test_hot_kernel_register_budgets(source, patterns, max_vgprs, agpr_spills_ok):
   """Hot kernels must keep their register budget and use no scratch -- a spill in the filter kernel
   puts `s_waitcnt vmcnt(0)` behind every stage prefetch.  Checked on the
   cross-compiled ISA metadata, no GPU needed."""
@@ -724,7 +731,8 @@ def test_hot_kernel_register_budgets(source, patterns, max_vgprs):
       continue
     found.add(hit[0])
     assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1)) == 0, name
-    assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", block).group(1)) == 0, name
+    if not agpr_spills_ok:
+      assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", block).group(1)) == 0, name
     assert int(re.search(r"\.vgpr_count:\s+(\d+)", block).group(1)) <= max_vgprs, name
   assert found == set(patterns)
 
