@@ -29,8 +29,10 @@ records per launch inside the timed region -- conservative for `value`): `roofli
 kernel the step spends most time in, priced with its ALGORITHMIC flop 2*B*N*D against the
 dense 16-bit MFMA peak.  N = 1 only: `cpu_baseline` (oracle restatement on the host cores),
 `secondary` (train steps/sec of `Model.fit` with its own roofline + cpu_baseline), `gather` (embedding
-gather GB/s at BASELINE configs[3] shapes) and `streaming` (Streaming over a dataset of blocks, one GPU's
-shard of configs[2]).  The CPU legs run after every GPU measurement.
+gather GB/s at BASELINE configs[3] shapes), `streaming` (Streaming over a dataset of blocks, one GPU's
+shard of configs[2]) and `config_legs` (bench_legs.py: fused Cross, DotInteraction, segment-sum, sparse
+Adagrad and the DCN-v2 / DLRM-shard train steps of configs[3] / configs[4], each with roofline, parity
+assert and cpu_baseline).  The CPU legs run after every GPU measurement.
 """
 
 import argparse
@@ -66,6 +68,7 @@ def parse_args():
   ap.add_argument("--no-scale-workload", action="store_true")
   ap.add_argument("--no-robustness", action="store_true")
   ap.add_argument("--no-streaming", action="store_true")
+  ap.add_argument("--no-config-legs", action="store_true")
   ap.add_argument("--no-single-gpu-reference", action="store_true")
   return ap.parse_args()
 
@@ -869,6 +872,11 @@ def main() -> None:
         result["streaming"] = streaming_metric(dev)
       if not args.no_robustness:
         result["robustness"] = robustness_block(dev, queries, pct["median"])
+      if not args.no_config_legs:
+        # BASELINE configs[3] / configs[4]: Cross, DotInteraction, segment-sum, sparse Adagrad and the two
+        # ranking train steps, each with roofline + parity assert (bench_legs.py); CPU baselines further down
+        import bench_legs
+        result["config_legs"] = bench_legs.gpu_legs(dev)
       if not args.no_scale_workload:
         # the N = 1 point of the strong-scaling configuration (what `value` at N > 1 compares with)
         del index, local
@@ -904,6 +912,9 @@ def main() -> None:
       }
       if "secondary" in result:
         result["secondary"]["cpu_baseline"] = train_step_cpu_baseline()
+      if "config_legs" in result:
+        import bench_legs
+        bench_legs.add_cpu_baselines(result["config_legs"])
     if world > 1 and not args.no_single_gpu_reference:
       # the SAME workload on one GPU, measured by rank 0 after the timed region (the other ranks
       # wait at the final barrier): makes the N > 1 line self-contained -- speedup = value / this --

@@ -120,3 +120,153 @@ def time_train_step(batch: int = 4096, dim: int = 64, vocab: int = 2000, users: 
     if dt >= budget_s or n >= 200:
       break
   return {"value": n / dt, "seconds": dt, "steps": n, "threads": torch.get_num_threads()}
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU legs of bench.py's configs[3] / configs[4] blocks (round 5).  Same rules as above: torch-CPU
+# restatements of the reference formulas on ALL host threads, on a bounded SAMPLE of the workload
+# (a slice of the batch; the per-example cost of every one of these ops does not depend on the
+# batch size), reported per unit of work so that bench.py can scale to the full batch and say so.
+# ------------------------------------------------------------------------------------------------
+def _timed(fn, budget_s: float, max_iters: int = 50):
+  fn()                                   # warm-up (thread pool, page faults of freshly allocated tables:
+  fn()                                   # the first two calls of the update legs run 5-20x slower)
+  n, t0 = 0, time.perf_counter()
+  while True:
+    fn()
+    n += 1
+    dt = time.perf_counter() - t0
+    if dt >= budget_s or n >= max_iters:
+      return dt / n, n
+
+
+def time_cross(rows: int, d: int, budget_s: float = 3.0, train: bool = False) -> dict:
+  """``Cross.call`` (dcn.py:151-186) ``y = x0 * (x @ W + b) + x`` on ``rows`` examples of width ``d``
+  (forward; ``train``: forward + backward through torch autograd = the reference's three sgemms + the
+  element-wise passes)."""
+  g = torch.Generator().manual_seed(0)
+  x0 = torch.randn((rows, d), generator=g)
+  x = torch.randn((rows, d), generator=g).requires_grad_(train)
+  w = (torch.randn((d, d), generator=g) * 0.05).requires_grad_(train)
+  b = torch.zeros((d,)).requires_grad_(train)
+  dy = torch.randn((rows, d), generator=g)
+
+  def fwd():
+    with torch.no_grad():
+      return x0 * (x @ w + b) + x
+
+  def pair():
+    y = x0 * (x @ w + b) + x
+    torch.autograd.grad(y, (x, w, b), grad_outputs=dy)
+
+  sec, n = _timed(pair if train else fwd, budget_s)
+  return {"seconds_per_call": sec, "rows": rows, "calls": n, "threads": torch.get_num_threads()}
+
+
+def time_dot_interaction(rows: int, f: int, d: int, budget_s: float = 3.0, backward: bool = False) -> dict:
+  """``DotInteraction.call`` (dot_interaction.py:69-104): batched Gram ``X X^T`` + the row-major strict
+  lower triangle (``boolean_mask``), optionally with its backward."""
+  g = torch.Generator().manual_seed(0)
+  x = torch.randn((rows, f, d), generator=g).requires_grad_(backward)
+  ii, jj = torch.tril_indices(f, f, -1)
+  dy = torch.randn((rows, ii.numel()), generator=g)
+
+  def fwd():
+    with torch.no_grad():
+      return torch.bmm(x, x.transpose(1, 2))[:, ii, jj]
+
+  def bwd():
+    out = torch.bmm(x, x.transpose(1, 2))[:, ii, jj]
+    torch.autograd.grad(out, x, grad_outputs=dy)
+
+  sec, n = _timed(bwd if backward else fwd, budget_s)
+  return {"seconds_per_call": sec, "rows": rows, "calls": n, "threads": torch.get_num_threads()}
+
+
+def time_segment_sum(vocab: int, d: int, bags: int, bag: int, budget_s: float = 3.0) -> dict:
+  """Sum-combiner lookup of ``bags`` bags of ``bag`` ids (tpu_embedding_layer.py:913-919 CPU branch):
+  ``torch.nn.functional.embedding_bag(mode="sum")``, the multithreaded gather + segment-sum TF-CPU's
+  ``embedding_lookup_sparse`` amounts to."""
+  g = torch.Generator().manual_seed(0)
+  table = torch.empty((vocab, d)).uniform_(-0.05, 0.05, generator=g)
+  ids = torch.randint(0, vocab, (bags * bag,), generator=g)
+  offs = torch.arange(0, bags * bag, bag)
+  sec, n = _timed(lambda: torch.nn.functional.embedding_bag(ids, table, offs, mode="sum"), budget_s)
+  return {"seconds_per_call": sec, "nnz": bags * bag, "vocab": vocab, "calls": n,
+          "threads": torch.get_num_threads()}
+
+
+def time_sparse_adagrad(vocab: int, d: int, n_ids: int, lr: float = 0.5, budget_s: float = 3.0) -> dict:
+  """Keras Adagrad on an ``IndexedSlices`` gradient (README.md:84, models/base.py:77-78): duplicate ids
+  summed (``unique`` + ``index_add_``), then ``acc += g^2; row -= lr g / sqrt(acc + eps)`` on the touched
+  rows only."""
+  g = torch.Generator().manual_seed(0)
+  table = torch.empty((vocab, d)).uniform_(-0.05, 0.05, generator=g)
+  acc = torch.full((vocab, d), 0.1)
+  ids = torch.randint(0, vocab, (n_ids,), generator=g)
+  rows = torch.randn((n_ids, d), generator=g)
+
+  def step():
+    uniq, inv = torch.unique(ids, return_inverse=True)
+    gsum = torch.zeros((uniq.numel(), d)).index_add_(0, inv, rows)
+    a = acc[uniq] + gsum * gsum
+    acc[uniq] = a
+    table[uniq] -= lr * gsum / torch.sqrt(a + 1e-7)
+
+  sec, n = _timed(step, budget_s)
+  return {"seconds_per_call": sec, "n_ids": n_ids, "vocab": vocab, "calls": n,
+          "threads": torch.get_num_threads()}
+
+
+def time_ranking_step(kind: str, rows: int, n_tables: int, vocab: int, dim: int, budget_s: float = 4.0) -> dict:
+  """One train step of ``experimental/models/ranking.py:135-236`` on ``rows`` examples, torch-CPU autograd:
+  per-feature embedding lookups (sparse gradients), bottom MLP [512, 256, dim] on 13 dense features,
+  ``kind`` = "dcn" (3 full-rank Cross layers on the concatenation) or "dlrm" (DotInteraction + concat with
+  the bottom output), top MLP [1024, 512, 1] + sigmoid, mean binary cross-entropy, Adagrad (sparse on the
+  tables).  ``vocab`` may be smaller than the configuration's (host RAM); say so where it is reported."""
+  g = torch.Generator().manual_seed(0)
+  emb = torch.nn.Embedding(n_tables * vocab, dim, sparse=True)
+  f = n_tables + 1
+  width = dim + (f * dim if kind == "dcn" else f * (f - 1) // 2)
+
+  def mlp(sizes, final):
+    layers = []
+    for a, b in zip(sizes[:-1], sizes[1:]):
+      layers += [torch.nn.Linear(a, b), torch.nn.ReLU()]
+    layers[-1] = final
+    return torch.nn.Sequential(*layers)
+
+  bottom = mlp([13, 512, 256, dim], torch.nn.ReLU())
+  top = mlp([width, 1024, 512, 1], torch.nn.Sigmoid())
+  cross_w = [torch.nn.Parameter(torch.randn((f * dim, f * dim), generator=g) * 0.01) for _ in range(3)] \
+      if kind == "dcn" else []
+  cross_b = [torch.nn.Parameter(torch.zeros((f * dim,))) for _ in cross_w]
+  dense_params = list(bottom.parameters()) + list(top.parameters()) + cross_w + cross_b
+  opt_d = torch.optim.Adagrad(dense_params, lr=0.01, initial_accumulator_value=0.1, eps=1e-7)
+  opt_s = torch.optim.Adagrad(emb.parameters(), lr=0.01, initial_accumulator_value=0.1, eps=1e-7)
+  dense = torch.rand((rows, 13), generator=g)
+  ids = torch.randint(0, vocab, (rows, n_tables), generator=g) + torch.arange(n_tables) * vocab
+  labels = torch.randint(0, 2, (rows,), generator=g).float()
+  ii, jj = torch.tril_indices(f, f, -1)
+
+  def step():
+    opt_d.zero_grad()
+    opt_s.zero_grad()
+    dv = bottom(dense)
+    x = torch.cat([emb(ids), dv[:, None, :]], dim=1)              # [rows, F + 1, dim]
+    if kind == "dcn":
+      x0 = x.reshape(rows, -1)
+      xl = x0
+      for w, b in zip(cross_w, cross_b):
+        xl = x0 * (xl @ w + b) + xl
+      inter = xl
+    else:
+      inter = torch.bmm(x, x.transpose(1, 2))[:, ii, jj]
+    p = top(torch.cat([dv, inter], dim=1)).reshape(-1)
+    loss = torch.nn.functional.binary_cross_entropy(p, labels)
+    loss.backward()
+    opt_d.step()
+    opt_s.step()
+
+  sec, n = _timed(step, budget_s, max_iters=20)
+  return {"seconds_per_call": sec, "rows": rows, "vocab": vocab, "calls": n, "threads": torch.get_num_threads()}

@@ -75,18 +75,134 @@ def ranking_task(labels, predictions, sample_weight=None) -> Dict[str, float]:
   }
 
 
+def _cross_stack(x0, kernels, biases):
+  """``x_{l+1} = x0 * (x_l W_l + b_l) + x_l`` for every layer of the stack (dcn.py:151-186 applied
+  ``len(kernels)`` times to the same ``x0``, as a DCN with several cross layers does), float64;
+  returns every ``x_l`` (``xs[0] = x0``)."""
+  xs = [np.asarray(x0, dtype=np.float64)]
+  for w, b in zip(kernels, biases):
+    z = xs[-1] @ np.asarray(w, dtype=np.float64)
+    if b is not None:
+      z = z + np.asarray(b, dtype=np.float64)
+    xs.append(xs[0] * z + xs[-1])
+  return xs
+
+
+def _as_stack(cross_kernel, cross_bias):
+  if isinstance(cross_kernel, (list, tuple)):
+    biases = list(cross_bias) if cross_bias is not None else [None] * len(cross_kernel)
+    return list(cross_kernel), biases
+  return [cross_kernel], [cross_bias]
+
+
 def ranking_model_forward(dense_features, sparse_embeddings: List[np.ndarray], bottom, top,
                           interaction: str, concat_dense: bool = True,
                           cross_kernel=None, cross_bias=None) -> np.ndarray:
   """experimental/models/ranking.py:208-236.  ``bottom`` / ``top`` = (kernels, biases,
   activation, final_activation); ``interaction`` = "dot" (DotInteraction defaults) or "cross"
-  (Concatenate + full-rank Cross with the given kernel/bias)."""
+  (Concatenate + full-rank Cross with the given kernel/bias; lists of kernels / biases = a stack of
+  cross layers on the same ``x0``, the "3 Cross layers" of BASELINE configs[3])."""
   dense_vec = mlp(dense_features, *bottom)
   args = list(sparse_embeddings) + [dense_vec]
   if interaction == "dot":
     inter = o_fi.dot_interaction(args)
   else:
     x0 = np.concatenate(args, axis=-1)
-    inter = o_fi.cross(x0, None, kernel=cross_kernel, bias=cross_bias)
+    kernels, biases = _as_stack(cross_kernel, cross_bias)
+    if len(kernels) == 1:
+      inter = o_fi.cross(x0, None, kernel=kernels[0], bias=biases[0])
+    else:
+      inter = _cross_stack(x0, kernels, biases)[-1].astype(np.float32)
   feat = np.concatenate([dense_vec, inter], axis=1) if concat_dense else inter
   return mlp(feat, *top).reshape(-1)
+
+
+def _mlp_forward64(x, kernels, biases, activation, final_activation):
+  """Float64 forward that keeps every layer's input and pre-activation (for the backward below)."""
+  h = np.asarray(x, dtype=np.float64)
+  ins, pre = [], []
+  n = len(kernels)
+  for li, (k, b) in enumerate(zip(kernels, biases)):
+    ins.append(h)
+    z = h @ np.asarray(k, dtype=np.float64)
+    if b is not None:
+      z = z + np.asarray(b, dtype=np.float64)
+    pre.append(z)
+    h = _ACT[final_activation if li == n - 1 else activation](z)
+  return h, ins, pre
+
+
+def _act_grad(name, z):
+  if name is None:
+    return np.ones_like(z)
+  if name == "relu":
+    return (z > 0).astype(np.float64)
+  if name == "sigmoid":
+    s = 1.0 / (1.0 + np.exp(-z))
+    return s * (1.0 - s)
+  if name == "tanh":
+    return 1.0 - np.tanh(z) ** 2
+  raise ValueError(name)
+
+
+def _mlp_backward64(dout, ins, pre, kernels, activation, final_activation):
+  """Gradient wrt the MLP's input (``tape.gradient`` through blocks.py:54-59), float64."""
+  g = dout
+  n = len(kernels)
+  for li in range(n - 1, -1, -1):
+    g = g * _act_grad(final_activation if li == n - 1 else activation, pre[li])
+    g = g @ np.asarray(kernels[li], dtype=np.float64).T
+  return g
+
+
+def ranking_model_embedding_grads(dense_features, sparse_embeddings: List[np.ndarray], labels, bottom, top,
+                                  interaction: str, batch_size: int, concat_dense: bool = True,
+                                  cross_kernel=None, cross_bias=None):
+  """What ``tape.gradient(loss, embedding rows)`` returns for the given examples
+  (``models/base.py:77`` under ``experimental/models/ranking.py:135-236``): the loss is the MEAN over the
+  ``batch_size`` examples of the per-example binary cross-entropy (``:118-121`` reduction NONE, then
+  ``:203-206``), and an example's prediction depends on no other example, so its gradient wrt its own
+  embedding vectors can be restated from that example alone.  Returns ``(predictions [n] float32,
+  d loss / d sparse_embeddings [n, F, D] float64, d loss / d bottom-stack output [n, D] float64)``.
+  PARITY UNPINNED like the forward (the reference's model test asserts only a falling loss); the
+  backward is checked against central differences of the forward in ``tests/test_ranking.py``."""
+  f = len(sparse_embeddings)
+  dense_vec, b_ins, b_pre = _mlp_forward64(dense_features, *bottom)
+  embs = [np.asarray(e, dtype=np.float64) for e in sparse_embeddings]
+  d = embs[0].shape[1]
+  args = embs + [dense_vec]
+  if interaction == "dot":
+    x = np.stack(args, axis=1)                           # dot_interaction.py:74-104 in float64
+    gram = np.einsum("bfd,bgd->bfg", x, x)
+    mask = np.tril(np.ones((f + 1, f + 1)), -1).astype(bool)
+    inter = gram[:, mask]
+  else:
+    kernels, biases = _as_stack(cross_kernel, cross_bias)
+    xs = _cross_stack(np.concatenate(args, axis=-1), kernels, biases)
+    inter = xs[-1]
+  feat = np.concatenate([dense_vec, inter], axis=1) if concat_dense else inter
+  out, t_ins, t_pre = _mlp_forward64(feat, *top)
+  p = out.reshape(-1)
+  y = np.asarray(labels, dtype=np.float64).reshape(-1)
+  pc = np.clip(p, _EPS, 1.0 - _EPS)
+  inside = (p > _EPS) & (p < 1.0 - _EPS)
+  dp = np.where(inside, -(y / pc) + (1.0 - y) / (1.0 - pc), 0.0) / float(batch_size)
+  dfeat = _mlp_backward64(dp.reshape(-1, 1), t_ins, t_pre, top[0], top[2], top[3])
+  d_dense = dfeat[:, :d].copy() if concat_dense else np.zeros_like(dense_vec)
+  dinter = dfeat[:, d:] if concat_dense else dfeat
+  if interaction == "dot":
+    g = np.zeros((p.shape[0], f + 1, f + 1))
+    g[:, mask] = dinter
+    dx = np.einsum("bfg,bgd->bfd", g, x) + np.einsum("bgf,bgd->bfd", g, x)
+  else:
+    x0 = xs[0]
+    dx0 = np.zeros_like(x0)
+    dy = dinter
+    for li in range(len(kernels) - 1, -1, -1):
+      w = np.asarray(kernels[li], dtype=np.float64)
+      z = xs[li] @ w + (0.0 if biases[li] is None else np.asarray(biases[li], dtype=np.float64))
+      dx0 += dy * z
+      dy = (dy * x0) @ w.T + dy
+    dx = (dx0 + dy).reshape(p.shape[0], f + 1, d)
+  d_dense += dx[:, -1, :]
+  return p.astype(np.float32), dx[:, :f, :], d_dense

@@ -142,19 +142,37 @@ class EmbeddingDict(torch.nn.Module):
 
 
 class ConcatCross(torch.nn.Module):
-  """``tf.keras.Sequential([Concatenate(), Cross()])`` -- the reference's DCN recipe (:41-46)."""
+  """``tf.keras.Sequential([Concatenate(), Cross()])`` -- the reference's DCN recipe (:41-46).
+  ``num_layers`` > 1 stacks that many ``Cross`` layers on the same ``x0`` (``x_{l+1} = cross_l(x0, x_l)``,
+  ``dcn.py:47-56``: "x0 = input; x1 = Cross()(x0, x0); x2 = Cross()(x0, x1)"): the "3 Cross layers" of
+  BASELINE.json configs[3]."""
 
-  def __init__(self, cross: Optional[torch.nn.Module] = None):
+  def __init__(self, cross: Optional[torch.nn.Module] = None, num_layers: int = 1):
     super().__init__()
     from recommenders_amd.layers.feature_interaction import dcn
-    self.cross = cross if cross is not None else dcn.Cross()
+    if num_layers < 1:
+      raise ValueError("ConcatCross: num_layers must be >= 1")
+    if cross is not None and num_layers != 1:
+      raise ValueError("ConcatCross: give either one `cross` layer or `num_layers`")
+    self.layers = torch.nn.ModuleList([cross if cross is not None else dcn.Cross()] +
+                                      [dcn.Cross() for _ in range(num_layers - 1)])
+
+  @property
+  def cross(self) -> torch.nn.Module:
+    return self.layers[0]
+
+  def _stack(self, x0: torch.Tensor) -> torch.Tensor:
+    x = x0
+    for layer in self.layers:
+      x = layer(x0, x)
+    return x
 
   def forward(self, inputs: Sequence[torch.Tensor]) -> torch.Tensor:
-    return self.cross(torch.cat(list(inputs), dim=-1))
+    return self._stack(torch.cat(list(inputs), dim=-1))
 
   def forward_stacked(self, x: torch.Tensor, prefix: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The same on an already concatenated block ``x[B, F, D]`` (``Ranking.call`` fast path)."""
-    out = self.cross(x.reshape(x.shape[0], -1))
+    out = self._stack(x.reshape(x.shape[0], -1))
     return out if prefix is None else torch.cat([prefix, out], dim=1)
 
 

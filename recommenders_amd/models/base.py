@@ -37,6 +37,7 @@ class Model(torch.nn.Module):
     self._process_group = process_group
     self._sync_gradients = sync_gradients
     self._bucket_bytes = int(bucket_bytes)
+    self.invalidate_captured_steps()     # captured steps belong to the configuration they were captured under
 
   # data-parallel gradient exchange ------------------------------------------------------
   def _sync_world(self) -> int:
@@ -292,9 +293,17 @@ class Model(torch.nn.Module):
     can_roll_back = bool(had_state) or callable(getattr(self.optimizer, "reset_state_", None))
     metric_before = [(t, t.detach().clone()) for t in self._metric_state_tensors()]
     known = {(t.data_ptr(), tuple(t.shape), t.dtype) for t, _ in metric_before}
+    # module buffers (BatchNorm running statistics, step counters) and the device's random stream are
+    # advanced by the warm-up steps as well: both are put back
+    buffers_before = [(b, b.detach().clone()) for b in self.buffers()]
+    rng_before = torch.cuda.get_rng_state(device) if device.type == "cuda" else None
 
     def roll_back():
       with torch.no_grad():
+        for b, v in buffers_before:
+          b.copy_(v)
+        if rng_before is not None:
+          torch.cuda.set_rng_state(rng_before, device)
         if training and can_roll_back:
           for p, v in zip(params, saved_params):
             p.copy_(v)
@@ -408,6 +417,53 @@ class Model(torch.nn.Module):
       return True
     return bool(opt.param_groups) and all(g.get("capturable", False) for g in opt.param_groups)
 
+  def invalidate_captured_steps(self) -> None:
+    """Drops every step `fit` / `evaluate` captured (and the private memory pools of their graphs).
+    Called by `compile`; call it yourself after changing host-side state a captured step read at capture
+    time and that `_capture_fingerprint` cannot see (e.g. a Python flag your `compute_loss` branches on)."""
+    for name in ("_fit_graphs", "_eval_graphs"):
+      self.__dict__.pop(name, None)
+    self.__dict__.pop("_capture_fp", None)
+
+  def _capture_fingerprint(self):
+    """What a captured step froze at capture time, as far as it can be seen from here: the optimizer
+    object and its hyper-parameters (this package's Adagrad passes `lr` / `eps` as kernel arguments), the
+    metric objects the step updates (a `task.factorized_metrics = ...` reassignment), the sub-modules.
+    Objects are kept by reference (compared with `is`), so a recycled `id()` cannot alias."""
+    hyper = []
+    if self.optimizer is not None:
+      for group in self.optimizer.param_groups:
+        hyper.append(tuple(sorted((k, v) for k, v in group.items()
+                                  if k != "params" and isinstance(v, (int, float, bool, str, tuple, type(None))))))
+    holders = []
+    for module in self.modules():
+      holders.extend(getattr(module, "_factorized_metrics", None) or [])
+    return (self.optimizer, tuple(hyper), tuple(self.metrics), tuple(holders), tuple(self.modules()))
+
+  def _check_capture_fingerprint(self) -> None:
+    """Start of every `fit` epoch / `evaluate` call: captured steps are dropped when
+    anything in `_capture_fingerprint` changed since they were captured."""
+    fp = self._capture_fingerprint()
+    old = self.__dict__.get("_capture_fp")
+
+    def same(a, b):
+      if isinstance(a, tuple) and isinstance(b, tuple):
+        return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+      if isinstance(a, (int, float, bool, str, type(None))) or isinstance(b, (int, float, bool, str, type(None))):
+        return type(a) is type(b) and a == b
+      return a is b
+
+    if old is not None and not same(old, fp):
+      self.invalidate_captured_steps()
+    self.__dict__["_capture_fp"] = fp
+
+  @staticmethod
+  def _max_captured_shapes() -> int:
+    """Every captured shape owns a graph with a private memory pool: ragged / sequence batches would
+    grow without bound.  Shapes beyond this many stay eager (TFRS_FIT_GRAPH_MAX_SHAPES, default 8)."""
+    import os
+    return int(os.environ.get("TFRS_FIT_GRAPH_MAX_SHAPES", "8"))
+
   def _run_epoch(self, dataset: Iterable, eager_step, make_graphed, cache: dict, allowed: bool):
     """One pass over ``dataset``.  A batch shape seen for the SECOND time is captured
     (``make_graphed``) and replayed from then on; first sightings -- among them the ragged last
@@ -422,8 +478,11 @@ class Model(torch.nn.Module):
         cache[key] = "seen"
         logs = eager_step(batch)
       elif entry == "seen":
+        if sum(callable(v) for v in cache.values()) >= self._max_captured_shapes():
+          logs = eager_step(batch)       # the cap is reached: this shape stays eager
+          continue
         try:
-          cache[key] = make_graphed(batch)
+          cache[key] = make_graphed(batch, warmup=1)   # (the shape already ran once, eagerly)
           logs = cache[key](batch)
         except (RuntimeError, ValueError) as e:
           cache[key] = "eager"
@@ -446,11 +505,9 @@ class Model(torch.nn.Module):
     if self.optimizer is None:
       raise RuntimeError("Call `compile(optimizer=...)` before training.")
     allowed = self._graph_steps_allowed(graph, training=True)
-    cache = self.__dict__.setdefault("_fit_graphs", {})
-    if self.__dict__.get("_fit_graphs_optimizer") is not self.optimizer:
-      cache.clear()                      # captured steps belong to the optimizer they were captured with
-      self.__dict__["_fit_graphs_optimizer"] = self.optimizer
     for _ in range(epochs):
+      self._check_capture_fingerprint()  # a changed lr / optimizer / metric object drops the captured steps
+      cache = self.__dict__.setdefault("_fit_graphs", {})
       self._reset_metrics()
       logs = self._run_epoch(dataset, self.train_step, self.make_graphed_train_step, cache, allowed)
       for k, v in self._logs_to_floats(logs).items():
@@ -475,6 +532,7 @@ class Model(torch.nn.Module):
   def evaluate(self, dataset: Iterable, return_dict: bool = True, graph: Optional[bool] = None):
     self._reset_metrics()
     allowed = self._graph_steps_allowed(graph, training=False)
+    self._check_capture_fingerprint()
     cache = self.__dict__.setdefault("_eval_graphs", {})
     logs = self._run_epoch(dataset, self.test_step, self.make_graphed_test_step, cache, allowed)
     logs = self._logs_to_floats(logs)

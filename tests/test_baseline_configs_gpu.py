@@ -962,3 +962,109 @@ def test_scale_workload_100m_x_64_search_vs_oracle():
   assert (iv[:, :-1][tie] < iv[:, 1:][tie]).all()
   assert iv.min() >= 0 and iv.max() < n
   assert (np.sort(iv, axis=1)[:, 1:] != np.sort(iv, axis=1)[:, :-1]).all()
+
+
+# experimental.models.Ranking composed at the BASELINE configs[3] / configs[4] shapes (missing 3b):
+# at these sizes the paths that run are the fast ones -- one gather into the [B, F + 1, D] block through
+# EmbeddingDict's row ranges, the 256 x 256-tile split-fp16 GEMMs of the Cross stack and the MLPs, the strided
+# DotInteraction into the concat buffer, sparse (ids, rows) gradient slices -- none of which the B = 256, D = 16
+# model test exercises.
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("config", ["c3_dcn_v2", "c4_dlrm_shard"])
+def test_ranking_model_at_config_shapes_vs_oracle(config):
+  """`experimental/models/ranking.py:203-236` forward + one backward + Adagrad step at
+  configs[3] (DCN-v2: B = 65536, 26 x 1M-row tables of dim 128 + 13 dense features through the bottom stack,
+  3 Cross layers on the 27 * 128 = 3456-wide concatenation) and at one GPU's share of configs[4] (DLRM:
+  B = 131072, 100 tables of dim 32 -- 1.25M rows each, the 1/8 row shard -- DotInteraction over 101 vectors)
+  against `oracle/ranking.py` on 256 sampled examples: predictions, the mean loss's gradient wrt every sampled
+  example's embedding vectors (read from the (ids, rows) slice the lookup's backward hands the optimizer), the
+  loss over the batch (float64 on the GPU's own predictions), and the fused Adagrad update of the sampled rows
+  (touched once) from that gradient; a never-looked-up guard row stays bit for bit."""
+  import recommenders_amd as tfrs
+  from recommenders_amd.experimental.models import ranking as rk
+  from oracle import ranking as o_rank
+  if config == "c3_dcn_v2":
+    n_tables, vocab, dim, batch, lr = 26, 1_000_000, 128, 65536, 0.5
+    bottom_units, fi, interaction = [512, 256, dim], rk.ConcatCross(num_layers=3), "cross"
+  else:
+    n_tables, vocab, dim, batch, lr = 100, 1_250_000, 32, 131072, 0.5
+    bottom_units, fi, interaction = [512, 256, dim], tfrs.layers.feature_interaction.DotInteraction(), "dot"
+  g = torch.Generator(device="cuda").manual_seed(2024)
+  emb = rk.EmbeddingDict({str(i): vocab for i in range(n_tables)}, dim)
+  bottom = tfrs.layers.blocks.MLP(units=bottom_units, final_activation="relu")
+  top = tfrs.layers.blocks.MLP(units=[1024, 512, 1], final_activation="sigmoid")
+  model = rk.Ranking(emb, bottom_stack=bottom, feature_interaction=fi, top_stack=top,
+                     task=tfrs.tasks.Ranking(loss=tfrs.losses.BinaryCrossentropy(reduction="none")))
+  dense = torch.rand((batch, 13), generator=g, device="cuda")
+  # the last row of every table is never looked up (the guard), sampled examples get ids nobody else has
+  ids = {str(i): torch.randint(0, vocab - 1 - 256, (batch,), generator=g, device="cuda") for i in range(n_tables)}
+  sample = torch.tensor(np.r_[0:96, batch // 2:batch // 2 + 64, batch - 96:batch], device="cuda")
+  ns = sample.numel()
+  for i in range(n_tables):
+    ids[str(i)][sample] = vocab - 1 - 256 + torch.arange(ns, device="cuda")
+  labels = torch.randint(0, 2, (batch,), generator=g, device="cuda")
+  feats = {"dense_features": dense, "sparse_features": ids}
+  with torch.no_grad():
+    model(feats)                                                   # builds the lazily shaped layers
+    if interaction == "cross":                                     # non-zero biases in the cross stack
+      for layer in fi.layers:
+        layer.bias.uniform_(-0.05, 0.05, generator=g)
+    for m in list(bottom._sublayers) + list(top._sublayers):
+      m.bias.uniform_(-0.05, 0.05, generator=g)
+  opt = tfrs.optimizers.Adagrad(model.parameters(), learning_rate=lr)
+  model.compile(optimizer=opt)
+  model.train()
+  opt.zero_grad(set_to_none=True)
+  loss = model.compute_loss((feats, labels), training=True)
+  with torch.no_grad():
+    pred = model(feats)
+  loss.backward()
+  table = emb.embeddings
+  slices = table._tfrs_slices
+  assert len(slices) == 1                                          # one (ids, rows) slice for all features
+  rows_idx, rows_grad = slices[0][0].reshape(batch, -1), slices[0][1].reshape(batch, -1, dim)
+  assert rows_idx.shape[1] in (n_tables, n_tables + 1)
+  starts = torch.arange(n_tables, device="cuda") * vocab
+  want_rows = torch.stack([ids[k] for k in sorted(ids, key=str)], dim=1) + starts[
+      torch.tensor([int(k) for k in sorted(ids, key=str)], device="cuda")]
+  assert torch.equal(rows_idx[:, :n_tables].long(), want_rows)
+  # ---- the oracle on the sampled examples
+  order = sorted(ids, key=str)
+  samp_rows = want_rows[sample]                                    # [ns, F] global rows
+  before = table.detach()[samp_rows.reshape(-1)].reshape(ns, n_tables, dim).clone()
+  embs = [_np(before[:, j, :]) for j in range(n_tables)]
+  bt = ([_np(l.kernel.detach()) for l in bottom._sublayers], [_np(l.bias.detach()) for l in bottom._sublayers],
+        "relu", "relu")
+  tp = ([_np(l.kernel.detach()) for l in top._sublayers], [_np(l.bias.detach()) for l in top._sublayers],
+        "relu", "sigmoid")
+  ck = [_np(l.kernel.detach()) for l in fi.layers] if interaction == "cross" else None
+  cb = [_np(l.bias.detach()) for l in fi.layers] if interaction == "cross" else None
+  p_ref, dx_ref, _ = o_rank.ranking_model_embedding_grads(
+      _np(dense[sample]), embs, _np(labels[sample]), bt, tp, interaction, batch, True, ck, cb)
+  # predictions: probabilities, error relative to 1 (north_star: 1e-5)
+  float_gate("ranking_%s.pred" % config, _np(pred[sample]), p_ref, np.ones_like(p_ref), 1e-5)
+  # gradient rows: relative to the largest entry of the example's gradient block
+  got = _np(rows_grad[sample][:, :n_tables, :]).astype(np.float64)
+  scale = np.abs(dx_ref).max(axis=(1, 2), keepdims=True)
+  assert scale.min() > 0
+  float_gate("ranking_%s.dembedding" % config, got, dx_ref, np.broadcast_to(scale, dx_ref.shape), 1e-4)
+  # the loss over the whole batch from the GPU's own predictions (float64; tasks/ranking.py:92-115 + :203-206)
+  p64 = pred.double().clamp(1e-7, 1 - 1e-7)
+  y64 = labels.double()
+  want_loss = float((-(y64 * p64.log() + (1 - y64) * (1 - p64).log())).mean())
+  assert abs(float(loss) - want_loss) <= 2e-6 * abs(want_loss), (float(loss), want_loss)
+  # ---- the optimizer step: sampled rows (each looked up exactly once) follow Adagrad from the GPU's gradient
+  guard = [(j + 1) * vocab - 1 for j in range(n_tables)]
+  guard_before = table.detach()[guard].clone()
+  opt.step()
+  after = table.detach()[samp_rows.reshape(-1)].reshape(ns, n_tables, dim)
+  gg = rows_grad[sample][:, :n_tables, :].double()
+  acc = 0.1 + gg * gg
+  want = before.double() - lr * gg / torch.sqrt(acc + 1e-7)
+  step_size = (lr * gg.abs() / torch.sqrt(acc + 1e-7))
+  err = (after.double() - want).abs().max()
+  assert float(err) <= 2.0 ** -24 * 0.06 * 2 + 1e-6 * float(step_size.max()), (float(err), float(step_size.max()))
+  assert float((after - before).abs().max()) > 0
+  assert torch.equal(table.detach()[guard], guard_before)
+  got_acc = opt.state[table]["accumulator"][samp_rows.reshape(-1)].reshape(ns, n_tables, dim)
+  assert torch.allclose(got_acc.double(), acc, rtol=1e-6, atol=0)

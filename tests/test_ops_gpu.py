@@ -2,6 +2,8 @@
 MultiLayerDCN and DotInteraction kernels against the oracle and the reference's golden
 vectors.  Float tolerances are written next to each check.  Run with `pytest -m gpu`."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -735,6 +737,135 @@ def test_fit_keeps_uncapturable_steps_eager():
   plain.compile(optimizer=torch.optim.Adam(plain.parameters(), lr=0.01))
   plain.fit(batches, epochs=2)
   assert not any(callable(v) for v in plain.__dict__["_fit_graphs"].values())
+
+
+def test_fit_drops_captured_steps_when_their_frozen_state_changes():
+  """a captured step froze the optimizer's hyper-parameters (Adagrad passes lr as a
+  kernel argument), the metric objects and the sub-modules at capture time.  A learning-rate change between
+  two fit() calls, a `task.factorized_metrics = ...` reassignment and `compile()` must each drop the captured
+  steps (the replay would otherwise keep the old lr / update the old metric objects); the trajectory stays
+  the eager one bit for bit.  The number of captured shapes is capped."""
+  import recommenders_amd as tfrs
+  rng = np.random.default_rng(18)
+  batches = _epoch_batches(rng, [1024] * 4)
+  eager, graphed = _quickstart_model(tfrs), _quickstart_model(tfrs)
+  assert eager.fit(batches, epochs=2, graph=False) == graphed.fit(batches, epochs=2)
+  old_cache = graphed.__dict__["_fit_graphs"]
+  assert sum(callable(v) for v in old_cache.values()) == 1
+  for m in (eager, graphed):                          # a manual schedule between fit() calls
+    for group in m.optimizer.param_groups:
+      group["learning_rate"] = 0.05
+  he, hg = eager.fit(batches, epochs=2, graph=False), graphed.fit(batches, epochs=2)
+  assert he == hg
+  assert graphed.__dict__["_fit_graphs"] is not old_cache           # dropped, then captured again
+  assert sum(callable(v) for v in graphed.__dict__["_fit_graphs"].values()) == 1
+  for a, b in zip(eager.parameters(), graphed.parameters()):
+    np.testing.assert_array_equal(_np(a), _np(b))
+  # new metric objects: the replay must update THEM, not the ones it was captured with
+  for m in (eager, graphed):
+    movies = tfrs.data.Dataset.from_tensor_slices(torch.arange(1682, device="cuda"))
+    m.task.factorized_metrics = tfrs.metrics.FactorizedTopK(candidates=movies.batch(128).map(m.item_model),
+                                                            ks=(1, 20))
+  he, hg = eager.fit(batches, epochs=2, graph=False), graphed.fit(batches, epochs=2)
+  assert he == hg and "factorized_top_k/top_20_categorical_accuracy" in hg
+  assert hg["factorized_top_k/top_20_categorical_accuracy"][-1] > 0.0
+  ee, eg = eager.evaluate(batches, graph=False), graphed.evaluate(batches)
+  assert ee == eg == graphed.evaluate(batches)
+  assert any(callable(v) for v in graphed.__dict__["_eval_graphs"].values())
+  graphed.compile(optimizer=graphed.optimizer)        # compile() drops both caches
+  assert "_fit_graphs" not in graphed.__dict__ and "_eval_graphs" not in graphed.__dict__
+  # the cap: with room for one captured shape the second shape stays eager (and still matches)
+  os.environ["TFRS_FIT_GRAPH_MAX_SHAPES"] = "1"
+  try:
+    two = _epoch_batches(rng, [512, 256] * 3)
+    he, hg = eager.fit(two, epochs=2, graph=False), graphed.fit(two, epochs=2)
+    assert he == hg
+    assert sum(callable(v) for v in graphed.__dict__["_fit_graphs"].values()) == 1
+  finally:
+    del os.environ["TFRS_FIT_GRAPH_MAX_SHAPES"]
+  for a, b in zip(eager.parameters(), graphed.parameters()):
+    np.testing.assert_array_equal(_np(a), _np(b))
+
+
+def test_quickstart_train_steps_follow_the_oracle_trajectory():
+  """BASELINE configs[0] as a TRAJECTORY (missing 3a): three `tfrs.Model.train_step`s of the
+  README quickstart model (models/base.py:64-85, README.md:58-97) at its real shapes -- batch 4096, 2k x 64
+  user and item tables, Adagrad(0.5), Retrieval(metrics=FactorizedTopK(movies.batch(128).map(item_model)))
+  called with compute_metrics=True -- against the oracle's restatement of the same step carried in its OWN
+  state: embedding gather -> in-batch softmax loss (tasks/retrieval.py:172-210) -> FactorizedTopK.update_state
+  on the pre-update tables (metrics/factorized_top_k.py:91-194) -> analytic gradients -> deduplicated Adagrad.
+  Per step: the loss within 1e-5 relative; both tables and both accumulators within 1e-5 relative (of the row's
+  largest entry) on the touched rows and BIT FOR BIT on the untouched ones; the running top-k accuracies equal
+  to the oracle's hit counts computed from the tables the GPU held at that step (near-ties must not be decided
+  by the 1e-7 drift between the two trajectories)."""
+  import recommenders_amd as tfrs
+  from oracle import embedding as o_emb
+  from oracle import metrics as o_metrics
+  from oracle import retrieval as o_ret
+  from oracle import topk as o_topk
+  rng = np.random.default_rng(77)
+  B, V, D, USERS, ITEMS, lr, ks = 4096, 2000, 64, 943, 1682, 0.5, (1, 5, 10, 50, 100)
+
+  class TwoTower(tfrs.Model):
+    def __init__(self):
+      super().__init__()
+      self.user_model = tfrs.layers.embedding.Embedding(V, D)
+      self.item_model = tfrs.layers.embedding.Embedding(V, D)
+      movies = tfrs.data.Dataset.from_tensor_slices(torch.arange(ITEMS, device="cuda"))
+      self.task = tfrs.tasks.Retrieval(metrics=tfrs.metrics.FactorizedTopK(
+          candidates=movies.batch(128).map(self.item_model)))
+
+    def compute_loss(self, features, training=False):
+      return self.task(self.user_model(features["user_id"]), self.item_model(features["movie_id"]))
+
+  model = TwoTower()
+  model.compile(optimizer=tfrs.optimizers.Adagrad(model.parameters(), learning_rate=lr))
+  tabs = [_np(model.user_model.embeddings.detach()).copy(), _np(model.item_model.embeddings.detach()).copy()]
+  assert np.abs(tabs[0]).max() <= 0.05                  # Keras Embedding default initialiser U(-0.05, 0.05)
+  accs = [np.full_like(t, 0.1) for t in tabs]
+  hit_sum, n_seen = np.zeros(len(ks)), 0
+  # item ids with a long tail (many duplicates in a batch), as MovieLens has
+  pop = 1.0 / np.arange(1, ITEMS + 1)
+  pop /= pop.sum()
+  for step in range(3):
+    uid = rng.integers(0, USERS, size=B)
+    iid = rng.choice(ITEMS, size=B, p=pop)
+    gpu_tabs = [_np(model.user_model.embeddings.detach()).copy(), _np(model.item_model.embeddings.detach()).copy()]
+    gpu_accs = [_np(model.optimizer.state[p]["accumulator"]).copy() if "accumulator" in model.optimizer.state[p]
+                else np.full((V, D), 0.1, np.float32)
+                for p in (model.user_model.embeddings, model.item_model.embeddings)]
+    logs = model.train_step({"user_id": _t(uid), "movie_id": _t(iid)})
+    # ---- the oracle's step on its own state
+    q, c = o_emb.gather(tabs[0], uid), o_emb.gather(tabs[1], iid)
+    want_loss = float(o_ret.loss(q, c))
+    dq, dc = o_ret.loss_grads(q, c)
+    new = [o_emb.adagrad_sparse_update(tabs[0], accs[0], dq, uid, lr),
+           o_emb.adagrad_sparse_update(tabs[1], accs[1], dc, iid, lr)]
+    got_loss = float(logs["loss"])
+    assert abs(got_loss - want_loss) <= 1e-5 * abs(want_loss), (step, got_loss, want_loss)
+    assert float(logs["total_loss"]) == got_loss and float(logs["regularization_loss"]) == 0.0
+    for t, (layer, ids) in enumerate(((model.user_model, uid), (model.item_model, iid))):
+      got_t = _np(layer.embeddings.detach())
+      got_a = _np(model.optimizer.state[layer.embeddings]["accumulator"])
+      touched = np.zeros(V, bool)
+      touched[ids] = True
+      np.testing.assert_array_equal(got_t[~touched], gpu_tabs[t][~touched])      # untouched rows: bit for bit
+      np.testing.assert_array_equal(got_a[~touched], gpu_accs[t][~touched])
+      np.testing.assert_array_equal(new[t][0][~touched], tabs[t][~touched])
+      for got, want in ((got_t, new[t][0]), (got_a, new[t][1])):
+        scale = np.abs(want[touched]).max(axis=1, keepdims=True)
+        err = np.abs(got[touched].astype(np.float64) - want[touched]) / scale
+        assert err.max() <= 1e-5, (step, t, float(err.max()))
+    # ---- the metric, from the tables the GPU held when the step ran
+    gq, gc = o_emb.gather(gpu_tabs[0], uid), o_emb.gather(gpu_tabs[1], iid)
+    hits = o_metrics.update(lambda qq, kk: o_topk.brute_force(qq, gpu_tabs[1][:ITEMS], kk), ks, gq, gc)
+    hit_sum += np.array([h.sum() for h in hits])
+    n_seen += B
+    for j, k in enumerate(ks):
+      got = float(logs["factorized_top_k/top_%d_categorical_accuracy" % k])
+      assert abs(got - hit_sum[j] / n_seen) <= 1e-6, (step, k, got, hit_sum[j] / n_seen)
+    tabs, accs = [new[0][0], new[1][0]], [new[0][1], new[1][1]]
+  assert hit_sum[-1] / n_seen > hit_sum[0] / n_seen > 0.0
 
 
 def test_metric_results_are_fresh_tensors_and_graphed_steps_bump_versions():

@@ -32,6 +32,57 @@ def test_oracle_mlp_shapes_and_relu():
   np.testing.assert_allclose(out, [[0.0]], atol=1e-7)
 
 
+@pytest.mark.parametrize("interaction", ["dot", "cross"])
+@pytest.mark.parametrize("concat_dense", [True, False])
+def test_oracle_ranking_embedding_grads_match_central_differences(interaction, concat_dense):
+  """The oracle's per-example backward of experimental/models/ranking.py:208-236 (used by the GPU tests at the
+  BASELINE configs[3]/[4] shapes) against central differences of its own float64 forward, and its predictions
+  against `ranking_model_forward` (three cross layers on one x0; DotInteraction defaults)."""
+  rng = np.random.default_rng(0)
+  n, F, D, nd, B = 4, 3, 4, 6, 64
+  width = (D + (F + 1) * F // 2) if interaction == "dot" else (D + (F + 1) * D)
+  if not concat_dense:
+    width -= D
+  bottom = ([rng.normal(size=(nd, 7)) * .5, rng.normal(size=(7, D)) * .5],
+            [rng.normal(size=7) * .1, rng.normal(size=D) * .1], "relu", "relu")
+  top = ([rng.normal(size=(width, 6)) * .5, rng.normal(size=(6, 1)) * .5],
+         [rng.normal(size=6) * .1, rng.normal(size=1) * .1], "relu", "sigmoid")
+  ck = [rng.normal(size=((F + 1) * D, (F + 1) * D)) * .2 for _ in range(3)]
+  cb = [rng.normal(size=(F + 1) * D) * .1 for _ in range(3)]
+  dense = rng.uniform(size=(n, nd))
+  embs = [rng.normal(size=(n, D)) for _ in range(F)]
+  y = rng.integers(0, 2, size=n)
+  p, dx, d_dense = o_rank.ranking_model_embedding_grads(dense, embs, y, bottom, top, interaction, B,
+                                                        concat_dense, ck, cb)
+  ref = o_rank.ranking_model_forward(dense.astype(np.float32), [e.astype(np.float32) for e in embs], bottom,
+                                     top, interaction, concat_dense, ck, cb)
+  np.testing.assert_allclose(p, ref, rtol=1e-6, atol=1e-7)
+
+  def loss64(es):
+    dv, _, _ = o_rank._mlp_forward64(dense, *bottom)
+    args = [np.asarray(e, float) for e in es] + [dv]
+    if interaction == "dot":
+      x = np.stack(args, 1)
+      it = np.einsum("bfd,bgd->bfg", x, x)[:, np.tril(np.ones((F + 1, F + 1)), -1).astype(bool)]
+    else:
+      it = o_rank._cross_stack(np.concatenate(args, -1), ck, cb)[-1]
+    out, _, _ = o_rank._mlp_forward64(np.concatenate([dv, it], 1) if concat_dense else it, *top)
+    pc = np.clip(out.reshape(-1), 1e-7, 1 - 1e-7)
+    return (-(y * np.log(pc) + (1 - y) * np.log(1 - pc))).sum() / B
+
+  num, h = np.zeros_like(dx), 1e-6
+  for f in range(F):
+    for i in range(n):
+      for k in range(D):
+        e1 = [e.copy() for e in embs]
+        e2 = [e.copy() for e in embs]
+        e1[f][i, k] += h
+        e2[f][i, k] -= h
+        num[i, f, k] = (loss64(e1) - loss64(e2)) / (2 * h)
+  assert np.abs(num - dx).max() <= 1e-8 * max(1.0, np.abs(dx).max() / 1e-2)
+  assert d_dense.shape == (n, D)
+
+
 # --------------------------------------------------------------------------- GPU
 def _np(t):
   return t.detach().cpu().numpy()
