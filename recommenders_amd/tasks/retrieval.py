@@ -261,8 +261,17 @@ class Retrieval(torch.nn.Module, base.Task):
   @factorized_metrics.setter
   def factorized_metrics(self, value) -> None:                          # :108-119
     if not isinstance(value, Sequence):
-      value = []
+      value = []                  # (the reference's behaviour: a bare metric object clears the list)
     self._factorized_metrics = list(value)
+
+  def __setattr__(self, name, value):
+    # torch.nn.Module.__setattr__ registers a Module VALUE as a sub-module before any property setter is
+    # consulted: `task.factorized_metrics = FactorizedTopK(...)` would add a child named like the property
+    # and leave the list the task updates untouched.  Route the name to the setter, as Keras does.
+    if name == "factorized_metrics":
+      type(self).factorized_metrics.fset(self, value)
+      return
+    super().__setattr__(name, value)
 
   @property
   def metrics(self):

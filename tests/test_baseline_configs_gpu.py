@@ -1042,12 +1042,12 @@ def test_ranking_model_at_config_shapes_vs_oracle(config):
   p_ref, dx_ref, _ = o_rank.ranking_model_embedding_grads(
       _np(dense[sample]), embs, _np(labels[sample]), bt, tp, interaction, batch, True, ck, cb)
   # predictions: probabilities, error relative to 1 (north_star: 1e-5)
-  float_gate("ranking_%s.pred" % config, _np(pred[sample]), p_ref, np.ones_like(p_ref), 1e-5)
+  float_gate("ranking_%s.pred" % config, _np(pred[sample]), p_ref, np.ones_like(p_ref), 1e-6)       # observed 6e-8 (round 5)
   # gradient rows: relative to the largest entry of the example's gradient block
   got = _np(rows_grad[sample][:, :n_tables, :]).astype(np.float64)
   scale = np.abs(dx_ref).max(axis=(1, 2), keepdims=True)
   assert scale.min() > 0
-  float_gate("ranking_%s.dembedding" % config, got, dx_ref, np.broadcast_to(scale, dx_ref.shape), 1e-4)
+  float_gate("ranking_%s.dembedding" % config, got, dx_ref, np.broadcast_to(scale, dx_ref.shape), 2e-5)   # observed 1.2e-6 / 7.9e-7
   # the loss over the whole batch from the GPU's own predictions (float64; tasks/ranking.py:92-115 + :203-206)
   p64 = pred.double().clamp(1e-7, 1 - 1e-7)
   y64 = labels.double()

@@ -764,8 +764,8 @@ def test_fit_drops_captured_steps_when_their_frozen_state_changes():
   # new metric objects: the replay must update THEM, not the ones it was captured with
   for m in (eager, graphed):
     movies = tfrs.data.Dataset.from_tensor_slices(torch.arange(1682, device="cuda"))
-    m.task.factorized_metrics = tfrs.metrics.FactorizedTopK(candidates=movies.batch(128).map(m.item_model),
-                                                            ks=(1, 20))
+    m.task.factorized_metrics = [tfrs.metrics.FactorizedTopK(candidates=movies.batch(128).map(m.item_model),
+                                                             ks=(1, 20))]
   he, hg = eager.fit(batches, epochs=2, graph=False), graphed.fit(batches, epochs=2)
   assert he == hg and "factorized_top_k/top_20_categorical_accuracy" in hg
   assert hg["factorized_top_k/top_20_categorical_accuracy"][-1] > 0.0
