@@ -34,6 +34,14 @@
 
 #include "common.h"
 
+// Timing ablations of scan16f_kernel (tools/ab_variants.sh builds one library per value; results are WRONG with
+// any of them set -- they answer "what does this part of the loop cost"): 1 = no per-stage s_barrier,
+// 2 = survivors ignored (no queue writes), 4 = A fragments read once per stage (no ds_reads in the sub-tile loop),
+// 8 = stage copies skipped after the first two (no L2 / HBM traffic), 16 = no max tree / compare at all.
+#ifndef TFRS_SCAN16_ABLATE
+#define TFRS_SCAN16_ABLATE 0
+#endif
+
 namespace tfrs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -386,18 +394,26 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
 // A tile that does not fit into the queue any more (adversarial data: near-duplicate clusters)
 // takes a direct per-element path with the same counters; nothing is ever dropped silently (counts
 // beyond cap_l flag the query for the exact redo exactly as before).
-template <int DP, int NW, int QG>
+template <int DP, int NW, int QG, int SPB = 1>
 struct Scan16FGeom : Scan16Geom<DP> {
   using B = Scan16Geom<DP>;
-  static_assert(NW * QG * 32 == kScan16QueriesPerWg, "queries per workgroup");
+  // TILES query tiles of kScan16QueriesPerWg queries share one workgroup -- and with it ONE copy of every stage
+  // (<16, 2>: the two tiles that otherwise sit on a CU as two workgroups, each copying the stage from L2)
+  static constexpr int kTiles = NW * QG * 32 / kScan16QueriesPerWg;
+  static constexpr int kWavesPerTile = NW / kTiles;
+  static_assert(kTiles >= 1 && kTiles * kScan16QueriesPerWg == NW * QG * 32, "queries per workgroup");
   static constexpr int kThreads = NW * 64;
   static constexpr int kLoadsF = (B::kChunks + kThreads - 1) / kThreads;
   static constexpr int kQCap = 32;                       // queue entries per wave
   static constexpr int kEntB = 80;                       // 16 scores + 16-byte header
   // queue + QG * 64 segment counters + QG * 64 x {flo, fqk, qscale, segment base} filter constants
   static constexpr int kWaveB = kQCap * kEntB + QG * 64 * 4 + QG * 64 * 16;
-  static constexpr int kQueueOff = (B::kLdsBytes + 15) / 16 * 16;
+  // SPB stages per barrier period, double-buffered: 2 * SPB stage slots + as many 16-byte StageMeta slots
+  static constexpr int kSlots = 2 * SPB;
+  static constexpr int kMetaOffF = kSlots * B::kStageB;
+  static constexpr int kQueueOff = (kMetaOffF + kSlots * 16 + 15) / 16 * 16;
   static constexpr int kLdsBytesF = kQueueOff + NW * kWaveB;
+  static_assert(kLdsBytesF <= 160 * 1024, "LDS budget");
 };
 
 // stage copy with NW waves (see stage16_glds)
@@ -422,9 +438,14 @@ __device__ __forceinline__ uint32_t lds_atomic_inc(uint32_t *p) {
 //   <8, 2>  four waves per SIMD at <= 128 VGPRs (two workgroups per CU)
 //   <4, 4>  two waves per SIMD at <= 256 VGPRs: one set of A fragments (4 ds_read_b128) feeds 16
 //           MFMAs instead of 8 -- half the LDS reads per flop, half the waves per barrier
-template <int DP, int NW, int QG>
-__global__ void __launch_bounds__(NW * 64, (DP <= 64 ? 2 : 1) * NW / 4) scan16f_kernel(const Scan16Args a) {
-  using G = Scan16FGeom<DP, NW, QG>;
+//   <16, 2> one workgroup of 16 waves per CU = two query tiles on one stage buffer: half the L2 -> LDS copies
+// SPB = stages per barrier period (the LDS a <16, 2> workgroup saves by sharing its stage buffers pays for two)
+// (Tried and dropped, round 5: one skewed sub-tile pipeline ACROSS the two stages of a period -- next stage's first A
+// fragments fetched under the current stage's last chains, stage constants switched per group at the boundary:
+// 0.931 ms against 0.895 for the plain two-stage period on the same box, profiles/r05_scan16f_shapes.txt.)
+template <int DP, int NW, int QG, int SPB = 1>
+__global__ void __launch_bounds__(NW * 64, NW * QG >= 32 ? 1 : (DP <= 64 ? 2 : 1) * NW / 4) scan16f_kernel(const Scan16Args a) {
+  using G = Scan16FGeom<DP, NW, QG, SPB>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -440,8 +461,11 @@ __global__ void __launch_bounds__(NW * 64, (DP <= 64 ? 2 : 1) * NW / 4) scan16f_
   const int q8 = nwg >> 3, r8 = nwg & 7;
   const int xcd = bid & 7, pos = bid >> 3;
   const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + pos;
-  const int split = logical / a.n_qtiles;
-  const int qt = logical - split * a.n_qtiles;
+  const int n_qgroups = (a.n_qtiles + G::kTiles - 1) / G::kTiles;      // workgroups per split
+  const int split = logical / n_qgroups;
+  // this wave's query tile (a tile beyond n_qtiles starts at a query >= nq: its waves only help to copy)
+  const int qt = (logical - split * n_qgroups) * G::kTiles + wave / G::kWavesPerTile;
+  const int wave_in_tile = wave % G::kWavesPerTile;
 
   const int i0 = split * a.stages_per_split;
   int i1 = i0 + a.stages_per_split;
@@ -455,7 +479,7 @@ __global__ void __launch_bounds__(NW * 64, (DP <= 64 ? 2 : 1) * NW / 4) scan16f_
   uint32_t *const wcnt = reinterpret_cast<uint32_t *>(qbase + G::kQCap * G::kEntB);
   #pragma unroll
   for (int g = 0; g < QG; ++g) wcnt[g * 64 + lane] = 0u;
-  const int64_t q0 = (int64_t)qt * kScan16QueriesPerWg + wave * (QG * 32);   // wave's first query
+  const int64_t q0 = (int64_t)qt * kScan16QueriesPerWg + wave_in_tile * (QG * 32);   // wave's first query
 
   // ---- this wave's 2 x 32 queries -> fp16 MFMA B operands (resident) -------------
   f16x8 bq[QG][G::kSteps];
@@ -560,25 +584,40 @@ __global__ void __launch_bounds__(NW * 64, (DP <= 64 ? 2 : 1) * NW / 4) scan16f_
     qtail = 0;
   };
 
-  // ---- stage 0 -> LDS ------------------------------------------------------------
+  // ---- the first period's stages -> LDS ----------------------------------------------
   static_assert(G::kChunks % 64 == 0, "stage size must be a whole number of wave copies");
   const char *gsrc = a.packed16 + first_stage * (int64_t)G::kStageB;
   const int64_t gstep = (int64_t)a.stage_stride * (int64_t)G::kStageB;
   const StageMeta *mp = a.meta + first_stage;
-  stage16f_glds<G::kChunks, G::kLoadsF, G::kThreads>(gsrc, smem, mp, smem + G::kMetaOff, tid, wave);
+  // stage `st` of this split's list lives in slot (period & 1) * SPB + st % SPB
+  auto copy_stage = [&](int st) __attribute__((always_inline)) {
+    const int slot = ((st / SPB) & 1) * SPB + (st % SPB);
+    stage16f_glds<G::kChunks, G::kLoadsF, G::kThreads>(gsrc + (int64_t)st * gstep, smem + slot * G::kStageB,
+                                                       mp + (int64_t)st * a.stage_stride,
+                                                       smem + G::kMetaOffF + slot * 16, tid, wave);
+  };
+#pragma unroll
+  for (int u = 0; u < SPB; ++u)
+    if (u < nst) copy_stage(u);
   wait_dma();
   __syncthreads();
 
-  for (int st = 0; st < nst; ++st) {
-    const char *tile = smem + (st & 1) * G::kStageB;
-    if (st + 1 < nst) {  // prefetch the next stage into the other buffer (its readers passed the barrier)
-      stage16f_glds<G::kChunks, G::kLoadsF, G::kThreads>(gsrc + (int64_t)(st + 1) * gstep,
-                                          smem + ((st + 1) & 1) * G::kStageB,
-                                          mp + (int64_t)(st + 1) * a.stage_stride,
-                                          smem + G::kMetaOff + ((st + 1) & 1) * 16, tid, wave);
+  const int n_periods = (nst + SPB - 1) / SPB;
+  for (int per = 0; per < n_periods; ++per) {
+    // prefetch the next period's stages into the other half of the slots (their readers passed the barrier)
+    if (!((TFRS_SCAN16_ABLATE & 8) && per >= 1)) {
+#pragma unroll
+      for (int u = 0; u < SPB; ++u)
+        if ((per + 1) * SPB + u < nst) copy_stage((per + 1) * SPB + u);
     }
+#pragma unroll
+    for (int u = 0; u < SPB; ++u) {
+    const int st = per * SPB + u;
+    if (SPB > 1 && st >= nst) break;
+    const int slot = (per & 1) * SPB + u;
+    const char *tile = smem + slot * G::kStageB;
     if (wave_active) {
-    const StageMeta sm = *reinterpret_cast<const StageMeta *>(smem + G::kMetaOff + (st & 1) * 16);
+    const StageMeta sm = *reinterpret_cast<const StageMeta *>(smem + G::kMetaOffF + slot * 16);
     // wave-uniform stage constants -> SGPRs
     const float s_norm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sm.norm)));
     const uint32_t s_scale_bits = __builtin_amdgcn_readfirstlane(__float_as_uint(sm.scale));
@@ -597,6 +636,7 @@ __global__ void __launch_bounds__(NW * 64, (DP <= 64 ? 2 : 1) * NW / 4) scan16f_
     for (int m = 0; m < G::kSteps; ++m) af[0][m] = *reinterpret_cast<const u32x4 *>(ap + m * 32);
 
     f32x16 acc[QG];
+    if (TFRS_SCAN16_ABLATE & 32) __builtin_amdgcn_s_setprio(2);
     auto chain = [&](int g, int sub) __attribute__((always_inline)) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[g][r] = 0.0f;
@@ -606,9 +646,11 @@ __global__ void __launch_bounds__(NW * 64, (DP <= 64 ? 2 : 1) * NW / 4) scan16f_
     };
     auto check = [&](int g, int sub) __attribute__((always_inline)) {
       const f32x16 &c = acc[g];
+      if (TFRS_SCAN16_ABLATE & 16) { asm volatile("" :: "v"(c[0]), "v"(c[15])); return; }
       const float m0 = max16(c);
       const bool hot = m0 > thr[g];
       const uint64_t hm = __ballot(hot);
+      if (TFRS_SCAN16_ABLATE & 2) { asm volatile("" :: "s"(hm)); return; }
       if (__builtin_expect(hm != 0ull, 0)) {   // wave-uniform: some lane's 16-score column holds a survivor
         const uint32_t rbase = stage_row + sub * 32 + 4u * h;
         uint64_t rem = hm;
@@ -648,6 +690,8 @@ __global__ void __launch_bounds__(NW * 64, (DP <= 64 ? 2 : 1) * NW / 4) scan16f_
       if (sub + 1 < kTileN / 32) {
 #pragma unroll
         for (int m = 0; m < G::kSteps; ++m)
+          if (TFRS_SCAN16_ABLATE & 4) af[(sub + 1) & 1][m] = af[sub & 1][m];
+          else
           af[(sub + 1) & 1][m] =
               *reinterpret_cast<const u32x4 *>(ap + (sub + 1) * 32 * G::kRowB + m * 32);
       }
@@ -691,11 +735,13 @@ __global__ void __launch_bounds__(NW * 64, (DP <= 64 ? 2 : 1) * NW / 4) scan16f_
     check(QG - 1, kTileN / 32 - 1);
     }
     }
-    // The stage copies were issued a whole stage ago and the previous drain's stores before
+    }   // stages of the period
+    // The stage copies were issued a whole period ago and the previous drain's stores before
     // them: nothing recent is outstanding here.
+    if (TFRS_SCAN16_ABLATE & 32) __builtin_amdgcn_s_setprio(0);
     wait_dma();
-    if (qtail > 0 && (qtail >= a.drain_min || st == nst - 1 || ((st + 1) % a.drain_every) == 0)) drain();
-    __builtin_amdgcn_s_barrier();
+    if (qtail > 0 && (qtail >= a.drain_min || per == n_periods - 1 || ((per + 1) % a.drain_every) == 0)) drain();
+    if (!(TFRS_SCAN16_ABLATE & 1)) __builtin_amdgcn_s_barrier();
   }
 
   // every segment's count is written (counts beyond cap_l flag the query for the exact redo)
@@ -709,21 +755,32 @@ __global__ void __launch_bounds__(NW * 64, (DP <= 64 ? 2 : 1) * NW / 4) scan16f_
 }
 
 
-template <int DP, int NW, int QG>
+template <int DP, int NW, int QG, int SPB = 1>
 static int launch_scan16f(const Scan16Args &a, hipStream_t stream) {
-  using G = Scan16FGeom<DP, NW, QG>;
-  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&scan16f_kernel<DP, NW, QG>), G::kLdsBytesF));
-  const dim3 grid((unsigned)(a.n_qtiles * a.n_splits));
-  hipLaunchKernelGGL((scan16f_kernel<DP, NW, QG>), grid, dim3(NW * 64), G::kLdsBytesF, stream, a);
+  using G = Scan16FGeom<DP, NW, QG, SPB>;
+  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&scan16f_kernel<DP, NW, QG, SPB>), G::kLdsBytesF));
+  const dim3 grid((unsigned)((a.n_qtiles + G::kTiles - 1) / G::kTiles * a.n_splits));
+  hipLaunchKernelGGL((scan16f_kernel<DP, NW, QG, SPB>), grid, dim3(NW * 64), G::kLdsBytesF, stream, a);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
 }
 
-// TFRS_SCAN16_SHAPE = 8x2 (default) | 4x4
+// TFRS_SCAN16_SHAPE = 16x2s2 | 16x2 | 8x2 | 4x4 | 8x4.  Default (round 5): batches of at least two query tiles take
+// the 16-wave workgroup (two tiles on one stage buffer), with two stages per barrier period where the LDS allows it
+// (dims <= 64); one tile (<= 512 queries) keeps <8, 2>.  Same-box measurements: profiles/r05_scan16f_shapes.txt.
 template <int DP>
 static int launch_scan16f_shape(const Scan16Args &a, hipStream_t stream) {
   const char *e = option("TFRS_SCAN16_SHAPE");
-  if (e && e[0] == '4' && DP <= 64) return launch_scan16f<DP, 4, 4>(a, stream);
+  const bool pair = a.n_qtiles >= 2;
+  if (e && e[0] == '8' && e[2] == '2') return launch_scan16f<DP, 8, 2>(a, stream);
+  if constexpr (DP <= 64) {
+    if (e && e[0] == '4') return launch_scan16f<DP, 4, 4>(a, stream);
+    if (e && e[0] == '8' && e[2] == '4' && pair) return launch_scan16f<DP, 8, 4>(a, stream);
+    if (e && e[0] == '1' && e[1] == '6' && e[4] != 's' && pair) return launch_scan16f<DP, 16, 2>(a, stream);
+    if (pair) return launch_scan16f<DP, 16, 2, 2>(a, stream);
+  } else {
+    if (e && e[0] == '1' && e[1] == '6' && pair) return launch_scan16f<DP, 16, 2>(a, stream);
+  }
   return launch_scan16f<DP, 8, 2>(a, stream);
 }
 

@@ -17,7 +17,8 @@ ref = None
 vals = [None] + sys.argv[1:] + [None]
 for v in vals:
   if v:
-    _lib.set_option(v.split("=")[0], v.split("=")[1])
+    for kv in v.split(","):          # several switches at once: A=1,B=2
+      _lib.set_option(kv.split("=")[0], kv.split("=")[1])
   for _ in range(3):
     out = index(queries)
   torch.cuda.synchronize()
@@ -39,6 +40,7 @@ for v in vals:
   lib.tfrs_profile_read(None, None, None)
   lib.tfrs_profile_enable(0)
   if v:
-    _lib.set_option(v.split("=")[0], None)
+    for kv in v.split(","):
+      _lib.set_option(kv.split("=")[0], None)
   print(json.dumps({"switch": v, "step_ms": round(dt * 1e3, 4), "filter_ms": round(res[1][0], 4),
                     "filter_tflops": round(res[1][1], 1), "same": same}), flush=True)
