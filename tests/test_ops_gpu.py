@@ -795,7 +795,8 @@ def test_quickstart_train_steps_follow_the_oracle_trajectory():
   state: embedding gather -> in-batch softmax loss (tasks/retrieval.py:172-210) -> FactorizedTopK.update_state
   on the pre-update tables (metrics/factorized_top_k.py:91-194) -> analytic gradients -> deduplicated Adagrad.
   Per step: the loss within 1e-5 relative; both tables and both accumulators within 1e-5 relative (of the row's
-  largest entry) on the touched rows and BIT FOR BIT on the untouched ones; the running top-k accuracies equal
+  largest entry) of the oracle's step FROM THE GPU'S PRE-STEP STATE on the touched rows (1e-4 of the oracle's own
+  trajectory after three steps) and BIT FOR BIT on the untouched ones; the running top-k accuracies equal
   to the oracle's hit counts computed from the tables the GPU held at that step (near-ties must not be decided
   by the 1e-7 drift between the two trajectories)."""
   import recommenders_amd as tfrs
@@ -835,14 +836,19 @@ def test_quickstart_train_steps_follow_the_oracle_trajectory():
                 else np.full((V, D), 0.1, np.float32)
                 for p in (model.user_model.embeddings, model.item_model.embeddings)]
     logs = model.train_step({"user_id": _t(uid), "movie_id": _t(iid)})
-    # ---- the oracle's step on its own state
+    # ---- the oracle's step on its own state (the trajectory) and from the GPU's pre-step state (one step)
     q, c = o_emb.gather(tabs[0], uid), o_emb.gather(tabs[1], iid)
     want_loss = float(o_ret.loss(q, c))
     dq, dc = o_ret.loss_grads(q, c)
     new = [o_emb.adagrad_sparse_update(tabs[0], accs[0], dq, uid, lr),
            o_emb.adagrad_sparse_update(tabs[1], accs[1], dc, iid, lr)]
+    gq, gc = o_emb.gather(gpu_tabs[0], uid), o_emb.gather(gpu_tabs[1], iid)
+    gdq, gdc = o_ret.loss_grads(gq, gc)
+    one = [o_emb.adagrad_sparse_update(gpu_tabs[0], gpu_accs[0], gdq, uid, lr),
+           o_emb.adagrad_sparse_update(gpu_tabs[1], gpu_accs[1], gdc, iid, lr)]
     got_loss = float(logs["loss"])
     assert abs(got_loss - want_loss) <= 1e-5 * abs(want_loss), (step, got_loss, want_loss)
+    assert abs(got_loss - float(o_ret.loss(gq, gc))) <= 2e-6 * abs(want_loss)
     assert float(logs["total_loss"]) == got_loss and float(logs["regularization_loss"]) == 0.0
     for t, (layer, ids) in enumerate(((model.user_model, uid), (model.item_model, iid))):
       got_t = _np(layer.embeddings.detach())
@@ -852,12 +858,15 @@ def test_quickstart_train_steps_follow_the_oracle_trajectory():
       np.testing.assert_array_equal(got_t[~touched], gpu_tabs[t][~touched])      # untouched rows: bit for bit
       np.testing.assert_array_equal(got_a[~touched], gpu_accs[t][~touched])
       np.testing.assert_array_equal(new[t][0][~touched], tabs[t][~touched])
-      for got, want in ((got_t, new[t][0]), (got_a, new[t][1])):
-        scale = np.abs(want[touched]).max(axis=1, keepdims=True)
-        err = np.abs(got[touched].astype(np.float64) - want[touched]) / scale
-        assert err.max() <= 1e-5, (step, t, float(err.max()))
+      # one step from the state the GPU held: 1e-5 of the row's largest entry; the oracle's OWN trajectory (each
+      # side carries its state: differences compound through the softmax, observed 1.6e-5 after the second
+      # step): 1e-4 after three steps
+      for limit, ref in ((1e-5, one[t]), (1e-4, new[t])):
+        for got, want in ((got_t, ref[0]), (got_a, ref[1])):
+          scale = np.abs(want[touched]).max(axis=1, keepdims=True)
+          err = np.abs(got[touched].astype(np.float64) - want[touched]) / scale
+          assert err.max() <= limit, (step, t, limit, float(err.max()))
     # ---- the metric, from the tables the GPU held when the step ran
-    gq, gc = o_emb.gather(gpu_tabs[0], uid), o_emb.gather(gpu_tabs[1], iid)
     hits = o_metrics.update(lambda qq, kk: o_topk.brute_force(qq, gpu_tabs[1][:ITEMS], kk), ks, gq, gc)
     hit_sum += np.array([h.sum() for h in hits])
     n_seen += B
