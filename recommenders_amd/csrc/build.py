@@ -63,8 +63,10 @@ def _newer(src_paths, target) -> bool:
 
 def _compile(src: str, force: bool) -> str:
   obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
-  deps = [os.path.join(HERE, src), os.path.join(HERE, "common.h"),
-          os.path.join(PKG, "..", "include", "tfrs_hip.h")]
+  # every header of this directory (common.h, mfma_tile.h, ...): a stale gemm16.o / interaction.o after an edit of
+  # mfma_tile.h was possible while only common.h was listed
+  headers = sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h"))
+  deps = [os.path.join(HERE, src), os.path.join(PKG, "..", "include", "tfrs_hip.h")] + headers
   if force or _newer(deps, obj):
     cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(src, []) + [
            "-x", "hip", "-c", os.path.join(HERE, src), "-o", obj]

@@ -762,7 +762,7 @@ class Streaming(TopK):
                handle_incomplete_batches: bool = True,
                num_parallel_calls: Optional[int] = None, sorted_order: bool = True,
                cache_packed_blocks: bool = True, cache_max_bytes: int = 64 << 30,
-               group_max_bytes: int = 8 << 30) -> None:
+               group_max_bytes: Optional[int] = None) -> None:
     super().__init__(k=k)
     self.query_model = query_model
     self._candidates = None
@@ -775,7 +775,10 @@ class Streaming(TopK):
     # candidate bytes (float32 rows) searched per library call on the block-by-block path: the
     # blocks of a group are read IN PLACE (tfrs_streaming_topk_update_blocks), so this bounds how
     # many lazily produced blocks are alive at once plus the fp16 image of the group
-    self._group_max_bytes = max(int(group_max_bytes), 1)
+    # rows kept alive per group of lazily produced blocks (+ their fp16 image for large batches): by default an
+    # eighth of the device memory that is free at the first call, at most 8 GiB (a fixed 8 GiB
+    # ran a `.map(model)` dataset out of memory on a busy GPU where the one-block-at-a-time path had fitted)
+    self._group_max_bytes = None if group_max_bytes is None else max(int(group_max_bytes), 1)
     self._last_ids: Optional[_Identifiers] = None
     self._cache_blocks = cache_packed_blocks
     self._cache_max_bytes = int(cache_max_bytes)
@@ -945,8 +948,14 @@ class Streaming(TopK):
           _lib.ptr(state_scores), _lib.ptr(state_rows), state_len, ctypes.byref(new_len),
           _lib.ptr(ws), ws.numel(), _lib.current_stream()))            # :424-472 for every block of the group
       state_len = int(new_len.value)
-      # (the blocks were only referenced by the enqueued kernels: the caching allocator reuses their
-      # memory in stream order, so dropping them here is safe)
+      # The blocks are only referenced by the kernels just enqueued on THIS stream.  A block the dataset
+      # produced on another stream would be handed back to that stream's allocator pool when the reference is
+      # dropped, and could be overwritten before these kernels have read it: tell the allocator who reads it
+      # (a no-op for blocks of the current stream).
+      stream = torch.cuda.current_stream(q.device)
+      for b in group:
+        if b.is_cuda:
+          b.record_stream(stream)
       group, group_rows = [], 0
 
     for element in self._candidates:
@@ -975,7 +984,7 @@ class Streaming(TopK):
         group.append(block)
         group_rows += nb
         counter += nb
-        if len(group) == _RAW_MAX_BLOCKS or group_rows * d * 4 >= self._group_max_bytes:
+        if len(group) == _RAW_MAX_BLOCKS or group_rows * d * 4 >= self._group_bytes(q.device):
           flush_group()
         continue
       flush_group()          # (a block the grouped path cannot take: keep the stream order)
@@ -992,11 +1001,19 @@ class Streaming(TopK):
     all_ids = None
     if has_ids:
       if all(isinstance(i, torch.Tensor) for i in ids):
-        all_ids = torch.cat([i.reshape(-1) for i in ids])
+        # along axis 0 as the reference concatenates them (2-D identifier blocks keep their rows), on the
+        # device of the first block (a mix of host and device blocks would make torch.cat raise)
+        all_ids = torch.cat([i.to(ids[0].device) for i in ids], dim=0)
       else:
         all_ids = np.concatenate([i.cpu().numpy() if isinstance(i, torch.Tensor) else i for i in ids], axis=0)
     self._last_ids = _Identifiers(all_ids, counter - self._base_row)
     return state_scores[:, :state_len], state_rows[:, :state_len]
+
+  def _group_bytes(self, device) -> int:
+    if self._group_max_bytes is None:
+      free = torch.cuda.mem_get_info(device)[0] if device.type == "cuda" else (8 << 30)
+      self._group_max_bytes = max(64 << 20, min(8 << 30, free // 8))
+    return self._group_max_bytes
 
   def _ids_of_rows(self, rows: Tensor):
     return self._last_ids.gather(rows - self._base_row if self._base_row else rows)
@@ -1011,6 +1028,23 @@ class Streaming(TopK):
 
 
 _INT32_MAX = 0x7FFFFFFF
+
+
+_BASE_WORDS: dict = {}
+
+
+def _base_row_words(base_row: int, dev) -> Tensor:
+  """The two int32 words of a shard's int64 base row as a device tensor, built once per (device, base row):
+  the wide exchange used to build them with ``torch.tensor([...])`` -- a host-to-device copy and a
+  synchronisation point in every query."""
+  key = (str(dev), int(base_row))
+  words = _BASE_WORDS.get(key)
+  if words is None:
+    if len(_BASE_WORDS) > 64:
+      _BASE_WORDS.clear()
+    words = torch.tensor([base_row & 0xFFFFFFFF, base_row >> 32], dtype=torch.int64).to(torch.int32).to(dev)
+    _BASE_WORDS[key] = words
+  return words
 
 
 def _exchange_and_merge_wide(scores: Tensor, local_rows: Tensor, k: int, group, merge: Optional[Callable],
@@ -1034,7 +1068,7 @@ def _exchange_and_merge_wide(scores: Tensor, local_rows: Tensor, k: int, group, 
   mine = torch.empty((words,), dtype=torch.int32, device=dev)
   mine[:nq * k].copy_(scores.contiguous().view(torch.int32).reshape(-1))
   mine[nq * k:2 * nq * k].copy_(local_rows.to(torch.int32).reshape(-1))
-  mine[2 * nq * k:].copy_(torch.tensor([base_row & 0xFFFFFFFF, base_row >> 32], dtype=torch.int64).to(torch.int32))
+  mine[2 * nq * k:].copy_(_base_row_words(base_row, dev))     # (device-resident: no host copy in the query path)
   gathered = torch.empty((world, words), dtype=torch.int32, device=dev)
   if world > 1 or os.environ.get("TFRS_FORCE_EXCHANGE", "0") == "1":
     dist.all_gather_into_tensor(gathered.view(-1), mine, group=group)

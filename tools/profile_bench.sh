@@ -10,8 +10,8 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/${1:-prof}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train-step --no-gather --no-scale-workload --no-robustness --no-streaming"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python $ROOT/bench.py --no-cpu-baseline --no-train-step --no-gather --no-scale-workload --no-robustness --no-streaming > "$OUT/trace.log" 2>&1
+BENCH="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train-step --no-gather --no-scale-workload --no-robustness --no-streaming --no-config-legs"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python $ROOT/bench.py --no-cpu-baseline --no-train-step --no-gather --no-scale-workload --no-robustness --no-streaming --no-config-legs > "$OUT/trace.log" 2>&1
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 -d "$OUT/pmc_a" -o bench -- $BENCH > "$OUT/pmc_a.log" 2>&1
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU -d "$OUT/pmc_b" -o bench -- $BENCH > "$OUT/pmc_b.log" 2>&1
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o bench -- $BENCH > "$OUT/pmc_fetch.log" 2>&1
