@@ -479,6 +479,39 @@ int tfrs_dense_bwd(const float *x, const float *kernel, const float *dy, int64_t
                    int dout, float *dx, float *dkernel, float *dbias, int f16, void *workspace,
                    size_t workspace_bytes, void *stream);
 
+/* Activations fused into the product's epilogue ("tfrs_cross_fwd(x0, x, w_or_(u,v), b, diag, act,
+ * y)"; Keras Dense(activation=...) of layers/blocks.py:46-52 and Cross(preactivation=...) of dcn.py:173-181).
+ * Codes: */
+#define TFRS_ACT_NONE 0
+#define TFRS_ACT_RELU 1
+#define TFRS_ACT_SIGMOID 2
+#define TFRS_ACT_TANH 3
+#define TFRS_ACT_SILU 4   /* swish */
+#define TFRS_ACT_GELU 5   /* exact (erf) form, Keras gelu(approximate=False) */
+/*   tfrs_dense_fwd_act: out = act(x @ kernel + bias); pre_out (optional, [batch, dout]) receives the
+ *     pre-activation.  f16 != 0: split-fp16 MFMA, workspace from tfrs_gemm_f16_workspace_bytes(batch, dout, din).
+ *   tfrs_cross_fwd_act: y = x0 * (act(a @ kernel + bias) + diag_scale * x) + x with a[batch, ka] = x (full rank,
+ *     ka == d) or x @ U (low rank); pre_out (optional) receives p = a @ kernel + bias.
+ *   tfrs_act_pointwise_bwd: the element-wise part of their backward in ONE pass over `count` elements:
+ *       dp  = dy * x0 * act'(pre)       (x0 == NULL: dy * act'(pre))            [optional output]
+ *       dx0 = dy * (act(pre) + diag_scale * x)                                  [optional output]
+ *       dxd = dy * (1 + diag_scale * x0)   (the direct terms of dx)             [optional output]
+ *     ref_is_output != 0: `pre` holds y = act(p) (relu / sigmoid / tanh only).
+ *   tfrs_dense_bwd_add: tfrs_dense_bwd with dx = dy @ kernel^T + addend[batch, din] (addend may be NULL): with
+ *     dy = dp and addend = dxd this is the input gradient of a full-rank Cross layer with a preactivation. */
+int tfrs_dense_fwd_act(const float *x, const float *kernel, const float *bias, int64_t batch, int din,
+                       int dout, int act, float *out, float *pre_out, int f16, void *workspace,
+                       size_t workspace_bytes, void *stream);
+int tfrs_cross_fwd_act(const float *x0, const float *x, const float *a, int ka, const float *kernel,
+                       const float *bias, float diag_scale, int act, int64_t batch, int d, float *y,
+                       float *pre_out, int f16, void *workspace, size_t workspace_bytes, void *stream);
+int tfrs_act_pointwise_bwd(int act, int ref_is_output, const float *pre, const float *dy, const float *x0,
+                           const float *x, float diag_scale, int64_t count, float *dp, float *dx0,
+                           float *dxd, void *stream);
+int tfrs_dense_bwd_add(const float *x, const float *kernel, const float *dy, const float *addend,
+                       int64_t batch, int din, int dout, float *dx, float *dkernel, float *dbias, int f16,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
 /* The same two products on the fp16 matrix cores with split operands (x = hi + lo per
  * power-of-two-scaled row / column; hi*hi + hi*lo + lo*hi with f32 accumulation): f32-grade
  * results at ~3x the rate for large shapes.  The caller provides the workspace that holds the

@@ -96,6 +96,10 @@ SIGNATURES = {
     "tfrs_dense_bwd_workspace_bytes": (c_size_t, [c_i64, c_int, c_int, c_int]),
     "tfrs_dense_bwd": (c_int, [P, P, P, c_i64, c_int, c_int, P, P, P, c_int, P, c_size_t, P]),
     "tfrs_dense_fwd": (c_int, [P, P, P, c_i64, c_int, c_int, P, P]),
+    "tfrs_dense_fwd_act": (c_int, [P, P, P, c_i64, c_int, c_int, c_int, P, P, c_int, P, c_size_t, P]),
+    "tfrs_cross_fwd_act": (c_int, [P, P, P, c_int, P, P, c_float, c_int, c_i64, c_int, P, P, c_int, P, c_size_t, P]),
+    "tfrs_act_pointwise_bwd": (c_int, [c_int, c_int, P, P, P, P, c_float, c_i64, P, P, P, P]),
+    "tfrs_dense_bwd_add": (c_int, [P, P, P, P, c_i64, c_int, c_int, P, P, P, c_int, P, c_size_t, P]),
     "tfrs_gemm_f16_workspace_bytes": (c_size_t, [c_i64, c_int, c_int]),
     "tfrs_dense_fwd_f16": (c_int, [P, P, P, c_i64, c_int, c_int, P, P, c_size_t, P]),
     "tfrs_cross_fwd_f16": (c_int, [P, P, P, P, c_float, c_i64, c_int, P, P, c_size_t, P]),

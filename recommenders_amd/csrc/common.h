@@ -58,6 +58,41 @@ const char *option(const char *name);
 // v_mfma_f32_32x32x2_f32 consumes features (2s, 2s+1) at step s: lanes 0-31 supply
 // k = 2s from the even plane, lanes 32-63 supply k = 2s+1 from the odd plane, so the
 // accumulation order is d = 0, 1, 2, ... exactly.
+// ---- activations fused into the GEMM epilogues (Keras names: layers/blocks.py:46-52 Dense(activation=...),
+// dcn.py:176-181 Cross(preactivation=...)); codes of the C ABI (include/tfrs_hip.h TFRS_ACT_*) -----------------
+enum { kActNone = 0, kActRelu = 1, kActSigmoid = 2, kActTanh = 3, kActSilu = 4, kActGelu = 5 };
+__device__ __forceinline__ float act_apply(int act, float v) {
+  switch (act) {
+    case kActRelu: return v > 0.0f ? v : 0.0f;
+    case kActSigmoid: return 1.0f / (1.0f + __expf(-v));
+    case kActTanh: return tanhf(v);
+    case kActSilu: return v / (1.0f + __expf(-v));
+    case kActGelu: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));    // Keras gelu(approximate=False)
+    default: return v;
+  }
+}
+// d act(p) / d p at the PRE-activation p
+__device__ __forceinline__ float act_grad(int act, float p) {
+  switch (act) {
+    case kActRelu: return p > 0.0f ? 1.0f : 0.0f;
+    case kActSigmoid: { const float s = 1.0f / (1.0f + __expf(-p)); return s * (1.0f - s); }
+    case kActTanh: { const float t = tanhf(p); return 1.0f - t * t; }
+    case kActSilu: { const float s = 1.0f / (1.0f + __expf(-p)); return s * (1.0f + p * (1.0f - s)); }
+    case kActGelu: return 0.5f * (1.0f + erff(p * 0.70710678118654752f)) +
+                          p * 0.3989422804014327f * __expf(-0.5f * p * p);
+    default: return 1.0f;
+  }
+}
+// ... and from the OUTPUT y = act(p) where that determines it (relu, sigmoid, tanh)
+__device__ __forceinline__ float act_grad_from_output(int act, float y) {
+  switch (act) {
+    case kActRelu: return y > 0.0f ? 1.0f : 0.0f;
+    case kActSigmoid: return y * (1.0f - y);
+    case kActTanh: return 1.0f - y * y;
+    default: return 1.0f;
+  }
+}
+
 constexpr int kTileN = 128;  // candidate rows per LDS stage; packed buffers are padded to it
 
 __host__ __device__ inline int padded_dim(int d) {

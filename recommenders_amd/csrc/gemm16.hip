@@ -491,6 +491,8 @@ struct Gemm16Args {
   int64_t mp, np;                      // padded image rows (block stride of K-blocked images)
   int kt_per;                          // big kernel, split-K: K steps per blockIdx.y slice (0 = all);
                                        // slice y writes its partial product to out + y * m * n
+  int act;                             // fused activation of v (common.h kAct*), before the epilogue formula
+  float *pre;                          // [m, n] or NULL: receives v (the pre-activation) for the backward
 };
 
 __device__ __forceinline__ void g16_dma16(const char *gsrc_lane, const char *lds_wave_base) {
@@ -512,7 +514,9 @@ __device__ __forceinline__ void g16_wait_dma() {
 // different 16-byte bank groups.
 __device__ __forceinline__ int g16_slot(int row, int kslot) { return kslot ^ ((row >> 2) & 3); }
 
-template <int EPI>
+// ACT: the instantiations that apply g.act / store g.pre (kept apart: the libm code of tanh / erf next to the
+// accumulators costs the plain Cross epilogues of the 128 x 128 kernel 20 spilled registers)
+template <int EPI, bool ACT = false>
 __global__ void __launch_bounds__(256, 2) gemm16_kernel(const Gemm16Args g) {
   // [buffer][Ah | Al | Bh | Bl]
   __shared__ __attribute__((aligned(16))) char lds[2][4 * kG16Img];
@@ -615,13 +619,15 @@ __global__ void __launch_bounds__(256, 2) gemm16_kernel(const Gemm16Args g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = bm + wm * 64 + i * 32 + tile_row_of_reg(r, h);
-        const float v = acc[i][jn][r] * (ra[r] * cs) + bias;
+        const float v0 = acc[i][jn][r] * (ra[r] * cs) + bias;
+        const float v = ACT ? act_apply(g.act, v0) : v0;
         float u = 0.0f;
         const float res = g16_epilogue_v<EPI>(v, e0v[r], e1v[r], g.diag, &u);
         if (row < g.m && col < g.n) {
           const int64_t o = row * g.n + col;
           g.out[o] = res;
           if (EPI == kG16EpiCross && g.aux) g.aux[o] = u;
+          if (ACT && g.pre) g.pre[o] = v0;
         }
       }
     }
@@ -645,7 +651,7 @@ __device__ __forceinline__ void g16_wait_vm() {
   __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
 }
 
-template <int EPI>
+template <int EPI, bool ACT = false>
 __global__ void __launch_bounds__(512) gemm16_big_kernel(const Gemm16Args g) {
   __shared__ __attribute__((aligned(16))) char lds[kB16Ring * kB16Stage];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -795,13 +801,15 @@ __global__ void __launch_bounds__(512) gemm16_big_kernel(const Gemm16Args g) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int lr = wm * 64 + i * 32 + tile_row_of_reg(q0 + q, h);
-          const float v = acc[i][jn][q0 + q] * (ra[q] * cs) + bias;
+          const float v0 = acc[i][jn][q0 + q] * (ra[q] * cs) + bias;
+          const float v = ACT ? act_apply(g.act, v0) : v0;
           float u = 0.0f;
           const float res = g16_epilogue_v<EPI>(v, e0v[q], e1v[q], g.diag, &u);
           if (lr < rows_here && lc < cols_here) {
             const uint32_t o = (uint32_t)lr * (uint32_t)g.n + (uint32_t)lc;
             outb[o] = res;
             if (EPI == kG16EpiCross && auxb) auxb[o] = u;
+            if (ACT && g.pre) g.pre[(int64_t)tile0 + o] = v0;
           }
         }
       }
@@ -871,16 +879,16 @@ struct G16Operand {
   bool t;
 };
 
-template <int EPI>
+template <int EPI, bool ACT = false>
 static void g16_launch(const Gemm16Args &g, bool big, hipStream_t s) {
   if (big) {
     const dim3 grid((unsigned)(((g.m + kB16M - 1) / kB16M) * ((g.n + kB16N - 1) / kB16N)));
-    hipLaunchKernelGGL((gemm16_big_kernel<EPI>), grid, dim3(512), 0, s, g);
+    hipLaunchKernelGGL((gemm16_big_kernel<EPI, ACT>), grid, dim3(512), 0, s, g);
   } else {
     // tiles that hold at least one real row and column (the kernel derives its tile
     // coordinates from ceil(n / 128), not from the 256-padded image sizes)
     const dim3 grid((unsigned)(((g.m + kG16M - 1) / kG16M) * ((g.n + kG16N - 1) / kG16N)));
-    hipLaunchKernelGGL((gemm16_kernel<EPI>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm16_kernel<EPI, ACT>), grid, dim3(256), 0, s, g);
   }
 }
 
@@ -888,7 +896,8 @@ static void g16_launch(const Gemm16Args &g, bool big, hipStream_t s) {
 // colsum[n] = sum_k (B * mul)[k, n].  ws from gemm16_workspace_bytes(m, n, k).
 int gemm16_run_ex(const G16Operand &a, const G16Operand &b, int64_t m, int n, int k,
                   const float *bias, int epi, const float *e0, const float *e1, float diag,
-                  float *out, float *colsum, void *ws, hipStream_t s, float *aux = nullptr) {
+                  float *out, float *colsum, void *ws, hipStream_t s, float *aux = nullptr, int act = 0,
+                  float *pre = nullptr) {
   const G16Layout L = g16_layout(m, n, k);
   char *w = static_cast<char *>(ws);
   _Float16 *ah = reinterpret_cast<_Float16 *>(w + L.ah), *al = reinterpret_cast<_Float16 *>(w + L.al);
@@ -902,7 +911,7 @@ int gemm16_run_ex(const G16Operand &a, const G16Operand &b, int64_t m, int n, in
   const char *tv = option("TFRS_GEMM16_TILE");
   const int forced = (tv && *tv) ? atoi(tv) : 0;
   const int64_t big_tiles = (L.mp / kB16M) * (L.np / kB16N);
-  const bool splitk = L.nsplit > 1 && epi == kG16EpiBias && !bias && forced != 128;
+  const bool splitk = L.nsplit > 1 && epi == kG16EpiBias && !bias && !act && !pre && forced != 128;
   const bool big = (forced == 256 || (forced != 128 && big_tiles >= 512) || splitk) && n < (1 << 23);   // (32-bit tile offsets in its epilogue)
   // the 256 x 256 kernel reads K-step-major images (kb = 16 halves): the operand tile of one K
   // step is 256 rows x 32 bytes CONTIGUOUS, so every direct-to-LDS copy instruction moves eight
@@ -943,6 +952,7 @@ int gemm16_run_ex(const G16Operand &a, const G16Operand &b, int64_t m, int n, in
   g.m = m; g.n = n; g.kp = L.kp;
   g.bias = bias; g.x0 = e0; g.x = e1; g.diag = diag; g.out = out; g.aux = aux;
   g.kb = kb; g.mp = L.mp; g.np = L.np;
+  g.act = act; g.pre = pre;
   // large shapes: 256 x 256 tiles with the 4-deep ring; otherwise (few tiles: fill the chip)
   // the 128 x 128 kernel.  TFRS_GEMM16_TILE = 128 | 256 forces one.
   if (splitk) {
@@ -955,6 +965,12 @@ int gemm16_run_ex(const G16Operand &a, const G16Operand &b, int64_t m, int n, in
     const int64_t count = m * (int64_t)n;
     hipLaunchKernelGGL(g16_splitk_reduce_kernel, dim3((unsigned)((count / 4 + 256) / 256)), dim3(256), 0, s,
                        g.out, slices, count, out);
+    TFRS_LAUNCH_CHECK();
+    return TFRS_OK;
+  }
+  if (act || pre) {     // (only the forward products take an activation: Dense and Cross)
+    if (epi == kG16EpiCross) g16_launch<kG16EpiCross, true>(g, big, s);
+    else g16_launch<kG16EpiBias, true>(g, big, s);
     TFRS_LAUNCH_CHECK();
     return TFRS_OK;
   }
@@ -974,6 +990,15 @@ int gemm16_run(const float *a, const float *b, int64_t m, int n, int k, const fl
                float *aux) {
   return gemm16_run_ex({a, nullptr, false}, {b, nullptr, false}, m, n, k, bias,
                        x0 ? kG16EpiCross : kG16EpiBias, x0, x, diag, out, nullptr, ws, s, x0 ? aux : nullptr);
+}
+
+// out = epilogue(act(a @ b + bias)), optionally storing the pre-activation: Dense with a fused activation
+// (x0 == NULL) or Cross with a preactivation / low-rank input (x0, x given): see tfrs_dense_fwd_act / tfrs_cross_fwd_act
+int gemm16_run_act(const float *a, const float *b, int64_t m, int n, int k, const float *bias, int act,
+                   const float *x0, const float *x, float diag, float *out, float *pre, void *ws,
+                   hipStream_t s) {
+  return gemm16_run_ex({a, nullptr, false}, {b, nullptr, false}, m, n, k, bias,
+                       x0 ? kG16EpiCross : kG16EpiBias, x0, x, diag, out, nullptr, ws, s, nullptr, act, pre);
 }
 
 // Cross backward (layers/feature_interaction/dcn.py:151-186 under models/base.py:77), full rank,
@@ -1042,12 +1067,14 @@ size_t gemm16_dense_bwd_workspace_bytes(int64_t batch, int din, int dout) {
 }
 
 // dx = dy W^T (W read as [N = din, K = dout]), dW = x^T dy, db = column sums of dy
+// (addend != NULL: dx = dy W^T + addend, through the CrossDx epilogue with diag = 0)
 int gemm16_dense_bwd(const float *x, const float *kernel, const float *dy, int64_t batch, int din,
-                     int dout, float *dx, float *dkernel, float *dbias, void *ws, hipStream_t s) {
+                     int dout, float *dx, float *dkernel, float *dbias, void *ws, hipStream_t s,
+                     const float *addend) {
   int rc = TFRS_OK;
   if (dx)
-    rc = gemm16_run_ex({dy, nullptr, false}, {kernel, nullptr, true}, batch, din, dout, nullptr, kG16EpiBias,
-                       nullptr, nullptr, 0.0f, dx, nullptr, ws, s);
+    rc = gemm16_run_ex({dy, nullptr, false}, {kernel, nullptr, true}, batch, din, dout, nullptr,
+                       addend ? kG16EpiCrossDx : kG16EpiBias, addend, addend, 0.0f, dx, nullptr, ws, s);
   if (rc != TFRS_OK) return rc;
   if (dkernel)
     return gemm16_run_ex({x, nullptr, true}, {dy, nullptr, false}, din, dout, (int)batch, nullptr,

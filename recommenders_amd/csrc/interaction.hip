@@ -57,6 +57,10 @@ struct GemmArgs {
   // k in [y * kper, min(k, (y + 1) * kper)) and writes its partial product to out + y * m * n
   // (no bias); kper == 0: no split.
   int kper;
+  // fused activation of v = product + bias (common.h kAct*), applied before the epilogue formula; `pre`
+  // (optional, [m, n]) receives v itself -- what the backward differentiates the activation at
+  int act;
+  float *pre;
 };
 
 // AT: `a` holds A^T ([K, M] row-major); BT: `b` holds B^T ([N, K] row-major).  The tiles are
@@ -199,6 +203,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
         if (row >= g.m) continue;
         float v = acc[i][jn][r] + bias;
         const int64_t o = row * g.n + col;
+        if (g.pre) g.pre[o] = v;
+        if (g.act) v = act_apply(g.act, v);
         if (EPI == kEpiCross) {
           const float xv = g.x[o];
           v = g.x0[o] * (v + g.diag * xv) + xv;
@@ -1987,6 +1993,107 @@ extern "C" int tfrs_dense_fwd(const float *x, const float *kernel, const float *
   return launch_gemm(g, kEpiBias, (hipStream_t)stream);
 }
 
+// ---- activations fused into the product's epilogue (round 5; SURVEY 8(b): tfrs_cross_fwd(..., act, ...)) -------
+namespace tfrs {
+size_t gemm16_workspace_bytes(int64_t m, int n, int k);
+int gemm16_run_act(const float *a, const float *b, int64_t m, int n, int k, const float *bias, int act,
+                   const float *x0, const float *x, float diag, float *out, float *pre, void *ws,
+                   hipStream_t s);
+// One pass over the element-wise part of a Cross layer's backward with a (pre)activation, or of a Dense layer's:
+//   s   = act(pre)                  (act == 0: s = pre)
+//   dx0 = dy * (s + diag * x)                                           [optional]
+//   dp  = dy * x0 * act'(pre)       (x0 == NULL: dp = dy * act'(pre))   [optional]
+//   dxd = dy * (1 + diag * x0)      the direct terms of dx              [optional]
+// ref_is_output: `pre` holds y = act(p) instead (relu / sigmoid / tanh: the derivative follows from y).
+__global__ void __launch_bounds__(256) act_pointwise_bwd_kernel(int act, int ref_is_output,
+                                                                const float *__restrict__ pre,
+                                                                const float *__restrict__ dy,
+                                                                const float *__restrict__ x0,
+                                                                const float *__restrict__ x, float diag,
+                                                                int64_t count, float *__restrict__ dp,
+                                                                float *__restrict__ dx0,
+                                                                float *__restrict__ dxd) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    const float p = pre[i], g = dy[i];
+    const float x0v = x0 ? x0[i] : 1.0f;
+    if (dp) dp[i] = g * x0v * (ref_is_output ? act_grad_from_output(act, p) : act_grad(act, p));
+    if (dx0) dx0[i] = g * ((ref_is_output ? p : act_apply(act, p)) + (diag != 0.0f ? diag * x[i] : 0.0f));
+    if (dxd) dxd[i] = g * (1.0f + diag * x0v);
+  }
+}
+}  // namespace tfrs
+
+extern "C" int tfrs_act_pointwise_bwd(int act, int ref_is_output, const float *pre, const float *dy,
+                                      const float *x0, const float *x, float diag_scale, int64_t count,
+                                      float *dp, float *dx0, float *dxd, void *stream) {
+  TFRS_CHECK_ARG(act >= kActNone && act <= kActGelu, "act_pointwise_bwd: unknown activation %d", act);
+  TFRS_CHECK_ARG(count >= 0, "act_pointwise_bwd: bad count");
+  TFRS_CHECK_ARG(!ref_is_output || act == kActNone || act == kActRelu || act == kActSigmoid || act == kActTanh,
+                 "act_pointwise_bwd: the derivative of activation %d needs the pre-activation", act);
+  if (count == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(pre && dy && (dp || dx0 || dxd), "act_pointwise_bwd: NULL pointer");
+  TFRS_CHECK_ARG(!(dx0 && diag_scale != 0.0f) || x, "act_pointwise_bwd: diag_scale needs x");
+  TFRS_CHECK_ARG(!dxd || x0, "act_pointwise_bwd: dxd needs x0");
+  const unsigned blocks = (unsigned)std::min<int64_t>((count + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(act_pointwise_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, act,
+                     ref_is_output, pre, dy, x0, x, diag_scale, count, dp, dx0, dxd);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
+// out = act(x @ kernel + bias); pre_out (optional) receives x @ kernel + bias.  f16 != 0: split-fp16 MFMA
+// (workspace from tfrs_gemm_f16_workspace_bytes(batch, dout, din)).
+extern "C" int tfrs_dense_fwd_act(const float *x, const float *kernel, const float *bias, int64_t batch,
+                                  int din, int dout, int act, float *out, float *pre_out, int f16,
+                                  void *workspace, size_t workspace_bytes, void *stream) {
+  TFRS_CHECK_ARG(batch >= 0 && din >= 1 && dout >= 1, "dense_fwd_act: bad shape");
+  TFRS_CHECK_ARG(act >= kActNone && act <= kActGelu, "dense_fwd_act: unknown activation %d", act);
+  if (batch == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(x && kernel && out, "dense_fwd_act: NULL pointer");
+  if (f16) {
+    TFRS_CHECK_ARG(workspace != nullptr, "dense_fwd_act: NULL workspace");
+    if (workspace_bytes < gemm16_workspace_bytes(batch, dout, din)) {
+      set_error("dense_fwd_act: workspace too small");
+      return TFRS_ENOMEM;
+    }
+    return gemm16_run_act(x, kernel, batch, dout, din, bias, act, nullptr, nullptr, 0.0f, out, pre_out,
+                          workspace, (hipStream_t)stream);
+  }
+  GemmArgs g = {};
+  g.a = x; g.b = kernel; g.m = batch; g.n = dout; g.k = din;
+  g.bias = bias; g.out = out; g.act = act; g.pre = pre_out;
+  return launch_gemm(g, kEpiBias, (hipStream_t)stream);
+}
+
+// Cross.call with a preactivation and / or a low-rank input (dcn.py:173-186):
+//   y = x0 * (act(a @ kernel + bias) + diag_scale * x) + x,   a[batch, ka] = x (full rank, ka == d) or x @ U
+// pre_out (optional) receives p = a @ kernel + bias for the backward (tfrs_act_pointwise_bwd + tfrs_dense_bwd[_add]).
+extern "C" int tfrs_cross_fwd_act(const float *x0, const float *x, const float *a, int ka,
+                                  const float *kernel, const float *bias, float diag_scale, int act,
+                                  int64_t batch, int d, float *y, float *pre_out, int f16,
+                                  void *workspace, size_t workspace_bytes, void *stream) {
+  TFRS_CHECK_ARG(batch >= 0 && d >= 1 && ka >= 1, "cross_fwd_act: bad shape");
+  TFRS_CHECK_ARG(diag_scale >= 0.0f, "`diag_scale` should be non-negative. Got `diag_scale` = %g",
+                 (double)diag_scale);
+  TFRS_CHECK_ARG(act >= kActNone && act <= kActGelu, "cross_fwd_act: unknown activation %d", act);
+  if (batch == 0) return TFRS_OK;
+  TFRS_CHECK_ARG(x0 && x && a && kernel && y, "cross_fwd_act: NULL pointer");
+  if (f16) {
+    TFRS_CHECK_ARG(workspace != nullptr, "cross_fwd_act: NULL workspace");
+    if (workspace_bytes < gemm16_workspace_bytes(batch, d, ka)) {
+      set_error("cross_fwd_act: workspace too small");
+      return TFRS_ENOMEM;
+    }
+    return gemm16_run_act(a, kernel, batch, d, ka, bias, act, x0, x, diag_scale, y, pre_out, workspace,
+                          (hipStream_t)stream);
+  }
+  GemmArgs g = {};
+  g.a = a; g.b = kernel; g.m = batch; g.n = d; g.k = ka;
+  g.bias = bias; g.x0 = x0; g.x = x; g.diag = diag_scale; g.out = y; g.act = act; g.pre = pre_out;
+  return launch_gemm(g, kEpiCross, (hipStream_t)stream);
+}
+
 // ---- split-fp16 variants (gemm16.hip): same results to f32 accuracy, ~3x the rate on large
 // products; the caller provides the workspace for the operand images --------------------------
 namespace tfrs {
@@ -1999,7 +2106,11 @@ size_t gemm16_dense_bwd_workspace_bytes(int64_t batch, int din, int dout);
 int gemm16_scores(const float *q, const float *c, int64_t nq, int nc, int d, float *out, void *ws,
                   hipStream_t s);
 int gemm16_dense_bwd(const float *x, const float *kernel, const float *dy, int64_t batch, int din,
-                     int dout, float *dx, float *dkernel, float *dbias, void *ws, hipStream_t s);
+                     int dout, float *dx, float *dkernel, float *dbias, void *ws, hipStream_t s,
+                     const float *addend = nullptr);
+int gemm16_run_act(const float *a, const float *b, int64_t m, int n, int k, const float *bias, int act,
+                   const float *x0, const float *x, float diag, float *out, float *pre, void *ws,
+                   hipStream_t s);
 int gemm16_cross_bwd(const float *x0, const float *x, const float *kernel, const float *bias,
                      float diag, const float *dy, int64_t batch, int d, float *dx0, float *dx,
                      float *dkernel, float *dbias, void *ws, hipStream_t s, const float *u = nullptr);
@@ -2133,9 +2244,21 @@ extern "C" size_t tfrs_dense_bwd_workspace_bytes(int64_t batch, int din, int dou
   return ((size_t)((batch + kDbSlab - 1) / kDbSlab) * dout * 4 + 255) / 256 * 256 + splitk_bytes(din, dout, batch) + 256;
 }
 
+extern "C" int tfrs_dense_bwd_add(const float *x, const float *kernel, const float *dy, const float *addend,
+                                  int64_t batch, int din, int dout, float *dx, float *dkernel, float *dbias,
+                                  int f16, void *workspace, size_t workspace_bytes, void *stream);
+
 extern "C" int tfrs_dense_bwd(const float *x, const float *kernel, const float *dy, int64_t batch,
                               int din, int dout, float *dx, float *dkernel, float *dbias,
                               int f16, void *workspace, size_t workspace_bytes, void *stream) {
+  return tfrs_dense_bwd_add(x, kernel, dy, nullptr, batch, din, dout, dx, dkernel, dbias, f16, workspace,
+                            workspace_bytes, stream);
+}
+
+// the same with dx = dy @ kernel^T + addend[batch, din] (the direct terms of a Cross layer's input gradient)
+extern "C" int tfrs_dense_bwd_add(const float *x, const float *kernel, const float *dy, const float *addend,
+                                  int64_t batch, int din, int dout, float *dx, float *dkernel, float *dbias,
+                                  int f16, void *workspace, size_t workspace_bytes, void *stream) {
   TFRS_CHECK_ARG(batch >= 0 && din >= 1 && dout >= 1, "dense_bwd: bad shape");
   if (batch == 0) return TFRS_OK;
   TFRS_CHECK_ARG(x && kernel && dy && workspace, "dense_bwd: NULL pointer");
@@ -2145,13 +2268,18 @@ extern "C" int tfrs_dense_bwd(const float *x, const float *kernel, const float *
     return TFRS_ENOMEM;
   }
   hipStream_t s = (hipStream_t)stream;
-  if (f16) return gemm16_dense_bwd(x, kernel, dy, batch, din, dout, dx, dkernel, dbias, workspace, s);
+  if (f16) return gemm16_dense_bwd(x, kernel, dy, batch, din, dout, dx, dkernel, dbias, workspace, s, addend);
   int rc;
   GemmArgs g = {};
-  if (dx) {        // dx[b, i] = sum_j dy[b, j] W[i, j]
+  if (dx) {        // dx[b, i] = sum_j dy[b, j] W[i, j] (+ addend[b, i]: CrossDx epilogue with diag = 0)
     g.a = dy; g.b = kernel; g.m = batch; g.n = din; g.k = dout; g.out = dx;
-    hipLaunchKernelGGL((gemm_kernel<kEpiBias, false, true>),
-                       dim3((unsigned)(((batch + kBM - 1) / kBM) * ((din + kBN - 1) / kBN))), dim3(256), 0, s, g);
+    const dim3 grid((unsigned)(((batch + kBM - 1) / kBM) * ((din + kBN - 1) / kBN)));
+    if (addend) {
+      g.x0 = addend; g.x = addend; g.diag = 0.0f;
+      hipLaunchKernelGGL((gemm_kernel<kEpiCrossDx, false, true>), grid, dim3(256), 0, s, g);
+    } else {
+      hipLaunchKernelGGL((gemm_kernel<kEpiBias, false, true>), grid, dim3(256), 0, s, g);
+    }
     TFRS_LAUNCH_CHECK();
   }
   if (dkernel) {   // dW[i, j] = sum_b x[b, i] dy[b, j]

@@ -3,8 +3,9 @@
 ``MLP(units, use_bias=True, activation="relu", final_activation=None)`` is a stack of Keras
 ``Dense`` layers: ``y = act(x @ kernel + bias)`` with ``kernel`` in ``[in, out]`` layout,
 ``glorot_uniform`` kernel / ``zeros`` bias initialisers and lazy building on the first call.
-Every matmul (forward and both backward GEMMs) runs on the f32-MFMA GEMM kernel
-(``tfrs_dense_fwd``); the activations are element-wise torch ops.
+Every matmul (forward and both backward GEMMs) runs on the HIP GEMM kernels; a named activation is applied
+in the forward product's epilogue (``tfrs_dense_fwd_act``) and differentiated in one element-wise pass of the
+backward (``tfrs_act_pointwise_bwd``); only a user callable stays a torch op.
 """
 
 import math
@@ -12,7 +13,7 @@ from typing import Callable, List, Optional, Union
 
 import torch
 
-from recommenders_amd.layers.feature_interaction.dcn import _DenseFn
+from recommenders_amd.layers.feature_interaction.dcn import _DenseFn, activation_code, dense_act
 
 Activation = Optional[Union[str, Callable[[torch.Tensor], torch.Tensor]]]
 
@@ -42,6 +43,8 @@ class Dense(torch.nn.Module):
     self.units = int(units)
     self.use_bias = use_bias
     self._activation = get_activation(activation)
+    # a Keras activation NAME runs in the product's epilogue (tfrs_dense_fwd_act); a callable stays a torch op
+    self._act_code = activation_code("linear" if activation is None else activation)
     self._device = device
     self.kernel: Optional[torch.nn.Parameter] = None
     self.bias: Optional[torch.nn.Parameter] = None
@@ -57,7 +60,10 @@ class Dense(torch.nn.Module):
     if self.kernel is None:
       self.build(x.shape[-1], self._device or x.device)
     lead = x.shape[:-1]
-    y = _DenseFn.apply(x.reshape(-1, x.shape[-1]).to(torch.float32), self.kernel, self.bias)
+    x2 = x.reshape(-1, x.shape[-1]).to(torch.float32)
+    if self._act_code is not None:
+      return dense_act(x2, self.kernel, self.bias, self._act_code).reshape(*lead, self.units)
+    y = _DenseFn.apply(x2, self.kernel, self.bias)
     return self._activation(y).reshape(*lead, self.units)
 
 

@@ -31,6 +31,22 @@ def _get_activation(spec):
   raise ValueError(f"Unknown activation: {spec!r}")
 
 
+# Activations the GEMM epilogues apply themselves (include/tfrs_hip.h TFRS_ACT_*): a Keras activation NAME runs
+# fused in the product's epilogue, its derivative in the backward's one element-wise pass
+# (tfrs_act_pointwise_bwd); a user CALLABLE is opaque and keeps the torch route.
+_ACT_CODES = {None: 0, "linear": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "swish": 4, "silu": 4, "gelu": 5}
+_ACT_FROM_OUTPUT = (1, 2, 3)      # relu / sigmoid / tanh: act'(p) follows from y = act(p): y is what is saved
+
+
+def activation_code(spec) -> Optional[int]:
+  """The library's code of a Keras activation name; ``None`` for a callable (not fusable)."""
+  if callable(spec):
+    return None
+  if spec in _ACT_CODES:
+    return _ACT_CODES[spec]
+  raise ValueError(f"Unknown activation: {spec!r}")
+
+
 def _initialize(spec: Union[str, Callable], shape, device) -> torch.Tensor:
   """Keras initialiser names used by the reference: truncated_normal (stddev 0.05,
   resampled beyond 2 sigma), zeros, ones, glorot_uniform."""
@@ -145,6 +161,106 @@ class _DenseFn(torch.autograd.Function):
     x, kernel = ctx.saved_tensors
     return dense_backward(x, kernel, dy, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                           ctx.has_bias and ctx.needs_input_grad[2])
+
+
+def _pointwise_bwd(act: int, ref_is_output: bool, ref, dy, x0=None, x=None, diag: float = 0.0,
+                  want_dp=True, want_dx0=False, want_dxd=False):
+  """``tfrs_act_pointwise_bwd``: dp = dy * x0 * act'(ref), dx0 = dy * (act(ref) + diag * x),
+  dxd = dy * (1 + diag * x0) in one pass (each optional)."""
+  dy = dy.contiguous()
+  dp = torch.empty_like(dy) if want_dp else None
+  dx0 = torch.empty_like(dy) if want_dx0 else None
+  dxd = torch.empty_like(dy) if want_dxd else None
+  _lib.check(_lib.load().tfrs_act_pointwise_bwd(
+      int(act), 1 if ref_is_output else 0, _lib.ptr(ref), _lib.ptr(dy), _lib.ptr(x0), _lib.ptr(x), float(diag),
+      dy.numel(), _lib.ptr(dp), _lib.ptr(dx0), _lib.ptr(dxd), _lib.current_stream()))
+  return dp, dx0, dxd
+
+
+class _DenseActFn(torch.autograd.Function):
+  """``act(x @ kernel + bias)`` with the activation in the product's epilogue (``tfrs_dense_fwd_act``); backward:
+  one element-wise pass ``dz = dy * act'`` (from the saved output for relu / sigmoid / tanh, else from the saved
+  pre-activation), then the two products of ``tfrs_dense_bwd``."""
+
+  @staticmethod
+  def forward(ctx, x, kernel, bias, act):
+    x, kernel = x.contiguous(), kernel.contiguous()
+    m, k, n = x.shape[0], kernel.shape[0], kernel.shape[1]
+    out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    need_grad = any(ctx.needs_input_grad[:3])
+    from_output = act in _ACT_FROM_OUTPUT
+    pre = torch.empty_like(out) if (need_grad and not from_output) else None
+    lib = _lib.load()
+    f16 = 1 if _use_f16_gemm(m, n, k) else 0
+    ws = _gemm_workspace(lib.tfrs_gemm_f16_workspace_bytes(m, n, k), x.device) if f16 else None
+    _lib.check(lib.tfrs_dense_fwd_act(
+        _lib.ptr(x), _lib.ptr(kernel), _lib.ptr(bias), m, k, n, int(act), _lib.ptr(out), _lib.ptr(pre), f16,
+        _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.current_stream()))
+    ctx.save_for_backward(x, kernel, out if from_output else pre)
+    ctx.act, ctx.from_output, ctx.has_bias = int(act), from_output, bias is not None
+    return out
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, kernel, ref = ctx.saved_tensors
+    dz, _, _ = _pointwise_bwd(ctx.act, ctx.from_output, ref, dy)
+    dx, dk, db = dense_backward(x, kernel, dz, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                ctx.has_bias and ctx.needs_input_grad[2])
+    return dx, dk, db, None
+
+
+def dense_act(x: torch.Tensor, kernel: torch.Tensor, bias: Optional[torch.Tensor], act: int) -> torch.Tensor:
+  """Keras ``Dense(activation=name)`` on the HIP kernels: plain product for ``act == 0``."""
+  if act == 0:
+    return _DenseFn.apply(x, kernel, bias)
+  return _DenseActFn.apply(x, kernel, bias, act)
+
+
+class _CrossActFn(torch.autograd.Function):
+  """``y = x0 * (act(a @ K + b) + diag * x) + x`` (``tfrs_cross_fwd_act``; dcn.py:173-186): ``a`` is ``x`` itself
+  (full rank, ``K = W``) or ``h = x @ U`` computed by the caller (low rank, ``K = V``).  The forward's epilogue also
+  stores ``p = a @ K + b``; the backward is one element-wise pass -- dp = dy * x0 * act'(p),
+  dx0 = dy * (act(p) + diag * x), dxd = dy * (1 + diag * x0) -- and the products of ``tfrs_dense_bwd``:
+  full rank ``dx = dp K^T + dxd`` (the addend rides in the product's epilogue), ``dK = x^T dp``; low rank
+  ``dh = dp K^T``, ``dK = h^T dp`` and ``dxd`` is the gradient of ``x``'s direct terms."""
+
+  @staticmethod
+  def forward(ctx, x0, x, a, kernel, bias, diag, act, full_rank):
+    x0, x, kernel = x0.contiguous(), x.contiguous(), kernel.contiguous()
+    a = x if full_rank else a.contiguous()
+    b, d, ka = x0.shape[0], x0.shape[1], kernel.shape[0]
+    y = torch.empty_like(x0)
+    need_grad = any(ctx.needs_input_grad[:5])
+    pre = torch.empty_like(x0) if need_grad else None
+    lib = _lib.load()
+    f16 = 1 if _use_f16_gemm(b, d, ka) else 0
+    ws = _gemm_workspace(lib.tfrs_gemm_f16_workspace_bytes(b, d, ka), x0.device) if f16 else None
+    _lib.check(lib.tfrs_cross_fwd_act(
+        _lib.ptr(x0), _lib.ptr(x), _lib.ptr(a), ka, _lib.ptr(kernel), _lib.ptr(bias), float(diag), int(act),
+        b, d, _lib.ptr(y), _lib.ptr(pre), f16, _lib.ptr(ws), ws.numel() if ws is not None else 0,
+        _lib.current_stream()))
+    ctx.save_for_backward(x0, x, a, kernel, pre)
+    ctx.diag, ctx.act, ctx.full_rank, ctx.has_bias = float(diag), int(act), bool(full_rank), bias is not None
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    x0, x, a, kernel, pre = ctx.saved_tensors
+    dp, dx0, dxd = _pointwise_bwd(ctx.act, False, pre, dy, x0, x, ctx.diag, True, True, True)
+    b, d, ka = x0.shape[0], x0.shape[1], kernel.shape[0]
+    lib = _lib.load()
+    f16 = 1 if _use_f16_gemm(b, ka, d) else 0
+    alloc = torch.zeros_like if b == 0 else torch.empty_like
+    da = torch.empty((b, ka), dtype=torch.float32, device=x0.device)
+    dk = alloc(kernel)
+    db = (torch.zeros if b == 0 else torch.empty)((d,), dtype=torch.float32, device=x0.device) if ctx.has_bias else None
+    ws = _gemm_workspace(lib.tfrs_dense_bwd_workspace_bytes(b, ka, d, f16), x0.device)
+    _lib.check(lib.tfrs_dense_bwd_add(
+        _lib.ptr(a), _lib.ptr(kernel), _lib.ptr(dp), _lib.ptr(dxd) if ctx.full_rank else None, b, ka, d,
+        _lib.ptr(da), _lib.ptr(dk), _lib.ptr(db), f16, _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+    if ctx.full_rank:
+      return dx0, da, None, dk, db, None, None, None      # da = dp K^T + dxd is the whole gradient of x
+    return dx0, dxd, da, dk, db, None, None, None
 
 
 class _CrossFn(torch.autograd.Function):
@@ -266,13 +382,17 @@ class Cross(torch.nn.Module):
     x0 = x0.to(torch.float32)
     x = x.to(torch.float32)
     diag = float(self._diag_scale or 0.0)
-    if self._preactivation is None:
+    act = activation_code(self._preactivation_spec)
+    if act == 0 and self._projection_dim is None:
+      return _CrossFn.apply(x0, x, self.kernel, self.bias, diag)       # :173-186 fused, linear full rank
+    if act is not None:
+      # a named preactivation and / or the low-rank form: activation and cross formula in the product's epilogue
       if self._projection_dim is None:
-        return _CrossFn.apply(x0, x, self.kernel, self.bias, diag)     # :173-186 fused
+        return _CrossActFn.apply(x0, x, None, self.kernel, self.bias, diag, act, True)
       h = _DenseFn.apply(x, self.kernel_u, None)                       # :176
-      return _LowRankCrossFn.apply(x0, x, h, self.kernel_v, self.bias, diag)
-    # non-linear preactivation: GEMM on the HIP kernel, activation + cross formula
-    # element-wise (the reference's unfused order, :173-186)
+      return _CrossActFn.apply(x0, x, h, self.kernel_v, self.bias, diag, act, False)
+    # a user CALLABLE as preactivation is opaque: product on the HIP kernel, the callable and the cross
+    # formula element-wise in torch (the reference's unfused order, :173-186)
     if self._projection_dim is None:
       prod = self._preactivation(_DenseFn.apply(x, self.kernel, self.bias))
     else:
@@ -300,32 +420,3 @@ class Cross(torch.nn.Module):
   @classmethod
   def from_config(cls, config):
     return cls(**config)
-
-
-class _LowRankCrossFn(torch.autograd.Function):
-  """y = x0 * (h @ V + b + diag * x) + x  with h = x @ U computed by the caller."""
-
-  @staticmethod
-  def forward(ctx, x0, x, h, kernel_v, bias, diag):
-    x0, x, h, kernel_v = x0.contiguous(), x.contiguous(), h.contiguous(), kernel_v.contiguous()
-    y = torch.empty_like(x0)
-    _lib.check(_lib.load().tfrs_cross_fwd_ex(
-        _lib.ptr(x0), _lib.ptr(x), _lib.ptr(h), h.shape[1], _lib.ptr(kernel_v),
-        _lib.ptr(bias), float(diag), x0.shape[0], x0.shape[1], _lib.ptr(y),
-        _lib.current_stream()))
-    ctx.save_for_backward(x0, x, h, kernel_v, bias)
-    ctx.diag = float(diag)
-    return y
-
-  @staticmethod
-  def backward(ctx, dy):
-    x0, x, h, kernel_v, bias = ctx.saved_tensors
-    dy = dy.contiguous()
-    z = dense(h, kernel_v, bias)
-    if ctx.diag:
-      z = z + ctx.diag * x
-    dz = dy * x0
-    dx0 = dy * z
-    dx = dy + (ctx.diag * dz if ctx.diag else 0.0)
-    dh, dv, db = dense_backward(h, kernel_v, dz, True, True, bias is not None)
-    return dx0, dx, dh, dv, db, None

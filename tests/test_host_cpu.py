@@ -705,9 +705,15 @@ def _device_asm(source):
 @pytest.mark.parametrize("source,patterns,max_vgprs,agpr_spills_ok", [
     # the fp16 filter kernel of the headline path: four waves per SIMD
     ("topk_scan16.hip", ("scan16f_kernelILi64ELi8ELi2E", "scan16f_kernelILi32ELi8ELi2E"), 128, False),
+    # ... and its 16-wave form (two query tiles on one stage buffer, two stages per barrier period: the
+    # default for batches of at least two tiles up to dim 64) -- one workgroup per CU, still four waves per SIMD
+    ("topk_scan16.hip", ("scan16f_kernelILi64ELi16ELi2ELi2E", "scan16f_kernelILi32ELi16ELi2ELi2E",
+                         "scan16f_kernelILi16ELi16ELi2ELi2E"), 128, False),
     # the 256 x 256 split-fp16 GEMM (one 8-wave workgroup per CU: two waves per SIMD), all epilogues
-    ("gemm16.hip", ("gemm16_big_kernelILi0E", "gemm16_big_kernelILi1E", "gemm16_big_kernelILi2E",
-                    "gemm16_big_kernelILi3E"), 256, False),
+    # (and the two instantiations that apply an activation in the epilogue)
+    ("gemm16.hip", ("gemm16_big_kernelILi0ELb0E", "gemm16_big_kernelILi1ELb0E", "gemm16_big_kernelILi2ELb0E",
+                    "gemm16_big_kernelILi3ELb0E", "gemm16_big_kernelILi0ELb1E", "gemm16_big_kernelILi1ELb1E"),
+     256, False),
     # the DotInteraction producer / consumer kernels: backward one 8-wave workgroup per CU, forward two
     ("interaction.hip", ("dot_interaction_bwd_h16_kernelILi7ELi5ELi4E", "dot_interaction_bwd_h16_kernelILi7ELi6ELi4E"), 256, False),
     ("interaction.hip", ("dot_interaction_fwd_pc_kernelILi4ELi4E",), 128, False),
@@ -742,7 +748,7 @@ def test_hot_kernel_register_budgets(source, patterns, max_vgprs, agpr_spills_ok
     ("interaction.hip", "dot_interaction_bwd_h16_kernelILi7ELi5ELi4E", 27),
     ("interaction.hip", "dot_interaction_fwd_pc_kernelILi4ELi4E", 12),
     # the Cross epilogue issues the 24 loads of eight rows of an accumulator tile before it waits
-    ("gemm16.hip", "gemm16_big_kernelILi1E", 16),
+    ("gemm16.hip", "gemm16_big_kernelILi1ELb0E", 16),
     # single-pass row images: a wave's share of four rows (14 + 14 16-byte loads) in flight
     ("gemm16.hip", "g16_prep_rows_ksm1_kernelILi8ELb0E", 8),
 ])

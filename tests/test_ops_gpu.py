@@ -504,6 +504,71 @@ def test_cross_random_fwd_bwd(b, d, p, gemm_mode):
       float_gate(f"cross_{gemm_mode}.{what}", _np(got), want, yard, GATE_CROSS["grad"])
 
 
+@pytest.mark.parametrize("act", ["relu", "sigmoid", "tanh", "swish", "gelu"])
+@pytest.mark.parametrize("p", [None, 24])
+def test_cross_named_preactivation_is_fused_and_matches_float64(act, p, gemm_mode):
+  """dcn.py:173-186 with `preactivation=<Keras name>`: the activation runs in the product's epilogue
+  (tfrs_cross_fwd_act), the backward is one element-wise pass + the products of tfrs_dense_bwd[_add] -- no torch
+  activation / element-wise op.  y and every gradient against a float64 restatement (torch-CPU autograd on
+  x0 * (act(x W + b) + diag x) + x, Keras gelu = the exact erf form), full rank and low rank, both GEMM paths;
+  relative to the largest entry of each tensor (2e-5)."""
+  from recommenders_amd.layers.feature_interaction import Cross, dcn
+  rng = np.random.default_rng(len(act) + (p or 0))
+  b, d, diag = 700, 160, 0.3
+  x0 = rng.normal(size=(b, d)).astype(np.float32)
+  x = rng.normal(size=(b, d)).astype(np.float32)
+  dy = rng.normal(size=(b, d)).astype(np.float32)
+  layer = Cross(projection_dim=p, diag_scale=diag, bias_initializer="ones", preactivation=act)
+  tx0, tx = _t(x0).requires_grad_(True), _t(x).requires_grad_(True)
+  assert dcn.activation_code(act) in (1, 2, 3, 4, 5)
+  y = layer(tx0, tx)
+  assert type(y.grad_fn).__name__ == "_CrossActFnBackward"           # the fused path, not torch glue
+  y.backward(_t(dy))
+  f64 = {"relu": torch.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh, "swish": torch.nn.functional.silu,
+         "gelu": lambda z: torch.nn.functional.gelu(z, approximate="none")}[act]
+  params = ([layer.kernel] if p is None else [layer.kernel_u, layer.kernel_v]) + [layer.bias]
+  rx0, rx = torch.tensor(x0, dtype=torch.float64, requires_grad=True), torch.tensor(x, dtype=torch.float64, requires_grad=True)
+  rp = [prm.detach().cpu().double().requires_grad_(True) for prm in params]
+  prod = (rx @ rp[0] if p is None else (rx @ rp[0]) @ rp[1]) + rp[-1]
+  ry = rx0 * (f64(prod) + diag * rx) + rx
+  ry.backward(torch.tensor(dy, dtype=torch.float64))
+  pairs = [("y", y, ry), ("dx0", tx0.grad, rx0.grad), ("dx", tx.grad, rx.grad)] + [
+      ("dparam%d" % i, prm.grad, r.grad) for i, (prm, r) in enumerate(zip(params, rp))]
+  for name, got, want in pairs:
+    w = want.detach().numpy()
+    float_gate(f"cross_act_{gemm_mode}.{name}", _np(got), w, np.full_like(w, np.abs(w).max()), 2e-5)
+
+
+@pytest.mark.parametrize("act", ["relu", "sigmoid", "tanh", "gelu"])
+def test_mlp_named_activations_are_fused_and_match_float64(act, gemm_mode):
+  """layers/blocks.py:46-59 `Dense(activation=<name>)`: activation in the epilogue (tfrs_dense_fwd_act), its
+  derivative in one element-wise pass of the backward; forward, input and weight gradients against float64."""
+  import recommenders_amd as tfrs
+  rng = np.random.default_rng(len(act))
+  b, din = 600, 140
+  x = rng.normal(size=(b, din)).astype(np.float32)
+  mlp = tfrs.layers.blocks.MLP(units=[192, 130, 3], activation=act, final_activation="sigmoid")
+  tx = _t(x).requires_grad_(True)
+  out = mlp(tx)
+  dy = rng.normal(size=(b, 3)).astype(np.float32)
+  out.backward(_t(dy))
+  f64 = {"relu": torch.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh,
+         "gelu": lambda z: torch.nn.functional.gelu(z, approximate="none")}[act]
+  rx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+  rk = [l.kernel.detach().cpu().double().requires_grad_(True) for l in mlp._sublayers]
+  rb = [l.bias.detach().cpu().double().requires_grad_(True) for l in mlp._sublayers]
+  h = rx
+  for i in range(3):
+    h = (f64 if i < 2 else torch.sigmoid)(h @ rk[i] + rb[i])
+  h.backward(torch.tensor(dy, dtype=torch.float64))
+  pairs = [("out", out, h), ("dx", tx.grad, rx.grad)]
+  for i, l in enumerate(mlp._sublayers):
+    pairs += [("dk%d" % i, l.kernel.grad, rk[i].grad), ("db%d" % i, l.bias.grad, rb[i].grad)]
+  for name, got, want in pairs:
+    w = want.detach().numpy()
+    float_gate(f"mlp_act_{gemm_mode}.{name}", _np(got), w, np.full_like(w, np.abs(w).max()), 2e-5)
+
+
 @pytest.mark.parametrize("tile", ["128", "256"])
 @pytest.mark.parametrize("m,k,n,sa,sb", [(1000, 300, 200, 1.0, 1.0), (257, 1030, 130, 1e-3, 50.0),
                                          (2048, 2048, 512, 1.0, 0.02), (129, 64, 129, 7.0, 1.0),
