@@ -427,6 +427,20 @@ int tfrs_inbatch_softmax_ce_bwd(const float *q, const float *c, int64_t nq, int6
                                 void *stream);
 
 /* ------------------------------------------------------------------------- *
+ * Keras CategoricalCrossentropy(from_logits=True, reduction=SUM) on an EXPLICIT logits matrix
+ * (tasks/retrieval.py:86-87, :210) -- only for the Retrieval paths that must build [nq, nc] (multi-head queries
+ * :172-176, dims above TFRS_MAX_DIM, batch metrics / hard negatives after a logit adjustment :205-208); the default
+ * loss is the fused tfrs_inbatch_softmax_ce_*.  labels[nq, nc] as the reference builds them (:185, loss.py:108-109).
+ *   fwd: row_loss[i] = w_i * (lse_i * sum_j y_ij - sum_j y_ij s_ij); lse[nq], ysum[nq] are kept for the backward
+ *   bwd: dlogits[i, j] = grad_scale[0] * w_i * (softmax(S_i)_j * ysum_i - y_ij)   (grad_scale: device scalar)
+ * ------------------------------------------------------------------------- */
+int tfrs_logits_ce_fwd(const float *logits, const float *labels, int64_t nq, int64_t nc,
+                       const float *sample_weight, float *row_loss, float *lse, float *ysum, void *stream);
+int tfrs_logits_ce_bwd(const float *logits, const float *labels, int64_t nq, int64_t nc,
+                       const float *sample_weight, const float *lse, const float *ysum,
+                       const float *grad_scale, float *dlogits, void *stream);
+
+/* ------------------------------------------------------------------------- *
  * Cross.call (layers/feature_interaction/dcn.py:151-186), full rank, linear
  * preactivation:  y = x0 * (x @ kernel + bias + diag_scale * x) + x
  * kernel[d, d] is Keras Dense layout [in, out]; bias may be NULL.

@@ -88,6 +88,8 @@ SIGNATURES = {
                                             P, P, P, P, c_size_t, P]),
     "tfrs_inbatch_softmax_ce_bwd": (c_int, [P, P, c_i64, c_i64, c_int, P, c_float, P, P, P,
                                             P, P, P, P, P, c_size_t, c_int, P]),
+    "tfrs_logits_ce_fwd": (c_int, [P, P, c_i64, c_i64, P, P, P, P, P]),
+    "tfrs_logits_ce_bwd": (c_int, [P, P, c_i64, c_i64, P, P, P, P, P, P]),
     "tfrs_cross_fwd": (c_int, [P, P, P, P, c_float, c_i64, c_int, P, P]),
     "tfrs_cross_fwd_ex": (c_int, [P, P, P, c_int, P, P, c_float, c_i64, c_int, P, P]),
     "tfrs_cross_bwd_workspace_bytes": (c_size_t, [c_i64, c_int, c_int]),

@@ -35,6 +35,7 @@ SOURCES = [
     "hashing.hip",
     "softmax.hip",
     "softmax16.hip",
+    "logits_ce.hip",
     "interaction.hip",
     "gemm16.hip",
 ]

@@ -3,7 +3,8 @@
 In the fused training path these transforms are folded into the softmax kernel's logit
 function (``csrc/softmax.hip``: ``make_logit``).  The classes below keep the reference's
 public layer names for code that applies them to an explicit ``[B, C]`` logits tensor
-(e.g. batch metrics); they are element-wise / tiny-top-k glue on torch tensors.
+(e.g. batch metrics); the element-wise ones are torch glue, the top-k of ``HardNegativeMining`` runs the
+library's selection kernel.
 """
 
 from typing import Tuple
@@ -13,6 +14,25 @@ import torch
 
 MAX_FLOAT = float(np.finfo(np.float32).max / 100.0)   # loss.py:22
 MIN_FLOAT = float(np.finfo(np.float32).min / 100.0)   # loss.py:23
+
+
+def _topk_columns(keyed: torch.Tensor, k: int) -> torch.Tensor:
+  """Column indices of the ``k`` largest entries of every row (``tf.math.top_k(..., sorted=False)`` of
+  loss.py:104-105; here sorted, ties to the lower column) through the library's score-block selection
+  (``tfrs_topk_update_from_scores``) -- rows of any width, ``k`` up to the library's page size."""
+  import ctypes
+  from recommenders_amd import _lib
+  keyed = keyed.detach().contiguous().to(torch.float32)
+  nq, nc = keyed.shape
+  if not keyed.is_cuda or k > 1024 or nc > 0x7FFFFFFF:
+    raise ValueError("HardNegativeMining: needs a GPU tensor and num_hard_negatives + 1 <= 1024")
+  vals = torch.empty((nq, k), dtype=torch.float32, device=keyed.device)
+  cols = torch.empty((nq, k), dtype=torch.int32, device=keyed.device)
+  new_len = ctypes.c_int32(0)
+  _lib.check(_lib.load().tfrs_topk_update_from_scores(
+      _lib.ptr(keyed), nq, nc, nc, 0, k, _lib.ptr(vals), _lib.ptr(cols), 0, ctypes.byref(new_len),
+      _lib.current_stream()))
+  return cols.long()
 
 
 class HardNegativeMining(torch.nn.Module):
@@ -26,7 +46,7 @@ class HardNegativeMining(torch.nn.Module):
   def forward(self, logits: torch.Tensor, labels: torch.Tensor
               ) -> Tuple[torch.Tensor, torch.Tensor]:
     num_sampled = min(self._num_hard_negatives + 1, logits.shape[1])   # :91
-    _, cols = torch.topk(logits + labels * MAX_FLOAT, k=num_sampled, dim=1)   # :104-105
+    cols = _topk_columns(logits + labels * MAX_FLOAT, num_sampled)     # :104-105
     return torch.gather(logits, 1, cols), torch.gather(labels, 1, cols)       # :108-109
 
 

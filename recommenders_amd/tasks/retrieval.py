@@ -222,6 +222,42 @@ class TopKCategoricalAccuracy:
     self._mean.reset_states()
 
 
+class _LogitsCeFn(torch.autograd.Function):
+  """``sum_i w_i * (-sum_j y_ij log_softmax(S_i)_j)`` on an explicit ``[B, C]`` logits matrix
+  (``tfrs_logits_ce_fwd`` / ``_bwd``): Keras ``CategoricalCrossentropy(from_logits=True, reduction=SUM)``
+  (reference ``tasks/retrieval.py:86-87``) for the paths that have to build the matrix."""
+
+  @staticmethod
+  def forward(ctx, scores, labels, sample_weight):
+    scores = scores.contiguous().to(torch.float32)
+    labels = labels.contiguous().to(torch.float32)
+    nq, nc = scores.shape
+    w = None if sample_weight is None else sample_weight.reshape(-1).to(scores.device, torch.float32).contiguous()
+    rows = torch.empty((3, max(nq, 1)), dtype=torch.float32, device=scores.device)   # row loss, lse, sum of labels
+    _lib.check(_lib.load().tfrs_logits_ce_fwd(_lib.ptr(scores), _lib.ptr(labels), nq, nc, _lib.ptr(w),
+                                              _lib.ptr(rows[0]), _lib.ptr(rows[1]), _lib.ptr(rows[2]),
+                                              _lib.current_stream()))
+    ctx.save_for_backward(scores, labels, rows)
+    ctx.weight = w
+    return rows[0, :nq].sum()
+
+  @staticmethod
+  def backward(ctx, grad):
+    scores, labels, rows = ctx.saved_tensors
+    nq, nc = scores.shape
+    ds = torch.empty_like(scores)
+    g = grad.reshape(1).to(torch.float32).contiguous()
+    _lib.check(_lib.load().tfrs_logits_ce_bwd(_lib.ptr(scores), _lib.ptr(labels), nq, nc, _lib.ptr(ctx.weight),
+                                              _lib.ptr(rows[1]), _lib.ptr(rows[2]), _lib.ptr(g), _lib.ptr(ds),
+                                              _lib.current_stream()))
+    return ds, None, None
+
+
+def logits_softmax_ce_sum(scores: torch.Tensor, labels: torch.Tensor,
+                          sample_weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+  return _LogitsCeFn.apply(scores, labels, sample_weight)
+
+
 class Retrieval(torch.nn.Module, base.Task):
   """A factorized retrieval task (reference :29-235)."""
 
@@ -365,11 +401,8 @@ class Retrieval(torch.nn.Module, base.Task):
     elif fused_hard_negatives:
       loss = hard_negative_softmax_loss(q, c, self._num_hard_negatives, sample_weight, self._temperature)
     elif self._loss is None:
-      # CategoricalCrossentropy(from_logits, SUM) on the explicit logits (:86-87, :210)
-      per_row = -(labels * torch.log_softmax(scores, dim=1)).sum(dim=1)
-      if sample_weight is not None:
-        per_row = per_row * sample_weight.reshape(-1)
-      loss = per_row.sum()
+      # CategoricalCrossentropy(from_logits, SUM) on the explicit logits (:86-87, :210): row-wise HIP kernels
+      loss = logits_softmax_ce_sum(scores, labels, sample_weight)
     else:
       loss = self._loss(y_true=labels, y_pred=scores, sample_weight=sample_weight)
 

@@ -281,6 +281,56 @@ def test_retrieval_hard_negatives_and_custom_paths():
   np.testing.assert_allclose(float(loss), float(ref), rtol=1e-5)
 
 
+def test_explicit_logits_paths_run_on_hip_kernels():
+  """The Retrieval paths that must build the [B, C] matrix (multi-head max-sim queries tasks/retrieval.py:172-176,
+  hard negatives after a logit adjustment layers/loss.py:61-111) take their cross-entropy from
+  tfrs_logits_ce_fwd/_bwd and their top-k from the library's selection kernel -- no torch.log_softmax /
+  torch.topk: loss and both embedding gradients against the float64 oracle, incl. sample weights, an accidental-hit
+  adjustment under hard-negative mining, more queries than candidates (rows without a positive) and ties."""
+  import recommenders_amd as tfrs
+  from recommenders_amd.tasks import retrieval as rt
+  rng = np.random.default_rng(41)
+  # ---- the kernel itself: any labels matrix, weights, backward
+  nq, nc = 70, 333
+  s = (rng.normal(size=(nq, nc)) * 3).astype(np.float32)
+  y = np.zeros((nq, nc), np.float32)
+  y[np.arange(50), rng.integers(0, nc, size=50)] = 1.0          # 20 rows have no positive
+  w = rng.uniform(0.1, 2.0, size=nq).astype(np.float32)
+  ts = _t(s).requires_grad_(True)
+  loss = rt.logits_softmax_ce_sum(ts, _t(y), _t(w))
+  loss.backward()
+  s64 = torch.tensor(s, dtype=torch.float64, requires_grad=True)
+  ref = -(torch.tensor(y, dtype=torch.float64) * torch.log_softmax(s64, dim=1)).sum(dim=1)
+  ref = (ref * torch.tensor(w, dtype=torch.float64)).sum()
+  ref.backward()
+  assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
+  np.testing.assert_allclose(_np(ts.grad), s64.grad.numpy(), rtol=2e-5, atol=2e-7)
+  assert float(o_ret.softmax_ce_sum(y, s, w)) == pytest.approx(float(ref), rel=1e-6)
+  # ---- max-sim queries (3-D): reference KAT 4.419999 is in the golden tests; random heads against the oracle
+  q3 = rng.normal(size=(48, 3, 16)).astype(np.float32)
+  c = rng.normal(size=(60, 16)).astype(np.float32)
+  tq, tc = _t(q3).requires_grad_(True), _t(c).requires_grad_(True)
+  loss = tfrs.tasks.Retrieval()(tq, tc, compute_metrics=False)
+  np.testing.assert_allclose(float(loss), float(o_ret.loss(q3, c)), rtol=1e-5)
+  loss.backward()
+  assert tq.grad is not None and tc.grad is not None and float(tq.grad.abs().sum()) > 0
+  # ---- hard negatives + accidental-hit removal (an adjustment that keeps the path on the explicit matrix)
+  q = rng.normal(size=(40, 16)).astype(np.float32)
+  c2 = rng.normal(size=(64, 16)).astype(np.float32)
+  ids = rng.integers(0, 20, size=64)
+  task = tfrs.tasks.Retrieval(num_hard_negatives=6, remove_accidental_hits=True, temperature=0.7)
+  got = task(_t(q), _t(c2), candidate_ids=_t(ids), sample_weight=_t(w[:40]), compute_metrics=False)
+  want = o_ret.loss(q, c2, sample_weight=w[:40], num_hard_negatives=6, remove_accidental_hits_flag=True,
+                    candidate_ids=ids, temperature=0.7)
+  np.testing.assert_allclose(float(got), float(want), rtol=1e-5)
+  # ... and the selection itself on rows with ties: lower column first, any width
+  from recommenders_amd.layers import loss as loss_layers
+  keyed = np.round(rng.normal(size=(9, 5000)) * 2).astype(np.float32)
+  cols = _np(loss_layers._topk_columns(_t(keyed), 17))
+  want_cols = np.argsort(-keyed, axis=1, kind="stable")[:, :17]
+  np.testing.assert_array_equal(cols, want_cols)
+
+
 @pytest.mark.parametrize("nq,nc,d,k", [(300, 300, 64, 7), (512, 2000, 32, 50), (100, 4000, 20, 3), (64, 64, 16, 200)])
 def test_retrieval_hard_negatives_without_the_logits_matrix(nq, nc, d, k):
   """`num_hard_negatives` over plain dot-product logits (layers/loss.py:61-111): the fused top-K search
