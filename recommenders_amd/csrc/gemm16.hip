@@ -491,6 +491,7 @@ struct Gemm16Args {
   int64_t mp, np;                      // padded image rows (block stride of K-blocked images)
   int kt_per;                          // big kernel, split-K: K steps per blockIdx.y slice (0 = all);
                                        // slice y writes its partial product to out + y * m * n
+  int raster;                          // big kernel: tile order of the workgroups (see gemm16_big_kernel)
   int act;                             // fused activation of v (common.h kAct*), before the epilogue formula
   float *pre;                          // [m, n] or NULL: receives v (the pre-activation) for the backward
 };
@@ -660,8 +661,31 @@ __global__ void __launch_bounds__(512) gemm16_big_kernel(const Gemm16Args g) {
   const int j = lane & 31, h = lane >> 5;
 
   const int nbn = (g.n + kB16N - 1) / kB16N;
-  const int64_t bm = (int64_t)(blockIdx.x / nbn) * kB16M;
-  const int bn = (int)(blockIdx.x % nbn) * kB16N;
+  // Tile of this workgroup.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own 4 MB
+  // L2), so in launch order an XCD's 32 resident workgroups were scattered over ~18 row panels of the output and
+  // shared almost nothing in their L2 (raster 0).  raster >= 1: every XCD gets a CONTIGUOUS range of tile ids
+  // (the bijective remap of the top-K scan); raster 2 additionally walks that range in groups of 4 row panels x
+  // all their column panels column by column, so that 32 consecutive tiles are 4 row panels x 8 column panels:
+  // 12 operand panels feed 32 workgroups instead of ~17 (row-major) or ~50 (round-robin).
+  int tile = (int)blockIdx.x;
+  if (g.raster >= 1 && gridDim.y == 1) {
+    const int nwg = (int)gridDim.x, q8 = nwg >> 3, r8 = nwg & 7;
+    const int xcd = tile & 7, pos = tile >> 3;
+    tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + pos;
+  }
+  int tm = tile / nbn, tn = tile % nbn;
+  if (g.raster == 2 && gridDim.y == 1) {
+    constexpr int kGroupM = 4;
+    const int nbm = ((int)gridDim.x + nbn - 1) / nbn;
+    const int per_group = kGroupM * nbn;
+    const int grp = tile / per_group, first = grp * kGroupM;
+    const int rows = nbm - first < kGroupM ? nbm - first : kGroupM;
+    const int in_grp = tile - grp * per_group;
+    tm = first + in_grp % rows;
+    tn = in_grp / rows;
+  }
+  const int64_t bm = (int64_t)tm * kB16M;
+  const int bn = tn * kB16N;
   const int nk_all = g.kp / kB16K;
   const int kbeg = g.kt_per ? (int)blockIdx.y * g.kt_per : 0;
   const int nk = g.kt_per ? (nk_all - kbeg < g.kt_per ? nk_all - kbeg : g.kt_per) : nk_all;
@@ -953,6 +977,11 @@ int gemm16_run_ex(const G16Operand &a, const G16Operand &b, int64_t m, int n, in
   g.bias = bias; g.x0 = e0; g.x = e1; g.diag = diag; g.out = out; g.aux = aux;
   g.kb = kb; g.mp = L.mp; g.np = L.np;
   g.act = act; g.pre = pre;
+  {
+    const char *rv = option("TFRS_GEMM16_RASTER");
+    g.raster = (rv && *rv) ? atoi(rv) : 1;   // (measured: 0 / 1 / 2 within 0.5 % on the Cross products, 1 and 2
+                                             // 2.4 % ahead on the DLRM top MLP -- profiles/r05_gemm_raster.jsonl)
+  }
   // large shapes: 256 x 256 tiles with the 4-deep ring; otherwise (few tiles: fill the chip)
   // the 128 x 128 kernel.  TFRS_GEMM16_TILE = 128 | 256 forces one.
   if (splitk) {
