@@ -1073,20 +1073,27 @@ constexpr int64_t kStreamFirstRange = 262144;   // rows of the first fp16 range 
 // Query batches up to this size take the block-fed fp16 filter (rawscan16_kernel: one pass over the f32
 // blocks, <= 256 queries per workgroup); 0 sends them to the exact f32-MFMA scan (<= TFRS_STREAM_RAW_MAX_NQ
 // queries) or the fp16 image (above)
-static int64_t stream_raw16_max_nq() { return std::max<int64_t>(0, env_i64("TFRS_STREAM_RAW16_MAX_NQ", 256)); }
+static int64_t stream_raw16_max_nq() { return std::max<int64_t>(0, env_i64("TFRS_STREAM_RAW16_MAX_NQ", 640)); }
+// (round 5: beyond one wave's registers -- 128 queries at dim 128, 256 below -- the waves of an 8-wave workgroup split
+// the queries, 512 per workgroup, and the stage is converted once per workgroup through LDS: rawscan16w_kernel.  Dims
+// below 32 keep the 256-query limit.  Measured on 12.5 M x 128 (profiles/r05_streaming_wide.txt): 257 queries 2.62 ms
+// against 3.30 through the group's fp16 image, 512: 3.2-3.4 against 3.7; from ~800 queries on the image wins again
+// (1024: 5.2-5.6 against 5.0) -- the kernel's scoring phase runs at a third of the matrix pipe's rate.)
+static int64_t raw16_max_nq(int d) { return d >= 32 ? stream_raw16_max_nq() : std::min<int64_t>(stream_raw16_max_nq(), 256); }
 // ... and, up to dim 64, from this size on: with one group of 32 queries the exact scan is copy-bound as well
 // there and needs half the launches per range (12.5 M x 64, one query: 0.89 against 1.00 ms); at dim 128 its
 // 64 matrix-core steps per row cost as much as the copy (one query 1.71 against 1.64 ms, 32: 1.88 against 1.70)
 static int64_t stream_raw16_min_nq() { return std::max<int64_t>(1, env_i64("TFRS_STREAM_RAW16_MIN_NQ", 33)); }
 static bool group_uses_raw16(int64_t nq, int d, int k, const TopkTuning &t) {
   return t.f16_filter && k <= kMaxKF16 && nq >= (d <= 64 ? stream_raw16_min_nq() : 1) &&
-         nq <= stream_raw16_max_nq();
+         nq <= raw16_max_nq(d);
 }
 // query groups of 32 per workgroup: eight up to dim 64, four at dim 128 (eight resident groups of dim 128 do
 // not fit the register file).  More queries than one workgroup holds make several query tiles per split of
 // the rows; the tiles of a split are neighbours in the XCD-aware workgroup order, so the second one reads the
 // rows from the XCD's L2
 static int raw16_qg(int64_t nq, int d) {
+  if (nq > 256 && d >= 32) return 16;     // rawscan16w_kernel: 512 queries per workgroup
   const int cap = d <= 64 ? 8 : 4;
   const int want = nq <= 32 ? 1 : nq <= 64 ? 2 : nq <= 128 ? 4 : 8;
   return std::min(want, cap);

@@ -566,6 +566,310 @@ static int launch_rawscan16_variant(const RawScanArgs &a, hipStream_t stream) {
   return TFRS_OK;
 }
 
+// ---- the same filter for query batches of 257 .. 2048 (round 5): ONE conversion of a stage per workgroup -------
+//
+// rawscan16_kernel keeps the tile's queries resident in EVERY wave and lets wave w score its 32 rows: the query tile
+// is bounded by one wave's registers (128 queries at dim 128, 256 below), and larger batches went through one fp16
+// image of the whole group (pack16_raw_kernel: 1.9 ms for 12.5 M x 128 -- 6.4 GB read, 3.4 GB written, then read
+// again by the filter passes), which dominated calls of 257 .. ~2000 queries (512 queries: 3.7 ms against 1.7 for a
+// resident index).  Here the WAVES split the queries instead: 8 waves x 2 groups of 32 = 512 queries per workgroup,
+// and the stage is converted to fp16 ONCE per workgroup:
+//   load     wave w reads rows [16 w, 16 w + 16) of a 128-row stage straight into registers (lane l takes the 16-byte
+//            pieces l, l + 64, .. of those 16 rows: 1 KiB per instruction, whole lines), TWO stages ahead of the
+//            one being scored -- two stages of 64 KiB in flight per CU, no f32 buffer in LDS (a first version
+//            staged the f32 rows through LDS with one stage in flight: 2.5 TB/s);
+//   convert  the wave's 16 rows share one power-of-two scale 2^ceil(log2 max|x|) and one norm bound (the largest of
+//            the 16 row norms): the contract of the fp16 image with a "stage" of 16 rows; fp16 rows go to one of TWO
+//            fp16 tiles in LDS (row pitch 2 DP + 16 bytes: the conflict-free A-operand layout of topk_scan16.hip),
+//            {1 / scale, scale, norm} of the 16-row group to a small table;
+//   score    after ONE barrier per stage every wave reads the A fragments of all 128 rows and runs them against
+//            its own two query groups; a 32 x 32 tile spans two 16-row groups = accumulator registers 0 .. 7 and
+//            8 .. 15 of a lane, each half tested against its own threshold.
+// Per stage and SIMD 2 x 64 MFMAs = 4096 matrix-core cycles for 64 KiB of rows.  LDS: 2 x 34.8 KB + counters at dim 128.
+// MEASURED (round 5, 12.5 M x 128, 512 queries; TFRS_RAWW_ABLATE builds): loads + conversion alone 1.16 ms per call =
+// 5.5 TB/s, the whole kernel 2.8-2.96 ms: the scoring phase runs at about a third of the matrix pipe's rate (waves
+// parked 48 % of their cycles: two waves per SIMD of ONE workgroup that converts, meets its barrier and scores in
+// lock step), so the kernel pays only between 257 and ~700 queries (topk_api.hip: TFRS_STREAM_RAW16_MAX_NQ = 640).
+// Tried on the way, each within +-3 %: rows staged through LDS by DMA (one stage in flight), two stages of rows in
+// flight in registers, the chains of the two groups in sequence instead of step by step, one counter round trip per
+// hot tile instead of sixteen, no cross-lane reductions at all (ablation).
+// timing ablations of rawscan16w_kernel (tools/ab_variants.sh; results WRONG): 1 = no cross-lane reductions in the
+// conversion, 2 = no scoring, 4 = no conversion at all, 8 = no loads after the first stage
+#ifndef TFRS_RAWW_ABLATE
+#define TFRS_RAWW_ABLATE 0
+#endif
+
+__device__ __forceinline__ void raw_lds_barrier() {
+  __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14));   // s_waitcnt lgkmcnt(0), vmcnt untouched
+  __builtin_amdgcn_s_barrier();
+}
+
+constexpr int kRawWWaves = 8;
+constexpr int kRawWQG = 2;                                  // query groups of 32 per wave
+constexpr int kRawWQueries = kRawWWaves * kRawWQG * 32;     // 512 per workgroup
+
+template <int DP>
+struct RawWGeom {
+  static constexpr int kRowB = DP * 4;
+  static constexpr int kPieces = 16 * kRowB / 16 / 64;        // 16-byte pieces per lane and stage (the wave's 16 rows)
+  static constexpr int kRow16B = DP * 2 + 16;
+  static constexpr int kTile16B = kTileN * kRow16B;
+  static constexpr int kMetaOff = 2 * kTile16B;               // [2][8] x float4 {1 / scale, scale, norm, -}
+  static constexpr int kCntOff = kMetaOff + 2 * kRawWWaves * 16;
+  static constexpr int kLdsBytes = kCntOff + kRawWQueries * 4;
+  static_assert(kPieces >= 1 && kPieces * 64 * 16 == 16 * kRowB, "a wave's 16 rows are whole 1 KiB pieces");
+};
+
+template <int DP>
+__global__ void __launch_bounds__(kRawWWaves * 64) rawscan16w_kernel(const RawScanArgs a) {
+  using G = RawWGeom<DP>;
+  constexpr int KS = DP / 16;           // MFMA steps of 16 features
+  constexpr int PPR = DP / 4;           // 16-byte pieces per f32 row
+  constexpr int NP = G::kPieces;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t *wg_cnt = reinterpret_cast<uint32_t *>(smem + G::kCntOff);
+  float4 *meta = reinterpret_cast<float4 *>(smem + G::kMetaOff);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31;
+  const int h = lane >> 5;
+  if (a.zero_word && blockIdx.x == 0 && tid == 0) *a.zero_word = 0u;
+  if (a.zero_aux && blockIdx.x == 0 && tid < 4) a.zero_aux[tid] = 0u;
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int xcd = bid & 7, pos = bid >> 3;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + pos;
+  const int split = logical / a.n_qtiles;
+  const int qt = logical - split * a.n_qtiles;
+
+  const int64_t c0 = a.c_begin + (int64_t)split * a.split_len;
+  int64_t c1 = c0 + a.split_len;
+  if (c1 > a.c_end) c1 = a.c_end;
+  const int nstages = c0 < c1 ? (int)((c1 - c0 + kTileN - 1) / kTileN) : 0;
+
+  // ---- this WAVE's 2 x 32 queries -> fp16 MFMA B operands (q / qscale), resident ------------------
+  f16x8r bq[kRawWQG][KS];
+  float flo[kRawWQG], fqk[kRawWQG], qsc[kRawWQG];
+  int64_t qrow[kRawWQG];
+#pragma unroll
+  for (int g = 0; g < kRawWQG; ++g) {
+    qrow[g] = (int64_t)qt * kRawWQueries + (wave * kRawWQG + g) * 32 + j;
+    const bool qvalid = qrow[g] < a.nq;
+    const int64_t qr = qvalid ? qrow[g] : 0;
+    const float qs = qvalid ? a.qscale[qr] : 1.0f;
+    const float qinv = 1.0f / qs;   // exact: power of two
+    const f32x4 *q4 = reinterpret_cast<const f32x4 *>(a.q + qr * DP);
+#pragma unroll
+    for (int m = 0; m < KS; ++m) {
+      const f32x4 lo = q4[4 * m + 2 * h], hi = q4[4 * m + 2 * h + 1];   // features 16 m + 8 h .. + 7
+      u32x4r w;
+      w[0] = raw_pack_f16x2(qvalid ? lo[0] * qinv : 0.0f, qvalid ? lo[1] * qinv : 0.0f);
+      w[1] = raw_pack_f16x2(qvalid ? lo[2] * qinv : 0.0f, qvalid ? lo[3] * qinv : 0.0f);
+      w[2] = raw_pack_f16x2(qvalid ? hi[0] * qinv : 0.0f, qvalid ? hi[1] * qinv : 0.0f);
+      w[3] = raw_pack_f16x2(qvalid ? hi[2] * qinv : 0.0f, qvalid ? hi[3] * qinv : 0.0f);
+      bq[g][m] = __builtin_bit_cast(f16x8r, w);
+    }
+    flo[g] = qvalid ? (a.thr[qr * (a.thr_stride > 0 ? a.thr_stride : 1)] - kF16Tiny) * qinv : __builtin_inff();
+    fqk[g] = qvalid ? a.qk[qr] * qinv : 0.0f;
+    qsc[g] = qs;
+  }
+  wg_cnt[tid] = 0u;   // 512 threads, 512 counters
+  const bool wave_active = (int64_t)qt * kRawWQueries + wave * (kRawWQG * 32) < a.nq;   // (uniform)
+
+  // ---- block cursor; the wave's loads of a stage (its own 16 rows) ----------------------------------
+  const RawTable *T = a.table;
+  const int nblk = T->n_blocks;
+  int blk = nstages > 0 ? __builtin_amdgcn_readfirstlane(raw_find_block(T, c0)) : 0;
+  int64_t blk_lo = T->row_start[blk], blk_hi = T->row_start[blk + 1];
+  const char *blk_ptr = reinterpret_cast<const char *>(T->ptr[blk]);
+  const uint32_t rows_here = (uint32_t)(c1 > c0 ? c1 - c0 : 0);   // rows of this split (a split holds < 2^31 rows)
+  const uint32_t row0 = (uint32_t)c0;                              // (group-local row numbers fit 32 bits)
+  auto load_stage = [&](int st, f32x4 (&dst)[NP]) __attribute__((always_inline)) {
+    const int64_t v0 = c0 + (int64_t)st * kTileN;
+    while (v0 >= blk_hi && blk + 1 < nblk) {
+      ++blk;
+      blk_lo = blk_hi;
+      blk_hi = T->row_start[blk + 1];
+      blk_ptr = reinterpret_cast<const char *>(T->ptr[blk]);
+    }
+    if (v0 + kTileN <= blk_hi && v0 + kTileN <= c1) {   // the whole stage lies in one block: linear loads
+      const char *src = blk_ptr + ((v0 - blk_lo) + 16 * wave) * (int64_t)G::kRowB + lane * 16;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) dst[i] = *reinterpret_cast<const f32x4 *>(src + i * 1024);
+      return;
+    }
+    // block boundary or the last, partly filled stage: every lane looks its row up; rows at or beyond c1
+    // re-read the last valid row (their scores are never used)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int piece = i * 64 + lane;
+      int64_t row = v0 + 16 * wave + piece / PPR;
+      if (row > c1 - 1) row = c1 - 1;
+      dst[i] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(raw_row_ptr(T, row, DP)) +
+                                                (piece % PPR) * 16);
+    }
+  };
+  float norm_run = 0.0f;
+  // the wave's 16 rows (registers) -> fp16 tile `buf`, group constants -> meta[buf][wave]
+  auto convert = [&](const f32x4 (&av)[NP], int buf) __attribute__((always_inline)) {
+    float am = 0.0f, nmax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      float ss = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        ss = __builtin_fmaf(av[i][c], av[i][c], ss);
+        am = fmaxf(am, __builtin_fabsf(av[i][c]));
+      }
+      // piece i * 64 + lane of the wave's 16 rows: PPR consecutive lanes hold one row
+      if (!(TFRS_RAWW_ABLATE & 1)) {
+#pragma unroll
+      for (int off = 1; off < PPR && off < 64; off <<= 1) ss += __shfl_xor(ss, off);
+      }
+      nmax = fmaxf(nmax, ss);
+    }
+    if (!(TFRS_RAWW_ABLATE & 1)) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      nmax = fmaxf(nmax, __shfl_xor(nmax, off));
+      am = fmaxf(am, __shfl_xor(am, off));
+    }
+    }
+    const float nrm = __builtin_sqrtf(nmax) * kNormSlack;   // (upper bound of the 16 row norms)
+    const float cs = pow2_ceil(am);
+    const float inv = 1.0f / cs;                            // exact: power of two
+    norm_run = fmaxf(norm_run, nrm);
+    char *t16 = smem + buf * G::kTile16B;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int piece = i * 64 + lane;
+      const int row = 16 * wave + piece / PPR, col = piece % PPR;
+      uint2 w;
+      w.x = raw_pack_f16x2(av[i][0] * inv, av[i][1] * inv);
+      w.y = raw_pack_f16x2(av[i][2] * inv, av[i][3] * inv);
+      *reinterpret_cast<uint2 *>(t16 + row * G::kRow16B + col * 8) = w;
+    }
+    if (lane == 0) meta[buf * kRawWWaves + wave] = make_float4(inv, cs, nrm, 0.0f);
+  };
+
+  // the rows of stage s + 1 wait in registers while stage s is scored (one stage = 64 KiB per CU in flight; a second
+  // set -- two stages ahead -- measured the same and its 32 registers are better spent on the second accumulator)
+  f32x4 nx[NP];
+  if (nstages > 0) load_stage(0, nx);
+  if (nstages > 0) convert(nx, 0);
+  __syncthreads();                      // fp16 tile 0 complete (and the counters zeroed)
+  if (nstages > 1) load_stage(1, nx);
+
+  for (int st = 0; st < nstages; ++st) {
+    const int buf = st & 1;
+    const char *t16 = smem + buf * G::kTile16B;
+    if (wave_active && !(TFRS_RAWW_ABLATE & 2)) {
+      const char *ap = t16 + j * G::kRow16B + h * 16;
+      // A fragments of the next sub-tile are fetched under the chains of the current one -- up to dim 64; at dim 128
+      // a second set (32 registers next to two stages of rows in flight) spills
+      constexpr int AFB = DP >= 128 ? 1 : 2;
+      u32x4r af[AFB][KS];
+#pragma unroll
+      for (int m = 0; m < KS; ++m) af[0][m] = *reinterpret_cast<const u32x4r *>(ap + m * 32);
+#pragma unroll
+      for (int sub = 0; sub < kTileN / 32; ++sub) {
+        if (AFB == 2 && sub + 1 < kTileN / 32) {
+#pragma unroll
+          for (int m = 0; m < KS; ++m)
+            af[(sub + 1) % AFB][m] = *reinterpret_cast<const u32x4r *>(ap + (sub + 1) * 32 * G::kRow16B + m * 32);
+        }
+        const float4 mA = meta[buf * kRawWWaves + 2 * sub], mB = meta[buf * kRawWWaves + 2 * sub + 1];
+        // the chains of the two groups step by step in turn: consecutive MFMAs never depend on each other
+        f32x16 acc[kRawWQG];
+#pragma unroll
+        for (int g = 0; g < kRawWQG; ++g)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[g][r] = 0.0f;
+#pragma unroll
+        for (int m = 0; m < KS; ++m)
+#pragma unroll
+          for (int g = 0; g < kRawWQG; ++g)
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8r, af[sub % AFB][m]), bq[g][m], acc[g], 0, 0, 0);
+        if (AFB == 1 && sub + 1 < kTileN / 32) {   // dim 128: the one fragment set is refilled under the chains' tail
+#pragma unroll
+          for (int m = 0; m < KS; ++m)
+            af[0][m] = *reinterpret_cast<const u32x4r *>(ap + (sub + 1) * 32 * G::kRow16B + m * 32);
+        }
+#pragma unroll
+        for (int g = 0; g < kRawWQG; ++g) {
+          // acc[g][r] = prefilter score of (query qrow[g], stage row 32 sub + (r & 3) + 8 (r >> 2) + 4 h) in units of
+          // qscale * (scale of the row's 16-row group): registers 0 .. 7 are rows of group 2 sub, 8 .. 15 of 2 sub + 1
+          const f32x16 &c = acc[g];
+          const float thrA = __builtin_fmaf(-fqk[g], mA.z, flo[g]) * mA.x;
+          const float thrB = __builtin_fmaf(-fqk[g], mB.z, flo[g]) * mB.x;
+          const float xa = fmaxf(fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])), fmaxf(fmaxf(c[4], c[5]), fmaxf(c[6], c[7])));
+          const float xb = fmaxf(fmaxf(fmaxf(c[8], c[9]), fmaxf(c[10], c[11])),
+                                 fmaxf(fmaxf(c[12], c[13]), fmaxf(c[14], c[15])));
+          if (__ballot(xa > thrA || xb > thrB) != 0ull) {   // rare once the bound is warm
+            // (32-bit row arithmetic relative to the split: sixteen 64-bit compares per tile were precomputed
+            // and spilled -- 42 scratch stores per stage)
+            const uint32_t rel0 = (uint32_t)st * kTileN + 32u * sub + 4u * h;
+            uint2 *const seg = a.buf + (qrow[g] * (int64_t)a.cap_l) * a.nseg + split;
+            const float unA = qsc[g] * mA.y, unB = qsc[g] * mB.y;
+            // ONE counter round trip per lane and hot tile: the lane counts its survivors, reserves that many
+            // slots, then stores them (sixteen dependent ds_add_rtn round trips per hot tile made the scoring
+            // phase 3x its matrix-core time: in a stream's early ranges every tile is hot)
+            uint32_t hits = 0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const uint32_t rel = rel0 + (r & 3) + 8 * (r >> 2);
+              hits |= (c[r] > (r < 8 ? thrA : thrB) && rel < rows_here) ? (1u << r) : 0u;
+            }
+            if (hits) {
+              uint32_t e = atomicAdd(&wg_cnt[(wave * kRawWQG + g) * 32 + j], (uint32_t)__builtin_popcount(hits));
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                if (hits & (1u << r)) {
+                  if (e < a.cap_l)
+                    seg[(uint64_t)e * (uint32_t)a.nseg] =
+                        make_uint2(__float_as_uint(c[r] * (r < 8 ? unA : unB)), row0 + rel0 + (r & 3) + 8 * (r >> 2));
+                  ++e;
+                }
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one sub-tile at a time (the chains of all four issued first keep
+                                             // 128 accumulators alive)
+      }
+    }
+    // the next stage's rows of this wave have landed long ago: convert them, then refill their registers with the
+    // rows of the stage after next
+    if (st + 1 < nstages && !(TFRS_RAWW_ABLATE & 4)) convert(nx, buf ^ 1);
+    if (st + 2 < nstages && !(TFRS_RAWW_ABLATE & 8)) load_stage(st + 2, nx);
+    // everybody scored stage st and converted its part of st + 1.  NOT __syncthreads(): its workgroup fence waits for
+    // vmcnt(0), i.e. for the loads of stage st + 2 issued one line above -- the whole HBM latency exposed once per
+    // stage (7.4 us per stage, 2.2 TB/s).  Only this wave's LDS writes have to be done before the barrier.
+    raw_lds_barrier();
+  }
+
+  {   // every (query, split) count is written (counts beyond cap_l flag the query for the exact redo)
+    const int64_t qr = (int64_t)qt * kRawWQueries + tid;
+    if (qr < a.nq) a.cnt[qr * a.nseg + split] = wg_cnt[tid];
+  }
+  if (nstages > 0 && lane == 0 && a.norm_max)
+    atomicMax(reinterpret_cast<uint32_t *>(a.norm_max), __float_as_uint(norm_run));   // >= 0
+}
+
+template <int DP>
+static int launch_rawscan16w(const RawScanArgs &a, hipStream_t stream) {
+  using G = RawWGeom<DP>;
+  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&rawscan16w_kernel<DP>), G::kLdsBytes));
+  const dim3 grid((unsigned)(a.n_qtiles * a.n_splits));
+  hipLaunchKernelGGL((rawscan16w_kernel<DP>), grid, dim3(kRawWWaves * 64), G::kLdsBytes, stream, a);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
 template <int DP>
 static int launch_rawscan16_dp(const RawScanArgs &a, hipStream_t stream) {
   switch (a.qg) {
@@ -574,6 +878,9 @@ static int launch_rawscan16_dp(const RawScanArgs &a, hipStream_t stream) {
     case 4: return launch_rawscan16_variant<DP, 4>(a, stream);
     case 8:   // (eight resident query groups of dim 128 do not fit the register file: 1.6 KB of scratch)
       if constexpr (DP <= 64) return launch_rawscan16_variant<DP, 8>(a, stream);
+      break;
+    case 16:  // 512 queries per workgroup: the waves split the queries, one conversion per workgroup
+      if constexpr (DP >= 32) return launch_rawscan16w<DP>(a, stream);
       break;
   }
   set_error("rawscan16: %d query groups per workgroup (1, 2, 4; 8 up to dim 64)", a.qg);

@@ -358,6 +358,51 @@ def test_streaming_block_fed_filter_awkward_data(seed, monkeypatch):
     assert torch.equal(i.to(torch.int64), ei.to(torch.int64)), (case, kind, d, k, nq, n)
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_streaming_wide_block_fed_filter(seed, monkeypatch):
+  """rawscan16w_kernel (257 .. 2048 queries over a lazily produced dataset, dims 32 .. 128: the waves of an 8-wave
+  workgroup split the queries, the stage is converted to fp16 once per workgroup with one scale and norm bound per 16
+  rows): bit for bit the all-f32 scan of the same rows on the data that stresses those scales and bounds, ragged
+  blocks (stages that straddle block boundaries take the per-lane row lookup), a ragged last stage, several query
+  tiles, queries that fill only part of the last tile, k = 1 .. 512, and the dims below 32 that stay on the image."""
+  ftk = _layers()
+  from recommenders_amd import _lib
+  rng = np.random.default_rng(1700 + seed)
+  dev = torch.device("cuda", 0)
+  for case in range(6):
+    d = int(rng.choice([16, 32, 64, 128, 128]))
+    k = int(rng.choice([1, 10, 100, 300, 512]))
+    nq = int(rng.choice([257, 300, 512, 513, 1000, 1025, 2048]))
+    n = int(rng.integers(60_000, 500_000))
+    kind = ["row_scales", "dups", "negative", "clustered", "zero_blocks", "gauss"][(case + seed) % 6]
+    g = torch.Generator(device=dev).manual_seed(int(rng.integers(1 << 30)))
+    c = torch.randn((n, d), generator=g, device=dev) / d ** 0.5
+    q = torch.randn((nq, d), generator=g, device=dev) / d ** 0.5
+    if kind == "row_scales":
+      c *= torch.exp(3.0 * torch.randn((n, 1), generator=g, device=dev))
+    elif kind == "dups":
+      c[n // 2:] = c[: n - n // 2].clone()
+    elif kind == "negative":
+      c = -c.abs(); q = q.abs()
+    elif kind == "clustered":
+      cen = torch.randn((64, d), generator=g, device=dev) / d ** 0.5
+      c = cen[torch.arange(n, device=dev) * 64 // n] + 0.3 * c
+      q = cen[torch.randint(0, 64, (nq,), generator=g, device=dev)] + 0.3 * q
+    elif kind == "zero_blocks":
+      c[1000:9000] = 0.0
+      c[n // 2: n // 2 + 77] = 0.0
+    sizes = _ragged_sizes(rng, n, int(rng.choice([500, 4096, 30000])))
+    _lib.set_option("TFRS_TOPK_FILTER", "f32")
+    try:
+      es, ei = ftk.BruteForce(k=k).index(c)(q)
+    finally:
+      _lib.set_option("TFRS_TOPK_FILTER", None)
+    layer = ftk.Streaming(k=k).index_from_dataset(_LazyBlocks(c.cpu().numpy(), sizes, None))
+    s, i = layer(q)
+    assert torch.equal(s, es), (case, kind, d, k, nq, n)
+    assert torch.equal(i.to(torch.int64), ei.to(torch.int64)), (case, kind, d, k, nq, n)
+
+
 def test_streaming_groups_edge_cases(monkeypatch):
   """The grouped path on the edges: fewer candidates than k (short state), empty blocks, a block
   that is not 16-byte aligned (falls back to the per-block entry point in stream order), ties

@@ -26,7 +26,7 @@ for rep in $(seq 1 ${REPS:-2}); do
   for lib in ab/lib_*.so; do
     cp $lib recommenders_amd/libtfrs_hip.so
     echo "== $lib (rep $rep)"
-    python tools/exp_filter_ms.py "$@" 2>&1 | tail -1
+    python ${EXP:-tools/exp_filter_ms.py} "$@" 2>&1 | grep "^{" | tail -${TAILN:-1}
   done
 done
 cp /tmp/lib_orig.so recommenders_amd/libtfrs_hip.so
