@@ -459,6 +459,8 @@ __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArg
   const int t_row = 32 * wave + j;
   const int a_off = (t_row % G::kChunks) * kRawChunkB + (t_row / G::kChunks) * G::kRowB + (DP >= 16 ? h * 32 : 0);
   float norm_run = 0.0f;   // largest row norm this wave has met
+  const uint32_t rows_here = (uint32_t)(c1 > c0 ? c1 - c0 : 0);   // rows of this split (< 2^31)
+  const uint32_t row0 = (uint32_t)c0;                              // (group-local row numbers fit 32 bits)
 
   for (int st = 0; st < nstages; ++st) {
     const char *tile = smem + (st & 1) * G::kStageB;
@@ -527,16 +529,29 @@ __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArg
       const float thr = __builtin_fmaf(-fqk[g], nrm, flo[g]) * inv;
       const float m0 = raw_max16(acc);
       if (__ballot(m0 > thr) != 0ull) {   // rare once the bound is warm
+        // (round 5, as in rawscan16w_kernel: 32-bit row arithmetic relative to the split and ONE counter round trip
+        // per lane and hot tile instead of sixteen dependent ones)
         const float un = qsc[g] * cs;
+        const uint32_t rel_stage = (uint32_t)st * kTileN;
+        uint32_t hits = 0u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int t = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int srow = (t % G::kChunks) * G::kRowsPerChunk + t / G::kChunks;
-          if (acc[r] > thr && stage_c + srow < c1) {
-            const uint32_t e = atomicAdd(&wg_cnt[g * 32 + j], 1u);
-            if (e < a.cap_l)
-              a.buf[(qrow[g] * (int64_t)a.cap_l + e) * a.nseg + split] =
-                  make_uint2(__float_as_uint(acc[r] * un), (uint32_t)(stage_c + srow));
+          const uint32_t srow = (uint32_t)((t % G::kChunks) * G::kRowsPerChunk + t / G::kChunks);
+          hits |= (acc[r] > thr && rel_stage + srow < rows_here) ? (1u << r) : 0u;
+        }
+        if (hits) {
+          uint32_t e = atomicAdd(&wg_cnt[g * 32 + j], (uint32_t)__builtin_popcount(hits));
+          uint2 *const seg = a.buf + (qrow[g] * (int64_t)a.cap_l) * a.nseg + split;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (hits & (1u << r)) {
+              const int t = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+              const uint32_t srow = (uint32_t)((t % G::kChunks) * G::kRowsPerChunk + t / G::kChunks);
+              if (e < a.cap_l)
+                seg[(uint64_t)e * (uint32_t)a.nseg] = make_uint2(__float_as_uint(acc[r] * un), row0 + rel_stage + srow);
+              ++e;
+            }
           }
         }
       }
