@@ -144,6 +144,23 @@ def gather_traffic() -> dict:
     return {"traffic": None}
 
 
+def softmax_chain_traffic() -> dict:
+  """HBM bytes per step of the in-batch softmax chain (tfrs::sm16_* kernels) of the README train step, from the
+  committed PMC passes (profiles/trainstep_traffic.json, tools/run_trainstep_traffic.sh: FETCH_SIZE with the gfx950 x2
+  correction + WRITE_SIZE, separate passes, graph-replayed step); null when the file is missing."""
+  try:
+    with open(os.path.join(ROOT, "profiles", "trainstep_traffic.json")) as f:
+      rec = json.load(f)
+    ks = {k: v for k, v in rec["kernels"].items() if k.startswith("tfrs::sm16_")}
+    if not ks:
+      return {"traffic": None}
+    total = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in ks.values())
+    return {"traffic": total, "traffic_source": "profiles/trainstep_traffic.json (%s; sum over %s; not measured in this run)"
+                                                % (rec["source"], ", ".join(sorted(ks)))}
+  except (OSError, KeyError, ValueError):
+    return {"traffic": None}
+
+
 def percentiles(xs):
   xs = sorted(xs)
   n = len(xs)
@@ -332,7 +349,7 @@ def train_step_metric(dev) -> dict:
          "roofline": {"kernel": "in-batch softmax forward + backward (tfrs::sm16_* chain, split-fp16 MFMA: "
                                 "3 fp16 products per f32 product), eager launches incl. autograd glue",
                       "bound": "mfma", "achieved": achieved, "peak": F16_MFMA_PEAK_TFLOPS,
-                      "unit": "TFLOP/s", "frac": achieved / F16_MFMA_PEAK_TFLOPS, "traffic": None,
+                      "unit": "TFLOP/s", "frac": achieved / F16_MFMA_PEAK_TFLOPS, **softmax_chain_traffic(),
                       "algorithmic_flop": flop, "ms_median": sm["median"], "ms_p10": sm["p10"],
                       "ms_p90": sm["p90"],
                       "note": "4096^2 x 64 is 6.4 GFLOP: the chain is launch/latency bound at this "
