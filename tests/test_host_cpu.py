@@ -162,8 +162,10 @@ def test_streaming_group_regimes_size_their_workspace(lib, monkeypatch):
   size = lambda nq, d: int(lib.tfrs_streaming_topk_blocks_workspace_bytes(nq, n, d, k))
   image = n * (128 * 2 + 16)                                  # fp16 image of the group at dim 128
   assert size(8192, 128) > image                              # large batches: the image regime
-  assert size(128, 128) < image and size(256, 128) < image    # block-fed filter up to 256 queries
-  assert size(512, 128) > image                               # ... and the image beyond
+  assert size(128, 128) < image and size(256, 128) < image    # block-fed filter up to 256 queries ...
+  assert size(512, 128) < image and size(640, 128) < image    # ... and, from dim 32 on, up to 640 (rawscan16w_kernel)
+  assert size(641, 128) > image                               # the image beyond ...
+  assert size(512, 16) > n * (16 * 2 + 16) > size(256, 16)    # ... and below dim 32 beyond 256 queries
   try:
     _lib.set_option("TFRS_STREAM_RAW16_MAX_NQ", "0")          # off: 65+ queries go through the image
     assert size(128, 128) > image and size(64, 128) < image
