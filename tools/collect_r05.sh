@@ -20,3 +20,4 @@ TFRS_BENCH_FORCE_DIST=1 TFRS_FORCE_EXCHANGE=1 TFRS_BENCH_ROWS=12500000 timeout 3
 timeout 120 ./tools/ubench/mfma_peak > "$O/mfma_peak.txt" 2>&1
 tail -3 "$O/pytest_gpu.log"
 head -c 600 "$O/bench.json"; echo
+timeout 300 python __graft_entry__.py smoke > "$O/smoke.log" 2>&1; tail -1 "$O/smoke.log"
