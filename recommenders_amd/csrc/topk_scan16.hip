@@ -41,6 +41,16 @@
 #ifndef TFRS_SCAN16_ABLATE
 #define TFRS_SCAN16_ABLATE 0
 #endif
+// The queue append of check() with the common case peeled out of the loop (every hot lane fits: one ballot, no
+// per-lane capacity compare): 0 = the loop only, 1 = peeled, 2 (default) = peeled + the MFMA -> VALU wait states in
+// front of the max tree written by hand.  Value 1 is kept because it reproduces a compiler fault: with the append as a
+// short side branch, the hazard recognizer of this ROCm's LLVM emits 1-6 wait states where gfx950 needs 12 between a
+// v_mfma_f32_32x32x16_f16 and the first VALU read of its result, the max tree reads a stale accumulator now and then
+// and survivors of the wave's last query group are lost (profiles/r05_scan16f_peel.txt;
+// tools/check_mfma_hazards.py finds it on the assembly, tests/test_host_cpu.py runs that over every MFMA kernel).
+#ifndef TFRS_SCAN16_PEEL
+#define TFRS_SCAN16_PEEL 2
+#endif
 
 namespace tfrs {
 
@@ -645,6 +655,9 @@ __global__ void __launch_bounds__(NW * 64, NW * QG >= 32 ? 1 : (DP <= 64 ? 2 : 1
         acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(af[sub & 1][m]), bq[g][m], acc[g], 0, 0, 0);
     };
     auto check = [&](int g, int sub) __attribute__((always_inline)) {
+      // 10 wait states + the >= 2 instructions between the chain's last MFMA and this point in every instantiation
+      // (checked on the assembly): the 12 the result needs before a VALU instruction may read it
+      if (TFRS_SCAN16_PEEL == 2) asm volatile("s_nop 9" : "+v"(acc[g]));
       const f32x16 &c = acc[g];
       if (TFRS_SCAN16_ABLATE & 16) { asm volatile("" :: "v"(c[0]), "v"(c[15])); return; }
       const float m0 = max16(c);
@@ -653,6 +666,24 @@ __global__ void __launch_bounds__(NW * 64, NW * QG >= 32 ? 1 : (DP <= 64 ? 2 : 1
       if (TFRS_SCAN16_ABLATE & 2) { asm volatile("" :: "s"(hm)); return; }
       if (__builtin_expect(hm != 0ull, 0)) {   // wave-uniform: some lane's 16-score column holds a survivor
         const uint32_t rbase = stage_row + sub * 32 + 4u * h;
+        if (TFRS_SCAN16_PEEL) {
+          const int nhot = __builtin_popcountll(hm);
+          if (__builtin_expect(qtail + nhot <= G::kQCap, 1)) {   // wave-uniform: every hot lane fits
+            if (hot) {
+              const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32),
+                                   __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+              char *e = qbase + (qtail + rank) * G::kEntB;
+#pragma unroll
+              for (int g4 = 0; g4 < 4; ++g4)
+                *reinterpret_cast<float4 *>(e + 16 * g4) =
+                    make_float4(c[4 * g4], c[4 * g4 + 1], c[4 * g4 + 2], c[4 * g4 + 3]);
+              *reinterpret_cast<uint4 *>(e + 64) =
+                  make_uint4(__float_as_uint(thr[g]), s_scale_bits, rbase, (uint32_t)(g * 64 + lane));
+            }
+            qtail += nhot;
+            return;
+          }
+        }
         uint64_t rem = hm;
         do {   // one round unless the queue is full (bursts of near-duplicates, identical queries)
           const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(rem >> 32),

@@ -689,19 +689,52 @@ def test_embedding_dict_host_logic():
 _ASM_CACHE = {}
 
 
-def _device_asm(source):
+def _device_asm(source, defines=()):
   """gfx950 assembly of one kernel source (cross-compiled once per test session, no GPU needed)."""
-  if source not in _ASM_CACHE:
+  key = (source, tuple(defines))
+  if key not in _ASM_CACHE:
     import subprocess, tempfile
     from recommenders_amd.csrc import build as csrc_build
     src = os.path.join(os.path.dirname(csrc_build.__file__), source)
     out = os.path.join(tempfile.mkdtemp(prefix="tfrs_asm_"), "kernel.s")
     cmd = [csrc_build.hipcc(), f"--offload-arch={csrc_build.ARCH}", "-O3", "-std=c++17",
-           *csrc_build.EXTRA_FLAGS.get(source, []), "-S", "--cuda-device-only", "-o", out, src]
+           *csrc_build.EXTRA_FLAGS.get(source, []), *[f"-D{d}" for d in defines],
+           "-S", "--cuda-device-only", "-o", out, src]
     subprocess.run(cmd, check=True, capture_output=True, cwd=os.path.dirname(src))
     with open(out) as f:
-      _ASM_CACHE[source] = f.read()
-  return _ASM_CACHE[source]
+      _ASM_CACHE[key] = f.read()
+  return _ASM_CACHE[key]
+
+
+def _mfma_hazard_checker():
+  import importlib.util
+  path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_mfma_hazards.py")
+  spec = importlib.util.spec_from_file_location("check_mfma_hazards", path)
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  return mod
+
+
+@pytest.mark.parametrize("source", ["topk_scan16.hip", "topk_raw.hip", "topk_scan.hip", "gemm16.hip", "interaction.hip",
+                                    "softmax.hip", "softmax16.hip", "metric_fused.hip"])
+def test_no_mfma_result_is_read_before_the_matrix_pipe_delivers_it(source):
+  """gfx950 has no interlock between an MFMA in flight and a VALU / LDS / memory instruction that touches its
+  destination: the wait states (12 behind v_mfma_f32_32x32x16_f16) are software's job, normally the compiler's.
+  Round 5 caught its hazard recognizer leaving them out in the fp16 filter kernel (below); every kernel of the
+  library that issues MFMAs is therefore walked on the cross-compiled assembly."""
+  res = _mfma_hazard_checker().check(_device_asm(source))
+  assert res, source
+  assert not {k: v[:3] for k, v in res.items() if v}
+
+
+def test_the_mfma_hazard_check_finds_the_peeled_filter_kernel_without_hand_wait_states():
+  """The build that lost survivors on the GPU (TFRS_SCAN16_PEEL=1: the queue append as a short side branch, wait
+  states left to the compiler; profiles/r05_scan16f_peel.txt) is the checker's known positive: the max tree of
+  every scan16f instantiation reads an accumulator 1-11 wait states early there, and nowhere else in the file."""
+  res = _mfma_hazard_checker().check(_device_asm("topk_scan16.hip", ("TFRS_SCAN16_PEEL=1",)))
+  bad = {k for k, v in res.items() if v}
+  assert bad and all("scan16f_kernel" in k for k in bad)
+  assert {k for k in res if "scan16f_kernelILi64ELi16ELi2ELi2E" in k} <= bad
 
 
 @pytest.mark.parametrize("source,patterns,max_vgprs,agpr_spills_ok", [
