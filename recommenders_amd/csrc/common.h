@@ -49,12 +49,13 @@ hipError_t ensure_dynamic_lds(const void *kernel, int bytes);
 const char *option(const char *name);
 
 // ---- packed candidate layout -------------------------------------------------
-// Row r of the packed corpus occupies row_bytes(dp) bytes:
+// Row r of the packed corpus occupies row_bytes(dp) = 4 dp bytes (round 5: no pad slot in memory, so a dim-64 row
+// is two whole 128-byte lines for the kernels that re-score single rows -- with the pad it straddled three):
 //   slots 0 .. dp/8-1      : even features  (d = 0, 2, 4, ...)  4 floats per 16-B slot
 //   slots dp/8 .. dp/4-1   : odd features   (d = 1, 3, 5, ...)
-//   slot  dp/4             : zero pad (makes the row stride an ODD number of 16-B
-//                            slots, so ds_read_b128 of 16 consecutive rows at one
-//                            slot index hits 16 distinct 16-B bank groups)
+// In LDS (scan_kernel's stages) the row stride is lds_row_bytes(dp) = 4 dp + 16, an ODD number of 16-B slots,
+// so ds_read_b128 of 16 consecutive rows at one slot index hits 16 distinct 16-B bank groups; the stage copy
+// re-pitches (every lane of the copy computes its own source address anyway).
 // v_mfma_f32_32x32x2_f32 consumes features (2s, 2s+1) at step s: lanes 0-31 supply
 // k = 2s from the even plane, lanes 32-63 supply k = 2s+1 from the odd plane, so the
 // accumulation order is d = 0, 1, 2, ... exactly.
@@ -103,7 +104,8 @@ __host__ __device__ inline int padded_dim(int d) {
   if (d <= 64) return 64;
   return 128;
 }
-__host__ __device__ inline int row_bytes(int dp) { return dp * 4 + 16; }
+__host__ __device__ inline int row_bytes(int dp) { return dp * 4; }
+__host__ __device__ inline int lds_row_bytes(int dp) { return dp * 4 + 16; }
 __host__ __device__ inline int64_t padded_rows(int64_t n) {
   return (n + kTileN - 1) / kTileN * kTileN;
 }

@@ -11,7 +11,7 @@ __global__ void __launch_bounds__(256) pack_kernel(const float *__restrict__ can
                                                    int64_t dst_row, int64_t total_rows,
                                                    int64_t mul, int64_t add,
                                                    int32_t *__restrict__ rowmap) {
-  const int slots = dp / 4 + 1;  // incl. pad slot
+  const int slots = dp / 4;
   const int half = dp / 8;       // slots per plane
   const int64_t nslots = total_rows * slots;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nslots;
@@ -64,7 +64,7 @@ int launch_pack(const float *cand, int64_t n, int d, char *packed, int64_t dst_r
   const int dp = padded_dim(d);
   const int64_t total_rows = zero_rows_to - dst_row;
   if (total_rows <= 0) return TFRS_OK;
-  const int64_t nslots = total_rows * (dp / 4 + 1);
+  const int64_t nslots = total_rows * (dp / 4);
   int64_t blocks = (nslots + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   int64_t mul = 1, add = 0;

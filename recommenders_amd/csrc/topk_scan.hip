@@ -44,28 +44,40 @@ constexpr int kQueriesPerWg = kWaves * 32;
 template <int DP>
 struct ScanGeom {
   static constexpr int kSteps = DP / 2;
-  static constexpr int kRowB = DP * 4 + 16;
+  static constexpr int kRowB = DP * 4 + 16;                           // row stride in LDS (lds_row_bytes: odd slot count)
+  static constexpr int kRowG = DP * 4;                                // row stride of the image in memory (row_bytes)
+  static constexpr int kSlotsL = kRowB / 16;                          // 16-B slots per LDS row, the last one a pad
   static constexpr int kStageB = kTileN * kRowB;
-  static constexpr int kChunks = kStageB / 16;                        // 16-B chunks per stage
+  static constexpr int kStageG = kTileN * kRowG;
+  static constexpr int kChunks = kStageB / 16;                        // 16-B chunks per stage IN LDS
   static constexpr int kLoads = (kChunks + kThreads - 1) / kThreads;  // per thread
   static constexpr int kLdsBytes = 2 * kStageB;
 };
 
 // Stage copy HBM/L2 -> LDS.  GLDS = true uses the gfx950 direct-to-LDS load
 // (global_load_lds_dwordx4: per-lane global address, LDS destination = wave-uniform base +
-// lane * 16): the packed corpus image is already in its final LDS layout, so the copy is
-// linear, needs no staging VGPRs and no ds_write pass.  GLDS = false stages through
-// registers (global_load_dwordx4 -> ds_write_b128).
+// lane * 16): no staging VGPRs and no ds_write pass.  GLDS = false stages through registers
+// (global_load_dwordx4 -> ds_write_b128).  Either way chunk P of the LDS stage (row P / kSlotsL, slot P % kSlotsL of
+// the padded LDS rows) comes from slot min(P % kSlotsL, last) of the unpadded row in memory: the 16 lanes of a row
+// still read one contiguous 4 DP bytes (the pad slot re-reads the row's last slot; nobody reads it back).
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-template <int CHUNKS, int LOADS>
+template <int DP>
+__device__ __forceinline__ int stage_src_offset(int chunk) {
+  constexpr int kSlotsL = DP / 4 + 1;
+  const int r = chunk / kSlotsL;
+  const int sl = chunk - r * kSlotsL;
+  return r * (DP * 4) + (sl < kSlotsL - 1 ? sl : kSlotsL - 2) * 16;
+}
+
+template <int DP, int CHUNKS, int LOADS>
 __device__ __forceinline__ void stage_glds(const char *gsrc, char *lds_dst, int tid, int wave) {
 #pragma unroll
   for (int i = 0; i < LOADS; ++i) {
     const int ch0 = i * kThreads + wave * 64;  // first chunk of this wave's instruction
     if (ch0 < CHUNKS) {                         // wave-uniform (CHUNKS is a multiple of 64)
-      __builtin_amdgcn_global_load_lds((gbl_void_t *)(gsrc + (size_t)(i * kThreads + tid) * 16),
+      __builtin_amdgcn_global_load_lds((gbl_void_t *)(gsrc + stage_src_offset<DP>(i * kThreads + tid)),
                                        (lds_void_t *)(lds_dst + ch0 * 16), 16, 0, 0);
     }
   }
@@ -130,19 +142,19 @@ __global__ void __launch_bounds__(kThreads, DP <= 64 ? 4 : 2) scan_kernel(const 
   uint32_t mycnt = 0;
 
   // ---- stage 0 -> LDS ------------------------------------------------------------
-  const char *gsrc = a.packed + c0 * (int64_t)G::kRowB;
+  const char *gsrc = a.packed + c0 * (int64_t)G::kRowG;
   // Every thread moves kLoads 16-byte chunks per stage; chunk numbers past the stage end are
   // clamped for the load (harmless re-read) and skipped for the LDS write, which keeps
   // the staging registers unconditionally defined (no scratch).
   static_assert(G::kChunks % 64 == 0, "stage size must be a whole number of wave copies");
   f32x4 stg[GLDS ? 1 : G::kLoads];
   if (GLDS) {
-    stage_glds<G::kChunks, G::kLoads>(gsrc, smem, tid, wave);
+    stage_glds<DP, G::kChunks, G::kLoads>(gsrc, smem, tid, wave);
   } else {
 #pragma unroll
     for (int i = 0; i < G::kLoads; ++i) {
       const int ch = min(tid + i * kThreads, G::kChunks - 1);
-      stg[i] = *reinterpret_cast<const f32x4 *>(gsrc + ch * 16);
+      stg[i] = *reinterpret_cast<const f32x4 *>(gsrc + stage_src_offset<DP>(ch));
     }
 #pragma unroll
     for (int i = 0; i < G::kLoads; ++i) {
@@ -156,14 +168,14 @@ __global__ void __launch_bounds__(kThreads, DP <= 64 ? 4 : 2) scan_kernel(const 
     const char *tile = smem + (st & 1) * G::kStageB;
     const bool more = (st + 1 < nstages);
     if (more) {  // prefetch the next stage (other LDS buffer: its readers passed the last barrier)
-      const char *g = gsrc + (int64_t)(st + 1) * G::kStageB;
+      const char *g = gsrc + (int64_t)(st + 1) * G::kStageG;
       if (GLDS) {
-        stage_glds<G::kChunks, G::kLoads>(g, smem + ((st + 1) & 1) * G::kStageB, tid, wave);
+        stage_glds<DP, G::kChunks, G::kLoads>(g, smem + ((st + 1) & 1) * G::kStageB, tid, wave);
       } else {
 #pragma unroll
         for (int i = 0; i < G::kLoads; ++i) {
           const int ch = min(tid + i * kThreads, G::kChunks - 1);
-          stg[i] = *reinterpret_cast<const f32x4 *>(g + ch * 16);
+          stg[i] = *reinterpret_cast<const f32x4 *>(g + stage_src_offset<DP>(ch));
         }
       }
     }

@@ -16,6 +16,12 @@ namespace tfrs {
 
 constexpr int kSel16Waves = 4;
 constexpr int kSlots = 16;     // values per lane held in registers (64 * 16 = 1024 per query)
+// Timing ablations of list_topk16_kernel (tools/ab_variants.sh; results are WRONG with any of them): 1 = no row
+// loads in the exact re-scoring, 2 = no final sort, 4 = stop behind the gather, 16 = twice the LDS per workgroup
+// (half the resident waves).
+#ifndef TFRS_LIST16_ABLATE
+#define TFRS_LIST16_ABLATE 0
+#endif
 constexpr int kRadixBits = 24; // the K-th key is resolved to its top 24 bits (rounded DOWN)
 
 __device__ __forceinline__ uint32_t sel16_mbcnt(uint64_t mask) {
@@ -31,10 +37,35 @@ __device__ __forceinline__ void sel16_lds_sync() {
 // slot; returns 0 when fewer than k non-empty keys exist).  The result is <= the true k-th
 // largest key, i.e. a lower bound of the k-th largest score.
 // Slots >= nslots (wave-uniform) hold no keys and are skipped.
+//
+// The search is one bit per pass; the bits every non-empty key shares (prefilter scores of one query's survivors:
+// the same sign and exponent and a few mantissa bits, typically 9-11 of the 24) are not searched: with at least k
+// keys the bit-by-bit search would set exactly those bits of the prefix and leave k alone, with fewer it returns 0.
 __device__ __forceinline__ uint32_t radix_kth(const uint32_t (&key)[kSlots], int k, int nslots = kSlots) {
-  uint32_t prefix = 0u;
+  uint32_t kmax = 0u, kmin = 0xFFFFFFFFu;
+  int n = 0;
+#pragma unroll
+  for (int s = 0; s < kSlots; ++s)
+    if (s < nslots) {
+      kmax = max(kmax, key[s]);
+      kmin = min(kmin, key[s] != 0u ? key[s] : 0xFFFFFFFFu);
+      n += (int)__popcll(__ballot(key[s] != 0u));
+    }
+  if (n < k) return 0u;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off));
+    kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off));
+  }
+  kmax = __builtin_amdgcn_readfirstlane(kmax);   // (the same in every lane: SGPRs, a uniform loop below)
+  kmin = __builtin_amdgcn_readfirstlane(kmin);   // (n >= k >= 1: kmin is a key)
+  constexpr uint32_t kLowBits = (1u << (32 - kRadixBits)) - 1u;
+  const uint32_t diff = kmax ^ kmin;
+  if ((diff & ~kLowBits) == 0u) return kmax & ~kLowBits;   // the keys agree on all searched bits
+  const int top = 31 - __builtin_clz(diff);                  // highest bit two keys differ in (>= 32 - kRadixBits)
+  uint32_t prefix = top == 31 ? 0u : (kmax & ~((2u << top) - 1u));
 #pragma unroll 1
-  for (int bit = 31; bit >= 32 - kRadixBits; --bit) {
+  for (int bit = top; bit >= 32 - kRadixBits; --bit) {
     const uint32_t test = prefix | (1u << bit);
     const uint32_t himask = ~((1u << bit) - 1u);
     int cnt = 0;
@@ -325,6 +356,7 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
     return;
   }
   sel16_lds_sync();
+  if (TFRS_LIST16_ABLATE & 4) { if (lane == 0) a.out_idx[row * K] = total; return; }
 
   // ---- list -> registers; K-th largest prefilter score ---------------------------------------
   uint32_t key[kSlots], rowid[kSlots];
@@ -403,14 +435,17 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
     if (u * 64 < m) {  // wave-uniform
       uint64_t kk = 0ull;
       if (u * 64 + lane < m)
-        kk = make_key(a.raw ? raw_score(a.raw, (int64_t)kid[u], a.d, qs) : packed_score16(a.packed, (int64_t)kid[u], dp, qs),
+        kk = make_key((TFRS_LIST16_ABLATE & 1) ? (float)kid[u] * 1e-9f :
+                      a.raw ? raw_score(a.raw, (int64_t)kid[u], a.d, qs) : packed_score16(a.packed, (int64_t)kid[u], dp, qs),
                       (int32_t)((a.rowmap ? (int64_t)a.rowmap[kid[u]] : (int64_t)kid[u]) + a.idx_base));
       ex[u * 64 + lane] = kk;
     }
   }
   for (int i = m + lane; i < KP; i += 64) ex[i] = 0ull;
   sel16_lds_sync();
-  if (KP > 128 && m <= 128) sort_desc16<128>(ex, lane); else sort_desc16<KP>(ex, lane);
+  if (!(TFRS_LIST16_ABLATE & 2)) {
+    if (KP > 128 && m <= 128) sort_desc16<128>(ex, lane); else sort_desc16<KP>(ex, lane);
+  }
 
   for (int i = lane; i < K; i += 64) {
     const uint64_t kk = ex[i];
@@ -421,7 +456,8 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
 
 template <int KP>
 static int launch_list16_kp(const List16Args &a, hipStream_t stream) {
-  const size_t lds = (size_t)kSel16Waves * (64 * kSlots * sizeof(uint2) + TFRS_MAX_DIM * sizeof(float));
+  const size_t lds = (size_t)kSel16Waves * (64 * kSlots * sizeof(uint2) + TFRS_MAX_DIM * sizeof(float)) *
+                     ((TFRS_LIST16_ABLATE & 16) ? 2 : 1);
   const dim3 grid((unsigned)((a.nq + kSel16Waves - 1) / kSel16Waves));
   hipLaunchKernelGGL((list_topk16_kernel<KP>), grid, dim3(kSel16Waves * 64), lds, stream, a);
   TFRS_LAUNCH_CHECK();
