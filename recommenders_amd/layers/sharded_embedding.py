@@ -16,7 +16,9 @@ make the host wait for the device: ``stage(ids)`` moves it OFF the critical path
 NEXT batch right after the current step has been enqueued, it routes the ids, exchanges the counts
 and starts their copy into pinned host memory without waiting; the lookup of that batch one step
 later finds the counts already on the host (the "input dist one batch ahead" pipelining of
-production recommenders).  Without ``stage`` the lookup does the same work inline and waits.
+production recommenders).  Without ``stage`` the lookup does the same work inline and waits.  ``stage``
+is explicit and collective: the lookup that follows must be of the staged tensor on every rank (anything
+else raises rather than letting the ranks disagree on which collectives to run).
 
 and the backward mirrors it: gradient rows travel to the owners (one all_to_all), where they
 become ``(ids, rows)`` slices for ``optimizers.Adagrad`` (fused sparse update on the shard) or
@@ -230,9 +232,13 @@ class ShardedEmbedding(torch.nn.Module):
   # -- split sizes one batch ahead -----------------------------------------------------------------
   def stage(self, ids: torch.Tensor) -> None:
     """Routes ``ids`` (a batch that will be looked up LATER, typically the next one) and starts the
-    exchange + device->host copy of the all-to-all split sizes without waiting for them.  The lookup
-    of the same tensor object then takes the staged routing; staging is dropped when the tensor has
-    been written to in between (version counter) or another batch is staged.  World size 1: no-op."""
+    exchange + device->host copy of the all-to-all split sizes without waiting for them.  A COLLECTIVE:
+    every rank calls it, or none.  The next lookup must then be of the same tensor object, unmodified, on
+    every rank -- it takes the staged routing and issues no collective for the split sizes.  A lookup of
+    anything else RAISES instead of falling back to the inline exchange: the choice would be made per rank
+    (object identity, version counter), and one rank taking the inline collective while its peers take the
+    staged path hangs the job.  ``unstage()`` (every rank) or staging another batch drops a staged batch
+    that will not be looked up.  World size 1: no-op."""
     group, world = self._group, _world(self._group)
     self._staged = None
     if _single(group) or not isinstance(ids, torch.Tensor) or ids.device != self.embeddings.device:
@@ -260,10 +266,21 @@ class ShardedEmbedding(torch.nn.Module):
       st.lists = ([int(v) for v in rows[me]], [int(rows[p][me]) for p in range(world)])
     self._staged = st
 
+  def unstage(self) -> None:
+    """Drops a staged batch that will not be looked up (call on every rank, like ``stage``)."""
+    self._staged = None
+
   def _take_staged(self, ids) -> Optional[_Staged]:
     st, self._staged = getattr(self, "_staged", None), None
-    if st is None or st.ids is not ids or ids._version != st.version:
+    if st is None:
       return None
+    if st.ids is not ids or ids._version != st.version:
+      raise RuntimeError(
+          "ShardedEmbedding: a batch was staged with stage(ids) but the lookup is of "
+          + ("another tensor" if st.ids is not ids else "the staged tensor after an in-place write")
+          + ". The staged split sizes cannot be used and the inline exchange is a collective the other "
+          "ranks would not join; look up the staged tensor unmodified, or call unstage() on every rank "
+          "first. (The staged batch has been dropped on this rank.)")
     return st
 
   def forward(self, ids: torch.Tensor) -> torch.Tensor:

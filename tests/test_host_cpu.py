@@ -344,8 +344,9 @@ all_ids = [np.random.default_rng(100 + r).integers(0, V, size=(B,)) for r in ran
 all_w = [np.random.default_rng(200 + r).normal(size=(B, D)).astype(np.float32) for r in range(world)]
 ref = o_emb.scatter_add_grad(np.concatenate(all_w), np.concatenate(all_ids), V)[lo:hi]
 np.testing.assert_allclose(layer.embeddings.grad.numpy(), ref, rtol=1e-6, atol=1e-6)
-# split sizes one batch ahead: stage(next ids) now, look them up later -- same result; a batch that was
-# written to after staging, or another tensor, falls back to the inline routing
+# split sizes one batch ahead: stage(next ids) now, look them up later -- same result; looking up a batch that
+# was written to after staging, or another tensor, RAISES (a per-rank fallback to the inline collective could
+# leave the ranks in different collectives) and drops the staged batch; unstage() drops it explicitly
 nxt = torch.from_numpy(np.random.default_rng(300 + rank).integers(0, V, size=(B,)))
 layer.stage(nxt)
 assert layer._staged is not None and layer._staged.ids is nxt
@@ -354,11 +355,23 @@ assert layer._staged is None
 assert np.array_equal(out2.detach().numpy(), o_emb.gather(full, nxt.numpy())), "staged lookup differs"
 layer.stage(nxt)
 nxt[0] = (int(nxt[0]) + 1) % V                          # in-place write: the staged routing is stale
-out3 = layer(nxt)
-assert np.array_equal(out3.detach().numpy(), o_emb.gather(full, nxt.numpy())), "stale staging was used"
+try:
+  layer(nxt)
+  raise AssertionError("stale staging was accepted")
+except RuntimeError as e:
+  assert "in-place write" in str(e) and layer._staged is None
+out3 = layer(nxt)                                      # (every rank raised: all are back on the inline path)
+assert np.array_equal(out3.detach().numpy(), o_emb.gather(full, nxt.numpy()))
 layer.stage(nxt)
 other = nxt.clone()
-out4 = layer(other)                                    # not the staged object
+try:
+  layer(other)                                         # not the staged object
+  raise AssertionError("a lookup of another tensor took the staged routing")
+except RuntimeError as e:
+  assert "another tensor" in str(e)
+layer.stage(nxt)
+layer.unstage()
+out4 = layer(other)
 assert np.array_equal(out4.detach().numpy(), o_emb.gather(full, other.numpy()))
 dist.barrier()
 dist.destroy_process_group()
