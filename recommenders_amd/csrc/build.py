@@ -44,6 +44,8 @@ SOURCES = [
 # topk_scan16.hip: its max trees must compile to bare v_max3_f32 (no sNaN-quieting
 # canonicalisation of the MFMA results); NaN inputs are outside the top-K contract anyway.
 EXTRA_FLAGS = {"topk_scan16.hip": ["-fno-honor-nans"],
+               # (the max trees over MFMA accumulators of the block-fed filters: v_max3_f32 without canonicalisation)
+               "topk_raw.hip": ["-fno-honor-nans"],
                # MFMA accumulators in VGPRs: the softmax arithmetic reads them directly
                "softmax16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 

@@ -81,6 +81,20 @@ __device__ __forceinline__ float raw_max16(const f32x16 &c) {
   const float e = fmaxf(fmaxf(c[12], c[13]), fmaxf(c[14], c[15]));
   return fmaxf(fmaxf(a, b), fmaxf(d, e));
 }
+// The same as maxima of three (v_max3_f32; this file is built with -fno-honor-nans like topk_scan16.hip: without it
+// fmaxf() of an MFMA result costs a canonicalising `v_max_f32 x, x` per input first -- 31 instructions for 16 values
+// instead of 8.  A NaN score fails `> threshold` either way.  NOT inline assembly: the compiler's hazard recognizer
+// does not look at the operands of an asm statement, and a v_max3 written that way read the accumulators right behind
+// the chain's last MFMA -- tools/check_mfma_hazards.py found it on the listing.)
+__device__ __forceinline__ float raw_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float raw_max8f(const f32x16 &c, int o) {   // max of c[o .. o + 7]
+  return raw_max3(raw_max3(c[o], c[o + 1], c[o + 2]), raw_max3(c[o + 3], c[o + 4], c[o + 5]), fmaxf(c[o + 6], c[o + 7]));
+}
+__device__ __forceinline__ float raw_max16f(const f32x16 &c) {
+  const float a = raw_max3(c[0], c[1], c[2]), b = raw_max3(c[3], c[4], c[5]), d = raw_max3(c[6], c[7], c[8]);
+  const float e = raw_max3(c[9], c[10], c[11]), f = raw_max3(c[12], c[13], c[14]);
+  return fmaxf(raw_max3(a, b, d), raw_max3(e, f, c[15]));
+}
 
 __global__ void raw_table_write_kernel(const RawTable t, RawTable *dst) {
   // (word-wise copy of the by-value argument; 3096 bytes)
@@ -527,7 +541,7 @@ __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArg
       // acc[r] = prefilter score of (query qrow[g], stage row of t = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h),
       // in units of qscale * cs.  keep s~ > lower - qk * N - tiny, the scales folded into the threshold
       const float thr = __builtin_fmaf(-fqk[g], nrm, flo[g]) * inv;
-      const float m0 = raw_max16(acc);
+      const float m0 = raw_max16f(acc);
       if (__ballot(m0 > thr) != 0ull) {   // rare once the bound is warm
         // (round 5, as in rawscan16w_kernel: 32-bit row arithmetic relative to the split and ONE counter round trip
         // per lane and hot tile instead of sixteen dependent ones)
@@ -535,10 +549,14 @@ __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArg
         const uint32_t rel_stage = (uint32_t)st * kTileN;
         uint32_t hits = 0u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int t = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const uint32_t srow = (uint32_t)((t % G::kChunks) * G::kRowsPerChunk + t / G::kChunks);
-          hits |= (acc[r] > thr && rel_stage + srow < rows_here) ? (1u << r) : 0u;
+        for (int r = 0; r < 16; ++r) hits |= acc[r] > thr ? (1u << r) : 0u;
+        if (rel_stage + kTileN > rows_here) {   // (uniform) the split's last, partly filled stage: rows beyond it score nothing
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int t = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const uint32_t srow = (uint32_t)((t % G::kChunks) * G::kRowsPerChunk + t / G::kChunks);
+            if (rel_stage + srow >= rows_here) hits &= ~(1u << r);
+          }
         }
         if (hits) {
           uint32_t e = atomicAdd(&wg_cnt[g * 32 + j], (uint32_t)__builtin_popcount(hits));
@@ -610,6 +628,11 @@ static int launch_rawscan16_variant(const RawScanArgs &a, hipStream_t stream) {
 // hot tile instead of sixteen, no cross-lane reductions at all (ablation).
 // timing ablations of rawscan16w_kernel (tools/ab_variants.sh; results WRONG): 1 = no cross-lane reductions in the
 // conversion, 2 = no scoring, 4 = no conversion at all, 8 = no loads after the first stage
+// 1 = a second A-fragment set at dim 128 too (the next sub-tile's fragments fetched under the current chains): needs
+// 5-9 registers more than the 256 a lane has next to the stage of rows in flight -- scratch in the stage loop; not built
+#ifndef TFRS_RAWW_AFB128
+#define TFRS_RAWW_AFB128 0
+#endif
 #ifndef TFRS_RAWW_ABLATE
 #define TFRS_RAWW_ABLATE 0
 #endif
@@ -669,12 +692,14 @@ __global__ void __launch_bounds__(kRawWWaves * 64) rawscan16w_kernel(const RawSc
   // ---- this WAVE's 2 x 32 queries -> fp16 MFMA B operands (q / qscale), resident ------------------
   f16x8r bq[kRawWQG][KS];
   float flo[kRawWQG], fqk[kRawWQG], qsc[kRawWQG];
-  int64_t qrow[kRawWQG];
+  // (one 32-bit query number per lane, group g adds 32 g: the batch holds < 2^31 queries; two 64-bit row numbers
+  // were four registers of a budget that the second A-fragment set needs)
+  const uint32_t qrow0 = (uint32_t)qt * kRawWQueries + (uint32_t)(wave * kRawWQG) * 32u + (uint32_t)j;
 #pragma unroll
   for (int g = 0; g < kRawWQG; ++g) {
-    qrow[g] = (int64_t)qt * kRawWQueries + (wave * kRawWQG + g) * 32 + j;
-    const bool qvalid = qrow[g] < a.nq;
-    const int64_t qr = qvalid ? qrow[g] : 0;
+    const int64_t qrow_g = (int64_t)qrow0 + 32 * g;
+    const bool qvalid = qrow_g < a.nq;
+    const int64_t qr = qvalid ? qrow_g : 0;
     const float qs = qvalid ? a.qscale[qr] : 1.0f;
     const float qinv = 1.0f / qs;   // exact: power of two
     const f32x4 *q4 = reinterpret_cast<const f32x4 *>(a.q + qr * DP);
@@ -786,7 +811,7 @@ __global__ void __launch_bounds__(kRawWWaves * 64) rawscan16w_kernel(const RawSc
       const char *ap = t16 + j * G::kRow16B + h * 16;
       // A fragments of the next sub-tile are fetched under the chains of the current one -- up to dim 64; at dim 128
       // a second set (32 registers next to two stages of rows in flight) spills
-      constexpr int AFB = DP >= 128 ? 1 : 2;
+      constexpr int AFB = TFRS_RAWW_AFB128 ? 2 : (DP >= 128 ? 1 : 2);
       u32x4r af[AFB][KS];
 #pragma unroll
       for (int m = 0; m < KS; ++m) af[0][m] = *reinterpret_cast<const u32x4r *>(ap + m * 32);
@@ -821,23 +846,23 @@ __global__ void __launch_bounds__(kRawWWaves * 64) rawscan16w_kernel(const RawSc
           const f32x16 &c = acc[g];
           const float thrA = __builtin_fmaf(-fqk[g], mA.z, flo[g]) * mA.x;
           const float thrB = __builtin_fmaf(-fqk[g], mB.z, flo[g]) * mB.x;
-          const float xa = fmaxf(fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])), fmaxf(fmaxf(c[4], c[5]), fmaxf(c[6], c[7])));
-          const float xb = fmaxf(fmaxf(fmaxf(c[8], c[9]), fmaxf(c[10], c[11])),
-                                 fmaxf(fmaxf(c[12], c[13]), fmaxf(c[14], c[15])));
+          const float xa = raw_max8f(c, 0), xb = raw_max8f(c, 8);
           if (__ballot(xa > thrA || xb > thrB) != 0ull) {   // rare once the bound is warm
             // (32-bit row arithmetic relative to the split: sixteen 64-bit compares per tile were precomputed
             // and spilled -- 42 scratch stores per stage)
             const uint32_t rel0 = (uint32_t)st * kTileN + 32u * sub + 4u * h;
-            uint2 *const seg = a.buf + (qrow[g] * (int64_t)a.cap_l) * a.nseg + split;
+            uint2 *const seg = a.buf + (((int64_t)qrow0 + 32 * g) * (int64_t)a.cap_l) * a.nseg + split;
             const float unA = qsc[g] * mA.y, unB = qsc[g] * mB.y;
             // ONE counter round trip per lane and hot tile: the lane counts its survivors, reserves that many
             // slots, then stores them (sixteen dependent ds_add_rtn round trips per hot tile made the scoring
             // phase 3x its matrix-core time: in a stream's early ranges every tile is hot)
             uint32_t hits = 0u;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const uint32_t rel = rel0 + (r & 3) + 8 * (r >> 2);
-              hits |= (c[r] > (r < 8 ? thrA : thrB) && rel < rows_here) ? (1u << r) : 0u;
+            for (int r = 0; r < 16; ++r) hits |= c[r] > (r < 8 ? thrA : thrB) ? (1u << r) : 0u;
+            if ((uint32_t)(st + 1) * kTileN > rows_here) {   // (uniform) the split's last, partly filled stage
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                if (rel0 + (r & 3) + 8 * (r >> 2) >= rows_here) hits &= ~(1u << r);
             }
             if (hits) {
               uint32_t e = atomicAdd(&wg_cnt[(wave * kRawWQG + g) * 32 + j], (uint32_t)__builtin_popcount(hits));

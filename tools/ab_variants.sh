@@ -9,7 +9,7 @@ if [ "$1" = build ]; then
   src=$2; def=$3; shift 3
   mkdir -p ab
   extra=""
-  [ "$src" = topk_scan16.hip ] && extra="-fno-honor-nans"
+  { [ "$src" = topk_scan16.hip ] || [ "$src" = topk_raw.hip ]; } && extra="-fno-honor-nans"
   [ "$src" = softmax16.hip ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
   base=$(basename $src .hip)
   for v in "$@"; do
