@@ -1077,7 +1077,7 @@ static int64_t stream_raw16_max_nq() { return std::max<int64_t>(0, env_i64("TFRS
 // (round 5: beyond one wave's registers -- 128 queries at dim 128, 256 below -- the waves of an 8-wave workgroup split
 // the queries, 512 per workgroup, and the stage is converted once per workgroup through LDS: rawscan16w_kernel.  Dims
 // below 32 keep the 256-query limit.  Measured on 12.5 M x 128 (profiles/r05_streaming_wide.txt): 257 queries 2.62 ms
-// against 3.30 through the group's fp16 image, 512: 3.2-3.4 against 3.7; from ~800 queries on the image wins again
+// against 3.30 through the group's fp16 image, 512: 2.9-3.1 against 3.7; from ~800 queries on the image wins again
 // (1024: 5.2-5.6 against 5.0) -- the kernel's scoring phase runs at a third of the matrix pipe's rate.)
 static int64_t raw16_max_nq(int d) { return d >= 32 ? stream_raw16_max_nq() : std::min<int64_t>(stream_raw16_max_nq(), 256); }
 // ... and, up to dim 64, from this size on: with one group of 32 queries the exact scan is copy-bound as well

@@ -620,7 +620,7 @@ static int launch_rawscan16_variant(const RawScanArgs &a, hipStream_t stream) {
 //            8 .. 15 of a lane, each half tested against its own threshold.
 // Per stage and SIMD 2 x 64 MFMAs = 4096 matrix-core cycles for 64 KiB of rows.  LDS: 2 x 34.8 KB + counters at dim 128.
 // MEASURED (round 5, 12.5 M x 128, 512 queries; TFRS_RAWW_ABLATE builds): loads + conversion alone 1.16 ms per call =
-// 5.5 TB/s, the whole kernel 2.8-2.96 ms: the scoring phase runs at about a third of the matrix pipe's rate (waves
+// 5.5 TB/s, the whole kernel 2.8-2.96 ms (2.6-2.75 with the trimmed check of the later part of round 5): the scoring phase runs at about a third of the matrix pipe's rate (waves
 // parked 48 % of their cycles: two waves per SIMD of ONE workgroup that converts, meets its barrier and scores in
 // lock step), so the kernel pays only between 257 and ~700 queries (topk_api.hip: TFRS_STREAM_RAW16_MAX_NQ = 640).
 // Tried on the way, each within +-3 %: rows staged through LDS by DMA (one stage in flight), two stages of rows in
