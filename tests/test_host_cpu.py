@@ -740,6 +740,34 @@ def test_no_mfma_result_is_read_before_the_matrix_pipe_delivers_it(source):
   assert not {k: v[:3] for k, v in res.items() if v}
 
 
+def test_mfma_hazard_checker_counts_wait_states_on_a_hand_written_listing():
+  """The checker's own arithmetic on listings small enough to read: 12 wait states behind the 8-pass fp16 shape
+  (an instruction is one, `s_nop N` is N + 1, comments and labels none), 18 behind the 16-pass f32 shape, the
+  chain's next MFMA is not a reader, an unconditional branch ends the fall-through path, AGPR destinations are
+  tracked separately from VGPRs of the same number."""
+  chk = _mfma_hazard_checker()
+
+  def listing(body):
+    return "_Z1kv:\n" + "\n".join("\t" + l for l in body) + "\n\t.amdhsa_kernel _Z1kv\n"
+
+  mf = "v_mfma_f32_32x32x16_f16 v[0:15], v[20:23], v[24:27], v[0:15]"
+  ok = [mf, "s_nop 7", "; a comment", ".LBB0_1:", "s_nop 3", "v_max_f32_e32 v40, v0, v1"]          # 8 + 4 = 12
+  assert chk.check(listing(ok)) == {"_Z1kv": []}
+  short = [mf, "s_nop 7", "s_nop 2", "v_max_f32_e32 v40, v0, v1"]                                    # 8 + 3 = 11
+  (bad,) = chk.check(listing(short))["_Z1kv"]
+  assert bad[1].startswith("v_max_f32") and bad[3] == 1
+  chain = [mf, mf, "s_nop 7", "s_nop 3", "ds_write_b128 v50, v[12:15]"]                              # counted from the LAST link
+  assert chk.check(listing(chain)) == {"_Z1kv": []}
+  assert chk.check(listing([mf, mf, "s_nop 7", "s_nop 2", "ds_write_b128 v50, v[12:15]"]))["_Z1kv"]
+  other = [mf, "v_add_u32_e32 v40, v41, v42", "v_accvgpr_read_b32 v43, a0"]                          # a0 is not v0
+  assert chk.check(listing(other)) == {"_Z1kv": []}
+  branch = [mf, "s_branch .LBB0_9", "v_max_f32_e32 v40, v0, v1"]                                     # not the fall-through
+  assert chk.check(listing(branch)) == {"_Z1kv": []}
+  f32 = "v_mfma_f32_32x32x2_f32 a[0:15], v20, v21, a[0:15]"
+  assert chk.check(listing([f32, "s_nop 15", "s_nop 1", "v_accvgpr_read_b32 v0, a3"])) == {"_Z1kv": []}   # 16 + 2 = 18
+  assert chk.check(listing([f32, "s_nop 15", "s_nop 0", "v_accvgpr_read_b32 v0, a3"]))["_Z1kv"]
+
+
 def test_the_mfma_hazard_check_finds_the_peeled_filter_kernel_without_hand_wait_states():
   """The build that lost survivors on the GPU (TFRS_SCAN16_PEEL=1: the queue append as a short side branch, wait
   states left to the compiler; profiles/r05_scan16f_peel.txt) is the checker's known positive: the max tree of
