@@ -376,7 +376,11 @@ __global__ void __launch_bounds__(STAGE ? 64 : 256, 2) dot_interaction_mfma_kern
       }
 #pragma unroll
       for (int bj = 0; bj <= bi; ++bj) {
-        const f32x16 acc = tile_dot<DP>(frag[bi], frag[bj]);
+        f32x16 acc = tile_dot<DP>(frag[bi], frag[bj]);
+        // The 18 wait states a v_mfma_f32_32x32x2_f32 result needs before a store may read it, by hand: behind the
+        // chain the direct-store variant is a web of predicated side blocks, and the compiler's hazard recognizer
+        // leaves them out on the short paths through it (14 instead of 18: tools/check_mfma_hazards.py)
+        if (!STAGE) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 1" : "+v"(acc));
         // acc[r] = G[row0 + dr(r)][bj*32 + j],  dr(r) = (r & 3) + 8 * (r >> 2)
         const int col = bj * 32 + jv;
         const int a0 = tri0 + col;

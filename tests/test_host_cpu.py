@@ -763,6 +763,12 @@ def test_mfma_hazard_checker_counts_wait_states_on_a_hand_written_listing():
   assert chk.check(listing(other)) == {"_Z1kv": []}
   branch = [mf, "s_branch .LBB0_9", "v_max_f32_e32 v40, v0, v1"]                                     # not the fall-through
   assert chk.check(listing(branch)) == {"_Z1kv": []}
+  # ... but the TAKEN path is followed too: a side block that reads the accumulator, a loop back edge to a reader
+  side = [mf, "s_cbranch_vccnz .LBB0_7", "s_nop 7", "s_nop 7", "s_endpgm", ".LBB0_7:", "ds_write_b128 v50, v[0:3]"]
+  (bad,) = chk.check(listing(side))["_Z1kv"]
+  assert bad[1].startswith("ds_write_b128") and bad[3] == 11
+  loop = [".LBB0_2:", "v_max_f32_e32 v40, v0, v1", "s_nop 7", "s_nop 7", mf, "s_cbranch_scc1 .LBB0_2"]
+  assert [b[1][:9] for b in chk.check(listing(loop))["_Z1kv"]] == ["v_max_f32"]
   f32 = "v_mfma_f32_32x32x2_f32 a[0:15], v20, v21, a[0:15]"
   assert chk.check(listing([f32, "s_nop 15", "s_nop 1", "v_accvgpr_read_b32 v0, a3"])) == {"_Z1kv": []}   # 16 + 2 = 18
   assert chk.check(listing([f32, "s_nop 15", "s_nop 0", "v_accvgpr_read_b32 v0, a3"]))["_Z1kv"]

@@ -6,8 +6,10 @@ int8 shapes (LLVM's GFX940_XDL_N_PassWriteVgprVALURawWaitStates with the gfx950 
 f32-operand shapes (..._SMFMA_...); an instruction is one wait state, `s_nop N` is N + 1.  The compiler's hazard recognizer normally does that, but it was caught emitting 3-5 wait states
 instead of 12 in front of the `max` tree of the filter kernel when the survivor append was a peeled side branch
 (profiles/r05_scan16f_peel.txt): the kernel then read a stale accumulator now and then and lost
-survivors of its last query group.  This walks every kernel of a `.s` file in layout order (fall-through path;
-the count restarts behind an unconditional branch) and reports each read that comes too early.
+survivors of its last query group; the same fault sat, harmless so far, in the direct-store f32 DotInteraction kernel.  This walks every kernel of a `.s` file in layout order (the fall-through
+path; behind an unconditional branch the count restarts) and, from every branch it meets while an MFMA is still in
+the pipe, the TAKEN path as well (three branches deep) -- side blocks and loop back edges -- and reports each read
+that comes too early.
 
   python tools/check_mfma_hazards.py file.s [kernel-name-substring]
 """
@@ -69,29 +71,72 @@ def kernels(asm):
   return out
 
 
-def short_reads(body):
-  """[(line_no, instruction, register, missing wait states)] of one kernel body."""
-  pending = []   # [file, lo, hi, wait states still required, line of the MFMA]
-  bad = []
+_BRANCH = re.compile(r"^(s_branch|s_cbranch_\w+)\s+(\.?\w+)")
+
+
+def _parse(body):
+  """[(line_no, op, operands, text)] of the instructions and {label: index of the instruction behind it}."""
+  ins, labels = [], {}
   for no, raw in body:
     text = raw.split(";")[0].strip()
-    if not text or text.endswith(":") or text.startswith("."):
+    if not text or text.startswith("."):
+      if text.endswith(":"):
+        labels[text[:-1]] = len(ins)
+      continue
+    if text.endswith(":"):
+      labels[text[:-1]] = len(ins)
       continue
     parts = text.split(None, 1)
-    op, operands = parts[0], parts[1] if len(parts) > 1 else ""
-    if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+    ins.append((no, parts[0], parts[1] if len(parts) > 1 else "", text))
+  return ins, labels
+
+
+def _required(op):
+  n = _passes(op)
+  xdl = not re.search(r"x\d+_?f32$|_f64$", op.split("_e64")[0])     # f32 / f64 operands: not the XDL pipe's rule
+  return (n + 3 + (1 if n != 2 else 0)) if xdl else n + 2
+
+
+def _walk(ins, labels, start, pending, bad, seen, depth):
+  """Follows the fall-through path from instruction `start` with the MFMAs in `pending` still in the pipe; at every
+  branch the TAKEN path is followed as well (a copy of the pending set, at most three branches deep) until the pipe
+  has delivered everything.  `start == 0` is the whole-kernel walk, which also picks up new MFMAs."""
+  top = depth == 0
+  i = start
+  while i < len(ins):
+    if not top and not pending:
+      return
+    no, op, operands, text = ins[i]
+    m = _BRANCH.match(text)
+    if m:
+      if pending and depth < 3 and m.group(2) in labels:
+        key = (labels[m.group(2)], tuple((p[0], p[1], p[2], p[3]) for p in pending))
+        if key not in seen:
+          seen.add(key)
+          taken = [[p[0], p[1], p[2], p[3] - 1, p[4]] for p in pending if p[3] - 1 > 0]   # the branch is one wait state
+          _walk(ins, labels, labels[m.group(2)], taken, bad, seen, depth + 1)
+      if m.group(1) == "s_branch":
+        if not top:
+          return
+        pending = []
+        i += 1
+        continue
+    if op in ("s_endpgm", "s_setpc_b64"):
+      if not top:
+        return
       pending = []
+      i += 1
       continue
     is_mfma = op.startswith("v_mfma") or op.startswith("v_smfmac")
     if not is_mfma and pending and (op.startswith(("v_", "ds_", "global_", "buffer_", "flat_", "scratch_"))):
       for f, lo, hi in _regs(operands):
         for p in pending:
           if p[0] == f and lo <= p[2] and hi >= p[1] and p[3] > 0:
-            bad.append((no, text, f"{f}[{lo}:{hi}]", p[3], p[4]))
-            p[3] = 0   # one report per MFMA
-    states = 1
-    if op == "s_nop":
-      states = int(operands.strip(), 0) + 1
+            rec = (no, text, f"{f}[{lo}:{hi}]", p[3], p[4])
+            if rec not in bad:
+              bad.append(rec)
+            p[3] = 0   # one report per MFMA and path
+    states = int(operands.strip(), 0) + 1 if op == "s_nop" else 1
     for p in pending:
       p[3] -= states
     pending = [p for p in pending if p[3] > 0]
@@ -99,10 +144,17 @@ def short_reads(body):
       regs = _regs(operands)
       if regs:
         f, lo, hi = regs[0]
-        n = _passes(op)
         pending = [p for p in pending if not (p[0] == f and p[1] == lo and p[2] == hi)]   # the chain's next link
-        xdl = not re.search(r"x\d+_?f32$|_f64$", op.split("_e64")[0])     # f32 / f64 operands: not the XDL pipe's rule
-        pending.append([f, lo, hi, (n + 3 + (1 if n != 2 else 0)) if xdl else n + 2, no])
+        if top:
+          pending.append([f, lo, hi, _required(op), no])
+    i += 1
+
+
+def short_reads(body):
+  """[(line_no, instruction, register, missing wait states, line of the MFMA)] of one kernel body."""
+  ins, labels = _parse(body)
+  bad = []
+  _walk(ins, labels, 0, [], bad, set(), 0)
   return bad
 
 
