@@ -804,6 +804,9 @@ def test_the_mfma_hazard_check_finds_the_peeled_filter_kernel_without_hand_wait_
     # 16 registers live in the accumulator file: no scratch memory, which is what the stage prefetch cares about)
     ("topk_raw.hip", ("rawscan16_kernelILi128ELi1E", "rawscan16_kernelILi128ELi2E", "rawscan16_kernelILi128ELi4E",
                       "rawscan16_kernelILi64ELi8E", "rawscan16_kernelILi32ELi8E", "rawscan16_kernelILi8ELi8E"), 512, True),
+    # the wide block-fed filter (257-640 queries: one 8-wave workgroup per CU, two waves per SIMD): the stage of rows in
+    # flight, the two query groups' B operands and one A-fragment set fill the 256 registers of a lane -- no scratch
+    ("topk_raw.hip", ("rawscan16w_kernelILi128E", "rawscan16w_kernelILi64E", "rawscan16w_kernelILi32E"), 256, False),
     # the fp16 image packer that keeps a stage's parity planes in registers
     ("topk_pack.hip", ("pack16_stage_regs_kernelILi128E", "pack16_stage_regs_kernelILi16E"), 128, False),
 ])
