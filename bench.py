@@ -161,6 +161,24 @@ def softmax_chain_traffic() -> dict:
     return {"traffic": None}
 
 
+def emit(result: dict) -> None:
+  """Rank 0's output: the full object to gpurun_out/bench_detail.json and to a PREFIXED stdout line (not a JSON
+  line), then the compact line -- the LAST stdout line, a few KB (bench_compact.py; round 5's 23.5 KB line could not
+  be parsed by the driver)."""
+  import bench_compact
+  detail = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+  try:
+    os.makedirs(os.path.dirname(detail), exist_ok=True)
+    with open(detail, "w") as f:
+      json.dump(result, f, indent=1)
+    result["detail_file"] = "gpurun_out/bench_detail.json"
+  except OSError as e:
+    print(f"bench.py: could not write {detail}: {e}", file=sys.stderr, flush=True)
+  print("bench_detail: " + json.dumps(result), flush=True)
+  sys.stdout.flush()
+  print(bench_compact.dumps(result), flush=True)
+
+
 def percentiles(xs):
   xs = sorted(xs)
   n = len(xs)
@@ -746,7 +764,7 @@ def main() -> None:
     fn = run_streaming128 if workload == "streaming128" else run_dlrm_embedding
     result = fn(args, rank, world, dev, rccl_ranks)
     if rank == 0:
-      print(json.dumps(result), flush=True)
+      emit(result)
     if world > 1:
       try:
         dist.barrier()
@@ -886,6 +904,16 @@ def main() -> None:
                          "the clock follows the power the operand data draws (profiles/r05_mfma_peak.txt)",
         },
     }
+    # this box's own ceilings, measured after the timed region (csrc/calibrate.hip through bench_legs.measure_ceilings)
+    import bench_legs
+    ceilings = bench_legs.measure_ceilings(dev)
+    roof = result["roofline"]
+    roof["shader_mhz"] = ceilings["shader_mhz"]
+    roof["measured_copy_gbs"] = ceilings["copy_gbs"]
+    if dom >= 1:
+      roof["measured_ceiling"] = ceilings["mfma_f16_tflops"]
+      roof["frac_of_measured_ceiling"] = achieved / ceilings["mfma_f16_tflops"]
+    roof["measured_ceiling_note"] = ceilings["note"]
     if world == 1 and workload == "headline":
       cpu_inputs = None
       if not args.no_cpu_baseline:   # (inputs of the CPU leg, which runs after every GPU measurement;
@@ -901,8 +929,7 @@ def main() -> None:
       if not args.no_config_legs:
         # BASELINE configs[3] / configs[4]: Cross, DotInteraction, segment-sum, sparse Adagrad and the two
         # ranking train steps, each with roofline + parity assert (bench_legs.py); CPU baselines further down
-        import bench_legs
-        result["config_legs"] = bench_legs.gpu_legs(dev)
+        result["config_legs"] = bench_legs.gpu_legs(dev, ceilings)
       if not args.no_scale_workload:
         # the N = 1 point of the strong-scaling configuration (what `value` at N > 1 compares with)
         del index, local
@@ -1010,7 +1037,7 @@ def main() -> None:
                                             "steps": 3, "warmup": 2, "measured_on": "rank 0, after the timed region"}
       result["speedup_vs_single_gpu_same_workload"] = value / (BATCH / one)
       del single
-    print(json.dumps(result), flush=True)
+    emit(result)
   sys.stdout.flush()
   if world > 1:
     try:

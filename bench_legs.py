@@ -45,25 +45,37 @@ def _event_ms(fn, iters, warmup):
   return _pct([a.elapsed_time(b) for a, b in ev])
 
 
-def _copy_rate_gbs(nbytes_moved: float, dev) -> float:
-  """GB/s of `dst.copy_(src)` moving `nbytes_moved` bytes in total (half read, half written) in THIS process on
-  THIS box: what a plain copy of a kernel's algorithmic bytes gets here (DESIGN.md 9.4 calibration)."""
-  n = max(int(nbytes_moved // 8), 1 << 20)          # float32 elements per side
-  src = torch.empty((n,), dtype=torch.float32, device=dev).normal_()
-  dst = torch.empty_like(src)
-  ms = _event_ms(lambda: dst.copy_(src), 10, 3)["median"]
-  del src, dst
-  return 2.0 * n * 4 / (ms * 1e-3) / 1e9
+def measure_ceilings(dev, mfma_iters: int = 4000, copy_bytes: int = 2 << 30) -> dict:
+  """What THIS box sustains, measured by the library in this process (csrc/calibrate.hip): the fp16 MFMA rate of a
+  saturating register-only loop on uniform random operands (+ the shader clock it ran at) and the rate of a float4
+  read + write copy.  Fractions of the spec peaks are only comparable between boxes next to these (VERDICT round 5,
+  next 1 / 5: the torch `copy_` this replaced ran at 4.56 TB/s on a box whose gather kernel sustained 6.3)."""
+  import ctypes
+  from recommenders_amd import _lib
+  lib = _lib.load()
+  st = _lib.current_stream()
+  ws = torch.empty((max(copy_bytes, lib.tfrs_calibrate_workspace_bytes()),), dtype=torch.uint8, device=dev)
+  tf, mhz, gbs = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+  _lib.check(lib.tfrs_calibrate_mfma_f16(_lib.ptr(ws), ws.numel(), mfma_iters, ctypes.byref(tf), ctypes.byref(mhz), st))
+  _lib.check(lib.tfrs_calibrate_copy(_lib.ptr(ws), ws.numel(), 10, ctypes.byref(gbs), st))
+  del ws
+  return {"mfma_f16_tflops": tf.value, "shader_mhz": mhz.value, "copy_gbs": gbs.value,
+          "note": "tfrs_calibrate_mfma_f16 (saturating v_mfma_f32_32x32x16_f16 loop, uniform random fp16 operands in "
+                  "registers, 2 waves per SIMD) and tfrs_calibrate_copy (float4 copy, %d MiB read + %d MiB written per "
+                  "launch), both in this process on this box" % (copy_bytes >> 21, copy_bytes >> 21)}
 
 
 def _hbm_roof(kernel, nbytes, ts, copy_gbs, **extra):
   gbs = nbytes / (ts["median"] * 1e-3) / 1e9
   out = {"kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": nbytes, "ms_median": ts["median"],
-         "ms_p10": ts["p10"], "ms_p90": ts["p90"], "same_process_copy_rate_gbs": copy_gbs,
-         "frac_of_copy_rate": gbs / copy_gbs}
+         "ms_p10": ts["p10"], "ms_p90": ts["p90"], "measured_copy_gbs": copy_gbs,
+         "frac_of_measured_ceiling": gbs / copy_gbs}
   out.update(extra)
   return out
+
+
+_MFMA_CEILING = {"tflops": None}   # set by gpu_legs() from measure_ceilings()
 
 
 def _mfma_roof(kernel, flop, ts, products=3, **extra):
@@ -76,6 +88,9 @@ def _mfma_roof(kernel, flop, ts, products=3, **extra):
          "note": "f32-grade results on the fp16 matrix cores: every f32 product is hi*hi + hi*lo + lo*hi (3 fp16 MFMA "
                  "products, f32 accumulation); `achieved` / `frac` count the ALGORITHMIC flop once, "
                  "`frac_of_fp16_pipe_incl_split` what the pipe executes"}
+  if _MFMA_CEILING["tflops"]:
+    out["measured_ceiling"] = _MFMA_CEILING["tflops"]
+    out["frac_of_measured_ceiling"] = products * tf / _MFMA_CEILING["tflops"]
   out.update(extra)
   return out
 
@@ -345,8 +360,10 @@ def ranking_step_leg(dev, kind: str) -> dict:
   return out
 
 
-def gpu_legs(dev) -> dict:
-  copy_gbs = _copy_rate_gbs(4.0e9, dev)
+def gpu_legs(dev, ceilings=None) -> dict:
+  ceilings = ceilings or measure_ceilings(dev)
+  copy_gbs = ceilings["copy_gbs"]
+  _MFMA_CEILING["tflops"] = ceilings["mfma_f16_tflops"]
   legs = {"cross": cross_leg(dev)}
   torch.cuda.empty_cache()
   legs["dot_interaction"] = dot_interaction_leg(dev, copy_gbs)

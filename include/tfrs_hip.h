@@ -71,6 +71,20 @@ int tfrs_profile_read(double *scan_ms_h, int *launches_h, double *flop_h);
  * tfrs_profile_read. */
 int tfrs_profile_read_kind(int kind, double *scan_ms_h, int *launches_h, double *flop_h);
 
+/* Per-box ceilings measured in the caller's process (bench.py `roofline.measured_ceiling`; no reference
+ * counterpart -- measurement plumbing).  Boxes of one pool differ by several per cent in what any kernel
+ * gets (the shader clock follows the power the operand data draws), so a fraction of the spec peak is only
+ * comparable between runs next to the box's own ceiling.  Both calls time with HIP events on `stream` and WAIT.
+ *   tfrs_calibrate_mfma_f16: saturating v_mfma_f32_32x32x16_f16 loop on uniform random fp16 operands in
+ *     registers, two waves per SIMD on every CU, `iters` x 64 MFMAs per wave; returns TFLOP/s and the shader
+ *     clock (MHz) the loop ran at.  `ws`: tfrs_calibrate_workspace_bytes() bytes.
+ *   tfrs_calibrate_copy: float4 grid-stride copy of ws_bytes / 2 bytes from the first half of `ws` to the
+ *     second (>= 64 MiB, 16-byte aligned), `iters` times; returns (bytes read + bytes written) / time in GB/s. */
+size_t tfrs_calibrate_workspace_bytes(void);
+int tfrs_calibrate_mfma_f16(void *ws, size_t ws_bytes, int iters, double *tflops_h, double *shader_mhz_h,
+                            void *stream);
+int tfrs_calibrate_copy(void *ws, size_t ws_bytes, int iters, double *gbs_h, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Candidate index (BruteForce.index, layers/factorized_top_k.py:540-584).
  * The handle owns a device copy of the candidates in an MFMA/LDS-friendly packed

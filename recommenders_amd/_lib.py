@@ -28,6 +28,9 @@ SIGNATURES = {
     "tfrs_profile_enable": (c_int, [c_int]),
     "tfrs_profile_read": (c_int, [P, P, P]),
     "tfrs_profile_read_kind": (c_int, [c_int, P, P, P]),
+    "tfrs_calibrate_workspace_bytes": (c_size_t, []),
+    "tfrs_calibrate_mfma_f16": (c_int, [P, c_size_t, c_int, P, P, P]),
+    "tfrs_calibrate_copy": (c_int, [P, c_size_t, c_int, P, P]),
     "tfrs_index_create": (c_int, [P]),
     "tfrs_index_destroy": (c_int, [P]),
     "tfrs_index_set": (c_int, [P, P, c_i64, c_int, P]),

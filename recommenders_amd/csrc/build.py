@@ -21,6 +21,7 @@ ARCH = "gfx950"
 
 SOURCES = [
     "api.cpp",
+    "calibrate.hip",
     "topk_pack.hip",
     "topk_scan.hip",
     "topk_scan16.hip",
