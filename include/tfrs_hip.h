@@ -88,9 +88,11 @@ int tfrs_calibrate_copy(void *ws, size_t ws_bytes, int iters, double *gbs_h, voi
 /* ------------------------------------------------------------------------- *
  * Candidate index (BruteForce.index, layers/factorized_top_k.py:540-584).
  * The handle owns a device copy of the candidates in an MFMA/LDS-friendly packed
- * layout (even/odd feature planes, one 16-byte pad slot per row so that
- * ds_read_b128 of 16 consecutive rows is bank-conflict free).  Re-indexing drops
- * and recreates the copy, as the reference does (:163-164).
+ * layout (even/odd feature planes per row, rows of 4 * padded_dim bytes with NO pad
+ * slot in memory -- a dim-64 row is two whole 128-byte lines; the scan kernels
+ * re-pitch rows to an odd number of 16-byte slots when they stage them in LDS, so
+ * that ds_read_b128 of 16 consecutive rows is bank-conflict free).  Re-indexing
+ * drops and recreates the copy, as the reference does (:163-164).
  * ------------------------------------------------------------------------- */
 typedef struct tfrs_index tfrs_index_t;
 

@@ -139,6 +139,13 @@ def load() -> ctypes.CDLL:
     raise HipExtensionMissing(
         f"{LIB_PATH} does not export {missing}: rebuild it with "
         "`python -m recommenders_amd.csrc.build --force`.")
+  ablated = [n for n in ("tfrs_ablation_build_scan16", "tfrs_ablation_build_raww", "tfrs_ablation_build_list16",
+             "tfrs_ablation_build_g16")
+             if hasattr(lib, n)]
+  if ablated and os.environ.get("TFRS_ALLOW_ABLATION") != "1":
+    raise HipExtensionMissing(
+        f"{LIB_PATH} is an ABLATION build ({ablated}: kernels with parts switched off, wrong results by design); "
+        "rebuild without the *_ABLATE macros or set TFRS_ALLOW_ABLATION=1 for a measurement run.")
   for name, (res, args) in SIGNATURES.items():
     fn = getattr(lib, name)
     fn.restype = res

@@ -7,7 +7,8 @@
 //                            persistent accumulators per wave, operands in registers (uniform random fp16 in
 //                            [-1, 1), the fill the guide quotes GEMM rates on), no memory traffic.  Also reports
 //                            the shader clock it ran at: s_memtime cycles over the 100 MHz constant clock.
-//   tfrs_calibrate_copy      a float4 grid-stride copy, half of the bytes read and half written: the ceiling of
+//   tfrs_calibrate_copy      a float4 copy (one 4-8 KiB chunk per workgroup, plain and nontemporal variants, the best
+//                            one reported), half of the bytes read and half written: the ceiling of
 //                            every HBM-bound kernel of the library (gather, segment-sum, DotInteraction, Adagrad).
 //
 // Both calls time with HIP events on `stream` and WAIT for them: they are measurement entry points, not part of
@@ -73,15 +74,44 @@ __global__ void __launch_bounds__(256) cal_fill_kernel(cal_f32x4 *__restrict__ p
   }
 }
 
+// One workgroup per U KiB * 4 chunk, no loop: lane t moves pieces t, t + 256, ... of the chunk (every wave instruction is
+// one contiguous 1 KiB line set); NT = nontemporal loads / stores.  The calibration reports the best variant.
+template <int U, bool NT>
 __global__ void __launch_bounds__(256) cal_copy_kernel(const cal_f32x4 *__restrict__ src, cal_f32x4 *__restrict__ dst,
                                                        size_t n4) {
-  const size_t stride = (size_t)gridDim.x * 256;
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {     // four 16-byte loads in flight per lane
-    const cal_f32x4 v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
-    dst[i] = v0; dst[i + stride] = v1; dst[i + 2 * stride] = v2; dst[i + 3 * stride] = v3;
+  const size_t base = (size_t)blockIdx.x * (256 * U) + threadIdx.x;
+  cal_f32x4 v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const size_t i = base + (size_t)u * 256;
+    if (i < n4) v[u] = NT ? __builtin_nontemporal_load(src + i) : src[i];
   }
-  for (; i < n4; i += stride) dst[i] = src[i];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const size_t i = base + (size_t)u * 256;
+    if (i < n4) {
+      if (NT) __builtin_nontemporal_store(v[u], dst + i); else dst[i] = v[u];
+    }
+  }
+}
+
+template <int U, bool NT>
+static hipError_t cal_copy_time(const cal_f32x4 *src, cal_f32x4 *dst, size_t n4, int iters, hipStream_t s, float *ms) {
+  const dim3 grid((unsigned)((n4 + 256 * U - 1) / (256 * U)));
+  hipEvent_t e0, e1;
+  hipError_t e;
+  if ((e = hipEventCreate(&e0)) != hipSuccess) return e;
+  if ((e = hipEventCreate(&e1)) != hipSuccess) return e;
+  hipLaunchKernelGGL((cal_copy_kernel<U, NT>), grid, dim3(256), 0, s, src, dst, n4);
+  hipEventRecord(e0, s);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((cal_copy_kernel<U, NT>), grid, dim3(256), 0, s, src, dst, n4);
+  hipEventRecord(e1, s);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if ((e = hipEventSynchronize(e1)) != hipSuccess) return e;
+  e = hipEventElapsedTime(ms, e0, e1);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return e;
 }
 
 }  // namespace tfrs
@@ -134,19 +164,12 @@ extern "C" int tfrs_calibrate_copy(void *ws, size_t ws_bytes, int iters, double 
   TFRS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const dim3 grid((unsigned)(cus * 16));
   hipLaunchKernelGGL(tfrs::cal_fill_kernel, grid, dim3(256), 0, s, src, n4);
-  hipEvent_t e0, e1;
-  TFRS_HIP(hipEventCreate(&e0));
-  TFRS_HIP(hipEventCreate(&e1));
-  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(tfrs::cal_copy_kernel, grid, dim3(256), 0, s, src, dst, n4);
-  TFRS_HIP(hipEventRecord(e0, s));
-  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(tfrs::cal_copy_kernel, grid, dim3(256), 0, s, src, dst, n4);
-  TFRS_HIP(hipEventRecord(e1, s));
   TFRS_LAUNCH_CHECK();
-  TFRS_HIP(hipEventSynchronize(e1));
-  float ms = 0.f;
-  TFRS_HIP(hipEventElapsedTime(&ms, e0, e1));
-  TFRS_HIP(hipEventDestroy(e0));
-  TFRS_HIP(hipEventDestroy(e1));
+  float ms = 1e30f, t = 0.f;
+  TFRS_HIP((tfrs::cal_copy_time<4, false>(src, dst, n4, iters, s, &t))); ms = t < ms ? t : ms;
+  TFRS_HIP((tfrs::cal_copy_time<8, false>(src, dst, n4, iters, s, &t))); ms = t < ms ? t : ms;
+  TFRS_HIP((tfrs::cal_copy_time<4, true>(src, dst, n4, iters, s, &t))); ms = t < ms ? t : ms;
+  TFRS_HIP((tfrs::cal_copy_time<8, true>(src, dst, n4, iters, s, &t))); ms = t < ms ? t : ms;
   if (gbs_h) *gbs_h = 2.0 * (double)n4 * 16.0 * iters / ((double)ms * 1e-3) / 1e9;
   return TFRS_OK;
 }

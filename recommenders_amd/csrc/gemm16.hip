@@ -494,6 +494,8 @@ struct Gemm16Args {
   int raster;                          // big kernel: tile order of the workgroups (see gemm16_big_kernel)
   int act;                             // fused activation of v (common.h kAct*), before the epilogue formula
   float *pre;                          // [m, n] or NULL: receives v (the pre-activation) for the backward
+  int vec4;                            // big kernel: n % 4 == 0 and out / x0 / x / aux / pre / bias 16-byte aligned (wide epilogue)
+  unsigned long long *clk;             // big kernel, measurement (TFRS_GEMM16_CLOCKS=1): += {shader cycles, 100 MHz ticks} per workgroup
 };
 
 __device__ __forceinline__ void g16_dma16(const char *gsrc_lane, const char *lds_wave_base) {
@@ -504,6 +506,18 @@ __device__ __forceinline__ void g16_dma16(const char *gsrc_lane, const char *lds
                "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(m0_saved)
                : "v"(gsrc_lane), "s"(m0v)
+               : "memory");
+}
+// the same copy with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: the base advances with
+// scalar adds, and a lane keeps ONE offset register per operand instead of a 64-bit address per image
+__device__ __forceinline__ void g16_dma16_s(uint32_t voff, const char *sbase, const char *lds_wave_base) {
+  const uint32_t m0v = (uint32_t)(uintptr_t)(
+      __attribute__((address_space(3))) const char *)lds_wave_base;
+  uint32_t m0_saved;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(m0_saved)
+               : "v"(voff), "s"(sbase), "s"(m0v)
                : "memory");
 }
 __device__ __forceinline__ void g16_wait_dma() {
@@ -642,6 +656,18 @@ __global__ void __launch_bounds__(256, 2) gemm16_kernel(const Gemm16Args g) {
 // CU, two waves per SIMD).  LDS rows are 32 bytes (16 halves): slot s of row r holds k-slot
 // s ^ ((r >> 3) & 1), which again gives the 16 lanes of a ds_read_b128 16 distinct bank groups.
 constexpr int kB16M = 256, kB16N = 256, kB16K = 16, kB16Ring = 4;
+// measurement builds only (tools/ab_variants.sh; wrong results): 1 = no copies after the prologue, 2 = no waits / barriers
+// in the K loop, 4 = fragments read once, 8 = K loop only (no epilogue loads / stores beyond one value per lane),
+// 16 = every copy re-reads the tile's first K step (same cache lines: no traffic behind the L2)
+#ifndef TFRS_G16_ABLATE
+#define TFRS_G16_ABLATE 0
+#endif
+#if TFRS_G16_ABLATE
+#ifndef TFRS_ALLOW_ABLATION
+#error "TFRS_G16_ABLATE != 0 is a measurement build with wrong results: add -DTFRS_ALLOW_ABLATION to confirm"
+#endif
+extern "C" int tfrs_ablation_build_g16(void) { return TFRS_G16_ABLATE; }
+#endif
 constexpr int kB16Img = 256 * 32;          // bytes of one 256-row x 16-half image
 constexpr int kB16Stage = 4 * kB16Img;     // Ah | Al | Bh | Bl
 
@@ -660,6 +686,7 @@ __global__ void __launch_bounds__(512) gemm16_big_kernel(const Gemm16Args g) {
   const int wm = wave >> 1, wn = wave & 1;     // 4 x 2 waves; wave tile 64 (M) x 128 (N)
   const int j = lane & 31, h = lane >> 5;
 
+  const long long clk_c0 = g.clk ? clock64() : 0, clk_w0 = g.clk ? wall_clock64() : 0;
   const int nbn = (g.n + kB16N - 1) / kB16N;
   // Tile of this workgroup.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own 4 MB
   // L2), so in launch order an XCD's 32 resident workgroups were scattered over ~18 row panels of the output and
@@ -691,26 +718,36 @@ __global__ void __launch_bounds__(512) gemm16_big_kernel(const Gemm16Args g) {
   const int nk = g.kt_per ? (nk_all - kbeg < g.kt_per ? nk_all - kbeg : g.kt_per) : nk_all;
   float *const outp = g.out + (g.kt_per ? (int64_t)blockIdx.y * g.m * g.n : 0);
 
-  // staging: one instruction = 32 rows x 2 slots; wave w copies rows [32w, 32w + 32) of each image
+  // staging: one instruction = 32 rows x 2 slots; wave w copies rows [32w, 32w + 32) of each image.  The images are
+  // K-step-major (kb == kB16K, checked by the launcher): the operand tile of K step t is ONE contiguous 256 x 32-byte
+  // range, block t of the image, so a lane's source address advances by one block pitch per step -- four 64-bit adds
+  // per stage (round 5 recomputed block and remainder with a scalar division per stage: 63 SALU instructions per step).
   const int sr = lane >> 1, ss = lane & 1;
   const int r = wave * 32 + sr;
   const int ks = ss ^ ((r >> 3) & 1);
-  const char *src[4];
-  // (K-blocked images: row pitch kb, block pitch rows_p * kb; plain images: kb == kp, one block)
-  src[0] = reinterpret_cast<const char *>(g.ah + (bm + r) * g.kb) + ks * 16;
-  src[1] = reinterpret_cast<const char *>(g.al + (bm + r) * g.kb) + ks * 16;
-  src[2] = reinterpret_cast<const char *>(g.bh + (int64_t)(bn + r) * g.kb) + ks * 16;
-  src[3] = reinterpret_cast<const char *>(g.bl + (int64_t)(bn + r) * g.kb) + ks * 16;
-  const int steps_per_blk = g.kb / kB16K;
-  const int64_t blk_a = g.mp * (int64_t)g.kb * 2, blk_b = g.np * (int64_t)g.kb * 2;   // bytes
-  auto stage = [&](int kt) __attribute__((always_inline)) {
-    char *buf = lds + (kt & (kB16Ring - 1)) * kB16Stage;
+  const int64_t blk_a = g.mp * (int64_t)(kB16K * 2), blk_b = g.np * (int64_t)(kB16K * 2);   // bytes per K step
+  // wave-uniform bases (SGPRs) of the tile's rows in the four images at the tile's first K step; one per-lane offset
+  const char *sb[4];
+  sb[0] = reinterpret_cast<const char *>(g.ah + bm * kB16K) + kbeg * blk_a;
+  sb[1] = reinterpret_cast<const char *>(g.al + bm * kB16K) + kbeg * blk_a;
+  sb[2] = reinterpret_cast<const char *>(g.bh + (int64_t)bn * kB16K) + kbeg * blk_b;
+  sb[3] = reinterpret_cast<const char *>(g.bl + (int64_t)bn * kB16K) + kbeg * blk_b;
+  // (readfirstlane: the values ARE uniform -- kernel arguments and workgroup ids -- but the compiler's divergence
+  // analysis does not always see it through the tile remap, and an "s" operand it believes divergent does not assemble)
 #pragma unroll
-    for (int im = 0; im < 4; ++im)
-    {
-      const int kq = (kbeg + kt) / steps_per_blk, kr = (kbeg + kt) - kq * steps_per_blk;   // uniform
-      g16_dma16(src[im] + kq * (im < 2 ? blk_a : blk_b) + (int64_t)kr * (kB16K * 2),
-                buf + im * kB16Img + wave * 32 * 32);
+  for (int im = 0; im < 4; ++im) {
+    const uint64_t a = reinterpret_cast<uint64_t>(sb[im]);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    sb[im] = reinterpret_cast<const char *>(((uint64_t)hi << 32) | lo);
+  }
+  const uint32_t voff = (uint32_t)(r * (kB16K * 2) + ks * 16);
+  // stage(kt): the copies of step kt; calls are made in increasing kt, each advancing the four bases
+  auto stage = [&](int kt) __attribute__((always_inline)) {
+    char *buf = lds + (kt & (kB16Ring - 1)) * kB16Stage + wave * 32 * 32;
+#pragma unroll
+    for (int im = 0; im < 4; ++im) {
+      g16_dma16_s(voff, sb[im], buf + im * kB16Img);
+      if (!(TFRS_G16_ABLATE & 16)) sb[im] += im < 2 ? blk_a : blk_b;
     }
   };
 
@@ -766,13 +803,83 @@ __global__ void __launch_bounds__(512) gemm16_big_kernel(const Gemm16Args g) {
   // step kt are issued, so the LDS latency and the barrier skew of a step hide under a full
   // step of matrix work (reading them at the top of their own step left the two waves of a
   // SIMD waiting together after every barrier: MFMA busy 47 %).
+  // half(): any step (conditions evaluated at run time) -- the first and the last few steps of a tile.
   auto half = [&](int kt, Frags &cur, Frags &nxt) __attribute__((always_inline)) {
     if (kt + 1 < nk) {
-      wait_step(kt + 1);
-      if (kt + kB16Ring < nk) stage(kt + kB16Ring);   // into the buffer of step kt (already in registers)
-      read_frags(kt + 1, nxt);
+      if (!(TFRS_G16_ABLATE & 2)) wait_step(kt + 1);
+      if (kt + kB16Ring < nk && !(TFRS_G16_ABLATE & 1)) stage(kt + kB16Ring);   // into the buffer of step kt (already in registers)
+      if (!(TFRS_G16_ABLATE & 4)) read_frags(kt + 1, nxt); else nxt = cur;
     }
     mfmas(cur);
+  };
+  // steady(): a step with kt + kB16Ring < nk -- NO branch between the LDS reads and the MFMAs.  Round 5 ran every
+  // step through half(): the join behind its `if` made the compiler wait for lgkmcnt(0) in front of the MFMAs,
+  // i.e. for the twelve reads of the NEXT step's fragments issued one line above -- the register double buffer was
+  // defeated and both waves of a SIMD sat out the LDS latency together after every barrier.  Straight-line code
+  // lets it count: the MFMAs of step kt need the reads of the previous step only (lgkmcnt(12)).
+  // The schedule of a steady step is pinned by hand (sched_barrier(0) between the groups; left to itself the compiler
+  // sinks the twelve fragment reads behind the MFMAs, right in front of the next step's lgkmcnt(0)): the barrier is
+  // followed by MFMAs at once, the copies of step kt + 4 and the reads of step kt + 1's fragments are issued in the
+  // shadow of the matrix work, and they have all returned long before the wait that ends the step.
+  auto mfma_n = [&](const Frags &f, int n) __attribute__((always_inline)) {   // n = term * 8 + i * 4 + jn
+    const int term = n >> 3, i = (n >> 2) & 1, jn = n & 3;
+    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? f.al[i] : f.ah[i], term == 1 ? f.bl[jn] : f.bh[jn],
+                                                        acc[i][jn], 0, 0, 0);
+  };
+  auto steady = [&](int kt, Frags &cur, Frags &nxt) __attribute__((always_inline)) {
+    if (!(TFRS_G16_ABLATE & 2)) {
+      g16_wait_vm<8>();
+      __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) mfma_n(cur, n);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(TFRS_G16_ABLATE & 1)) stage(kt + kB16Ring);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 4; n < 8; ++n) mfma_n(cur, n);
+    __builtin_amdgcn_sched_barrier(0);
+    const char *nb = lds + ((kt + 1) & (kB16Ring - 1)) * kB16Stage;
+    if (!(TFRS_G16_ABLATE & 4)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ra = wm * 64 + i * 32 + j;
+        const int oa = ra * 32 + (h ^ ((ra >> 3) & 1)) * 16;
+        nxt.ah[i] = *reinterpret_cast<const g16h8 *>(nb + oa);
+        nxt.al[i] = *reinterpret_cast<const g16h8 *>(nb + kB16Img + oa);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 8; n < 12; ++n) mfma_n(cur, n);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(TFRS_G16_ABLATE & 4)) {
+#pragma unroll
+      for (int jn = 0; jn < 4; ++jn) {
+        const int rb = wn * 128 + jn * 32 + j;
+        const int ob = rb * 32 + (h ^ ((rb >> 3) & 1)) * 16;
+        nxt.bh[jn] = *reinterpret_cast<const g16h8 *>(nb + 2 * kB16Img + ob);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 12; n < 16; ++n) mfma_n(cur, n);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(TFRS_G16_ABLATE & 4)) {
+#pragma unroll
+      for (int jn = 0; jn < 4; ++jn) {
+        const int rb = wn * 128 + jn * 32 + j;
+        const int ob = rb * 32 + (h ^ ((rb >> 3) & 1)) * 16;
+        nxt.bl[jn] = *reinterpret_cast<const g16h8 *>(nb + 3 * kB16Img + ob);
+      }
+    } else {
+      nxt = cur;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 16; n < 24; ++n) mfma_n(cur, n);
+    __builtin_amdgcn_sched_barrier(0);
   };
 #pragma unroll
   for (int p = 0; p < kB16Ring; ++p)
@@ -785,14 +892,41 @@ __global__ void __launch_bounds__(512) gemm16_big_kernel(const Gemm16Args g) {
     __builtin_amdgcn_s_barrier();
   }
   read_frags(0, fa);
-  for (int kt = 0; kt < nk; kt += 2) {
+  int kt = 0;
+  for (; kt + kB16Ring + 1 < nk; kt += 2) {    // both steps of the pair are steady ones
+    steady(kt, fa, fb);
+    steady(kt + 1, fb, fa);
+  }
+  for (; kt < nk; kt += 2) {                   // the last four or five steps
     half(kt, fa, fb);
     if (kt + 1 < nk) half(kt + 1, fb, fa);
+  }
+  if (TFRS_G16_ABLATE & 1) g16_wait_vm<0>();
+  if (TFRS_G16_ABLATE & 8) {
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sum += acc[i][jn][q];
+    if (sum == 123.456f) outp[tid] = sum;
+    if (g.clk && tid == 0) {
+      atomicAdd(g.clk, (unsigned long long)(clock64() - clk_c0));
+      atomicAdd(g.clk + 1, (unsigned long long)(wall_clock64() - clk_w0));
+    }
+    return;
   }
 
   // Epilogue addressing: one 64-bit base per array for the tile (uniform) + 32-bit per-lane offsets (a 256-row
   // tile spans < 2^31 elements for n < 2^23, checked by the launcher): sixteen 64-bit addresses per batch next
   // to the 128 accumulators spilled.
+  auto clocks_out = [&]() __attribute__((always_inline)) {
+    if (g.clk && tid == 0) {
+      atomicAdd(g.clk, (unsigned long long)(clock64() - clk_c0));
+      atomicAdd(g.clk + 1, (unsigned long long)(wall_clock64() - clk_w0));
+    }
+  };
   const int64_t tile0 = bm * (int64_t)g.n + bn;
   const float *const x0b = EPI != kG16EpiBias ? g.x0 + tile0 : nullptr;
   const float *const xb = EPI != kG16EpiBias ? g.x + tile0 : nullptr;
@@ -800,6 +934,91 @@ __global__ void __launch_bounds__(512) gemm16_big_kernel(const Gemm16Args g) {
   float *const auxb = (EPI == kG16EpiCross && g.aux) ? g.aux + tile0 : nullptr;
   const int rows_here = (int)(g.m - bm < kB16M ? g.m - bm : kB16M);   // >= 1
   const int cols_here = g.n - bn < kB16N ? g.n - bn : kB16N;           // >= 1
+  if (g.vec4) {
+    // Wide epilogue (round 6; n % 4 == 0 and every array 16-byte aligned -- the launcher decides): the scalar form
+    // below moves one float per lane and instruction (an accumulator lane holds a COLUMN of its 32 x 32 tile) and can
+    // keep only 24 loads of a 32 x 32 tile in flight next to the 128 accumulators: 16 dependent memory round trips per
+    // wave and tile, 0.44 ms of the 4.36 ms Cross forward at configs[3] with the matrix pipe of the CU idle
+    // (TFRS_G16_ABLATE=8).  Here a wave transposes two accumulator tiles at a time through its own 8 KB of the (now
+    // free) stage ring -- 32 rows x 64 columns, row pitch 256 bytes: conflict-free for the ds_write_b32 of a tile column
+    // and for the ds_read_b128 of four consecutive columns -- so that a lane owns four consecutive columns of a row:
+    // every global access is a dwordx4 (a wave instruction = four rows x 256 contiguous bytes), 16 of them in flight
+    // per batch, four batches per wave.  Same arithmetic per element as the scalar form, bit for bit.
+    __syncthreads();                       // every wave holds its last fragments: the stage ring is free
+    float *scr = reinterpret_cast<float *>(lds) + wave * (32 * 64);
+    const int fr = lane >> 4, fc = (lane & 15) * 4;
+    // Eight half batches hb = (i, jp, hp): 32 rows x 64 columns of the wave's tile in two halves of four passes (a
+    // pass = one dwordx4 per lane = four rows x 256 bytes).  The loads of half batch hb + 1 are issued BEFORE half
+    // batch hb is computed and stored (two register sets): a CU runs one workgroup, so its epilogue is a chain of
+    // memory round trips with nothing else to run -- bytes in flight are what sets its length.
+    float ra[2][4];
+    f32x4 e0v[2][4], e1v[2][4];
+    auto issue = [&](int hb, int set) __attribute__((always_inline)) {
+      const int i = hb >> 2, jp = (hb >> 1) & 1, hp = hb & 1;
+      const int lc = wn * 128 + jp * 64 + fc;
+      const int lcc = lc < cols_here ? lc : 0;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int lr = wm * 64 + i * 32 + 4 * (4 * hp + p) + fr;
+        const int lrc = lr < rows_here ? lr : rows_here - 1;
+        const uint32_t o = (uint32_t)lrc * (uint32_t)g.n + (uint32_t)lcc;
+        ra[set][p] = g.inva[bm + lrc];
+        if (EPI != kG16EpiBias) {
+          e0v[set][p] = *reinterpret_cast<const f32x4 *>(x0b + o);
+          e1v[set][p] = *reinterpret_cast<const f32x4 *>(xb + o);
+        }
+      }
+    };
+    issue(0, 0);
+#pragma unroll
+    for (int hb = 0; hb < 8; ++hb) {
+      const int i = hb >> 2, jp = (hb >> 1) & 1, hp = hb & 1, set = hb & 1;
+      const int lc = wn * 128 + jp * 64 + fc;                        // first of this lane's four columns
+      const bool col_ok = lc < cols_here;                            // (cols_here % 4 == 0: all four or none)
+      const int lcc = col_ok ? lc : 0;
+      const f32x4 cs = *reinterpret_cast<const f32x4 *>(g.invb + bn + lcc);
+      f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+      if (g.bias) bias = *reinterpret_cast<const f32x4 *>(g.bias + bn + lcc);
+      if (hp == 0) {
+        // the two accumulator tiles of this batch go to the wave's LDS scratch (their registers are free afterwards)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) scr[tile_row_of_reg(q, h) * 64 + t * 32 + j] = acc[i][2 * jp + t][q];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (hb + 1 < 8) issue(hb + 1, set ^ 1);      // (behind the LDS writes: 32 accumulator registers fewer are live)
+      f32x4 av[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) av[p] = *reinterpret_cast<const f32x4 *>(scr + (4 * (4 * hp + p) + fr) * 64 + fc);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int lr = wm * 64 + i * 32 + 4 * (4 * hp + p) + fr;
+        f32x4 res, uu, pv;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float v0 = av[p][c] * (ra[set][p] * cs[c]) + bias[c];
+          const float v = ACT ? act_apply(g.act, v0) : v0;
+          float u = 0.0f;
+          res[c] = g16_epilogue_v<EPI>(v, EPI != kG16EpiBias ? e0v[set][p][c] : 0.0f,
+                                       EPI != kG16EpiBias ? e1v[set][p][c] : 0.0f, g.diag, &u);
+          uu[c] = u;
+          pv[c] = v0;
+        }
+        if (lr < rows_here && col_ok) {
+          const uint32_t o = (uint32_t)lr * (uint32_t)g.n + (uint32_t)lc;
+          *reinterpret_cast<f32x4 *>(outb + o) = res;
+          if (EPI == kG16EpiCross && auxb) *reinterpret_cast<f32x4 *>(auxb + o) = uu;
+          if (ACT && g.pre) *reinterpret_cast<f32x4 *>(g.pre + (int64_t)tile0 + o) = pv;
+        }
+      }
+    }
+    clocks_out();
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -838,6 +1057,7 @@ __global__ void __launch_bounds__(512) gemm16_big_kernel(const Gemm16Args g) {
         }
       }
     }
+  clocks_out();
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -847,7 +1067,7 @@ static inline int64_t g16_pad(int64_t x, int64_t q) { return (x + q - 1) / q * q
 struct G16Layout {
   int64_t mp, np;
   int kp;
-  size_t ah, al, bh, bl, inva, invb, colmax, colmax_a, psum, part, total;
+  size_t ah, al, bh, bl, inva, invb, colmax, colmax_a, psum, part, clk, total;
   int nsplit;
 };
 
@@ -887,6 +1107,7 @@ static G16Layout g16_layout(int64_t m, int n, int k) {
   L.psum = o; o += g16_al((size_t)((k + kG16Slab - 1) / kG16Slab) * L.np * 4);
   L.nsplit = g16_splits(m, n, k);
   L.part = o; o += L.nsplit > 1 ? g16_al((size_t)L.nsplit * m * n * 4) : 0;
+  L.clk = o; o += 256;      // measurement: {cycles, ticks} sums of the last big-kernel launch (TFRS_GEMM16_CLOCKS)
   L.total = o;
   return L;
 }
@@ -940,8 +1161,7 @@ int gemm16_run_ex(const G16Operand &a, const G16Operand &b, int64_t m, int n, in
   // the 256 x 256 kernel reads K-step-major images (kb = 16 halves): the operand tile of one K
   // step is 256 rows x 32 bytes CONTIGUOUS, so every direct-to-LDS copy instruction moves eight
   // full 128-byte lines instead of 32 quarter lines 2 * kp bytes apart
-  const char *kbv = option("TFRS_GEMM16_KB");
-  const int kb = big ? ((kbv && *kbv) ? atoi(kbv) : kB16K) : L.kp;
+  const int kb = big ? kB16K : L.kp;
   // column maxima are combined with atomicMax: re-armed by a kernel, not a memset node
   hipLaunchKernelGGL(g16_zero_kernel, dim3((unsigned)((L.np + L.mp + 255) / 256)), dim3(256), 0, s,
                      colmax, (int)(L.np + L.mp));   // colmax and colmax_a are adjacent
@@ -977,6 +1197,21 @@ int gemm16_run_ex(const G16Operand &a, const G16Operand &b, int64_t m, int n, in
   g.bias = bias; g.x0 = e0; g.x = e1; g.diag = diag; g.out = out; g.aux = aux;
   g.kb = kb; g.mp = L.mp; g.np = L.np;
   g.act = act; g.pre = pre;
+  {
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(e0) | reinterpret_cast<uintptr_t>(e1) |
+                           reinterpret_cast<uintptr_t>(aux) | reinterpret_cast<uintptr_t>(pre) | reinterpret_cast<uintptr_t>(bias);
+    // TFRS_GEMM16_EPILOGUE=wide selects the dwordx4 form (bit-identical; measured on one box, tools/exp_gemm16_ms.py,
+    // profiles/r06_gemm16_ab.txt: Cross forward 4.39 ms wide against 4.27 scalar, training pair 14.47 against 14.40 --
+    // the epilogue's cost is its HBM traffic under the chip's power cap, not its instruction count), default scalar
+    const char *ev = option("TFRS_GEMM16_EPILOGUE");
+    g.vec4 = (n % 4 == 0 && (bits & 15) == 0 && ev && ev[0] == 'w') ? 1 : 0;
+    const char *cv = option("TFRS_GEMM16_CLOCKS");
+    g.clk = nullptr;
+    if (cv && cv[0] == '1' && big) {
+      g.clk = reinterpret_cast<unsigned long long *>(w + L.clk);
+      hipLaunchKernelGGL(g16_zero_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<uint32_t *>(g.clk), 4);
+    }
+  }
   {
     const char *rv = option("TFRS_GEMM16_RASTER");
     g.raster = (rv && *rv) ? atoi(rv) : 1;   // (measured: 0 / 1 / 2 within 0.5 % on the Cross products, 1 and 2

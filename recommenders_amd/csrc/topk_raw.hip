@@ -636,10 +636,23 @@ static int launch_rawscan16_variant(const RawScanArgs &a, hipStream_t stream) {
 #ifndef TFRS_RAWW_ABLATE
 #define TFRS_RAWW_ABLATE 0
 #endif
+#if TFRS_RAWW_ABLATE
+// An ablation build computes WRONG results by design: it needs -DTFRS_ALLOW_ABLATION next to -DTFRS_RAWW_ABLATE=..., and the
+// marker symbol below makes recommenders_amd/_lib.py refuse the library unless TFRS_ALLOW_ABLATION=1 is set.
+#ifndef TFRS_ALLOW_ABLATION
+#error "TFRS_RAWW_ABLATE != 0 is a measurement build with wrong results: add -DTFRS_ALLOW_ABLATION to confirm"
+#endif
+extern "C" int tfrs_ablation_build_raww(void) { return TFRS_RAWW_ABLATE; }
+#endif
 
 __device__ __forceinline__ void raw_lds_barrier() {
+  // s_barrier is IntrNoMem for LLVM: without a compiler-level fence the optimizer may move LDS loads / stores across
+  // it.  The empty asm statements with a "memory" clobber pin every memory access on its side of the
+  // barrier without emitting anything -- a workgroup-scope __builtin_amdgcn_fence would bring the vmcnt(0) back.
+  asm volatile("" ::: "memory");
   __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14));   // s_waitcnt lgkmcnt(0), vmcnt untouched
   __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 }
 
 constexpr int kRawWWaves = 8;

@@ -32,6 +32,8 @@
 // Built with -fno-honor-nans (build.py): fmaxf trees become bare v_max3_f32.
 #include <stdlib.h>
 
+#include <string.h>
+
 #include "common.h"
 
 // Timing ablations of scan16f_kernel (tools/ab_variants.sh builds one library per value; results are WRONG with
@@ -40,6 +42,14 @@
 // 8 = stage copies skipped after the first two (no L2 / HBM traffic), 16 = no max tree / compare at all.
 #ifndef TFRS_SCAN16_ABLATE
 #define TFRS_SCAN16_ABLATE 0
+#endif
+#if TFRS_SCAN16_ABLATE
+// An ablation build computes WRONG results by design: it needs -DTFRS_ALLOW_ABLATION next to -DTFRS_SCAN16_ABLATE=..., and the
+// marker symbol below makes recommenders_amd/_lib.py refuse the library unless TFRS_ALLOW_ABLATION=1 is set.
+#ifndef TFRS_ALLOW_ABLATION
+#error "TFRS_SCAN16_ABLATE != 0 is a measurement build with wrong results: add -DTFRS_ALLOW_ABLATION to confirm"
+#endif
+extern "C" int tfrs_ablation_build_scan16(void) { return TFRS_SCAN16_ABLATE; }
 #endif
 // The queue append of check() with the common case peeled out of the loop (every hot lane fits: one ballot, no
 // per-lane capacity compare): 0 = the loop only, 1 = peeled, 2 (default) = peeled + the MFMA -> VALU wait states in
@@ -803,11 +813,16 @@ template <int DP>
 static int launch_scan16f_shape(const Scan16Args &a, hipStream_t stream) {
   const char *e = option("TFRS_SCAN16_SHAPE");
   const bool pair = a.n_qtiles >= 2;
-  if (e && e[0] == '8' && e[2] == '2') return launch_scan16f<DP, 8, 2>(a, stream);
+  auto is = [&](const char *v) { return e && strcmp(e, v) == 0; };   // whole-string matches only
+  if (e && !(is("16x2s2") || is("16x2") || is("8x2") || is("4x4") || is("8x4"))) {
+    set_error("TFRS_SCAN16_SHAPE=%s: expected one of 16x2s2, 16x2, 8x2, 4x4, 8x4", e);
+    return TFRS_EINVAL;
+  }
+  if (is("8x2")) return launch_scan16f<DP, 8, 2>(a, stream);
   if constexpr (DP <= 64) {
-    if (e && e[0] == '4') return launch_scan16f<DP, 4, 4>(a, stream);
-    if (e && e[0] == '8' && e[2] == '4' && pair) return launch_scan16f<DP, 8, 4>(a, stream);
-    if (e && e[0] == '1' && e[1] == '6' && e[4] != 's' && pair) return launch_scan16f<DP, 16, 2>(a, stream);
+    if (is("4x4")) return launch_scan16f<DP, 4, 4>(a, stream);
+    if (is("8x4") && pair) return launch_scan16f<DP, 8, 4>(a, stream);
+    if (is("16x2") && pair) return launch_scan16f<DP, 16, 2>(a, stream);
     if (pair) return launch_scan16f<DP, 16, 2, 2>(a, stream);
   }
   // (dim 128: the 16-wave instantiation needs more than 128 registers -- 15.0 ms against 3.4 -- and stays out)

@@ -22,6 +22,14 @@ constexpr int kSlots = 16;     // values per lane held in registers (64 * 16 = 1
 #ifndef TFRS_LIST16_ABLATE
 #define TFRS_LIST16_ABLATE 0
 #endif
+#if TFRS_LIST16_ABLATE
+// An ablation build computes WRONG results by design: it needs -DTFRS_ALLOW_ABLATION next to -DTFRS_LIST16_ABLATE=..., and the
+// marker symbol below makes recommenders_amd/_lib.py refuse the library unless TFRS_ALLOW_ABLATION=1 is set.
+#ifndef TFRS_ALLOW_ABLATION
+#error "TFRS_LIST16_ABLATE != 0 is a measurement build with wrong results: add -DTFRS_ALLOW_ABLATION to confirm"
+#endif
+extern "C" int tfrs_ablation_build_list16(void) { return TFRS_LIST16_ABLATE; }
+#endif
 constexpr int kRadixBits = 24; // the K-th key is resolved to its top 24 bits (rounded DOWN)
 
 __device__ __forceinline__ uint32_t sel16_mbcnt(uint64_t mask) {

@@ -246,20 +246,32 @@ class _CrossActFn(torch.autograd.Function):
   @staticmethod
   def backward(ctx, dy):
     x0, x, a, kernel, pre = ctx.saved_tensors
-    dp, dx0, dxd = _pointwise_bwd(ctx.act, False, pre, dy, x0, x, ctx.diag, True, True, True)
-    b, d, ka = x0.shape[0], x0.shape[1], kernel.shape[0]
-    lib = _lib.load()
-    f16 = 1 if _use_f16_gemm(b, ka, d) else 0
-    alloc = torch.zeros_like if b == 0 else torch.empty_like
-    da = torch.empty((b, ka), dtype=torch.float32, device=x0.device)
-    dk = alloc(kernel)
-    db = (torch.zeros if b == 0 else torch.empty)((d,), dtype=torch.float32, device=x0.device) if ctx.has_bias else None
-    ws = _gemm_workspace(lib.tfrs_dense_bwd_workspace_bytes(b, ka, d, f16), x0.device)
-    _lib.check(lib.tfrs_dense_bwd_add(
-        _lib.ptr(a), _lib.ptr(kernel), _lib.ptr(dp), _lib.ptr(dxd) if ctx.full_rank else None, b, ka, d,
-        _lib.ptr(da), _lib.ptr(dk), _lib.ptr(db), f16, _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+    # inputs: (x0, x, a, kernel, bias, ...).  Only the gradients autograd asks for are computed.
+    need_x0, need_x, need_a, need_k, need_b = ctx.needs_input_grad[:5]
+    need_b = need_b and ctx.has_bias
     if ctx.full_rank:
-      return dx0, da, None, dk, db, None, None, None      # da = dp K^T + dxd is the whole gradient of x
+      need_a = need_x                   # a IS x: da = dp K^T + dxd is the whole gradient of x
+    need_dp = need_a or need_k or need_b
+    need_dxd = need_x
+    dp, dx0, dxd = _pointwise_bwd(ctx.act, False, pre, dy, x0, x, ctx.diag, need_dp, need_x0, need_dxd)
+    b, d, ka = x0.shape[0], x0.shape[1], kernel.shape[0]
+    da = dk = db = None
+    if need_dp:
+      lib = _lib.load()
+      f16 = 1 if _use_f16_gemm(b, d, ka) else 0      # (m, n, k) of p = a @ kernel, as dense_backward passes them
+      zeros = b == 0
+      if need_a:
+        da = torch.empty((b, ka), dtype=torch.float32, device=x0.device)
+      if need_k:
+        dk = (torch.zeros_like if zeros else torch.empty_like)(kernel)
+      if need_b:
+        db = (torch.zeros if zeros else torch.empty)((d,), dtype=torch.float32, device=x0.device)
+      ws = _gemm_workspace(lib.tfrs_dense_bwd_workspace_bytes(b, ka, d, f16), x0.device)
+      _lib.check(lib.tfrs_dense_bwd_add(
+          _lib.ptr(a), _lib.ptr(kernel), _lib.ptr(dp), _lib.ptr(dxd) if ctx.full_rank else None, b, ka, d,
+          _lib.ptr(da), _lib.ptr(dk), _lib.ptr(db), f16, _lib.ptr(ws), ws.numel(), _lib.current_stream()))
+    if ctx.full_rank:
+      return dx0, da, None, dk, db, None, None, None
     return dx0, dxd, da, dk, db, None, None, None
 
 

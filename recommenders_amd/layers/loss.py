@@ -16,23 +16,45 @@ MAX_FLOAT = float(np.finfo(np.float32).max / 100.0)   # loss.py:22
 MIN_FLOAT = float(np.finfo(np.float32).min / 100.0)   # loss.py:23
 
 
+_PAGE = 1024   # include/tfrs_hip.h TFRS_MAX_K: what one selection call returns per row
+
+
 def _topk_columns(keyed: torch.Tensor, k: int) -> torch.Tensor:
   """Column indices of the ``k`` largest entries of every row (``tf.math.top_k(..., sorted=False)`` of
   loss.py:104-105; here sorted, ties to the lower column) through the library's score-block selection
-  (``tfrs_topk_update_from_scores``) -- rows of any width, ``k`` up to the library's page size."""
+  (``tfrs_topk_update_from_scores``) -- rows of any width and, like the reference, ANY ``k``: beyond the library's
+  page of 1024 the selection runs page by page, the columns already taken pushed to -inf in a scratch copy (each
+  page is the next 1024 of the same (value descending, column ascending) order, so the union is the top ``k``)."""
   import ctypes
   from recommenders_amd import _lib
+  if not keyed.is_cuda:
+    raise ValueError("HardNegativeMining: the logits must live on the GPU (this package has no CPU path; "
+                     "the reference's layers/loss.py:61-111 is the CPU implementation)")
   keyed = keyed.detach().contiguous().to(torch.float32)
   nq, nc = keyed.shape
-  if not keyed.is_cuda or k > 1024 or nc > 0x7FFFFFFF:
-    raise ValueError("HardNegativeMining: needs a GPU tensor and num_hard_negatives + 1 <= 1024")
-  vals = torch.empty((nq, k), dtype=torch.float32, device=keyed.device)
-  cols = torch.empty((nq, k), dtype=torch.int32, device=keyed.device)
-  new_len = ctypes.c_int32(0)
-  _lib.check(_lib.load().tfrs_topk_update_from_scores(
-      _lib.ptr(keyed), nq, nc, nc, 0, k, _lib.ptr(vals), _lib.ptr(cols), 0, ctypes.byref(new_len),
-      _lib.current_stream()))
-  return cols.long()
+  if nc > 0x7FFFFFFF:
+    raise ValueError("HardNegativeMining: more than 2^31 - 1 columns")
+  k = min(k, nc)
+  lib, stream = _lib.load(), _lib.current_stream()
+  pages = []
+  taken = 0
+  while taken < k:
+    kk = min(_PAGE, k - taken)
+    vals = torch.empty((nq, kk), dtype=torch.float32, device=keyed.device)
+    cols = torch.empty((nq, kk), dtype=torch.int32, device=keyed.device)
+    new_len = ctypes.c_int32(0)
+    _lib.check(lib.tfrs_topk_update_from_scores(_lib.ptr(keyed), nq, nc, nc, 0, kk, _lib.ptr(vals), _lib.ptr(cols), 0,
+                                                ctypes.byref(new_len), stream))
+    pages.append(cols.long())
+    taken += kk
+    if taken < k:
+      if len(pages) == 1:
+        # never the caller's tensor; -inf entries become the lowest finite float, so that the -inf written over the
+        # columns already taken sorts strictly below everything still to come (ties between an original -inf and an
+        # original -FLT_MAX -- the reference's masks use MIN_FLOAT = -FLT_MAX / 100 -- are the only order given up)
+        keyed = keyed.clamp(min=-3.4028234663852886e38)
+      keyed.scatter_(1, pages[-1], float("-inf"))
+  return pages[0] if len(pages) == 1 else torch.cat(pages, dim=1)
 
 
 class HardNegativeMining(torch.nn.Module):

@@ -232,7 +232,16 @@ class _LogitsCeFn(torch.autograd.Function):
     scores = scores.contiguous().to(torch.float32)
     labels = labels.contiguous().to(torch.float32)
     nq, nc = scores.shape
-    w = None if sample_weight is None else sample_weight.reshape(-1).to(scores.device, torch.float32).contiguous()
+    w = None
+    if sample_weight is not None:
+      # one weight per row; a scalar / one-element weight broadcasts as in Keras -- anything else is an error here,
+      # not an out-of-bounds read in the kernel
+      w = torch.as_tensor(sample_weight).reshape(-1).to(scores.device, torch.float32)
+      if w.numel() == 1:
+        w = w.expand(nq)
+      elif w.numel() != nq:
+        raise ValueError(f"sample_weight has {w.numel()} elements for {nq} rows of logits")
+      w = w.contiguous()
     rows = torch.empty((3, max(nq, 1)), dtype=torch.float32, device=scores.device)   # row loss, lse, sum of labels
     _lib.check(_lib.load().tfrs_logits_ce_fwd(_lib.ptr(scores), _lib.ptr(labels), nq, nc, _lib.ptr(w),
                                               _lib.ptr(rows[0]), _lib.ptr(rows[1]), _lib.ptr(rows[2]),

@@ -331,6 +331,42 @@ def test_explicit_logits_paths_run_on_hip_kernels():
   np.testing.assert_array_equal(cols, want_cols)
 
 
+def test_hard_negative_mining_any_k_and_weight_shapes():
+  """the reference's HardNegativeMining takes any k (tf.math.top_k, layers/loss.py:104-105) -- beyond
+  the library's page of 1024 the selection runs page by page (rows with ties and -inf entries included); a CPU
+  tensor is refused loudly (no CPU path); `Retrieval(num_hard_negatives >= 1023)` on a wide batch works; a
+  sample_weight of the wrong length is a ValueError, a scalar / one-element weight broadcasts (Keras)."""
+  import recommenders_amd as tfrs
+  from recommenders_amd.layers import loss as loss_layers
+  from recommenders_amd.tasks import retrieval as rt
+  rng = np.random.default_rng(77)
+  keyed = np.round(rng.normal(size=(7, 3000)) * 20).astype(np.float32)       # many ties
+  keyed[2, 100:400] = -np.inf
+  keyed0 = keyed.copy()
+  tk = _t(keyed)
+  for k in (1024, 1025, 2500, 3000, 5000):
+    cols = _np(loss_layers._topk_columns(tk, k))
+    want = np.argsort(-keyed0, axis=1, kind="stable")[:, :min(k, 3000)]
+    np.testing.assert_array_equal(cols, want)
+  np.testing.assert_array_equal(_np(tk), keyed0)                              # the caller's tensor is untouched
+  with pytest.raises(ValueError, match="GPU"):
+    loss_layers._topk_columns(torch.zeros((2, 8)), 3)
+  # the task: 1200 hard negatives out of 1500 candidates, explicit-logits path, against the oracle
+  q = (rng.normal(size=(64, 16)) / 4).astype(np.float32)
+  c = (rng.normal(size=(1500, 16)) / 4).astype(np.float32)
+  got = tfrs.tasks.Retrieval(num_hard_negatives=1200)(_t(q), _t(c), compute_metrics=False)
+  np.testing.assert_allclose(float(got), float(o_ret.loss(q, c, num_hard_negatives=1200)), rtol=1e-5)
+  # sample weights of the explicit-logits cross-entropy
+  s = (rng.normal(size=(10, 33))).astype(np.float32)
+  y = np.eye(10, 33, dtype=np.float32)
+  base = float(rt.logits_softmax_ce_sum(_t(s), _t(y), None))
+  assert float(rt.logits_softmax_ce_sum(_t(s), _t(y), _t(np.float32(2.0)))) == pytest.approx(2 * base, rel=1e-6)
+  assert float(rt.logits_softmax_ce_sum(_t(s), _t(y), _t(np.full((1,), 2.0, np.float32)))) == pytest.approx(2 * base, rel=1e-6)
+  assert float(rt.logits_softmax_ce_sum(_t(s), _t(y), _t(np.full((10, 1), 2.0, np.float32)))) == pytest.approx(2 * base, rel=1e-6)
+  with pytest.raises(ValueError, match="sample_weight"):
+    rt.logits_softmax_ce_sum(_t(s), _t(y), _t(np.ones(7, np.float32)))
+
+
 @pytest.mark.parametrize("nq,nc,d,k", [(300, 300, 64, 7), (512, 2000, 32, 50), (100, 4000, 20, 3), (64, 64, 16, 200)])
 def test_retrieval_hard_negatives_without_the_logits_matrix(nq, nc, d, k):
   """`num_hard_negatives` over plain dot-product logits (layers/loss.py:61-111): the fused top-K search

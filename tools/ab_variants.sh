@@ -13,7 +13,7 @@ if [ "$1" = build ]; then
   [ "$src" = softmax16.hip ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
   base=$(basename $src .hip)
   for v in "$@"; do
-    ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra -D$def=$v -x hip -c recommenders_amd/csrc/$src -o ab/${base}_$v.o &&
+    ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra -DTFRS_ALLOW_ABLATION -D$def=$v -x hip -c recommenders_amd/csrc/$src -o ab/${base}_$v.o &&
       objs=$(ls $OBJ/*.o | grep -v "/${base}.o") &&
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab/lib_$v.so $objs ab/${base}_$v.o && echo built ab/lib_$v.so ) &
   done
