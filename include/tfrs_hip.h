@@ -105,6 +105,19 @@ int tfrs_index_set(tfrs_index_t *index, const float *candidates, int64_t n, int 
  * append blocks in dataset order. */
 int tfrs_index_reserve(tfrs_index_t *index, int64_t capacity, int d, void *stream);
 int tfrs_index_append(tfrs_index_t *index, const float *block, int64_t nb, void *stream);
+/* Non-finite inputs (the reference's tf.math.top_k, layers/factorized_top_k.py:605, tolerates NaN / Inf scores; this
+ * library's fp16-prefiltered search does NOT: its error bound is built from row norms, and the filter kernels are
+ * compiled without NaN semantics).  CONTRACT: candidates and queries must be finite, |x| < 1.8e19 (so that a squared
+ * norm stays finite).  Violations are recorded, never silent:
+ *   bit 0 (1)  an indexed candidate row holds NaN / Inf -- set by tfrs_index_set / _append; the host layer raises
+ *              ValueError from BruteForce.index / index_from_dataset and drops the index;
+ *   bit 1 (2)  a query row of a tfrs_bruteforce_topk[_below] call held NaN / Inf.  Only THAT row of the result is
+ *              affected (its scores are non-finite, its indices valid but unspecified); every other row of the call is
+ *              the exact top-K as always.  The host layer raises ValueError at the next call (or at once under
+ *              BruteForce(check_finite=True), which synchronises).
+ * The word lives in pinned host memory the kernels OR into: reading it never touches the stream, and reflects
+ * every launch that has completed.  reset_mask: bits to clear after the read. */
+int tfrs_index_nonfinite(const tfrs_index_t *index, int reset_mask, int32_t *flags_h);
 int64_t tfrs_index_size(const tfrs_index_t *index);
 int tfrs_index_dim(const tfrs_index_t *index);
 /* Writes the original row-major candidates[n, d] back (checkpoint/state_dict). */

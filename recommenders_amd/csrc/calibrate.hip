@@ -103,14 +103,14 @@ static hipError_t cal_copy_time(const cal_f32x4 *src, cal_f32x4 *dst, size_t n4,
   if ((e = hipEventCreate(&e0)) != hipSuccess) return e;
   if ((e = hipEventCreate(&e1)) != hipSuccess) return e;
   hipLaunchKernelGGL((cal_copy_kernel<U, NT>), grid, dim3(256), 0, s, src, dst, n4);
-  hipEventRecord(e0, s);
+  (void)hipEventRecord(e0, s);
   for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((cal_copy_kernel<U, NT>), grid, dim3(256), 0, s, src, dst, n4);
-  hipEventRecord(e1, s);
+  (void)hipEventRecord(e1, s);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if ((e = hipEventSynchronize(e1)) != hipSuccess) return e;
   e = hipEventElapsedTime(ms, e0, e1);
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return e;
 }
 

@@ -449,8 +449,14 @@ __host__ __device__ inline int recompute_chunks(int64_t nq, int64_t flagged) {
 // rowmap != NULL: the block is stored SHUFFLED -- image row dst_row + r holds block row
 // (mul * r + add) mod n (mul coprime to n, near n / golden ratio: consecutive block rows land far
 // apart) and rowmap[dst_row + r] = dst_row + that row.
+// bits of an index handle's host-visible flag word (tfrs_index_nonfinite)
+constexpr uint32_t kNonfiniteCandidates = 1u, kNonfiniteQueries = 2u;
+__device__ __forceinline__ uint32_t nonfinite_bits(float x) {
+  return ((__builtin_bit_cast(uint32_t, x) & 0x7f800000u) == 0x7f800000u) ? 1u : 0u;
+}
+int launch_nonfinite_flag(const float *x, int64_t count, uint32_t *flags, uint32_t bit, hipStream_t stream);
 int launch_pack(const float *cand, int64_t n, int d, char *packed, int64_t dst_row,
-                int64_t zero_rows_to, int32_t *rowmap, hipStream_t stream);
+                int64_t zero_rows_to, int32_t *rowmap, hipStream_t stream, uint32_t *flags = nullptr);
 int launch_unpack(const char *packed, int64_t n, int d, const int32_t *rowmap, float *out,
                   hipStream_t stream);
 // (Re)builds the fp16 image, StageMeta and the global max row norm for the stages that hold
@@ -460,8 +466,9 @@ int launch_pack16(const char *packed, int d, int64_t row_begin, int64_t row_end,
                   StageMeta *meta, float *norm_max, hipStream_t stream);
 // qk[q] = ||q||_2 * kNormSlack * kF16Kappa;  qscale[q] = 2^ceil(log2 max|q_d|)
 // (also re-arms zero_u32[q] = 0 when given: the per-query overflow counters of the filter pass)
+// (flags: |= kNonfiniteQueries when a query row holds NaN / Inf)
 int launch_query_kappa(const float *q, int64_t nq, int d, float *qk, float *qscale,
-                       uint32_t *zero_u32, hipStream_t stream);
+                       uint32_t *zero_u32, hipStream_t stream, uint32_t *flags = nullptr);
 constexpr uint32_t kOvfCap = 1024;   // overflow entries per query (= the list kernel's capacity)
 constexpr uint32_t kOvfPerSeg = 256;  // ... of which at most this many from one segment (a segment
                                       // that overflows by more flags the query for the exact redo)

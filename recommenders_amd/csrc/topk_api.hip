@@ -504,12 +504,13 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
                    int64_t n, int64_t idx_base, int k, const SamplePlan &sp, bool lower_preset,
                    float *out_scores, int32_t *out_idx, const RoundWs &w, const TopkTuning &t,
                    hipStream_t stream, const int32_t *rowmap = nullptr, int64_t row_lo = 0,
-                   const RawTable *raw = nullptr) {
+                   const RawTable *raw = nullptr, uint32_t *flags = nullptr) {
   const int n_qtiles = (int)((nq + kScan16QueriesPerWg - 1) / kScan16QueriesPerWg);
   const int64_t stage_lo = row_lo / kTileN;
   int rc;
-  // (the per-query overflow counters are re-armed here whether or not the filter pass uses them)
-  if ((rc = launch_query_kappa(q, nq, d, w.qk, w.qscale, w.ovf_cnt, stream)) != TFRS_OK) return rc;
+  // (the per-query overflow counters are re-armed here whether or not the filter pass uses them; flags: the index
+  // handle's host-visible word, |= kNonfiniteQueries when a query row holds NaN / Inf)
+  if ((rc = launch_query_kappa(q, nq, d, w.qk, w.qscale, w.ovf_cnt, stream, flags)) != TFRS_OK) return rc;
 
   Scan16Args s16 = {};
   s16.q = q;
@@ -653,6 +654,11 @@ struct tfrs_index {
   // cluster (any locality in the row order) breaks that -- the shuffle restores it for every
   // input order.  Keys are formed from ORIGINAL row numbers, so results and tie order are unchanged.
   int32_t *rowmap = nullptr;
+  // Host-visible flag word (pinned, mapped into the device address space; allocated with the first reserve and
+  // kept for the life of the handle): kNonfiniteCandidates is set by the packer when an indexed row holds NaN / Inf,
+  // kNonfiniteQueries by the query pass of a search.  Kernels write it with atomicOr ONLY in the error case, the
+  // host reads it without touching the stream (tfrs_index_nonfinite).
+  uint32_t *flags_h = nullptr, *flags_d = nullptr;
 };
 
 static void index_free(tfrs_index *index) {
@@ -679,6 +685,7 @@ extern "C" int tfrs_index_create(tfrs_index_t **out_h) {
 extern "C" int tfrs_index_destroy(tfrs_index_t *index) {
   if (!index) return TFRS_OK;
   index_free(index);
+  if (index->flags_h) (void)hipHostFree(index->flags_h);
   delete index;
   return TFRS_OK;
 }
@@ -692,6 +699,17 @@ extern "C" int tfrs_index_reserve(tfrs_index_t *index, int64_t capacity, int d, 
     return TFRS_ENOTIMPL;
   }
   index_free(index);
+  if (!index->flags_h) {
+    hipError_t fe = hipHostMalloc(reinterpret_cast<void **>(&index->flags_h), 64, hipHostMallocMapped);
+    if (fe == hipSuccess) fe = hipHostGetDevicePointer(reinterpret_cast<void **>(&index->flags_d), index->flags_h, 0);
+    if (fe != hipSuccess) {
+      if (index->flags_h) (void)hipHostFree(index->flags_h);
+      index->flags_h = index->flags_d = nullptr;
+      set_error("index: hipHostMalloc of the flag word failed: %s", hipGetErrorString(fe));
+      return TFRS_ENOMEM;
+    }
+  }
+  *index->flags_h = 0u;          // (re-index: a new corpus, a clean record)
   index->n = 0;
   index->d = d;
   index->capacity = padded_rows(std::max<int64_t>(capacity, 1));
@@ -727,7 +745,7 @@ extern "C" int tfrs_index_append(tfrs_index_t *index, const float *block, int64_
   // zero-fill up to the next stage boundary so whole stages can always be read
   const int64_t zero_to = padded_rows(index->n + nb);
   int rc = launch_pack(block, nb, index->d, index->packed, index->n, zero_to, index->rowmap,
-                       (hipStream_t)stream);
+                       (hipStream_t)stream, index->flags_d);
   if (rc != TFRS_OK) return rc;
   // (re)build the fp16 image of every stage this block touched, from the f32 image
   rc = launch_pack16(index->packed, index->d, index->n, zero_to, index->packed16, index->meta,
@@ -743,6 +761,18 @@ extern "C" int tfrs_index_set(tfrs_index_t *index, const float *candidates, int6
   int rc = tfrs_index_reserve(index, n, d, stream);
   if (rc != TFRS_OK) return rc;
   return tfrs_index_append(index, candidates, n, stream);
+}
+
+extern "C" int tfrs_index_nonfinite(const tfrs_index_t *index, int reset_mask, int32_t *flags_h) {
+  TFRS_CHECK_ARG(index && flags_h, "index_nonfinite: NULL argument");
+  *flags_h = 0;
+  if (!index->flags_h) return TFRS_OK;           // nothing indexed yet
+  // plain read of pinned host memory: reflects every kernel that has COMPLETED (synchronise first for a verdict on
+  // work still in flight); the device only ever ORs bits in, the host only clears them here
+  const uint32_t v = __atomic_load_n(index->flags_h, __ATOMIC_ACQUIRE);
+  *flags_h = (int32_t)v;
+  if (reset_mask) __atomic_fetch_and(index->flags_h, ~(uint32_t)reset_mask, __ATOMIC_ACQ_REL);
+  return TFRS_OK;
 }
 
 extern "C" int64_t tfrs_index_size(const tfrs_index_t *index) { return index ? index->n : -1; }
@@ -790,9 +820,12 @@ extern "C" int tfrs_bruteforce_topk(const tfrs_index_t *index, const float *quer
       const F16Image img = {index->packed16, index->meta, index->norm_max};
       return run_f16(queries, nq, index->d, index->packed, img, index->n, /*idx_base=*/0, k, sp,
                      /*lower_preset=*/false, out_scores, out_idx, w, t, (hipStream_t)stream,
-                     index->rowmap);
+                     index->rowmap, /*row_lo=*/0, /*raw=*/nullptr, index->flags_d);
     }
   }
+  // (all-f32 rounds: IEEE comparisons, but the same contract -- a NaN / Inf query row is recorded in the flag word)
+  int frc = launch_nonfinite_flag(queries, nq * (int64_t)index->d, index->flags_d, kNonfiniteQueries, (hipStream_t)stream);
+  if (frc != TFRS_OK) return frc;
   int new_len = 0;
   return run_rounds(queries, nq, index->d, index->packed, index->n, /*idx_base=*/0,
                     /*seen=*/0, k, out_scores, out_idx, /*state_len=*/0, w, t,
@@ -853,6 +886,8 @@ extern "C" int tfrs_bruteforce_topk_below(const tfrs_index_t *index, const float
                        (hipStream_t)stream, last_scores, last_rows, nq, last_ld, ceil_score, ceil_key);
     TFRS_LAUNCH_CHECK();
   }
+  int frc = launch_nonfinite_flag(queries, nq * (int64_t)index->d, index->flags_d, kNonfiniteQueries, (hipStream_t)stream);
+  if (frc != TFRS_OK) return frc;
   int new_len = 0;
   return run_rounds(queries, nq, index->d, index->packed, index->n, /*idx_base=*/0, /*seen=*/0, k, out_scores,
                     out_idx, /*state_len=*/0, w, t, (hipStream_t)stream, &new_len, index->rowmap, ceil_score,

@@ -1,6 +1,8 @@
 // topk_pack.hip -- row-major candidates[n, d]  <->  packed MFMA/LDS layout (common.h).
 // HBM-bound copy kernels: one thread moves one 16-byte slot; a wave therefore writes
 // 1 KiB of contiguous packed rows per instruction.
+#include <algorithm>
+
 #include "common.h"
 
 namespace tfrs {
@@ -10,7 +12,8 @@ __global__ void __launch_bounds__(256) pack_kernel(const float *__restrict__ can
                                                    char *__restrict__ packed,
                                                    int64_t dst_row, int64_t total_rows,
                                                    int64_t mul, int64_t add,
-                                                   int32_t *__restrict__ rowmap) {
+                                                   int32_t *__restrict__ rowmap,
+                                                   uint32_t *__restrict__ flags) {
   const int slots = dp / 4;
   const int half = dp / 8;       // slots per plane
   const int64_t nslots = total_rows * slots;
@@ -30,6 +33,10 @@ __global__ void __launch_bounds__(256) pack_kernel(const float *__restrict__ can
       v.y = (k0 + 2 < d) ? row[k0 + 2] : 0.f;
       v.z = (k0 + 4 < d) ? row[k0 + 4] : 0.f;
       v.w = (k0 + 6 < d) ? row[k0 + 6] : 0.f;
+      // non-finite candidates (NaN / Inf: exponent bits all ones) void the filter's error bound for their whole stage:
+      // flagged once per offending slot into the index's host-visible flag word (bit 0), BruteForce.index raises
+      if (flags && (nonfinite_bits(v.x) | nonfinite_bits(v.y) | nonfinite_bits(v.z) | nonfinite_bits(v.w)))
+        atomicOr(flags, kNonfiniteCandidates);
     }
     *reinterpret_cast<float4 *>(packed + (dst_row + r) * (int64_t)row_bytes(dp) +
                                 (int64_t)s * 16) = v;
@@ -60,7 +67,7 @@ static int64_t gcd64(int64_t a, int64_t b) {
 }
 
 int launch_pack(const float *cand, int64_t n, int d, char *packed, int64_t dst_row,
-                int64_t zero_rows_to, int32_t *rowmap, hipStream_t stream) {
+                int64_t zero_rows_to, int32_t *rowmap, hipStream_t stream, uint32_t *flags) {
   const int dp = padded_dim(d);
   const int64_t total_rows = zero_rows_to - dst_row;
   if (total_rows <= 0) return TFRS_OK;
@@ -74,7 +81,7 @@ int launch_pack(const float *cand, int64_t n, int d, char *packed, int64_t dst_r
     add = n / 3;
   }
   hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, cand, n, d,
-                     dp, packed, dst_row, total_rows, mul, add, rowmap);
+                     dp, packed, dst_row, total_rows, mul, add, rowmap, flags);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
 }
@@ -273,7 +280,8 @@ __global__ void __launch_bounds__(256) pack16_stage_regs_kernel(const char *__re
 __global__ void __launch_bounds__(256) query_kappa_kernel(const float *__restrict__ q, int64_t nq,
                                                           int d, float *__restrict__ qk,
                                                           float *__restrict__ qscale,
-                                                          uint32_t *__restrict__ zero_u32) {
+                                                          uint32_t *__restrict__ zero_u32,
+                                                          uint32_t *__restrict__ flags) {
   const int sub = threadIdx.x & 15;
   const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const bool ok = r < nq;
@@ -312,10 +320,29 @@ __global__ void __launch_bounds__(256) query_kappa_kernel(const float *__restric
     amax = fmaxf(amax, __shfl_xor(amax, off));
   }
   if (ok && sub == 0) {
+    // a NaN / Inf element (or a norm beyond the f32 range) makes the sum of squares non-finite: bit 1 of the flag word
+    if (flags && nonfinite_bits(ssq)) atomicOr(flags, kNonfiniteQueries);
     if (zero_u32) zero_u32[r] = 0u;
     qk[r] = __builtin_sqrtf(ssq) * kNormSlack * kF16Kappa;
     qscale[r] = pow2_ceil(amax);
   }
+}
+
+// flags |= bit when any of x[0, count) is NaN / Inf (the search paths that do not run query_kappa_kernel)
+__global__ void __launch_bounds__(256) nonfinite_flag_kernel(const float *__restrict__ x, int64_t count,
+                                                             uint32_t *__restrict__ flags, uint32_t bit) {
+  uint32_t bad = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+    bad |= nonfinite_bits(x[i]);
+  if (__ballot(bad != 0u) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flags, bit);
+}
+
+int launch_nonfinite_flag(const float *x, int64_t count, uint32_t *flags, uint32_t bit, hipStream_t stream) {
+  if (count <= 0 || !flags) return TFRS_OK;
+  const int64_t blocks = std::min<int64_t>((count + 1023) / 1024, 1024);
+  hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, count, flags, bit);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
 }
 
 int launch_pack16(const char *packed, int d, int64_t row_begin, int64_t row_end, char *packed16,
@@ -338,10 +365,10 @@ int launch_pack16(const char *packed, int d, int64_t row_begin, int64_t row_end,
 }
 
 int launch_query_kappa(const float *q, int64_t nq, int d, float *qk, float *qscale,
-                       uint32_t *zero_u32, hipStream_t stream) {
+                       uint32_t *zero_u32, hipStream_t stream, uint32_t *flags) {
   if (nq <= 0) return TFRS_OK;
   hipLaunchKernelGGL(query_kappa_kernel, dim3((unsigned)((nq * 16 + 255) / 256)), dim3(256), 0,
-                     stream, q, nq, d, qk, qscale, zero_u32);
+                     stream, q, nq, d, qk, qscale, zero_u32, flags);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
 }

@@ -405,6 +405,47 @@ def _find_duplicates(cand: Tensor, min_multiplicity: int = 16, min_fraction: flo
                                    distinct_of_row.to(torch.int32).contiguous(), max_mult)
 
 
+class _DeferredFinite:
+  """Deferred finiteness record for the searches that have no index handle (``Streaming`` over blocks read in
+  place): ``note`` ORs "some element is NaN / Inf" into a device word and copies it to pinned host memory without
+  synchronising; ``check`` (at the next call) raises if a completed call set it -- the same deferred contract as
+  ``BruteForce``'s flag word."""
+
+  def __init__(self) -> None:
+    self._dev: Optional[Tensor] = None
+    self._host: Optional[Tensor] = None
+
+  def note(self, *tensors: Tensor) -> None:
+    if torch.cuda.is_current_stream_capturing():
+      return                     # (a replayed graph runs no host code: nothing could read the flag)
+    bad = None
+    for t in tensors:
+      b = torch.isfinite(t).all().logical_not()
+      bad = b if bad is None else bad | b
+    if self._dev is None or self._dev.device != bad.device:
+      self._dev = torch.zeros((), dtype=torch.bool, device=bad.device)
+      self._host = torch.zeros((), dtype=torch.bool).pin_memory()
+    self._dev |= bad
+    self._host.copy_(self._dev, non_blocking=True)
+
+  def check(self, what: str) -> None:
+    if self._host is not None and bool(self._host):
+      self._dev.zero_()
+      self._host.zero_()
+      raise ValueError(f"{what}: the queries or the best scores of an earlier call contained NaN or Inf; queries and "
+                       "candidate blocks must be finite (include/tfrs_hip.h).")
+
+
+def _raise_if_nonfinite_candidates(handle) -> None:
+  """After the packer has run and the stream was synchronised: bit 0 of the handle's flag word."""
+  out = ctypes.c_int32(0)
+  _lib.check(handle._lib.tfrs_index_nonfinite(handle.handle, 0, ctypes.byref(out)))
+  if out.value & 1:
+    raise ValueError("The candidates contain NaN or Inf: the fp16-prefiltered search needs finite candidate rows "
+                     "(its error bound is built from row norms; include/tfrs_hip.h).  Clean the embeddings -- a "
+                     "diverged training run is the usual source -- before indexing them.")
+
+
 class BruteForce(TopK):
   """Brute force retrieval (reference :515-610): exact top-K of ``q @ candidates^T``.
 
@@ -425,9 +466,16 @@ class BruteForce(TopK):
   """
 
   def __init__(self, query_model: Optional[Callable] = None, k: int = 10,
-               name: Optional[str] = None, dedup="auto"):
+               name: Optional[str] = None, dedup="auto", check_finite: bool = False):
+    """``check_finite`` (not in the reference's signature): candidates and queries must be finite -- the reference's
+    ``tf.math.top_k`` (:605) tolerates NaN / Inf scores, the fp16-prefiltered search here does not (include/tfrs_hip.h,
+    ``tfrs_index_nonfinite``).  Non-finite CANDIDATES always raise ``ValueError`` from ``index`` /
+    ``index_from_dataset``.  Non-finite QUERIES are recorded by the search kernels without a host synchronisation:
+    only their own result rows are affected, and the ``ValueError`` is raised by the NEXT call (deferred, like an
+    asynchronous device error); ``check_finite=True`` synchronises after every call and raises at once."""
     super().__init__(k=k, name=name)
     self.query_model = query_model
+    self._check_finite = bool(check_finite)
     self._index: Optional[_IndexHandle] = None
     self._ids: Optional[_Identifiers] = None
     self._n = 0
@@ -470,6 +518,7 @@ class BruteForce(TopK):
     _lib.check(handle._lib.tfrs_index_set(handle.handle, _lib.ptr(packed_rows), packed_rows.shape[0],
                                           packed_rows.shape[1], _lib.current_stream()))
     torch.cuda.current_stream().synchronize()  # `cand` may be a temporary upload
+    _raise_if_nonfinite_candidates(handle)
     self._index = handle                       # the previous index (if any) is dropped
     self._ids = _Identifiers(identifiers, cand.shape[0])
     self._n, self._d = cand.shape
@@ -537,6 +586,7 @@ class BruteForce(TopK):
     if handle is None:
       raise ValueError("The candidate dataset is empty.")
     flush()
+    _raise_if_nonfinite_candidates(handle)
     self._index = handle
     self._dup, self._plain = None, None        # (streamed ingest: blocks are indexed as they come)
     self._ids = _Identifiers(np.concatenate(ids, axis=0) if has_ids else None, n)
@@ -570,6 +620,7 @@ class BruteForce(TopK):
           self._plain = BruteForce(k=self._k, dedup=False).index(self.candidates())
         return self._plain._query_rows_paged(q, k)
       return self._query_rows_paged(q, k)
+    self._raise_if_nonfinite_queries()             # (deferred: recorded by an EARLIER call's kernels)
     kk = min(k, self._index_rows)                   # (de-duplicated: the best kk DISTINCT rows)
     scores = torch.empty((nq, kk), dtype=torch.float32, device=q.device)
     rows = torch.empty((nq, kk), dtype=torch.int32, device=q.device)
@@ -578,6 +629,9 @@ class BruteForce(TopK):
         self._index.handle, _lib.ptr(q), nq, kk, _lib.ptr(scores), _lib.ptr(rows),
         _lib.ptr(ws), ws.numel(), _lib.current_stream()))               # :603-605
     self._last_call = (ws, nq, kk)
+    if self._check_finite:
+      torch.cuda.current_stream().synchronize()
+      self._raise_if_nonfinite_queries()
     if self._dup is None:
       return scores, rows
     # every original row is a candidate with its distinct row's score: exact top-k of the corpus
@@ -619,6 +673,22 @@ class BruteForce(TopK):
       done += kk
     self._last_call = None
     return scores, rows
+
+  def nonfinite_flags(self, reset: int = 0) -> int:
+    """The index handle's flag word (``tfrs_index_nonfinite``): bit 0 non-finite candidates, bit 1 non-finite
+    queries in a call whose kernels have completed.  Reading it does not synchronise."""
+    if not isinstance(self._index, _IndexHandle):
+      return 0
+    out = ctypes.c_int32(0)
+    _lib.check(self._index._lib.tfrs_index_nonfinite(self._index.handle, int(reset), ctypes.byref(out)))
+    return int(out.value)
+
+  def _raise_if_nonfinite_queries(self) -> None:
+    if self.nonfinite_flags() & 2:
+      self.nonfinite_flags(reset=2)
+      raise ValueError("BruteForce: the queries of this or an earlier call contained NaN or Inf (or a row norm beyond "
+                       "the float32 range): the result rows of those queries hold non-finite scores and unspecified "
+                       "indices; every other row is exact.  Queries must be finite (include/tfrs_hip.h).")
 
   def last_redo_count(self) -> int:
     """Queries of the most recent ``call`` that were answered by the exact-recompute path of
@@ -917,6 +987,12 @@ class Streaming(TopK):
       return scores, (rows + self._base_row if self._base_row else rows)
     lib = _lib.load()
     nq, d = q.shape
+    # non-finite inputs: Streaming re-reads its dataset on every call, so the blocks are NOT validated (that would
+    # double the traffic); the queries and the best score of every row are, without a synchronisation -- a violation
+    # raises at the next call (see BruteForce.__init__ / include/tfrs_hip.h)
+    if not hasattr(self, "_finite"):
+      self._finite = _DeferredFinite()
+    self._finite.check("Streaming")
     state_scores = torch.zeros((nq, k), dtype=torch.float32, device=q.device)
     state_rows = torch.zeros((nq, k), dtype=torch.int32, device=q.device)
     state_len = 0
@@ -1007,6 +1083,8 @@ class Streaming(TopK):
       else:
         all_ids = np.concatenate([i.cpu().numpy() if isinstance(i, torch.Tensor) else i for i in ids], axis=0)
     self._last_ids = _Identifiers(all_ids, counter - self._base_row)
+    if state_len > 0 and nq > 0:
+      self._finite.note(q, state_scores[:, :1])
     return state_scores[:, :state_len], state_rows[:, :state_len]
 
   def _group_bytes(self, device) -> int:

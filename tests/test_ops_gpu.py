@@ -239,7 +239,17 @@ def test_inbatch_softmax_f16_path_sizes(nq, nc, d, scale, waves, monkeypatch):
                                  temperature=kw.get("temperature"))
     np.testing.assert_allclose(float(loss), float(ref), rtol=1e-5)
     (loss * 0.5).backward()
-    float_gate("softmax_f16.sizes.dq", _np(tq.grad) * 2.0, dq_ref, dq_y, GATE_SOFTMAX_MIXED)
+    # The ZERO query row (q[5] = 0: every logit 0, softmax uniform) is gated on its own: its gradient is a sum of nc
+    # terms of EQUAL magnitude, and the float32 accumulation of 16500 such terms alone costs ~1e-6 of their sum --
+    # the all-f32 kernels (TFRS_SOFTMAX_MODE=f32) measure 6.7e-7 ... 9.9e-7 on this row, the split-fp16 ones 4.5e-7 ...
+    # 1.08e-6 depending on the summation order of the workgroup shape (tools/exp_softmax_dq.py,
+    # profiles/r06_softmax_dq.txt); every other row stays below 2.4e-7.  Round 3's frozen observation of this gate
+    # (8.3e-8) was taken under the mixed yardstick that gave this row a floor; with the own-terms yardstick it is the
+    # row that sets the maximum on every path (not a regression of the 8-wave shape).
+    dq_got = _np(tq.grad) * 2.0
+    nz = np.flatnonzero(np.abs(q).sum(axis=1) > 0)
+    float_gate("softmax_f16.sizes.dq", dq_got[nz], dq_ref[nz], dq_y[nz], GATE_SOFTMAX_MIXED)
+    float_gate("softmax_f16.sizes.dq_zero_row", dq_got[5:6], dq_ref[5:6], dq_y[5:6], GATE_SOFTMAX_MIXED)
     float_gate("softmax_f16.sizes.dc", _np(tc.grad) * 2.0, dc_ref, dc_y, GATE_SOFTMAX_MIXED)
 
 
