@@ -118,6 +118,12 @@ int tfrs_index_append(tfrs_index_t *index, const float *block, int64_t nb, void 
  * The word lives in pinned host memory the kernels OR into: reading it never touches the stream, and reflects
  * every launch that has completed.  reset_mask: bits to clear after the read. */
 int tfrs_index_nonfinite(const tfrs_index_t *index, int reset_mask, int32_t *flags_h);
+/* ORs `bits` into the handle's flag word when any element of x[0, count) or y[0, county) (either may be NULL / empty) is
+ * NaN / Inf: ONE launch, no synchronisation.  For the searches that have no indexed corpus -- Streaming over blocks read
+ * in place (layers/factorized_top_k.py:404-509) records its queries and its carried state through an otherwise empty
+ * handle; the flag word is allocated on first use. */
+int tfrs_index_note_nonfinite(tfrs_index_t *index, const float *x, int64_t count, const float *y, int64_t county,
+                              int bits, void *stream);
 int64_t tfrs_index_size(const tfrs_index_t *index);
 int tfrs_index_dim(const tfrs_index_t *index);
 /* Writes the original row-major candidates[n, d] back (checkpoint/state_dict). */
@@ -349,7 +355,9 @@ int tfrs_embedding_segment_reduce_bwd(const float *grad_out, int d, const void *
  * Produces the dense grad_table[vocab, d] rows for the touched ids only (other rows
  * untouched) -- or, when adagrad != 0, applies the fused row-wise Adagrad update
  * (models/base.py:77-78 with Adagrad, README.md:84):
- *   g = sum of duplicate grads; acc += g*g; row -= lr * g / sqrt(acc + eps).
+ *   g = sum of duplicate grads; acc += g*g; row -= lr * g / sqrt(acc + eps)      (adagrad == 1:
+ *   tf.keras.optimizers.Adagrad of TF >= 2.11 / tf-keras), or ... / (sqrt(acc) + eps)   (adagrad == 2: the optimizer_v2
+ *   kernel ResourceApplyAdagradV2 of TF <= 2.10, also torch.optim.Adagrad's form).
  * Negative ids (the padding slots of a max_sequence_length feature) contribute nothing. */
 int tfrs_embedding_scatter_add_bwd(const float *grad_out, const int64_t *sorted_ids,
                                    const int64_t *perm, int64_t n, int d,

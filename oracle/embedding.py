@@ -125,17 +125,20 @@ def scatter_add_grad(grad_out: np.ndarray, ids: np.ndarray, vocab: int) -> np.nd
 
 
 def adagrad_sparse_update(table: np.ndarray, accum: np.ndarray, grad_out: np.ndarray,
-                          ids: np.ndarray, lr: float, eps: float = 1e-7
+                          ids: np.ndarray, lr: float, eps: float = 1e-7, legacy: bool = False
                           ) -> Tuple[np.ndarray, np.ndarray]:
   """Keras Adagrad on deduplicated IndexedSlices (README.md:84; SURVEY.md App.
   A.7, tf-keras new-style formula): for each touched row, g = sum of duplicate
-  grads; acc += g*g; row -= lr * g / sqrt(acc + eps).  PARITY UNPINNED by the
-  reference (``models/base_test.py`` asserts metric keys only)."""
+  grads; acc += g*g; row -= lr * g / sqrt(acc + eps).  ``legacy``: the optimizer_v2 /
+  ``ResourceApplyAdagradV2`` form of TF <= 2.10, ``/ (sqrt(acc) + eps)`` (also
+  ``torch.optim.Adagrad``'s, which tests/test_oracle_golden.py checks this function against).
+  PARITY UNPINNED by the reference (``models/base_test.py`` asserts metric keys only);
+  ``tools/tf_reference_vectors.py`` produces the TensorFlow-side vectors of both forms."""
   table = np.array(table, dtype=np.float32)
   accum = np.array(accum, dtype=np.float32)
   g = scatter_add_grad(grad_out, ids, table.shape[0])
   touched = np.unique(np.asarray(ids).reshape(-1))
   accum[touched] = accum[touched] + g[touched] * g[touched]
-  table[touched] = table[touched] - np.float32(lr) * g[touched] / np.sqrt(
-      accum[touched] + np.float32(eps))
+  den = (np.sqrt(accum[touched]) + np.float32(eps)) if legacy else np.sqrt(accum[touched] + np.float32(eps))
+  table[touched] = table[touched] - np.float32(lr) * g[touched] / den
   return table, accum

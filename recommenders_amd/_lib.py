@@ -37,6 +37,7 @@ SIGNATURES = {
     "tfrs_index_reserve": (c_int, [P, c_i64, c_int, P]),
     "tfrs_index_append": (c_int, [P, P, c_i64, P]),
     "tfrs_index_nonfinite": (c_int, [P, c_int, P]),
+    "tfrs_index_note_nonfinite": (c_int, [P, P, c_i64, P, c_i64, c_int, P]),
     "tfrs_index_size": (c_i64, [P]),
     "tfrs_index_dim": (c_int, [P]),
     "tfrs_index_unpack": (c_int, [P, P, P]),

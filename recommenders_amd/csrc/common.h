@@ -454,7 +454,8 @@ constexpr uint32_t kNonfiniteCandidates = 1u, kNonfiniteQueries = 2u;
 __device__ __forceinline__ uint32_t nonfinite_bits(float x) {
   return ((__builtin_bit_cast(uint32_t, x) & 0x7f800000u) == 0x7f800000u) ? 1u : 0u;
 }
-int launch_nonfinite_flag(const float *x, int64_t count, uint32_t *flags, uint32_t bit, hipStream_t stream);
+int launch_nonfinite_flag(const float *x, int64_t count, uint32_t *flags, uint32_t bit, hipStream_t stream,
+                          const float *y = nullptr, int64_t county = 0);
 int launch_pack(const float *cand, int64_t n, int d, char *packed, int64_t dst_row,
                 int64_t zero_rows_to, int32_t *rowmap, hipStream_t stream, uint32_t *flags = nullptr);
 int launch_unpack(const char *packed, int64_t n, int d, const int32_t *rowmap, float *out,

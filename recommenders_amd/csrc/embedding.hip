@@ -20,6 +20,15 @@
 
 namespace tfrs {
 
+// Denominator of the fused Adagrad update.  adagrad == 1: sqrt(acc + eps), tf.keras.optimizers.Adagrad of TF >= 2.11 /
+// tf-keras (`variable.assign_sub(lr * grad / sqrt(accumulator + epsilon))`); adagrad == 2: sqrt(acc) + eps, the
+// optimizer_v2 / ResourceApplyAdagradV2 form of TF <= 2.10 (the reference's release script pins TF 2.9.0,
+// tools/build_scripts/release.sh:6) -- also torch.optim.Adagrad's, which the tests cross-check it against.
+__device__ __forceinline__ float adagrad_denom(float acc, float eps, int adagrad) {
+  return adagrad == 2 ? sqrtf(acc) + eps : sqrtf(acc + eps);
+}
+
+
 template <typename IdT>
 __device__ __forceinline__ int64_t load_id(const void *ids, int64_t i) {
   return (int64_t) reinterpret_cast<const IdT *>(ids)[i];
@@ -295,7 +304,7 @@ __global__ void __launch_bounds__(256) scatter_add_kernel(
       if (adagrad) {
         const float a = accum[o] + g[v] * g[v];
         accum[o] = a;
-        dst[o] = dst[o] - lr * g[v] / sqrtf(a + eps);
+        dst[o] = dst[o] - lr * g[v] / adagrad_denom(a, eps, adagrad);
       } else {
         dst[o] = g[v];
       }
@@ -398,7 +407,7 @@ __device__ __forceinline__ void scatter_rowscan_body(
       if (touched) {
         const float a = accum[o] + g[s] * g[s];
         accum[o] = a;
-        dst[o] = dst[o] - lr * g[s] / sqrtf(a + eps);
+        dst[o] = dst[o] - lr * g[s] / adagrad_denom(a, eps, adagrad);
       }
     } else {
       dst[o] = g[s];  // untouched rows get their zeros here: no separate fill
@@ -834,8 +843,8 @@ __global__ void __launch_bounds__(256) scatter_add_u32_kernel(
         float4 *a4 = reinterpret_cast<float4 *>(accum) + o4;
         float4 a = a_pre, w = w_pre;
         a.x += g[0] * g[0]; a.y += g[1 % VEC] * g[1 % VEC]; a.z += g[2 % VEC] * g[2 % VEC]; a.w += g[3 % VEC] * g[3 % VEC];
-        w.x -= lr * g[0] / sqrtf(a.x + eps); w.y -= lr * g[1 % VEC] / sqrtf(a.y + eps);
-        w.z -= lr * g[2 % VEC] / sqrtf(a.z + eps); w.w -= lr * g[3 % VEC] / sqrtf(a.w + eps);
+        w.x -= lr * g[0] / adagrad_denom(a.x, eps, adagrad); w.y -= lr * g[1 % VEC] / adagrad_denom(a.y, eps, adagrad);
+        w.z -= lr * g[2 % VEC] / adagrad_denom(a.z, eps, adagrad); w.w -= lr * g[3 % VEC] / adagrad_denom(a.w, eps, adagrad);
         *a4 = a;
         *d4 = w;
       } else {
@@ -846,7 +855,7 @@ __global__ void __launch_bounds__(256) scatter_add_u32_kernel(
       if (adagrad) {
         const float a = accum[o] + g[0] * g[0];
         accum[o] = a;
-        dst[o] = dst[o] - lr * g[0] / sqrtf(a + eps);
+        dst[o] = dst[o] - lr * g[0] / adagrad_denom(a, eps, adagrad);
       } else {
         dst[o] = g[0];
       }

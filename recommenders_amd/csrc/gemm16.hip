@@ -494,7 +494,6 @@ struct Gemm16Args {
   int raster;                          // big kernel: tile order of the workgroups (see gemm16_big_kernel)
   int act;                             // fused activation of v (common.h kAct*), before the epilogue formula
   float *pre;                          // [m, n] or NULL: receives v (the pre-activation) for the backward
-  int vec4;                            // big kernel: n % 4 == 0 and out / x0 / x / aux / pre / bias 16-byte aligned (wide epilogue)
   unsigned long long *clk;             // big kernel, measurement (TFRS_GEMM16_CLOCKS=1): += {shader cycles, 100 MHz ticks} per workgroup
 };
 
@@ -934,91 +933,11 @@ __global__ void __launch_bounds__(512) gemm16_big_kernel(const Gemm16Args g) {
   float *const auxb = (EPI == kG16EpiCross && g.aux) ? g.aux + tile0 : nullptr;
   const int rows_here = (int)(g.m - bm < kB16M ? g.m - bm : kB16M);   // >= 1
   const int cols_here = g.n - bn < kB16N ? g.n - bn : kB16N;           // >= 1
-  if (g.vec4) {
-    // Wide epilogue (round 6; n % 4 == 0 and every array 16-byte aligned -- the launcher decides): the scalar form
-    // below moves one float per lane and instruction (an accumulator lane holds a COLUMN of its 32 x 32 tile) and can
-    // keep only 24 loads of a 32 x 32 tile in flight next to the 128 accumulators: 16 dependent memory round trips per
-    // wave and tile, 0.44 ms of the 4.36 ms Cross forward at configs[3] with the matrix pipe of the CU idle
-    // (TFRS_G16_ABLATE=8).  Here a wave transposes two accumulator tiles at a time through its own 8 KB of the (now
-    // free) stage ring -- 32 rows x 64 columns, row pitch 256 bytes: conflict-free for the ds_write_b32 of a tile column
-    // and for the ds_read_b128 of four consecutive columns -- so that a lane owns four consecutive columns of a row:
-    // every global access is a dwordx4 (a wave instruction = four rows x 256 contiguous bytes), 16 of them in flight
-    // per batch, four batches per wave.  Same arithmetic per element as the scalar form, bit for bit.
-    __syncthreads();                       // every wave holds its last fragments: the stage ring is free
-    float *scr = reinterpret_cast<float *>(lds) + wave * (32 * 64);
-    const int fr = lane >> 4, fc = (lane & 15) * 4;
-    // Eight half batches hb = (i, jp, hp): 32 rows x 64 columns of the wave's tile in two halves of four passes (a
-    // pass = one dwordx4 per lane = four rows x 256 bytes).  The loads of half batch hb + 1 are issued BEFORE half
-    // batch hb is computed and stored (two register sets): a CU runs one workgroup, so its epilogue is a chain of
-    // memory round trips with nothing else to run -- bytes in flight are what sets its length.
-    float ra[2][4];
-    f32x4 e0v[2][4], e1v[2][4];
-    auto issue = [&](int hb, int set) __attribute__((always_inline)) {
-      const int i = hb >> 2, jp = (hb >> 1) & 1, hp = hb & 1;
-      const int lc = wn * 128 + jp * 64 + fc;
-      const int lcc = lc < cols_here ? lc : 0;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int lr = wm * 64 + i * 32 + 4 * (4 * hp + p) + fr;
-        const int lrc = lr < rows_here ? lr : rows_here - 1;
-        const uint32_t o = (uint32_t)lrc * (uint32_t)g.n + (uint32_t)lcc;
-        ra[set][p] = g.inva[bm + lrc];
-        if (EPI != kG16EpiBias) {
-          e0v[set][p] = *reinterpret_cast<const f32x4 *>(x0b + o);
-          e1v[set][p] = *reinterpret_cast<const f32x4 *>(xb + o);
-        }
-      }
-    };
-    issue(0, 0);
-#pragma unroll
-    for (int hb = 0; hb < 8; ++hb) {
-      const int i = hb >> 2, jp = (hb >> 1) & 1, hp = hb & 1, set = hb & 1;
-      const int lc = wn * 128 + jp * 64 + fc;                        // first of this lane's four columns
-      const bool col_ok = lc < cols_here;                            // (cols_here % 4 == 0: all four or none)
-      const int lcc = col_ok ? lc : 0;
-      const f32x4 cs = *reinterpret_cast<const f32x4 *>(g.invb + bn + lcc);
-      f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-      if (g.bias) bias = *reinterpret_cast<const f32x4 *>(g.bias + bn + lcc);
-      if (hp == 0) {
-        // the two accumulator tiles of this batch go to the wave's LDS scratch (their registers are free afterwards)
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int q = 0; q < 16; ++q) scr[tile_row_of_reg(q, h) * 64 + t * 32 + j] = acc[i][2 * jp + t][q];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
-      if (hb + 1 < 8) issue(hb + 1, set ^ 1);      // (behind the LDS writes: 32 accumulator registers fewer are live)
-      f32x4 av[4];
-#pragma unroll
-      for (int p = 0; p < 4; ++p) av[p] = *reinterpret_cast<const f32x4 *>(scr + (4 * (4 * hp + p) + fr) * 64 + fc);
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int lr = wm * 64 + i * 32 + 4 * (4 * hp + p) + fr;
-        f32x4 res, uu, pv;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float v0 = av[p][c] * (ra[set][p] * cs[c]) + bias[c];
-          const float v = ACT ? act_apply(g.act, v0) : v0;
-          float u = 0.0f;
-          res[c] = g16_epilogue_v<EPI>(v, EPI != kG16EpiBias ? e0v[set][p][c] : 0.0f,
-                                       EPI != kG16EpiBias ? e1v[set][p][c] : 0.0f, g.diag, &u);
-          uu[c] = u;
-          pv[c] = v0;
-        }
-        if (lr < rows_here && col_ok) {
-          const uint32_t o = (uint32_t)lr * (uint32_t)g.n + (uint32_t)lc;
-          *reinterpret_cast<f32x4 *>(outb + o) = res;
-          if (EPI == kG16EpiCross && auxb) *reinterpret_cast<f32x4 *>(auxb + o) = uu;
-          if (ACT && g.pre) *reinterpret_cast<f32x4 *>(g.pre + (int64_t)tile0 + o) = pv;
-        }
-      }
-    }
-    clocks_out();
-    return;
-  }
+  // (Round 6 measured a wide form of this epilogue -- accumulator tiles transposed through the free stage ring so that
+  // every global access is a dwordx4, loads of the next half batch issued ahead -- bit-identical and NOT faster: Cross
+  // forward 4.39 ms against 4.27 ms scalar, training pair 14.47 against 14.40 (profiles/r06_gemm16_ab.txt); its two
+  // register sets next to the accumulators spilled 63-80 registers in every Cross instantiation.  Removed: the epilogue's
+  // cost is its HBM traffic with the matrix pipe of the CU idle, not its instruction count.)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1198,13 +1117,6 @@ int gemm16_run_ex(const G16Operand &a, const G16Operand &b, int64_t m, int n, in
   g.kb = kb; g.mp = L.mp; g.np = L.np;
   g.act = act; g.pre = pre;
   {
-    const uintptr_t bits = reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(e0) | reinterpret_cast<uintptr_t>(e1) |
-                           reinterpret_cast<uintptr_t>(aux) | reinterpret_cast<uintptr_t>(pre) | reinterpret_cast<uintptr_t>(bias);
-    // TFRS_GEMM16_EPILOGUE=wide selects the dwordx4 form (bit-identical; measured on one box, tools/exp_gemm16_ms.py,
-    // profiles/r06_gemm16_ab.txt: Cross forward 4.39 ms wide against 4.27 scalar, training pair 14.47 against 14.40 --
-    // the epilogue's cost is its HBM traffic under the chip's power cap, not its instruction count), default scalar
-    const char *ev = option("TFRS_GEMM16_EPILOGUE");
-    g.vec4 = (n % 4 == 0 && (bits & 15) == 0 && ev && ev[0] == 'w') ? 1 : 0;
     const char *cv = option("TFRS_GEMM16_CLOCKS");
     g.clk = nullptr;
     if (cv && cv[0] == '1' && big) {

@@ -672,6 +672,21 @@ static void index_free(tfrs_index *index) {
   index->norm_max = nullptr;
 }
 
+// the handle's host-visible flag word, allocated on first use
+static int index_flag_word(tfrs_index *index) {
+  if (index->flags_h) return TFRS_OK;
+  hipError_t fe = hipHostMalloc(reinterpret_cast<void **>(&index->flags_h), 64, hipHostMallocMapped);
+  if (fe == hipSuccess) fe = hipHostGetDevicePointer(reinterpret_cast<void **>(&index->flags_d), index->flags_h, 0);
+  if (fe != hipSuccess) {
+    if (index->flags_h) (void)hipHostFree(index->flags_h);
+    index->flags_h = index->flags_d = nullptr;
+    set_error("index: hipHostMalloc of the flag word failed: %s", hipGetErrorString(fe));
+    return TFRS_ENOMEM;
+  }
+  *index->flags_h = 0u;
+  return TFRS_OK;
+}
+
 extern "C" int tfrs_index_create(tfrs_index_t **out_h) {
   TFRS_CHECK_ARG(out_h != nullptr, "index_create: NULL output");
   *out_h = new (std::nothrow) tfrs_index();
@@ -699,16 +714,8 @@ extern "C" int tfrs_index_reserve(tfrs_index_t *index, int64_t capacity, int d, 
     return TFRS_ENOTIMPL;
   }
   index_free(index);
-  if (!index->flags_h) {
-    hipError_t fe = hipHostMalloc(reinterpret_cast<void **>(&index->flags_h), 64, hipHostMallocMapped);
-    if (fe == hipSuccess) fe = hipHostGetDevicePointer(reinterpret_cast<void **>(&index->flags_d), index->flags_h, 0);
-    if (fe != hipSuccess) {
-      if (index->flags_h) (void)hipHostFree(index->flags_h);
-      index->flags_h = index->flags_d = nullptr;
-      set_error("index: hipHostMalloc of the flag word failed: %s", hipGetErrorString(fe));
-      return TFRS_ENOMEM;
-    }
-  }
+  int frc = index_flag_word(index);
+  if (frc != TFRS_OK) return frc;
   *index->flags_h = 0u;          // (re-index: a new corpus, a clean record)
   index->n = 0;
   index->d = d;
@@ -773,6 +780,16 @@ extern "C" int tfrs_index_nonfinite(const tfrs_index_t *index, int reset_mask, i
   *flags_h = (int32_t)v;
   if (reset_mask) __atomic_fetch_and(index->flags_h, ~(uint32_t)reset_mask, __ATOMIC_ACQ_REL);
   return TFRS_OK;
+}
+
+extern "C" int tfrs_index_note_nonfinite(tfrs_index_t *index, const float *x, int64_t count, const float *y,
+                                         int64_t county, int bits, void *stream) {
+  TFRS_CHECK_ARG(index && count >= 0 && county >= 0 && bits > 0, "index_note_nonfinite: bad argument");
+  TFRS_CHECK_ARG((x || count == 0) && (y || county == 0), "index_note_nonfinite: NULL array");
+  const int rc = index_flag_word(index);
+  if (rc != TFRS_OK) return rc;
+  if (!x) return launch_nonfinite_flag(y, county, index->flags_d, (uint32_t)bits, (hipStream_t)stream);
+  return launch_nonfinite_flag(x, count, index->flags_d, (uint32_t)bits, (hipStream_t)stream, y, county);
 }
 
 extern "C" int64_t tfrs_index_size(const tfrs_index_t *index) { return index ? index->n : -1; }

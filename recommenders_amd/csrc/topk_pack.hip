@@ -328,19 +328,24 @@ __global__ void __launch_bounds__(256) query_kappa_kernel(const float *__restric
   }
 }
 
-// flags |= bit when any of x[0, count) is NaN / Inf (the search paths that do not run query_kappa_kernel)
+// flags |= bit when any of x[0, count) -- or of the optional second array y[0, county) -- is NaN / Inf (the search
+// paths that do not run query_kappa_kernel; Streaming over blocks read in place: queries + carried state, ONE launch)
 __global__ void __launch_bounds__(256) nonfinite_flag_kernel(const float *__restrict__ x, int64_t count,
+                                                             const float *__restrict__ y, int64_t county,
                                                              uint32_t *__restrict__ flags, uint32_t bit) {
   uint32_t bad = 0u;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
-    bad |= nonfinite_bits(x[i]);
+  const int64_t total = count + county;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    bad |= nonfinite_bits(i < count ? x[i] : y[i - count]);
   if (__ballot(bad != 0u) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flags, bit);
 }
 
-int launch_nonfinite_flag(const float *x, int64_t count, uint32_t *flags, uint32_t bit, hipStream_t stream) {
-  if (count <= 0 || !flags) return TFRS_OK;
-  const int64_t blocks = std::min<int64_t>((count + 1023) / 1024, 1024);
-  hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, count, flags, bit);
+int launch_nonfinite_flag(const float *x, int64_t count, uint32_t *flags, uint32_t bit, hipStream_t stream,
+                          const float *y, int64_t county) {
+  if (!y) county = 0;
+  if (count + county <= 0 || !flags) return TFRS_OK;
+  const int64_t blocks = std::min<int64_t>((count + county + 1023) / 1024, 1024);
+  hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, count, y, county, flags, bit);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
 }

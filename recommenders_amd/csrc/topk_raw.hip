@@ -623,6 +623,11 @@ static int launch_rawscan16_variant(const RawScanArgs &a, hipStream_t stream) {
 // 5.5 TB/s, the whole kernel 2.8-2.96 ms (2.6-2.75 with the trimmed check of the later part of round 5): the scoring phase runs at about a third of the matrix pipe's rate (waves
 // parked 48 % of their cycles: two waves per SIMD of ONE workgroup that converts, meets its barrier and scores in
 // lock step), so the kernel pays only between 257 and ~700 queries (topk_api.hip: TFRS_STREAM_RAW16_MAX_NQ = 640).
+// Round 6 tried the remedy the lock step suggests -- ONE query group per wave (256 queries per workgroup, <= 128 registers),
+// TWO workgroups per CU so that one converts while the other scores: SLOWER at every size (12.5 M x 128: 257 / 384 / 512 /
+// 640 queries 3.19 / 3.13 / 3.38 / 8.2 ms against 2.54 / 2.67 / 2.87 / 5.0; 25 M x 64: 3.45 / 3.56 against 3.03 / 3.40) --
+// every stage is then loaded and converted twice per CU (the conversion is the phase that was to be hidden), and dim 128
+// needs 25 registers of scratch at 128.  Not kept.
 // Tried on the way, each within +-3 %: rows staged through LDS by DMA (one stage in flight), two stages of rows in
 // flight in registers, the chains of the two groups in sequence instead of step by step, one counter round trip per
 // hot tile instead of sixteen, no cross-lane reductions at all (ablation).

@@ -85,10 +85,12 @@ def _scatter_unsorted(g, flat, vocab, dst, accum, lr, eps, adagrad) -> None:
 
 
 def adagrad_sparse_update_(table: torch.Tensor, accum: torch.Tensor, grad_out: torch.Tensor,
-                           ids: torch.Tensor, lr: float, eps: float = 1e-7) -> None:
+                           ids: torch.Tensor, lr: float, eps: float = 1e-7, legacy: bool = False) -> None:
   """In-place fused scatter-add + Keras Adagrad on the touched rows only
   (``models/base.py:77-78`` with ``Adagrad``, ``README.md:84``):
-  g = sum of duplicate grads; acc += g*g; row -= lr * g / sqrt(acc + eps)."""
+  g = sum of duplicate grads; acc += g*g; row -= lr * g / sqrt(acc + eps)
+  (``legacy``: ``/ (sqrt(acc) + eps)``, the optimizer_v2 form of TF <= 2.10 and ``torch.optim.Adagrad``)."""
+  mode = 2 if legacy else 1
   d = grad_out.shape[-1]
   g = grad_out.reshape(-1, d).contiguous()
   if ids.dtype not in (torch.int32, torch.int64):
@@ -97,13 +99,13 @@ def adagrad_sparse_update_(table: torch.Tensor, accum: torch.Tensor, grad_out: t
     flat = ids.reshape(-1).contiguous()
     _lib.check(_lib.load().tfrs_embedding_scatter_add_rowscan(
         _lib.ptr(g), _lib.ptr(flat), 1 if flat.dtype == torch.int64 else 0, flat.numel(), d,
-        table.shape[0], _lib.ptr(table), _lib.ptr(accum), float(lr), float(eps), 1,
+        table.shape[0], _lib.ptr(table), _lib.ptr(accum), float(lr), float(eps), mode,
         _lib.current_stream()))
     return
-  _scatter_unsorted(g, ids.reshape(-1).contiguous(), table.shape[0], table, accum, lr, eps, 1)
+  _scatter_unsorted(g, ids.reshape(-1).contiguous(), table.shape[0], table, accum, lr, eps, mode)
 
 
-def adagrad_sparse_update_multi_(updates, lr: float, eps: float = 1e-7) -> None:
+def adagrad_sparse_update_multi_(updates, lr: float, eps: float = 1e-7, legacy: bool = False) -> None:
   """``adagrad_sparse_update_`` for several tables of one optimizer step; ``updates`` is a list of
   ``(table, accum, grad_rows, ids)``.  The small tables (row-scan path) of the step go out in
   ONE launch (``tfrs_embedding_scatter_add_rowscan_multi``): each table's update is a chain of
@@ -116,12 +118,12 @@ def adagrad_sparse_update_multi_(updates, lr: float, eps: float = 1e-7) -> None:
     (small if _use_rowscan(table.shape[0], ids.numel(), d) else rest).append(
         (table, accum, grad_out.reshape(-1, d).contiguous(), ids.reshape(-1).contiguous()))
   for table, accum, g, ids in rest:
-    adagrad_sparse_update_(table, accum, g, ids, lr, eps)
+    adagrad_sparse_update_(table, accum, g, ids, lr, eps, legacy)
   for lo in range(0, len(small), 8):
     grp = small[lo:lo + 8]
     if len(grp) == 1:
       table, accum, g, ids = grp[0]
-      adagrad_sparse_update_(table, accum, g, ids, lr, eps)
+      adagrad_sparse_update_(table, accum, g, ids, lr, eps, legacy)
       continue
     import ctypes
     n = len(grp)
@@ -131,7 +133,8 @@ def adagrad_sparse_update_multi_(updates, lr: float, eps: float = 1e-7) -> None:
         ia(*[1 if i.dtype == torch.int64 else 0 for _, _, _, i in grp]),
         i64a(*[i.numel() for _, _, _, i in grp]), ia(*[g.shape[-1] for _, _, g, _ in grp]),
         i64a(*[t.shape[0] for t, _, _, _ in grp]), vp(*[t.data_ptr() for t, _, _, _ in grp]),
-        vp(*[a.data_ptr() for _, a, _, _ in grp]), float(lr), float(eps), 1, _lib.current_stream()))
+        vp(*[a.data_ptr() for _, a, _, _ in grp]), float(lr), float(eps), 2 if legacy else 1,
+        _lib.current_stream()))
 
 
 def _emit_table_grad(ctx, grad_out):

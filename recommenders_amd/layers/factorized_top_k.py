@@ -407,31 +407,38 @@ def _find_duplicates(cand: Tensor, min_multiplicity: int = 16, min_fraction: flo
 
 class _DeferredFinite:
   """Deferred finiteness record for the searches that have no index handle (``Streaming`` over blocks read in
-  place): ``note`` ORs "some element is NaN / Inf" into a device word and copies it to pinned host memory without
-  synchronising; ``check`` (at the next call) raises if a completed call set it -- the same deferred contract as
-  ``BruteForce``'s flag word."""
+  place): ``note`` ORs "some element is NaN / Inf" into the host-visible flag word of an otherwise empty library
+  handle -- ONE tiny launch, no synchronisation (``tfrs_index_note_nonfinite``; the first version of this record was
+  ten torch kernels, 50 us of a 1.4 ms single-query call); ``check`` (at the next call) raises if a completed call set
+  it -- the same deferred contract as ``BruteForce``'s flag word."""
 
   def __init__(self) -> None:
-    self._dev: Optional[Tensor] = None
-    self._host: Optional[Tensor] = None
+    self._lib = _lib.load()
+    self._handle = ctypes.c_void_p()
+    _lib.check(self._lib.tfrs_index_create(ctypes.byref(self._handle)))
+
+  def __del__(self):
+    try:
+      if self._handle:
+        self._lib.tfrs_index_destroy(self._handle)
+        self._handle = None
+    except Exception:   # interpreter shutdown
+      pass
 
   def note(self, *tensors: Tensor) -> None:
     if torch.cuda.is_current_stream_capturing():
       return                     # (a replayed graph runs no host code: nothing could read the flag)
-    bad = None
-    for t in tensors:
-      b = torch.isfinite(t).all().logical_not()
-      bad = b if bad is None else bad | b
-    if self._dev is None or self._dev.device != bad.device:
-      self._dev = torch.zeros((), dtype=torch.bool, device=bad.device)
-      self._host = torch.zeros((), dtype=torch.bool).pin_memory()
-    self._dev |= bad
-    self._host.copy_(self._dev, non_blocking=True)
+    flat = [t.contiguous() for t in tensors if t.numel() > 0]
+    for i in range(0, len(flat), 2):
+      x, y = flat[i], (flat[i + 1] if i + 1 < len(flat) else None)
+      _lib.check(self._lib.tfrs_index_note_nonfinite(
+          self._handle, _lib.ptr(x), x.numel(), _lib.ptr(y), y.numel() if y is not None else 0, 2,
+          _lib.current_stream()))
 
   def check(self, what: str) -> None:
-    if self._host is not None and bool(self._host):
-      self._dev.zero_()
-      self._host.zero_()
+    out = ctypes.c_int32(0)
+    _lib.check(self._lib.tfrs_index_nonfinite(self._handle, 2, ctypes.byref(out)))
+    if out.value & 2:
       raise ValueError(f"{what}: the queries or the best scores of an earlier call contained NaN or Inf; queries and "
                        "candidate blocks must be finite (include/tfrs_hip.h).")
 
@@ -1084,7 +1091,8 @@ class Streaming(TopK):
         all_ids = np.concatenate([i.cpu().numpy() if isinstance(i, torch.Tensor) else i for i in ids], axis=0)
     self._last_ids = _Identifiers(all_ids, counter - self._base_row)
     if state_len > 0 and nq > 0:
-      self._finite.note(q, state_scores[:, :1])
+      # (the carried state with the queries in one launch; a state shorter than k -- fewer candidates than k -- is copied first)
+      self._finite.note(q, state_scores[:, :state_len])
     return state_scores[:, :state_len], state_rows[:, :state_len]
 
   def _group_bytes(self, device) -> int:

@@ -16,7 +16,14 @@ scatter-add + Adagrad kernel (``tfrs_embedding_scatter_add_bwd`` with ``adagrad=
 Dense parameters (Cross kernels, MLPs) take the same formula element-wise.
 
 The reference's tests do not pin Adagrad numerics ("parity unpinned"); the
-formula above is the tf-keras one; the test oracle restates the same formula.
+formula above is the one of ``tf.keras.optimizers.Adagrad`` since TF 2.11 and of tf-keras
+(``variable.assign_sub(lr * grad / sqrt(accumulator + epsilon))``); the test oracle restates the same
+formula.  TF <= 2.10 (the reference's release script pins TF 2.9.0, ``tools/build_scripts/release.sh:6``)
+runs the optimizer_v2 kernel ``ResourceApplyAdagradV2``, which divides by ``sqrt(acc) + epsilon``:
+``Adagrad(..., legacy=True)`` selects that form -- it is also ``torch.optim.Adagrad``'s, which
+``tests/test_ops_gpu.py`` cross-checks it against as an independent implementation;
+``tools/tf_reference_vectors.py`` writes the TensorFlow-side vectors of both forms for a maintainer with
+TensorFlow installed (``tests/test_tf_vectors.py`` consumes them when present).
 """
 
 from typing import Iterable
@@ -31,12 +38,12 @@ class Adagrad(torch.optim.Optimizer):
   """``tf.keras.optimizers.Adagrad(learning_rate, initial_accumulator_value, epsilon)``."""
 
   def __init__(self, params: Iterable, learning_rate: float = 0.001,
-               initial_accumulator_value: float = 0.1, epsilon: float = 1e-7):
+               initial_accumulator_value: float = 0.1, epsilon: float = 1e-7, legacy: bool = False):
     if initial_accumulator_value < 0.0:
       raise ValueError("initial_accumulator_value must be non-negative")
     defaults = dict(learning_rate=float(learning_rate),
                     initial_accumulator_value=float(initial_accumulator_value),
-                    epsilon=float(epsilon))
+                    epsilon=float(epsilon), legacy=bool(legacy))
     super().__init__(params, defaults)
     for group in self.param_groups:
       for p in group["params"]:
@@ -109,7 +116,7 @@ class Adagrad(torch.optim.Optimizer):
       with torch.enable_grad():
         loss = closure()
     for group in self.param_groups:
-      lr, eps = group["learning_rate"], group["epsilon"]
+      lr, eps, legacy = group["learning_rate"], group["epsilon"], group.get("legacy", False)
       sparse = []     # (table, accumulator, grad rows, ids) of every looked-up table of the group
       touched = []
       for p in group["params"]:
@@ -125,7 +132,7 @@ class Adagrad(torch.optim.Optimizer):
           touched.append(p)
           slices.clear()
       if sparse:
-        emb.adagrad_sparse_update_multi_(sparse, lr, eps)   # small tables: one launch for all
+        emb.adagrad_sparse_update_multi_(sparse, lr, eps, legacy)   # small tables: one launch for all
         # the kernels wrote through raw pointers: bump the version counters so that anything
         # keyed on them (Streaming's packed-block cache over views of a table) sees the change
         for table in touched:
@@ -135,5 +142,5 @@ class Adagrad(torch.optim.Optimizer):
         if p.grad is not None:
           g = p.grad
           acc.addcmul_(g, g)
-          p.addcdiv_(g, torch.sqrt(acc + eps), value=-lr)
+          p.addcdiv_(g, torch.sqrt(acc) + eps if legacy else torch.sqrt(acc + eps), value=-lr)
     return loss

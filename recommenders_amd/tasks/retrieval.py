@@ -25,6 +25,7 @@ import numpy as np
 import torch
 
 from recommenders_amd import _lib
+from recommenders_amd import _streams
 from recommenders_amd.layers import loss as loss_layers
 from recommenders_amd.layers.feature_interaction.dcn import _DenseFn
 from recommenders_amd.metrics import factorized_top_k as tfrs_metrics
@@ -376,6 +377,9 @@ class Retrieval(torch.nn.Module, base.Task):
     if sample_weight is not None:
       sample_weight = sample_weight.to(q.device)
 
+    # (captured step: the metric branch below forks HERE, in front of the loss kernels -- _streams.mark)
+    fork_point = (_streams.mark(q.device) if compute_metrics and q.dim() == 2 and self._factorized_metrics else None)
+
     # the fused kernels hold an embedding row in registers: dims above 128 (outside their
     # envelope; the reference accepts any dim) take the explicit-logits path below
     wide = q.dim() == 2 and q.shape[-1] > 128
@@ -419,7 +423,8 @@ class Retrieval(torch.nn.Module, base.Task):
       metric.update_state(loss.detach())
 
     if compute_metrics and q.dim() == 2:                                # :216-226
-      with torch.no_grad():
+      # (a parallel branch of a captured step: the update needs the embeddings only, not the loss -- _streams.py)
+      with torch.no_grad(), _streams.forked(q.device, after=fork_point):
         for metric in self._factorized_metrics:
           metric.update_state(q.detach(), c.detach()[:q.shape[0]],
                               true_candidate_ids=candidate_ids, sample_weight=sample_weight)
