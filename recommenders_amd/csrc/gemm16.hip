@@ -198,13 +198,18 @@ __global__ void __launch_bounds__(256) g16_prep_rows_ksm_kernel(const float *__r
 // again for the conversion, and at 55 KB per wave the second read comes from HBM (0.51 ms for a
 // 65536 x 3456 activation, 0.88 with the fused multiplier; both operands twice).  The row maxima meet in
 // LDS.  Same scale, same conversion, same image as the two-pass kernel, bit for bit.
-template <int STEPS, bool MUL>
-__global__ void __launch_bounds__(256) g16_prep_rows_ksm1_kernel(const float *__restrict__ x,
+// V2 (round 6): rows that are only 8-byte aligned (k % 4 == 2: the DLRM top MLP reads a [batch, 5082] matrix -- 5050
+// interaction pairs + 32 bottom-stack outputs) load 8 bytes per instruction instead of 16 and take the row's last, partial
+// chunk from the clamped load; they used to fall back to the two-pass kernel: 2.08 ms for 131072 x 5082 (1.9 TB/s).
+// NW = waves per workgroup (= per group of four rows): 8 for the long unaligned rows -- sixteen steps of 8-byte loads per
+// lane on four waves ran at 2.4 TB/s (177 registers: two waves per SIMD), eight steps on eight waves fit twice the waves.
+template <int STEPS, bool MUL, bool V2 = false, int NW = 4>
+__global__ void __launch_bounds__(NW * 64) g16_prep_rows_ksm1_kernel(const float *__restrict__ x,
                                                                  const float *__restrict__ mul, int64_t m,
                                                                  int k, int kp, _Float16 *__restrict__ hi,
                                                                  _Float16 *__restrict__ lo,
                                                                  float *__restrict__ inv, int64_t rows_p) {
-  __shared__ float s_mx[4][4];
+  __shared__ float s_mx[NW][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // lane roles per step: 8 K blocks x 4 rows x 2 halves of a block (8 floats in, one 16-byte store per image out)
   const int part = lane & 1, rr = (lane >> 1) & 3, qi = lane >> 3;
@@ -213,7 +218,7 @@ __global__ void __launch_bounds__(256) g16_prep_rows_ksm1_kernel(const float *__
   const int64_t rowc = valid ? row : m - 1;     // (loads are unconditional: clamped, zeroed afterwards)
   const float *xr = x + rowc * (int64_t)k;
   const float *mr = MUL ? mul + rowc * (int64_t)k : nullptr;   // (launched only for k % 4 == 0 and 16-byte aligned operands)
-  const int nq = kp / 16, nq4 = (nq + 3) / 4;   // K blocks of a row, per wave
+  const int nq = kp / 16, nq4 = (nq + NW - 1) / NW;   // K blocks of a row, per wave
   const int q_base = wave * nq4;
   float v[STEPS][8];
   float mx = 0.0f;
@@ -225,11 +230,31 @@ __global__ void __launch_bounds__(256) g16_prep_rows_ksm1_kernel(const float *__
     for (int hf = 0; hf < 2; ++hf) {
       const int c = q * 16 + part * 8 + hf * 4;
       const int cl = c + 3 < k ? c : k - 4;   // clamped: every load is issued, nothing waits before the last one
-      f32x4 t = *reinterpret_cast<const f32x4 *>(xr + cl);
-      if (MUL) t = t * *reinterpret_cast<const f32x4 *>(mr + cl);
-      const bool ok = in && c + 3 < k;
+      f32x4 t;
+      if (V2) {
+        typedef float f32x2v __attribute__((ext_vector_type(2)));
+        f32x2v t0 = *reinterpret_cast<const f32x2v *>(xr + cl), t1 = *reinterpret_cast<const f32x2v *>(xr + cl + 2);
+        if (MUL) {
+          t0 = t0 * *reinterpret_cast<const f32x2v *>(mr + cl);
+          t1 = t1 * *reinterpret_cast<const f32x2v *>(mr + cl + 2);
+        }
+        t = f32x4{t0[0], t0[1], t1[0], t1[1]};
+      } else {
+        t = *reinterpret_cast<const f32x4 *>(xr + cl);
+        if (MUL) t = t * *reinterpret_cast<const f32x4 *>(mr + cl);
+      }
+      if (V2) {
+        // element c + u sits at t[u + sh]: sh = 0 except in the row's last chunk when k % 4 == 2 (sh = 2: its two valid
+        // elements are the upper half of the clamped load)
+        const bool part_chunk = c + 3 >= k;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[st][hf * 4 + u] = ok ? t[u] : 0.0f;
+        for (int u = 0; u < 4; ++u)
+          v[st][hf * 4 + u] = (in && c + u < k) ? (part_chunk ? (u < 2 ? t[u + 2] : 0.0f) : t[u]) : 0.0f;
+      } else {
+        const bool ok = in && c + 3 < k;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[st][hf * 4 + u] = ok ? t[u] : 0.0f;
+      }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) mx = fmaxf(mx, fabsf(v[st][u]));
@@ -242,6 +267,7 @@ __global__ void __launch_bounds__(256) g16_prep_rows_ksm1_kernel(const float *__
   if (part == 0 && qi == 0) s_mx[wave][rr] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(s_mx[0][rr], s_mx[1][rr]), fmaxf(s_mx[2][rr], s_mx[3][rr]));
+  if (NW == 8) mx = fmaxf(mx, fmaxf(fmaxf(s_mx[4][rr], s_mx[5][rr]), fmaxf(s_mx[6][rr], s_mx[7][rr])));
   float s, iv;
   g16_scale_of(mx, &s, &iv);
   if (wave == 0 && part == 0 && qi == 0 && row < rows_p) inv[row] = iv;
@@ -268,6 +294,20 @@ static void g16_launch_prep_rows_ksm(const float *x, const float *mul, int64_t m
   const dim3 grid1((unsigned)(rows_p / 4));
   const bool vec = (k % 4 == 0) && k >= 4 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                    (!mul || (reinterpret_cast<uintptr_t>(mul) & 15) == 0);
+  // 8-byte aligned rows (k % 4 == 2): the same single-pass kernel with 8-byte loads
+  const bool vec2 = !vec && (k % 4 == 2) && k >= 6 && ((reinterpret_cast<uintptr_t>(x) & 7) == 0) &&
+                    (!mul || (reinterpret_cast<uintptr_t>(mul) & 7) == 0);
+#define TFRS_KSM1V2(S, M) \
+  hipLaunchKernelGGL((g16_prep_rows_ksm1_kernel<S, M, true>), grid1, dim3(256), 0, s, x, mul, m, k, kp, hi, lo, inv, rows_p)
+  if (vec2 && steps <= 4) { if (mul) TFRS_KSM1V2(4, true); else TFRS_KSM1V2(4, false); return; }
+  if (vec2 && steps <= 16) {    // (eight waves per four rows: eight steps per lane)
+    if (mul)
+      hipLaunchKernelGGL((g16_prep_rows_ksm1_kernel<8, true, true, 8>), grid1, dim3(512), 0, s, x, mul, m, k, kp, hi, lo, inv, rows_p);
+    else
+      hipLaunchKernelGGL((g16_prep_rows_ksm1_kernel<8, false, true, 8>), grid1, dim3(512), 0, s, x, mul, m, k, kp, hi, lo, inv, rows_p);
+    return;
+  }
+#undef TFRS_KSM1V2
 #define TFRS_KSM1(S, M) \
   hipLaunchKernelGGL((g16_prep_rows_ksm1_kernel<S, M>), grid1, dim3(256), 0, s, x, mul, m, k, kp, hi, lo, inv, rows_p)
   if (vec && steps <= 2) { if (mul) TFRS_KSM1(2, true); else TFRS_KSM1(2, false); }
@@ -403,14 +443,24 @@ __global__ void __launch_bounds__(256) g16_prep_cols_kernel(const float *__restr
       for (int e = 0; e < 4; ++e) tile[rr + 16 * u][cc + e] = ok ? v[u][e] : 0.0f;
     }
   } else {
-    for (int e = tid; e < 64 * 64; e += 256) {
+    // rows that are not 16-byte aligned (n % 4 != 0: the [batch, 5082] input of the DLRM top MLP): one float per lane,
+    // a wave instruction = 256 contiguous bytes of a row; ALL sixteen loads of a thread are issued (clamped coordinates)
+    // before the first one is used -- with the load inside `if (in range)` in a runtime loop every one of them was a
+    // memory round trip of its own: 1.45 ms for the 131072 x 5082 activation (2.75 TB/s)
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = tid + 256 * u;
       const int r = e >> 6, cc = e & 63;
-      float v = 0.0f;
-      if (k0 + r < k && n0 + cc < n) {
-        const int64_t o = (int64_t)(k0 + r) * n + n0 + cc;
-        v = mul ? b[o] * mul[o] : b[o];
-      }
-      tile[r][cc] = v;
+      const int rc = k0 + r < k ? k0 + r : k - 1, ccl = n0 + cc < n ? n0 + cc : n - 1;
+      const int64_t o = (int64_t)rc * n + ccl;
+      v[u] = mul ? b[o] * mul[o] : b[o];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = tid + 256 * u;
+      const int r = e >> 6, cc = e & 63;
+      tile[r][cc] = (k0 + r < k && n0 + cc < n) ? v[u] : 0.0f;
     }
   }
   __syncthreads();
@@ -996,15 +1046,20 @@ struct G16Layout {
 // partial product, a second kernel sums the slices in fixed order.
 static int g16_splits(int64_t m, int n, int k) {
   const int64_t tiles = ((m + kB16M - 1) / kB16M) * ((n + kB16N - 1) / kB16N);
-  if (tiles >= 512 || tiles < 8 || k < 8192) return 1;
+  if (tiles >= 512 || k < 8192) return 1;
   const char *ev = option("TFRS_GEMM16_SPLITK");
   if (ev && *ev) return std::max(1, atoi(ev));
+  // slices of at least 2048 K rows; the number that fills whole rounds of the chip's 256 workgroup slots best -- or, for
+  // products of a handful of tiles (round 6: the 512 x 256 weight gradient of the bottom MLP at batch 131072 is TWO
+  // tiles; unsplit it ran on 8 workgroups of the 128 x 128 kernel for 4.2 ms of a 31 ms DLRM step), as much of one
+  // round as the K length allows
   int best = 1;
   double best_eff = 0.0;
-  for (int s = 2; s <= 16; ++s) {
+  const int smax = tiles < 8 ? 128 : 16;
+  for (int s = 2; s <= smax; ++s) {
     if (k / s < 2048) break;
     const double waves = (double)(tiles * s) / 256.0;
-    const double eff = waves / (double)(int64_t)(waves + 0.999999);
+    const double eff = waves <= 1.0 ? waves : waves / (double)(int64_t)(waves + 0.999999);
     if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
   }
   return best;

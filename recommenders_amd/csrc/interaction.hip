@@ -1905,7 +1905,8 @@ using namespace tfrs;
 // with K = batch: 4 workgroups for a 512 -> 1 layer, 11.5 ms at batch 131072 on a 256-CU chip.  The
 // K range is therefore cut into slices (grid.y) until tiles x slices covers the chip about four
 // times; slices write partial products, splitk_sum_kernel adds them in a fixed order.
-constexpr int kSplitMinK = 4096;          // rows of K per slice at least (whole kBK steps)
+constexpr int kSplitMinK = 1024;          // rows of K per slice at least (whole kBK steps; round 6: 4096 left the skinny weight gradients of a
+                                          // batch-131072 step -- 13 x 512, 256 x 32, 512 x 1 -- on 128 workgroups, 0.5-0.6 ms each)
 static int splitk_slices(int64_t m, int n, int64_t k) {
   const int64_t tiles = ((m + kBM - 1) / kBM) * ((n + kBN - 1) / kBN);
   if (tiles >= 256 || k < 2 * kSplitMinK) return 1;
