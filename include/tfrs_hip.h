@@ -391,6 +391,11 @@ int tfrs_embedding_scatter_add_rowscan_multi(int ntables, const float *const *gr
                                              const int64_t *vocab_h, float *const *tables_h,
                                              float *const *accum_h, float lr, float eps,
                                              int adagrad, void *stream);
+/* Dense Adagrad of up to 32 parameters in ONE launch (models/base.py:77-78 with tf.keras.optimizers.Adagrad on the dense
+ * variables -- Cross kernels, MLP kernels and biases): acc += g * g; p -= lr * g / denom, denom = sqrt(acc + eps) (mode 1)
+ * or sqrt(acc) + eps (mode 2), the same arithmetic as the fused sparse update above.  Host arrays of device pointers. */
+int tfrs_adagrad_dense_multi(int ntensors, float *const *params_h, float *const *accum_h, const float *const *grads_h,
+                             const int64_t *n_h, float lr, float eps, int mode, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * tf.keras.layers.Hashing(num_bins, salt=[s0, s1]) as UnifiedEmbedding applies it per
@@ -512,6 +517,15 @@ int tfrs_cross_bwd_f16_saved(const float *x0, const float *x, const float *u, co
                              float diag_scale, const float *dy, int64_t batch, int d, float *dx0,
                              float *dx, float *dkernel, float *dbias, void *workspace,
                              size_t workspace_bytes, void *stream);
+/* tfrs_cross_bwd_f16_saved inside a STACK of Cross layers on one x0 (layers/feature_interaction/dcn.py:47-56,
+ * "x1 = Cross()(x0, x0); x2 = Cross()(x0, x1)"): dx0 = dy * u + dx0_add, where dx0_add (NULL or [batch, d]) may be dx0
+ * itself -- x0's gradient accumulates in place from layer to layer instead of through batch x d additions of the host
+ * framework's autograd; add_dx != 0 (the stack's first layer, whose x is x0) folds that layer's dx in as well:
+ * dx0 = dy * u + dx0_add + dx. */
+int tfrs_cross_bwd_f16_saved_acc(const float *x0, const float *x, const float *u, const float *kernel,
+                                 float diag_scale, const float *dy, int64_t batch, int d, const float *dx0_add,
+                                 int add_dx, float *dx0, float *dx, float *dkernel, float *dbias, void *workspace,
+                                 size_t workspace_bytes, void *stream);
 /* Low-rank form (dcn.py:131-148, multi_layer_dcn.py:147-153): a[batch, ka] = x @ U is
  * computed first (tfrs_dense_fwd); this call does  y = x0 * (a @ kernel[ka, d] + bias +
  * diag_scale * x) + x  with the same fused epilogue. */

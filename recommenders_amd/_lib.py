@@ -86,6 +86,7 @@ SIGNATURES = {
                                                     c_float, c_int, P, c_size_t, P]),
     "tfrs_embedding_scatter_add_rowscan_multi": (c_int, [c_int, P, P, P, P, P, P, P, P, c_float, c_float,
                                                          c_int, P]),
+    "tfrs_adagrad_dense_multi": (c_int, [c_int, P, P, P, P, c_float, c_float, c_int, P]),
     "tfrs_embedding_scatter_add_rowscan": (c_int, [P, P, c_int, c_i64, c_int, c_i64, P, P, c_float,
                                                    c_float, c_int, P]),
     "tfrs_inbatch_softmax_workspace_bytes": (c_size_t, [c_i64, c_i64, c_int]),
@@ -112,6 +113,8 @@ SIGNATURES = {
     "tfrs_cross_fwd_f16": (c_int, [P, P, P, P, c_float, c_i64, c_int, P, P, c_size_t, P]),
     "tfrs_cross_fwd_f16_train": (c_int, [P, P, P, P, c_float, c_i64, c_int, P, P, P, c_size_t, P]),
     "tfrs_cross_bwd_f16_saved": (c_int, [P, P, P, P, c_float, P, c_i64, c_int, P, P, P, P, P, c_size_t, P]),
+    "tfrs_cross_bwd_f16_saved_acc": (c_int, [P, P, P, P, c_float, P, c_i64, c_int, P, c_int, P, P, P, P, P, c_size_t,
+                                             P]),
     "tfrs_dot_interaction_fwd": (c_int, [P, c_i64, c_int, c_int, c_int, c_int, P, P]),
     "tfrs_dot_interaction_bwd": (c_int, [P, P, c_i64, c_int, c_int, c_int, c_int, P, P]),
     "tfrs_dot_interaction_fwd_strided": (c_int, [P, c_i64, c_int, c_int, c_int, P, c_i64, P]),

@@ -1244,35 +1244,52 @@ size_t gemm16_cross_bwd_workspace_bytes(int64_t batch, int d) {
   return std::max(g16_layout(batch, d, d).total, g16_layout(d, d, (int)batch).total);
 }
 
+// out = a * b (+ c) (+ e): the addends are optional.  c may alias out (accumulation in place: same index read and written
+// by the same thread).
 __global__ void __launch_bounds__(256) g16_mul_kernel(const float *__restrict__ a, const float *__restrict__ b,
-                                                      int64_t count, float *__restrict__ out) {
-  const bool vec = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) |
-                     reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+                                                      int64_t count, float *out, const float *c, const float *e) {
+  const bool vec = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out) |
+                     reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(e)) & 15) == 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (vec) {
     for (; i * 4 + 3 < count; i += stride) {
       const float4 x = reinterpret_cast<const float4 *>(a)[i], y = reinterpret_cast<const float4 *>(b)[i];
-      reinterpret_cast<float4 *>(out)[i] = make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
+      float4 r = make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
+      if (c) {
+        const float4 z = reinterpret_cast<const float4 *>(c)[i];
+        r.x += z.x; r.y += z.y; r.z += z.z; r.w += z.w;
+      }
+      if (e) {
+        const float4 z = reinterpret_cast<const float4 *>(e)[i];
+        r.x += z.x; r.y += z.y; r.z += z.z; r.w += z.w;
+      }
+      reinterpret_cast<float4 *>(out)[i] = r;
     }
     for (int64_t t = (count & ~(int64_t)3) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride)
-      out[t] = a[t] * b[t];
+      out[t] = a[t] * b[t] + (c ? c[t] : 0.0f) + (e ? e[t] : 0.0f);
   } else {
-    for (; i < count; i += stride) out[i] = a[i] * b[i];
+    for (; i < count; i += stride) out[i] = a[i] * b[i] + (c ? c[i] : 0.0f) + (e ? e[i] : 0.0f);
   }
 }
 
 // `u` (optional) = x W + b + diag x saved by the training forward (tfrs_cross_fwd_f16_train): the
 // first product is then replaced by the elementwise dx0 = dy * u.
+// dx0_add (with u only; may alias dx0): dx0 = dy * u + dx0_add -- a STACK of Cross layers on one x0 (dcn.py:47-56)
+// accumulates x0's gradient across its layers in place instead of leaving 906 MB additions to the autograd engine;
+// add_dx != 0 (first layer of such a stack, where x IS x0): dx0 = dy * u + dx0_add + dx, formed after the dx product.
 int gemm16_cross_bwd(const float *x0, const float *x, const float *kernel, const float *bias,
                      float diag, const float *dy, int64_t batch, int d, float *dx0, float *dx,
-                     float *dkernel, float *dbias, void *ws, hipStream_t s, const float *u) {
+                     float *dkernel, float *dbias, void *ws, hipStream_t s, const float *u, const float *dx0_add,
+                     int add_dx) {
   int rc = TFRS_OK;
+  const int64_t count = batch * (int64_t)d;
+  const dim3 mgrid((unsigned)std::min<int64_t>((count / 4 + 255) / 256 + 1, 256 * 32));
   if (u) {
-    const int64_t count = batch * (int64_t)d;
-    hipLaunchKernelGGL(g16_mul_kernel, dim3((unsigned)std::min<int64_t>((count / 4 + 255) / 256 + 1, 256 * 32)),
-                       dim3(256), 0, s, dy, u, count, dx0);
-    TFRS_LAUNCH_CHECK();
+    if (!add_dx) {
+      hipLaunchKernelGGL(g16_mul_kernel, mgrid, dim3(256), 0, s, dy, u, count, dx0, dx0_add, (const float *)nullptr);
+      TFRS_LAUNCH_CHECK();
+    }
   } else {
     rc = gemm16_run_ex({x, nullptr, false}, {kernel, nullptr, false}, batch, d, d, bias,
                        kG16EpiCrossDx0, dy, x, diag, dx0, nullptr, ws, s);
@@ -1281,6 +1298,10 @@ int gemm16_cross_bwd(const float *x0, const float *x, const float *kernel, const
   rc = gemm16_run_ex({dy, x0, false}, {kernel, nullptr, true}, batch, d, d, nullptr, kG16EpiCrossDx, dy,
                      x0, diag, dx, nullptr, ws, s);
   if (rc != TFRS_OK) return rc;
+  if (u && add_dx) {
+    hipLaunchKernelGGL(g16_mul_kernel, mgrid, dim3(256), 0, s, dy, u, count, dx0, dx0_add, (const float *)dx);
+    TFRS_LAUNCH_CHECK();
+  }
   return gemm16_run_ex({x, nullptr, true}, {dy, x0, false}, d, d, (int)batch, nullptr, kG16EpiBias, nullptr,
                        nullptr, 0.0f, dkernel, dbias, ws, s);
 }

@@ -2118,7 +2118,8 @@ int gemm16_run_act(const float *a, const float *b, int64_t m, int n, int k, cons
                    hipStream_t s);
 int gemm16_cross_bwd(const float *x0, const float *x, const float *kernel, const float *bias,
                      float diag, const float *dy, int64_t batch, int d, float *dx0, float *dx,
-                     float *dkernel, float *dbias, void *ws, hipStream_t s, const float *u = nullptr);
+                     float *dkernel, float *dbias, void *ws, hipStream_t s, const float *u = nullptr,
+                     const float *dx0_add = nullptr, int add_dx = 0);
 
 // db[j] = sum_b dy[b, j] * x0[b, j]: partial sums over slabs of 256 rows (one workgroup per
 // 64 columns x slab, coalesced rows), then a fixed-order reduction: deterministic, no atomics.
@@ -2390,6 +2391,27 @@ extern "C" int tfrs_cross_bwd_f16_saved(const float *x0, const float *x, const f
   }
   return gemm16_cross_bwd(x0, x, kernel, nullptr, diag_scale, dy, batch, d, dx0, dx, dkernel, dbias,
                           workspace, (hipStream_t)stream, u);
+}
+
+// The same inside a STACK of Cross layers that share x0 (dcn.py:47-56): dx0 = dy * u + dx0_add (dx0_add may be dx0
+// itself: x0's gradient accumulates in place across the layers), and for the stack's first layer -- whose x IS x0 --
+// add_dx != 0 also folds that layer's dx in: dx0 = dy * u + dx0_add + dx.  dx0_add may be NULL.
+extern "C" int tfrs_cross_bwd_f16_saved_acc(const float *x0, const float *x, const float *u, const float *kernel,
+                                            float diag_scale, const float *dy, int64_t batch, int d,
+                                            const float *dx0_add, int add_dx, float *dx0, float *dx, float *dkernel,
+                                            float *dbias, void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = cross_bwd_check("cross_bwd_f16_saved_acc", x0, x, kernel, diag_scale, dy, batch, d, dx0, dx, dkernel,
+                           workspace);
+  if (rc != TFRS_OK || batch == 0) return rc;
+  TFRS_CHECK_ARG(u, "cross_bwd_f16_saved_acc: NULL pointer");
+  TFRS_CHECK_ARG(batch <= 0x7FFFFFFFll, "cross_bwd_f16_saved_acc: batch too large");
+  TFRS_CHECK_ARG(dx != dx0 && dx0_add != dx, "cross_bwd_f16_saved_acc: dx must not alias dx0 / dx0_add");
+  if (workspace_bytes < gemm16_cross_bwd_workspace_bytes(batch, d)) {
+    set_error("cross_bwd_f16_saved_acc: workspace too small");
+    return TFRS_ENOMEM;
+  }
+  return gemm16_cross_bwd(x0, x, kernel, nullptr, diag_scale, dy, batch, d, dx0, dx, dkernel, dbias,
+                          workspace, (hipStream_t)stream, u, dx0_add, add_dx);
 }
 
 extern "C" int tfrs_dot_interaction_fwd(const float *x, int64_t batch, int f, int d,

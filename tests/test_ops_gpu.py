@@ -600,6 +600,48 @@ def test_cross_random_fwd_bwd(b, d, p, gemm_mode):
       float_gate(f"cross_{gemm_mode}.{what}", _np(got), want, yard, GATE_CROSS["grad"])
 
 
+@pytest.mark.parametrize("b,d,n_layers,bias", [(1024, 256, 3, True), (700, 130, 2, False), (512, 384, 4, True)])
+def test_cross_stack_one_autograd_node_equals_the_layer_loop(b, d, n_layers, bias, monkeypatch):
+  """``dcn.cross_stack`` (round 6: a stack of full-rank Cross layers on one x0 as ONE autograd node that accumulates x0's
+  gradient in place, ``tfrs_cross_bwd_f16_saved_acc``) against the layer loop it replaces (reference dcn.py:47-56): the
+  same kernels run layer by layer, so the output and the weight gradients are EQUAL; x0's gradient is the same sum in
+  another order (in-kernel accumulation instead of autograd's additions) and is held to 4 ulp of its largest term."""
+  from recommenders_amd.layers.feature_interaction import Cross, dcn
+  monkeypatch.setenv("TFRS_GEMM_MODE", "f16")
+  rng = np.random.default_rng(b + d)
+  x0 = rng.normal(size=(b, d)).astype(np.float32)
+  dy = rng.normal(size=(b, d)).astype(np.float32)
+  layers = [Cross(diag_scale=0.1 * l, use_bias=bias, bias_initializer="ones") for l in range(n_layers)]
+  for layer in layers:
+    layer.build((b, d), torch.device("cuda"))
+  def run(fused):
+    for layer in layers:
+      layer.zero_grad(set_to_none=True)
+    t0 = _t(x0).requires_grad_(True)
+    if fused:
+      y = dcn.cross_stack(t0, layers)
+      assert y is not None
+    else:
+      y = t0
+      for layer in layers:
+        y = layer(t0, y)
+    y.backward(_t(dy))
+    grads = [_np(layer.kernel.grad) for layer in layers] + ([_np(layer.bias.grad) for layer in layers] if bias else [])
+    return _np(y), _np(t0.grad), grads
+  y_a, g_a, w_a = run(False)
+  y_b, g_b, w_b = run(True)
+  assert np.array_equal(y_a, y_b)
+  for ga, gb in zip(w_a, w_b):
+    assert np.array_equal(ga, gb)
+  # x0's gradient: n_layers + 1 terms added in a different order
+  assert np.max(np.abs(g_a - g_b)) <= 4 * np.finfo(np.float32).eps * max(1.0, float(np.abs(g_a).max())) * (n_layers + 1)
+  # not taken without gradients, for a single layer, or for layers it does not cover
+  with torch.no_grad():
+    assert dcn.cross_stack(_t(x0), layers) is None
+  assert dcn.cross_stack(_t(x0).requires_grad_(True), layers[:1]) is None
+  assert dcn.cross_stack(_t(x0).requires_grad_(True), layers + [Cross(projection_dim=8)]) is None
+
+
 @pytest.mark.parametrize("act", ["relu", "sigmoid", "tanh", "swish", "gelu"])
 @pytest.mark.parametrize("p", [None, 24])
 def test_cross_named_preactivation_is_fused_and_matches_float64(act, p, gemm_mode):
