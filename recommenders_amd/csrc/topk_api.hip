@@ -1125,12 +1125,15 @@ constexpr int64_t kStreamFirstRange = 262144;   // rows of the first fp16 range 
 // Query batches up to this size take the block-fed fp16 filter (rawscan16_kernel: one pass over the f32
 // blocks, <= 256 queries per workgroup); 0 sends them to the exact f32-MFMA scan (<= TFRS_STREAM_RAW_MAX_NQ
 // queries) or the fp16 image (above)
-static int64_t stream_raw16_max_nq() { return std::max<int64_t>(0, env_i64("TFRS_STREAM_RAW16_MAX_NQ", 640)); }
+static int64_t stream_raw16_max_nq() { return std::max<int64_t>(0, env_i64("TFRS_STREAM_RAW16_MAX_NQ", 1024)); }
 // (round 5: beyond one wave's registers -- 128 queries at dim 128, 256 below -- the waves of an 8-wave workgroup split
 // the queries, 512 per workgroup, and the stage is converted once per workgroup through LDS: rawscan16w_kernel.  Dims
 // below 32 keep the 256-query limit.  Measured on 12.5 M x 128 (profiles/r05_streaming_wide.txt): 257 queries 2.62 ms
 // against 3.30 through the group's fp16 image, 512: 2.9-3.1 against 3.7; from ~800 queries on the image wins again
-// (1024: 5.2-5.6 against 5.0) -- the kernel's scoring phase runs at a third of the matrix pipe's rate.)
+// (1024: 5.2-5.6 against 5.0) -- the kernel's scoring phase runs at a third of the matrix pipe's rate.
+// Round 6: rawscan16pc_kernel (producer / consumer waves) takes 15-20 % off these -- 512 queries 2.46-2.51 ms -- and wins
+// up to two full query tiles: 768 / 1024 queries 4.50 / 4.46 ms against 4.74 / 4.97 through the image, 1536: 8.6 against 7.8;
+// the limit moved from 640 to 1024.)
 static int64_t raw16_max_nq(int d) { return d >= 32 ? stream_raw16_max_nq() : std::min<int64_t>(stream_raw16_max_nq(), 256); }
 // ... and, up to dim 64, from this size on: with one group of 32 queries the exact scan is copy-bound as well
 // there and needs half the launches per range (12.5 M x 64, one query: 0.89 against 1.00 ms); at dim 128 its

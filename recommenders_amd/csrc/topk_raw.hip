@@ -918,6 +918,310 @@ __global__ void __launch_bounds__(kRawWWaves * 64) rawscan16w_kernel(const RawSc
     atomicMax(reinterpret_cast<uint32_t *>(a.norm_max), __float_as_uint(norm_run));   // >= 0
 }
 
+// ---- the wide filter, producer / consumer form (round 6) ---------------------------------------------------------------
+// rawscan16w_kernel above converts, meets its barrier and scores in lock step: all eight waves do the same thing at the
+// same time, the matrix pipe idles while the stage is converted and the vector units idle while it is scored (waves
+// parked 48 % of their cycles; two such workgroups per CU were measured and are slower: every stage converted twice).
+// Here the ROLES are split inside one workgroup, the structure of dot_interaction_fwd_pc_kernel:
+//   waves 4-7  producers: wave p loads rows [32 p, 32 p + 32) of a 128-row stage into registers TWO stages ahead (two
+//              register sets: 2 x 64 KiB per CU in flight), converts them to fp16 with one power-of-two scale and one
+//              norm bound per 16-row group (the same contract and LDS layout as above) and writes tile (st + 1) & 1;
+//   waves 0-3  consumers: each keeps FOUR groups of 32 queries resident (512 queries per workgroup as before) and scores
+//              all 128 rows of tile st & 1: 4 sub-tiles x 4 groups x DP / 16 MFMAs = the same 4096 matrix-core cycles per
+//              stage and SIMD, now issued by ONE wave per SIMD while the producer wave of that SIMD converts.
+// One barrier per stage for all eight waves.  Same survivors, same lists, same counters as the lock-step kernel.
+
+// CW consumer waves of 16 / CW query groups each + four producer waves.  Shipped: <8> = 12 waves, three per SIMD -- two
+// consumers that alternate between their MFMA chains and their checks, as the lock-step kernel's waves do while scoring,
+// and one producer converting beside them.  Measured (12.5 M x 128, whole call, same box): 257 / 384 / 512 / 640 queries
+// 2.52 / 2.75 / 2.98 / 4.95 ms lock-step -> 2.01-2.04 / 2.27-2.30 / 2.46-2.51 / 4.24; 25 M x 64: 3.05 / 3.38 -> 2.47 / 2.99.
+// <4> (8 waves, ONE consumer wave per SIMD with four groups) was built first and is no faster than lock-step (3.10 ms at
+// 512 queries): a single wave per SIMD leaves the matrix pipe idle while it reduces its own tiles.
+template <int DP, int CW>
+struct RawPcGeom {
+  static constexpr int kQG = 16 / CW;                         // query groups of 32 per consumer wave
+  static constexpr int kThreads = (CW + 4) * 64;
+  static constexpr int kRowB = DP * 4;
+  static constexpr int kPieces = 32 * kRowB / 16 / 64;        // 16-byte pieces per producer lane and stage (32 rows)
+  static constexpr int kRow16B = DP * 2 + 16;
+  static constexpr int kTile16B = kTileN * kRow16B;
+  static constexpr int kMetaOff = 2 * kTile16B;               // [2][8] x float4 {1 / scale, scale, norm, -}
+  static constexpr int kCntOff = kMetaOff + 2 * 8 * 16;
+  static constexpr int kQcOff = kCntOff + kRawWQueries * 4;   // per (consumer wave, group, lane): {(bound - tiny) / qscale, qk / qscale, qscale, -}
+  static constexpr int kLdsBytes = kQcOff + CW * kQG * 64 * 16;
+};
+
+template <int DP, int CW>
+__global__ void __launch_bounds__((CW + 4) * 64) rawscan16pc_kernel(const RawScanArgs a) {
+  using G = RawPcGeom<DP, CW>;
+  constexpr int kRawPcQG = G::kQG;
+  constexpr int KS = DP / 16;           // MFMA steps of 16 features
+  constexpr int PPR = DP / 4;           // 16-byte pieces per f32 row
+  constexpr int NP = G::kPieces;
+  constexpr int RPI = 64 / PPR;         // rows covered by one load instruction of a wave (2 / 4 / 8 at dim 128 / 64 / 32)
+  static_assert(DP >= 32 && NP * RPI == 32 && 16 % RPI == 0, "a producer wave's 32 rows are whole instructions, groups of 16 rows too");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t *wg_cnt = reinterpret_cast<uint32_t *>(smem + G::kCntOff);
+  float4 *meta = reinterpret_cast<float4 *>(smem + G::kMetaOff);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31;
+  const int h = lane >> 5;
+  if (a.zero_word && blockIdx.x == 0 && tid == 0) *a.zero_word = 0u;
+  if (a.zero_aux && blockIdx.x == 0 && tid < 4) a.zero_aux[tid] = 0u;
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int xcd = bid & 7, pos = bid >> 3;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + pos;
+  const int split = logical / a.n_qtiles;
+  const int qt = logical - split * a.n_qtiles;
+
+  const int64_t c0 = a.c_begin + (int64_t)split * a.split_len;
+  int64_t c1 = c0 + a.split_len;
+  if (c1 > a.c_end) c1 = a.c_end;
+  const int nstages = c0 < c1 ? (int)((c1 - c0 + kTileN - 1) / kTileN) : 0;
+  if (tid < kRawWQueries) wg_cnt[tid] = 0u;   // one counter per query of the workgroup
+  const uint32_t rows_here = (uint32_t)(c1 > c0 ? c1 - c0 : 0);   // rows of this split (a split holds < 2^31 rows)
+  const uint32_t row0 = (uint32_t)c0;                              // (group-local row numbers fit 32 bits)
+
+  if (wave >= CW) {
+    // ------------------------------------------------ producers ------------------------------------------------
+    const int pw = wave - CW;
+    const RawTable *T = a.table;
+    const int nblk = T->n_blocks;
+    int blk = nstages > 0 ? __builtin_amdgcn_readfirstlane(raw_find_block(T, c0)) : 0;
+    int64_t blk_lo = T->row_start[blk], blk_hi = T->row_start[blk + 1];
+    const char *blk_ptr = reinterpret_cast<const char *>(T->ptr[blk]);
+    auto load_stage = [&](int st, f32x4 (&dst)[NP]) __attribute__((always_inline)) {
+      const int64_t v0 = c0 + (int64_t)st * kTileN;
+      while (v0 >= blk_hi && blk + 1 < nblk) {
+        ++blk;
+        blk_lo = blk_hi;
+        blk_hi = T->row_start[blk + 1];
+        blk_ptr = reinterpret_cast<const char *>(T->ptr[blk]);
+      }
+      if (v0 + kTileN <= blk_hi && v0 + kTileN <= c1) {   // the whole stage lies in one block: linear loads
+        const char *src = blk_ptr + ((v0 - blk_lo) + 32 * pw) * (int64_t)G::kRowB + lane * 16;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) dst[i] = *reinterpret_cast<const f32x4 *>(src + i * 1024);
+        return;
+      }
+      // block boundary or the last, partly filled stage: every lane looks its row up; rows at or beyond c1
+      // re-read the last valid row (their scores are never used)
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int piece = i * 64 + lane;
+        int64_t row = v0 + 32 * pw + piece / PPR;
+        if (row > c1 - 1) row = c1 - 1;
+        dst[i] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(raw_row_ptr(T, row, DP)) +
+                                                  (piece % PPR) * 16);
+        asm volatile("" ::: "memory");   // one address at a time (sixteen 64-bit addresses next to two stages of rows spilled)
+      }
+    };
+    float norm_run = 0.0f;
+    // the wave's 32 rows (registers) -> fp16 tile `buf`; the constants of its two 16-row groups -> meta[buf][2 pw + {0, 1}]
+    auto convert = [&](const f32x4 (&av)[NP], int buf) __attribute__((always_inline)) {
+      float am[2] = {0.0f, 0.0f}, nmax[2] = {0.0f, 0.0f};
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        constexpr int kHalf = NP / 2;        // pieces i < NP / 2 are rows 0 .. 15 of the wave, the rest rows 16 .. 31
+        const int gi = i >= kHalf ? 1 : 0;
+        float ss = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          ss = __builtin_fmaf(av[i][c], av[i][c], ss);
+          am[gi] = fmaxf(am[gi], __builtin_fabsf(av[i][c]));
+        }
+#pragma unroll
+        for (int off = 1; off < PPR && off < 64; off <<= 1) ss += __shfl_xor(ss, off);   // PPR consecutive lanes = one row
+        nmax[gi] = fmaxf(nmax[gi], ss);
+      }
+      float inv[2];
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          nmax[gi] = fmaxf(nmax[gi], __shfl_xor(nmax[gi], off));
+          am[gi] = fmaxf(am[gi], __shfl_xor(am[gi], off));
+        }
+        const float nrm = __builtin_sqrtf(nmax[gi]) * kNormSlack;   // (upper bound of the 16 row norms)
+        const float cs = pow2_ceil(am[gi]);
+        inv[gi] = 1.0f / cs;                                        // exact: power of two
+        norm_run = fmaxf(norm_run, nrm);
+        if (lane == 0) meta[buf * 8 + 2 * pw + gi] = make_float4(inv[gi], cs, nrm, 0.0f);
+      }
+      char *t16 = smem + buf * G::kTile16B;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int piece = i * 64 + lane;
+        const int row = 32 * pw + piece / PPR, col = piece % PPR;
+        const float sc = inv[i >= NP / 2 ? 1 : 0];
+        uint2 w;
+        w.x = raw_pack_f16x2(av[i][0] * sc, av[i][1] * sc);
+        w.y = raw_pack_f16x2(av[i][2] * sc, av[i][3] * sc);
+        *reinterpret_cast<uint2 *>(t16 + row * G::kRow16B + col * 8) = w;
+      }
+    };
+    // two register sets (stages of even / odd index, each loaded TWO stages ahead) where 2 x NP x 4 registers fit; with
+    // three waves per SIMD at dim 128 (170 registers a wave) ONE set, loaded one stage ahead -- 64 KiB per CU in flight,
+    // what the lock-step kernel has
+    constexpr bool kTwoSets = !(CW == 8 && DP >= 128);
+    f32x4 ra[NP], rb[kTwoSets ? NP : 1];
+    if constexpr (kTwoSets) {
+      if (nstages > 0) load_stage(0, ra);
+      if (nstages > 1) load_stage(1, rb);
+      if (nstages > 0) convert(ra, 0);
+      if (nstages > 2) load_stage(2, ra);
+      __syncthreads();                    // fp16 tile 0 complete (and the counters zeroed)
+      for (int st = 0; st < nstages; st += 2) {
+        // consumers score stage st (tile 0) now: stage st + 1 -> tile 1
+        if (st + 1 < nstages) convert(rb, 1);
+        if (st + 3 < nstages) load_stage(st + 3, rb);
+        raw_lds_barrier();
+        if (st + 1 >= nstages) break;
+        // consumers score stage st + 1 (tile 1): stage st + 2 -> tile 0
+        if (st + 2 < nstages) convert(ra, 0);
+        if (st + 4 < nstages) load_stage(st + 4, ra);
+        raw_lds_barrier();
+      }
+    } else {
+      if (nstages > 0) load_stage(0, ra);
+      if (nstages > 0) convert(ra, 0);
+      if (nstages > 1) load_stage(1, ra);
+      __syncthreads();
+      for (int st = 0; st < nstages; ++st) {
+        if (st + 1 < nstages) convert(ra, (st + 1) & 1);
+        if (st + 2 < nstages) load_stage(st + 2, ra);
+        raw_lds_barrier();
+      }
+    }
+    if (nstages > 0 && lane == 0 && a.norm_max)
+      atomicMax(reinterpret_cast<uint32_t *>(a.norm_max), __float_as_uint(norm_run));   // >= 0
+  } else {
+    // ------------------------------------------------ consumers ------------------------------------------------
+    f16x8r bq[kRawPcQG][KS];
+    // the filter constants of a (group, lane) are parked in LDS and re-read once per sub-tile: twelve resident registers
+    // next to four query groups and four accumulators spilled at dim 128
+    float4 *const qconst = reinterpret_cast<float4 *>(smem + G::kQcOff) + wave * (kRawPcQG * 64);
+    const uint32_t qrow0 = (uint32_t)qt * kRawWQueries + (uint32_t)(wave * kRawPcQG) * 32u + (uint32_t)j;
+#pragma unroll
+    for (int g = 0; g < kRawPcQG; ++g) {
+      const int64_t qrow_g = (int64_t)qrow0 + 32 * g;
+      const bool qvalid = qrow_g < a.nq;
+      const int64_t qr = qvalid ? qrow_g : 0;
+      const float qs = qvalid ? a.qscale[qr] : 1.0f;
+      const float qinv = 1.0f / qs;   // exact: power of two
+      const f32x4 *q4 = reinterpret_cast<const f32x4 *>(a.q + qr * DP);
+#pragma unroll
+      for (int m = 0; m < KS; ++m) {
+        const f32x4 lo = q4[4 * m + 2 * h], hi = q4[4 * m + 2 * h + 1];   // features 16 m + 8 h .. + 7
+        u32x4r w;
+        w[0] = raw_pack_f16x2(qvalid ? lo[0] * qinv : 0.0f, qvalid ? lo[1] * qinv : 0.0f);
+        w[1] = raw_pack_f16x2(qvalid ? lo[2] * qinv : 0.0f, qvalid ? lo[3] * qinv : 0.0f);
+        w[2] = raw_pack_f16x2(qvalid ? hi[0] * qinv : 0.0f, qvalid ? hi[1] * qinv : 0.0f);
+        w[3] = raw_pack_f16x2(qvalid ? hi[2] * qinv : 0.0f, qvalid ? hi[3] * qinv : 0.0f);
+        bq[g][m] = __builtin_bit_cast(f16x8r, w);
+        if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // eight loads at a time
+      }
+      qconst[g * 64 + lane] = make_float4(
+          qvalid ? (a.thr[qr * (a.thr_stride > 0 ? a.thr_stride : 1)] - kF16Tiny) * qinv : __builtin_inff(),
+          qvalid ? a.qk[qr] * qinv : 0.0f, qs, 0.0f);
+      __builtin_amdgcn_sched_barrier(0);   // one group's sixteen loads at a time (all 64 issued up front spilled 50 registers)
+    }
+    const bool wave_active = (int64_t)qt * kRawWQueries + wave * (kRawPcQG * 32) < a.nq;   // (uniform)
+    __syncthreads();                    // fp16 tile 0 complete (and the counters zeroed)
+    for (int st = 0; st < nstages; ++st) {
+      const int buf = st & 1;
+      const char *t16 = smem + buf * G::kTile16B;
+      if (wave_active) {
+        const char *ap = t16 + j * G::kRow16B + h * 16;
+        // A fragments in two halves of KS / 2 steps, each right in front of its MFMAs (measured against whole sets fetched
+        // a sub-tile ahead, the lock-step kernel's scheme: 2.46-2.51 ms against 2.79 at dim 128, equal at dim 64 -- the
+        // finer interleave of LDS reads and matrix instructions wins, and a whole set spilled 10 registers at dim 128)
+        constexpr int KH = KS >= 2 ? KS / 2 : KS;
+#pragma unroll
+        for (int sub = 0; sub < kTileN / 32; ++sub) {
+          const float4 mA = meta[buf * 8 + 2 * sub], mB = meta[buf * 8 + 2 * sub + 1];
+          f32x16 acc[kRawPcQG];
+#pragma unroll
+          for (int g = 0; g < kRawPcQG; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.0f;
+#pragma unroll
+          for (int hf = 0; hf < KS / KH; ++hf) {
+            u32x4r af[KH];
+#pragma unroll
+            for (int m = 0; m < KH; ++m)
+              af[m] = *reinterpret_cast<const u32x4r *>(ap + sub * 32 * G::kRow16B + (hf * KH + m) * 32);
+#pragma unroll
+            for (int m = 0; m < KH; ++m)
+#pragma unroll
+              for (int g = 0; g < kRawPcQG; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8r, af[m]), bq[g][hf * KH + m], acc[g], 0, 0, 0);
+          }
+#pragma unroll
+          for (int g = 0; g < kRawPcQG; ++g) {
+            // acc[g][r] = prefilter score of (query qrow[g], stage row 32 sub + (r & 3) + 8 (r >> 2) + 4 h) in units of
+            // qscale * (scale of the row's 16-row group): registers 0 .. 7 are rows of group 2 sub, 8 .. 15 of 2 sub + 1
+            const f32x16 &c = acc[g];
+            const float4 qc = qconst[g * 64 + lane];
+            const float thrA = __builtin_fmaf(-qc.y, mA.z, qc.x) * mA.x;
+            const float thrB = __builtin_fmaf(-qc.y, mB.z, qc.x) * mB.x;
+            const float xa = raw_max8f(c, 0), xb = raw_max8f(c, 8);
+            if (__ballot(xa > thrA || xb > thrB) != 0ull) {   // rare once the bound is warm
+              const uint32_t rel0 = (uint32_t)st * kTileN + 32u * sub + 4u * h;
+              uint2 *const seg = a.buf + (((int64_t)qrow0 + 32 * g) * (int64_t)a.cap_l) * a.nseg + split;
+              const float unA = qc.z * mA.y, unB = qc.z * mB.y;
+              uint32_t hits = 0u;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) hits |= c[r] > (r < 8 ? thrA : thrB) ? (1u << r) : 0u;
+              if ((uint32_t)(st + 1) * kTileN > rows_here) {   // (uniform) the split's last, partly filled stage
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                  if (rel0 + (r & 3) + 8 * (r >> 2) >= rows_here) hits &= ~(1u << r);
+              }
+              if (hits) {
+                uint32_t e = atomicAdd(&wg_cnt[(wave * kRawPcQG + g) * 32 + j], (uint32_t)__builtin_popcount(hits));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                  if (hits & (1u << r)) {
+                    if (e < a.cap_l)
+                      seg[(uint64_t)e * (uint32_t)a.nseg] =
+                          make_uint2(__float_as_uint(c[r] * (r < 8 ? unA : unB)), row0 + rel0 + (r & 3) + 8 * (r >> 2));
+                    ++e;
+                  }
+                }
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);   // one sub-tile at a time
+        }
+      }
+      raw_lds_barrier();
+    }
+  }
+
+  __syncthreads();
+  {   // every (query, split) count is written (counts beyond cap_l flag the query for the exact redo)
+    const int64_t qr = (int64_t)qt * kRawWQueries + tid;
+    if (tid < kRawWQueries && qr < a.nq) a.cnt[qr * a.nseg + split] = wg_cnt[tid];
+  }
+}
+
+template <int DP, int CW>
+static int launch_rawscan16pc(const RawScanArgs &a, hipStream_t stream) {
+  using G = RawPcGeom<DP, CW>;
+  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&rawscan16pc_kernel<DP, CW>), G::kLdsBytes));
+  const dim3 grid((unsigned)(a.n_qtiles * a.n_splits));
+  hipLaunchKernelGGL((rawscan16pc_kernel<DP, CW>), grid, dim3(G::kThreads), G::kLdsBytes, stream, a);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
 template <int DP>
 static int launch_rawscan16w(const RawScanArgs &a, hipStream_t stream) {
   using G = RawWGeom<DP>;
@@ -938,7 +1242,11 @@ static int launch_rawscan16_dp(const RawScanArgs &a, hipStream_t stream) {
       if constexpr (DP <= 64) return launch_rawscan16_variant<DP, 8>(a, stream);
       break;
     case 16:  // 512 queries per workgroup: the waves split the queries, one conversion per workgroup
-      if constexpr (DP >= 32) return launch_rawscan16w<DP>(a, stream);
+      if constexpr (DP >= 32) {
+        const char *wv = option("TFRS_STREAM_RAW16_WIDE");    // pc (producer / consumer waves, default) | lockstep
+        if (wv && wv[0] == 'l') return launch_rawscan16w<DP>(a, stream);
+        return launch_rawscan16pc<DP, 8>(a, stream);
+      }
       break;
   }
   set_error("rawscan16: %d query groups per workgroup (1, 2, 4; 8 up to dim 64)", a.qg);

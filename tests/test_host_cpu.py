@@ -163,8 +163,8 @@ def test_streaming_group_regimes_size_their_workspace(lib, monkeypatch):
   image = n * (128 * 2 + 16)                                  # fp16 image of the group at dim 128
   assert size(8192, 128) > image                              # large batches: the image regime
   assert size(128, 128) < image and size(256, 128) < image    # block-fed filter up to 256 queries ...
-  assert size(512, 128) < image and size(640, 128) < image    # ... and, from dim 32 on, up to 640 (rawscan16w_kernel)
-  assert size(641, 128) > image                               # the image beyond ...
+  assert size(512, 128) < image and size(1024, 128) < image   # ... and, from dim 32 on, up to 1024 (rawscan16pc_kernel)
+  assert size(1025, 128) > image                              # the image beyond ...
   assert size(512, 16) > n * (16 * 2 + 16) > size(256, 16)    # ... and below dim 32 beyond 256 queries
   try:
     _lib.set_option("TFRS_STREAM_RAW16_MAX_NQ", "0")          # off: 65+ queries go through the image
@@ -804,9 +804,11 @@ def test_the_mfma_hazard_check_finds_the_peeled_filter_kernel_without_hand_wait_
     # 16 registers live in the accumulator file: no scratch memory, which is what the stage prefetch cares about)
     ("topk_raw.hip", ("rawscan16_kernelILi128ELi1E", "rawscan16_kernelILi128ELi2E", "rawscan16_kernelILi128ELi4E",
                       "rawscan16_kernelILi64ELi8E", "rawscan16_kernelILi32ELi8E", "rawscan16_kernelILi8ELi8E"), 512, True),
-    # the wide block-fed filter (257-640 queries: one 8-wave workgroup per CU, two waves per SIMD): the stage of rows in
-    # flight, the two query groups' B operands and one A-fragment set fill the 256 registers of a lane -- no scratch
+    # the wide block-fed filter, lock-step form (round 5; kept for A/B runs: one 8-wave workgroup per CU, two waves per
+    # SIMD): the stage of rows in flight, the two query groups' B operands and one A-fragment set fill the 256 registers
     ("topk_raw.hip", ("rawscan16w_kernelILi128E", "rawscan16w_kernelILi64E", "rawscan16w_kernelILi32E"), 256, False),
+    # ... and its producer / consumer form (round 6, default for 257-1024 queries): 12 waves = three per SIMD, 168 registers
+    ("topk_raw.hip", ("rawscan16pc_kernelILi128ELi8E", "rawscan16pc_kernelILi64ELi8E", "rawscan16pc_kernelILi32ELi8E"), 168, False),
     # the fp16 image packer that keeps a stage's parity planes in registers
     ("topk_pack.hip", ("pack16_stage_regs_kernelILi128E", "pack16_stage_regs_kernelILi16E"), 128, False),
 ])

@@ -358,15 +358,19 @@ def test_streaming_block_fed_filter_awkward_data(seed, monkeypatch):
     assert torch.equal(i.to(torch.int64), ei.to(torch.int64)), (case, kind, d, k, nq, n)
 
 
+@pytest.mark.parametrize("form", ["pc", "lockstep"])
 @pytest.mark.parametrize("seed", [0, 1, 2])
-def test_streaming_wide_block_fed_filter(seed, monkeypatch):
-  """rawscan16w_kernel (257 .. 2048 queries over a lazily produced dataset, dims 32 .. 128: the waves of an 8-wave
-  workgroup split the queries, the stage is converted to fp16 once per workgroup with one scale and norm bound per 16
-  rows): bit for bit the all-f32 scan of the same rows on the data that stresses those scales and bounds, ragged
+def test_streaming_wide_block_fed_filter(seed, form, monkeypatch):
+  """rawscan16pc_kernel (round 6, default: eight consumer waves score while four producer waves load and convert the next
+  stage) and rawscan16w_kernel (round 5, `TFRS_STREAM_RAW16_WIDE=lockstep`) -- 257 .. 1024 queries over a lazily produced
+  dataset, dims 32 .. 128: the waves of a workgroup split the queries, the stage is converted to fp16 once per workgroup
+  with one scale and norm bound per 16 rows: bit for bit the all-f32 scan of the same rows on the data that stresses those scales and bounds, ragged
   blocks (stages that straddle block boundaries take the per-lane row lookup), a ragged last stage, several query
   tiles, queries that fill only part of the last tile, k = 1 .. 512, and the dims below 32 that stay on the image."""
   ftk = _layers()
   from recommenders_amd import _lib
+  monkeypatch.setenv("TFRS_STREAM_RAW16_WIDE", form)
+  monkeypatch.setenv("TFRS_STREAM_RAW16_MAX_NQ", "2048")     # (default 1024: the 1025- and 2048-query cases take the filter too)
   rng = np.random.default_rng(1700 + seed)
   dev = torch.device("cuda", 0)
   for case in range(6):
