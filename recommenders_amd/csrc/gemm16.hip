@@ -232,25 +232,23 @@ __global__ void __launch_bounds__(NW * 64) g16_prep_rows_ksm1_kernel(const float
       const int cl = c + 3 < k ? c : k - 4;   // clamped: every load is issued, nothing waits before the last one
       f32x4 t;
       if (V2) {
-        typedef float f32x2v __attribute__((ext_vector_type(2)));
-        f32x2v t0 = *reinterpret_cast<const f32x2v *>(xr + cl), t1 = *reinterpret_cast<const f32x2v *>(xr + cl + 2);
-        if (MUL) {
-          t0 = t0 * *reinterpret_cast<const f32x2v *>(mr + cl);
-          t1 = t1 * *reinterpret_cast<const f32x2v *>(mr + cl + 2);
-        }
-        t = f32x4{t0[0], t0[1], t1[0], t1[1]};
+        // (global loads need no natural alignment on gfx950: one 16-byte load from an 8-byte aligned address)
+        typedef float f32x4a8 __attribute__((ext_vector_type(4), aligned(8)));
+        t = *reinterpret_cast<const f32x4a8 *>(xr + cl);
+        if (MUL) t = t * *reinterpret_cast<const f32x4a8 *>(mr + cl);
+        // element c + u sits at t[u + 2] in the row's last chunk when k % 4 == 2 (its two valid elements are the upper
+        // half of the clamped load), at t[u] everywhere else.  Plain selects: a nested ternary here compiled to a branch
+        // per element with `s_waitcnt vmcnt(0)` behind every load -- one memory round trip per 16 bytes, 2.85 TB/s
+        const bool part_chunk = c + 3 >= k;
+        const float e0 = part_chunk ? t[2] : t[0], e1 = part_chunk ? t[3] : t[1];
+        const float e2 = part_chunk ? 0.0f : t[2], e3 = part_chunk ? 0.0f : t[3];
+        v[st][hf * 4 + 0] = (in && c + 0 < k) ? e0 : 0.0f;
+        v[st][hf * 4 + 1] = (in && c + 1 < k) ? e1 : 0.0f;
+        v[st][hf * 4 + 2] = (in && c + 2 < k) ? e2 : 0.0f;
+        v[st][hf * 4 + 3] = (in && c + 3 < k) ? e3 : 0.0f;
       } else {
         t = *reinterpret_cast<const f32x4 *>(xr + cl);
         if (MUL) t = t * *reinterpret_cast<const f32x4 *>(mr + cl);
-      }
-      if (V2) {
-        // element c + u sits at t[u + sh]: sh = 0 except in the row's last chunk when k % 4 == 2 (sh = 2: its two valid
-        // elements are the upper half of the clamped load)
-        const bool part_chunk = c + 3 >= k;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          v[st][hf * 4 + u] = (in && c + u < k) ? (part_chunk ? (u < 2 ? t[u + 2] : 0.0f) : t[u]) : 0.0f;
-      } else {
         const bool ok = in && c + 3 < k;
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[st][hf * 4 + u] = ok ? t[u] : 0.0f;

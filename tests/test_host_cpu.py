@@ -837,7 +837,10 @@ def test_hot_kernel_register_budgets(source, patterns, max_vgprs, agpr_spills_ok
     # the Cross epilogue issues the 24 loads of eight rows of an accumulator tile before it waits
     ("gemm16.hip", "gemm16_big_kernelILi1ELb0E", 16),
     # single-pass row images: a wave's share of four rows (14 + 14 16-byte loads) in flight
-    ("gemm16.hip", "g16_prep_rows_ksm1_kernelILi8ELb0E", 8),
+    ("gemm16.hip", "g16_prep_rows_ksm1_kernelILi8ELb0ELb0E", 8),
+    # ... and its form for 8-byte aligned rows (k % 4 == 2, eight waves per four rows): first built with a nested ternary per
+    # element that compiled to a branch + vmcnt(0) behind every load (2.85 TB/s); the selects keep 4-5 loads in flight
+    ("gemm16.hip", "g16_prep_rows_ksm1_kernelILi8ELb0ELb1ELi8E", 4),
 ])
 def test_pipelined_kernels_keep_loads_in_flight(source, pattern, min_in_flight):
   """gfx950 tracks a wave's outstanding loads with ONE in-order counter; a load inside a branch makes the

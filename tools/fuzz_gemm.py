@@ -13,7 +13,7 @@ def main(seed: int = 0, cases: int = 30) -> int:
     return float((a.double() - ref).abs().max()) / max(float(scale), 1e-30)
   for case in range(cases):
     m = int(rng.choice([1, 3, 100, 257, 4096, 20000, 65536, 70001]))
-    k = int(rng.choice([1, 7, 13, 64, 129, 500, 1024, 3000]))
+    k = int(rng.choice([1, 7, 13, 64, 129, 130, 500, 1002, 1024, 3000, 5082]))   # (k % 4 == 2: the 8-byte aligned row images)
     n = int(rng.choice([1, 5, 32, 127, 256, 1000, 2049]))
     if m * k * n > 3e11:
       m = 4096

@@ -12,7 +12,7 @@ def main(seed: int = 0, cases: int = 30) -> int:
   for case in range(cases):
     d = int(rng.choice([4, 16, 32, 64, 100, 128]))
     k = int(rng.choice([1, 5, 10, 100, 300]))
-    nq = int(rng.choice([1, 33, 512, 3000]))
+    nq = int(rng.choice([1, 33, 300, 512, 700, 1024, 3000]))
     nblocks = int(rng.integers(1, 12))
     sizes = [int(rng.choice([1, 17, 128, 1000, 4096, 65536, 70001])) for _ in range(nblocks)]
     if sum(sizes) < k:
