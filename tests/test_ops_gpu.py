@@ -1117,6 +1117,38 @@ def test_metric_results_are_fresh_tensors_and_graphed_steps_bump_versions():
   np.testing.assert_array_equal(_np(s), es)
 
 
+@pytest.mark.parametrize("legacy", [False, True])
+def test_adagrad_dense_parameters_one_launch_equals_the_torch_formula(legacy):
+  """``tfrs_adagrad_dense_multi`` (round 6: every dense parameter of a group in ONE launch) against the four torch kernels it
+  replaces -- acc += g * g; p -= lr * g / denom -- on tensors of awkward sizes (1, 7, a size that ends in the middle of a
+  16-byte piece and of a block, 4-byte aligned views that take the scalar path, 40 tensors: two launches), both forms of
+  the denominator; two steps so that the accumulator's carry-over is checked as well."""
+  import recommenders_amd as tfrs
+  rng = np.random.default_rng(77)
+  sizes = [1, 7, 4096 * 16 + 3, 130_001, 256 * 16, 3] + [int(rng.integers(1, 5000)) for _ in range(34)]
+  base = [torch.as_tensor(rng.normal(size=(n + 1,)).astype(np.float32)).cuda() for n in sizes]
+  # (every third parameter is a view that starts 4 bytes into its storage: not 16-byte aligned)
+  params = [torch.nn.Parameter(b[1:] if i % 3 == 2 else b[:-1].clone()) for i, b in enumerate(base)]
+  assert any(p.data_ptr() % 16 for p in params)
+  opt = tfrs.optimizers.Adagrad(params, learning_rate=0.3, initial_accumulator_value=0.1, epsilon=1e-7, legacy=legacy)
+  want = [p.detach().clone() for p in params]
+  acc = [torch.full_like(p, 0.1) for p in want]
+  for step in range(2):
+    grads = [torch.as_tensor(rng.normal(size=(n,)).astype(np.float32)).cuda() for n in sizes]
+    for p, g in zip(params, grads):
+      p.grad = g
+    opt.step()
+    for w, a, g in zip(want, acc, grads):
+      a.addcmul_(g, g)
+      w.addcdiv_(g, torch.sqrt(a) + 1e-7 if legacy else torch.sqrt(a + 1e-7), value=-0.3)
+    for p, w in zip(params, want):
+      # (same operations in the same order on the same floats: a division by the same denominator; 1 ulp for the
+      # kernel's fused multiply-subtract)
+      np.testing.assert_allclose(_np(p.detach()), _np(w), rtol=3e-7, atol=1e-7)
+  for i, p in enumerate(params):
+    np.testing.assert_allclose(_np(opt.state[p]["accumulator"]), _np(acc[i]), rtol=4e-7, atol=0)      # (fused multiply-add: 1 ulp per step)
+
+
 def test_adagrad_optimizer_sparse_slices_match_dense_formula():
   """optimizers.Adagrad: embedding tables are updated from (ids, rows) slices by the fused
   kernel (no dense gradient), dense parameters element-wise; both follow
