@@ -733,14 +733,22 @@ static inline size_t rec_bytes(int dp) {
   return dp == 32 ? Rec16<32>::kBytes : (dp == 64 ? Rec16<64>::kBytes : Rec16<128>::kBytes);
 }
 
-static void plan16(int64_t n_rows, int64_t n_stream, int *nsplit, int64_t *split_len) {
+static void plan16(int64_t n_rows, int64_t n_stream, int *nsplit, int64_t *split_len, bool backward = false) {
   const int64_t per_wg = nw_of(n_rows) * 32;
   const int64_t row_blocks = (n_rows + per_wg - 1) / per_wg;
   const int64_t tiles = (n_stream + 31) / 32;
-  static const int64_t target = [] {
+  static const int64_t target_fwd = [] {
     const char *v = option("TFRS_SOFTMAX_WGS");
     return (v && *v) ? (int64_t)atoll(v) : (int64_t)512;   // 2 workgroups per CU
   }();
+  // The backward's two sides share one launch, and LDS holds two of its workgroups per CU: 256 per side are ONE
+  // round of resident workgroups (512 per side ran as two rounds, each paying the ~3 us prologue -- first touch of the
+  // records, owned rows -- and wrote twice the partial gradients: 4096 x 4096 x 64, bwd + reduce 45.0 -> 41.9 us)
+  static const int64_t target_bwd = [] {
+    const char *v = option("TFRS_SOFTMAX_WGS_BWD");
+    return (v && *v) ? (int64_t)atoll(v) : (int64_t)256;
+  }();
+  const int64_t target = backward ? target_bwd : target_fwd;
   int64_t want = (target + row_blocks - 1) / row_blocks;
   if (want > tiles) want = tiles;
   if (want < 1) want = 1;
@@ -767,8 +775,8 @@ static Layout16 layout16(int64_t nq, int64_t nc, int d) {
   int nsf, nsq, nsc;
   int64_t len;
   plan16(nq, nc, &nsf, &len);
-  plan16(nq, nc, &nsq, &len);
-  plan16(nc, nq, &nsc, &len);
+  plan16(nq, nc, &nsq, &len, true);
+  plan16(nc, nq, &nsc, &len, true);
   const size_t fwd = 2 * al16((size_t)nsf * nq * 4) + al16((size_t)nq * 4) +
                      al16((size_t)((nq + 63) / 64) * 8);
   const size_t bwd = al16((size_t)nsq * nq * d * 4) + al16((size_t)nsc * nc * d * 4);
@@ -846,12 +854,12 @@ static int bwd16(const float *q, const float *c, int64_t nq, int64_t nc, int d, 
   char *p = ws + L.scratch;
 
   Sm16Args aq = a, ac = a;
-  plan16(nq, nc, &aq.nsplit, &aq.split_len);
+  plan16(nq, nc, &aq.nsplit, &aq.split_len, true);
   const int nsq = aq.nsplit;
   float *part_q = nsq == 1 ? dq : reinterpret_cast<float *>(p);
   aq.partial = part_q;
   p += al16((size_t)nsq * nq * d * 4);
-  plan16(nc, nq, &ac.nsplit, &ac.split_len);
+  plan16(nc, nq, &ac.nsplit, &ac.split_len, true);
   const int nsc = ac.nsplit;
   float *part_c = nsc == 1 ? dc : reinterpret_cast<float *>(p);
   ac.partial = part_c;
