@@ -396,6 +396,10 @@ int tfrs_embedding_scatter_add_rowscan_multi(int ntables, const float *const *gr
  * or sqrt(acc) + eps (mode 2), the same arithmetic as the fused sparse update above.  Host arrays of device pointers. */
 int tfrs_adagrad_dense_multi(int ntensors, float *const *params_h, float *const *accum_h, const float *const *grads_h,
                              const int64_t *n_h, float lr, float eps, int mode, void *stream);
+/* Up to 16 device buffers copied in ONE launch: a batch's input tensors into the static buffers of a captured
+ * train / test step (the `Model.fit` loop of models/base.py:64-85 replays HIP graphs; README.md:84-98).  Host arrays of
+ * device pointers and byte counts; buffers must not overlap. */
+int tfrs_copy_multi(int nbuffers, void *const *dst_h, const void *const *src_h, const int64_t *bytes_h, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * tf.keras.layers.Hashing(num_bins, salt=[s0, s1]) as UnifiedEmbedding applies it per

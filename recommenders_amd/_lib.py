@@ -87,6 +87,7 @@ SIGNATURES = {
     "tfrs_embedding_scatter_add_rowscan_multi": (c_int, [c_int, P, P, P, P, P, P, P, P, c_float, c_float,
                                                          c_int, P]),
     "tfrs_adagrad_dense_multi": (c_int, [c_int, P, P, P, P, c_float, c_float, c_int, P]),
+    "tfrs_copy_multi": (c_int, [c_int, P, P, P, P]),
     "tfrs_embedding_scatter_add_rowscan": (c_int, [P, P, c_int, c_i64, c_int, c_i64, P, P, c_float,
                                                    c_float, c_int, P]),
     "tfrs_inbatch_softmax_workspace_bytes": (c_size_t, [c_i64, c_i64, c_int]),

@@ -1042,6 +1042,70 @@ extern "C" int tfrs_adagrad_dense_multi(int ntensors, float *const *params_h, fl
   return TFRS_OK;
 }
 
+// ---- a batch's input tensors -> the static buffers of a captured step, ONE launch ----------------------------------
+// `Model.fit` replays a captured train step on static input buffers; the batch (two id vectors of 32 KB at the quickstart
+// shapes) was copied in by torch._foreach_copy_: 6.0-6.4 us of a 113 us step for 64 KB.  Buffer t owns blocks
+// [first_block[t], first_block[t + 1]) of 256 threads x 4 x 16 bytes.
+namespace tfrs {
+struct CopyBuffers {
+  int n;
+  int first_block[17];
+  char *dst[16];
+  const char *src[16];
+  int64_t bytes[16];
+};
+constexpr int kCopyPerBlock = 256 * 64;
+__global__ void __launch_bounds__(256) copy_multi_kernel(const CopyBuffers t) {
+  int k = 0;
+  while (k + 1 < t.n && (int)blockIdx.x >= t.first_block[k + 1]) ++k;
+  char *__restrict__ dst = t.dst[k];
+  const char *__restrict__ src = t.src[k];
+  const int64_t n = t.bytes[k];
+  const int64_t base = (int64_t)((int)blockIdx.x - t.first_block[k]) * kCopyPerBlock;
+  const bool vec = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0 && n >= 16;
+  if (vec) {
+    // unconditional (clamped) loads first, then the stores: one memory round trip per block
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t o = base + (int64_t)(u * 256 + threadIdx.x) * 16;
+      v[u] = *reinterpret_cast<const uint4 *>(src + (o + 16 <= n ? o : 0));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t o = base + (int64_t)(u * 256 + threadIdx.x) * 16;
+      if (o + 16 <= n) *reinterpret_cast<uint4 *>(dst + o) = v[u];
+    }
+    // the last n % 16 bytes of the buffer: the block that owns them
+    const int64_t tail = n & ~(int64_t)15;
+    if (tail >= base && tail < base + kCopyPerBlock && (int64_t)threadIdx.x < n - tail) dst[tail + threadIdx.x] = src[tail + threadIdx.x];
+    return;
+  }
+  for (int64_t o = base + threadIdx.x; o < n && o < base + kCopyPerBlock; o += 256) dst[o] = src[o];
+}
+}  // namespace tfrs
+
+extern "C" int tfrs_copy_multi(int nbuffers, void *const *dst_h, const void *const *src_h, const int64_t *bytes_h,
+                               void *stream) {
+  TFRS_CHECK_ARG(nbuffers >= 1 && nbuffers <= 16, "copy_multi: 1..16 buffers");
+  TFRS_CHECK_ARG(dst_h && src_h && bytes_h, "copy_multi: NULL argument array");
+  tfrs::CopyBuffers t = {};
+  t.n = nbuffers;
+  int64_t blocks = 0;
+  for (int i = 0; i < nbuffers; ++i) {
+    TFRS_CHECK_ARG(bytes_h[i] >= 0 && (bytes_h[i] == 0 || (dst_h[i] && src_h[i])), "copy_multi: bad buffer %d", i);
+    t.first_block[i] = (int)blocks;
+    blocks += (bytes_h[i] + tfrs::kCopyPerBlock - 1) / tfrs::kCopyPerBlock;
+    TFRS_CHECK_ARG(blocks < (1ll << 31), "copy_multi: too many bytes for one launch");
+    t.dst[i] = static_cast<char *>(dst_h[i]); t.src[i] = static_cast<const char *>(src_h[i]); t.bytes[i] = bytes_h[i];
+  }
+  t.first_block[nbuffers] = (int)blocks;
+  if (blocks == 0) return TFRS_OK;
+  hipLaunchKernelGGL(tfrs::copy_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
+  TFRS_LAUNCH_CHECK();
+  return TFRS_OK;
+}
+
 extern "C" int tfrs_embedding_scatter_add_rowscan_multi(int ntables, const float *const *grad_out_h,
                                                         const void *const *ids_h,
                                                         const int *ids_are_i64_h, const int64_t *n_h,

@@ -1149,6 +1149,45 @@ def test_adagrad_dense_parameters_one_launch_equals_the_torch_formula(legacy):
     np.testing.assert_allclose(_np(opt.state[p]["accumulator"]), _np(acc[i]), rtol=4e-7, atol=0)      # (fused multiply-add: 1 ulp per step)
 
 
+def test_copy_multi_moves_every_byte_and_nothing_else():
+  """``tfrs_copy_multi`` (the batch -> static-buffer copy of a replayed step, one launch): buffers of awkward byte counts
+  (0, 1, 15, 16, 17, one block + 5, several blocks), int64 / uint8 / float32, 16-byte aligned and 1- / 4-byte offset views
+  (the scalar path), sixteen buffers in one call; the bytes around every destination stay what they were."""
+  import ctypes
+  from recommenders_amd import _lib
+  rng = np.random.default_rng(5)
+  sizes = [0, 1, 15, 16, 17, 256 * 64 + 5, 3 * 256 * 64, 4096 * 8, 33, 1000, 64, 7, 16384, 100_000, 2, 48]
+  offs = [0, 1, 4, 0, 3, 0, 0, 0, 16, 5, 0, 0, 8, 0, 0, 1]
+  pad = 64
+  srcs, dsts, before = [], [], []
+  for n, o in zip(sizes, offs):
+    src = torch.as_tensor(rng.integers(0, 256, size=(n + 32,), dtype=np.uint8)).cuda()[o:o + n]
+    whole = torch.as_tensor(rng.integers(0, 256, size=(n + 2 * pad + 32,), dtype=np.uint8)).cuda()
+    srcs.append(src)
+    dsts.append((whole, pad + o))
+    before.append(_np(whole).copy())
+  n = len(sizes)
+  vp, i64a = ctypes.c_void_p * n, ctypes.c_int64 * n
+  _lib.check(_lib.load().tfrs_copy_multi(n, vp(*[w.data_ptr() + o for w, o in dsts]), vp(*[s.data_ptr() for s in srcs]),
+                                         i64a(*sizes), _lib.current_stream()))
+  torch.cuda.synchronize()
+  for (w, o), s, b, nb in zip(dsts, srcs, before, sizes):
+    got = _np(w)
+    np.testing.assert_array_equal(got[o:o + nb], _np(s))
+    np.testing.assert_array_equal(got[:o], b[:o])
+    np.testing.assert_array_equal(got[o + nb:], b[o + nb:])
+  # typed tensors, as the replayed step hands them over
+  a = torch.arange(4096, dtype=torch.int64, device="cuda") * 3
+  f = torch.as_tensor(rng.normal(size=(777,)).astype(np.float32)).cuda()
+  da, df = torch.zeros_like(a), torch.zeros_like(f)
+  _lib.check(_lib.load().tfrs_copy_multi(2, (ctypes.c_void_p * 2)(da.data_ptr(), df.data_ptr()),
+                                         (ctypes.c_void_p * 2)(a.data_ptr(), f.data_ptr()),
+                                         (ctypes.c_int64 * 2)(a.numel() * 8, f.numel() * 4), _lib.current_stream()))
+  assert torch.equal(da, a) and torch.equal(df, f)
+  with pytest.raises(ValueError):
+    _lib.check(_lib.load().tfrs_copy_multi(17, None, None, None, _lib.current_stream()))
+
+
 def test_adagrad_optimizer_sparse_slices_match_dense_formula():
   """optimizers.Adagrad: embedding tables are updated from (ids, rows) slices by the fused
   kernel (no dense gradient), dense parameters element-wise; both follow
