@@ -318,37 +318,46 @@ __global__ void __launch_bounds__(256) scatter_add_kernel(
 // the oracle -- adds that gradient row (lane = feature).  O(vocab * n / 64) wave-steps: used
 // when vocab * n is small (the MovieLens-sized tables of BASELINE configs[0]), where it
 // replaces a 40 us radix sort + zero-fill per table with one ~5 us kernel.
-template <typename IdT>
-__device__ __forceinline__ void scatter_rowscan_body(
+constexpr int kRowscanChunk = 4096;   // ids per LDS chunk (int32 in LDS: anything outside [0, 2^31) matches no row: -1)
+constexpr int kRowscanHitCap = 128;
+// NS = number of 64-feature groups of a row (d <= 64 * NS): a template parameter so that every load of the gradient-row
+// fetch is unconditional -- a load under `if (lane + 64 s < d)` makes the number of loads in flight unknown to the
+// compiler, which then waits for each one (the ISA of the runtime-d version: 176 loads, at most ONE in flight).
+template <typename IdT, int NS>
+__device__ __forceinline__ void scatter_rowscan_body_ns(
     const float *__restrict__ grad_out, const void *__restrict__ ids, int64_t n, int d,
     int64_t vocab, float *__restrict__ dst, float *__restrict__ accum, float lr, float eps,
-    int adagrad, int64_t block) {
+    int adagrad, int64_t block, int32_t *s_ids, int *s_hits) {
   // the id list goes through LDS in chunks shared by the workgroup's 4 rows, so a wave's scan
   // is 64 LDS reads per 4096 ids instead of 64 dependent global loads
-  constexpr int kChunk = 4096;
-  constexpr int kHitCap = 128;
-  // ids as int32 in LDS (anything outside [0, 2^31) can match no row: stored as -1): half the
-  // LDS footprint and half the bytes per scan step of the int64 image
-  __shared__ int32_t s_ids[kChunk];
-  __shared__ int s_hits[4][kHitCap];
-  int *my_hits = s_hits[threadIdx.x >> 6];
+  constexpr int kChunk = kRowscanChunk;
+  constexpr int kHitCap = kRowscanHitCap;
+  int *my_hits = s_hits + (threadIdx.x >> 6) * kHitCap;
   const int lane = threadIdx.x & 63;
   const int64_t v = block * 4 + (threadIdx.x >> 6);
   const bool row_ok = v < vocab;
-  float g[4] = {0.f, 0.f, 0.f, 0.f};  // features lane, lane + 64, lane + 128, lane + 192
+  float g[NS];  // features lane, lane + 64, ...
+#pragma unroll
+  for (int s = 0; s < NS; ++s) g[s] = 0.0f;
+  int fo[NS];   // clamped feature offsets (a lane beyond d re-reads the row's last feature and drops it)
+  bool fok[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    fok[s] = lane + 64 * s < d;
+    fo[s] = fok[s] ? lane + 64 * s : d - 1;
+  }
   bool touched = false;
   for (int64_t c0 = 0; c0 < n; c0 += kChunk) {
     const int m = (int)((n - c0 < kChunk) ? (n - c0) : kChunk);
     __syncthreads();
     {
-      // all 16 loads of a thread in flight before the first LDS write: one memory round trip per
-      // chunk (the runtime-bound copy loop it replaces was compiled to one round trip per
-      // iteration -- most of this kernel's 24 us at the quickstart shapes)
+      // all 16 loads of a thread in flight before the first LDS write, unconditionally (clamped into the chunk): one
+      // memory round trip per chunk
       int64_t t[kChunk / 256];
 #pragma unroll
       for (int i = 0; i < kChunk / 256; ++i) {
         const int e = threadIdx.x + i * 256;
-        t[i] = e < m ? load_id<IdT>(ids, c0 + e) : (int64_t)-1;
+        t[i] = load_id<IdT>(ids, c0 + (e < m ? e : m - 1));
       }
 #pragma unroll
       for (int i = 0; i < kChunk / 256; ++i) {
@@ -364,19 +373,19 @@ __device__ __forceinline__ void scatter_rowscan_body(
     int nh = 0;   // wave-uniform
     auto flush = [&]() __attribute__((always_inline)) {
       for (int i0 = 0; i0 < nh; i0 += 8) {
-        float r[8][4];
+        float r[8][NS];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int hp = (i0 + u < nh) ? my_hits[i0 + u] : my_hits[i0];
           const float *row = grad_out + (c0 + hp) * d;
 #pragma unroll
-          for (int s = 0; s < 4; ++s) r[u][s] = (lane + 64 * s < d) ? row[lane + 64 * s] : 0.0f;
+          for (int s = 0; s < NS; ++s) r[u][s] = row[fo[s]];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
           if (i0 + u < nh) {   // uniform
 #pragma unroll
-            for (int s = 0; s < 4; ++s) g[s] += r[u][s];
+            for (int s = 0; s < NS; ++s) g[s] += r[u][s];
           }
       }
       nh = 0;
@@ -398,21 +407,40 @@ __device__ __forceinline__ void scatter_rowscan_body(
     flush();
   }
   if (!row_ok) return;
+  if (adagrad) {
+    if (touched) {   // wave-uniform
+      float av[NS], pv[NS];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int f = lane + 64 * s;
-    if (f >= d) continue;
-    const int64_t o = v * d + f;
-    if (adagrad) {
-      if (touched) {
-        const float a = accum[o] + g[s] * g[s];
-        accum[o] = a;
-        dst[o] = dst[o] - lr * g[s] / adagrad_denom(a, eps, adagrad);
+      for (int s = 0; s < NS; ++s) {
+        av[s] = accum[v * d + fo[s]];
+        pv[s] = dst[v * d + fo[s]];
       }
-    } else {
-      dst[o] = g[s];  // untouched rows get their zeros here: no separate fill
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (fok[s]) {
+          const float a = av[s] + g[s] * g[s];
+          accum[v * d + fo[s]] = a;
+          dst[v * d + fo[s]] = pv[s] - lr * g[s] / adagrad_denom(a, eps, adagrad);
+        }
+      }
     }
+  } else {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      if (fok[s]) dst[v * d + fo[s]] = g[s];  // untouched rows get their zeros here: no separate fill
   }
+}
+
+// (the LDS arrays are declared ONCE by the kernel: static __shared__ arrays inside the template would be allocated per
+// instantiation -- six copies of 18 KB)
+template <typename IdT>
+__device__ __forceinline__ void scatter_rowscan_body(
+    const float *__restrict__ grad_out, const void *__restrict__ ids, int64_t n, int d,
+    int64_t vocab, float *__restrict__ dst, float *__restrict__ accum, float lr, float eps,
+    int adagrad, int64_t block, int32_t *s_ids, int *s_hits) {
+  if (d <= 64) scatter_rowscan_body_ns<IdT, 1>(grad_out, ids, n, d, vocab, dst, accum, lr, eps, adagrad, block, s_ids, s_hits);
+  else if (d <= 128) scatter_rowscan_body_ns<IdT, 2>(grad_out, ids, n, d, vocab, dst, accum, lr, eps, adagrad, block, s_ids, s_hits);
+  else scatter_rowscan_body_ns<IdT, 4>(grad_out, ids, n, d, vocab, dst, accum, lr, eps, adagrad, block, s_ids, s_hits);
 }
 
 template <typename IdT>
@@ -420,7 +448,9 @@ __global__ void __launch_bounds__(256) scatter_rowscan_kernel(
     const float *__restrict__ grad_out, const void *__restrict__ ids, int64_t n, int d,
     int64_t vocab, float *__restrict__ dst, float *__restrict__ accum, float lr, float eps,
     int adagrad) {
-  scatter_rowscan_body<IdT>(grad_out, ids, n, d, vocab, dst, accum, lr, eps, adagrad, blockIdx.x);
+  __shared__ int32_t s_ids[kRowscanChunk];
+  __shared__ int s_hits[4 * kRowscanHitCap];
+  scatter_rowscan_body<IdT>(grad_out, ids, n, d, vocab, dst, accum, lr, eps, adagrad, blockIdx.x, s_ids, s_hits);
 }
 
 // Several small tables in ONE launch (the user and item tables of a two-tower step): each table's
@@ -445,12 +475,14 @@ __global__ void __launch_bounds__(256) scatter_rowscan_multi_kernel(const Rowsca
   for (int i = 1; i < 8; ++i)
     if (i < t.ntab && (int)blockIdx.x >= t.first_block[i]) k = i;
   const int64_t block = (int)blockIdx.x - t.first_block[k];
+  __shared__ int32_t s_ids[kRowscanChunk];
+  __shared__ int s_hits[4 * kRowscanHitCap];
   if (t.i64[k])
     scatter_rowscan_body<int64_t>(t.grad_out[k], t.ids[k], t.n[k], t.d[k], t.vocab[k], t.dst[k], t.accum[k], lr,
-                                  eps, adagrad, block);
+                                  eps, adagrad, block, s_ids, s_hits);
   else
     scatter_rowscan_body<int32_t>(t.grad_out[k], t.ids[k], t.n[k], t.d[k], t.vocab[k], t.dst[k], t.accum[k], lr,
-                                  eps, adagrad, block);
+                                  eps, adagrad, block, s_ids, s_hits);
 }
 
 static unsigned grid_for(int64_t total_threads, int64_t cap = 256 * 8) {
