@@ -396,7 +396,8 @@ __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArg
     qrow[g] = ((int64_t)qt * QG + g) * 32 + j;
     const bool qvalid = qrow[g] < a.nq;
     const int64_t qr = qvalid ? qrow[g] : 0;
-    const float qs = qvalid ? a.qscale[qr] : 1.0f;
+    const float qs_ld = a.qscale[qr], thr_ld = a.thr[qr * (a.thr_stride > 0 ? a.thr_stride : 1)], qk_ld = a.qk[qr];   // unconditional: counted loads
+    const float qs = qvalid ? qs_ld : 1.0f;
     const float qinv = 1.0f / qs;   // exact: power of two
     const f32x4 *q4 = reinterpret_cast<const f32x4 *>(a.q + qr * DP);
 #pragma unroll
@@ -412,8 +413,8 @@ __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArg
       w[3] = raw_pack_f16x2(on ? hi[2] * qinv : 0.0f, on ? hi[3] * qinv : 0.0f);
       bq[g][m] = __builtin_bit_cast(f16x8r, w);
     }
-    flo[g] = qvalid ? (a.thr[qr * (a.thr_stride > 0 ? a.thr_stride : 1)] - kF16Tiny) * qinv : __builtin_inff();
-    fqk[g] = qvalid ? a.qk[qr] * qinv : 0.0f;
+    flo[g] = qvalid ? (thr_ld - kF16Tiny) * qinv : __builtin_inff();
+    fqk[g] = qvalid ? qk_ld * qinv : 0.0f;
     qsc[g] = qs;
   }
   wg_cnt[tid] = 0u;   // 256 threads, 256 counters
@@ -718,7 +719,8 @@ __global__ void __launch_bounds__(kRawWWaves * 64) rawscan16w_kernel(const RawSc
     const int64_t qrow_g = (int64_t)qrow0 + 32 * g;
     const bool qvalid = qrow_g < a.nq;
     const int64_t qr = qvalid ? qrow_g : 0;
-    const float qs = qvalid ? a.qscale[qr] : 1.0f;
+    const float qs_ld = a.qscale[qr], thr_ld = a.thr[qr * (a.thr_stride > 0 ? a.thr_stride : 1)], qk_ld = a.qk[qr];   // unconditional: counted loads
+    const float qs = qvalid ? qs_ld : 1.0f;
     const float qinv = 1.0f / qs;   // exact: power of two
     const f32x4 *q4 = reinterpret_cast<const f32x4 *>(a.q + qr * DP);
 #pragma unroll
@@ -731,8 +733,8 @@ __global__ void __launch_bounds__(kRawWWaves * 64) rawscan16w_kernel(const RawSc
       w[3] = raw_pack_f16x2(qvalid ? hi[2] * qinv : 0.0f, qvalid ? hi[3] * qinv : 0.0f);
       bq[g][m] = __builtin_bit_cast(f16x8r, w);
     }
-    flo[g] = qvalid ? (a.thr[qr * (a.thr_stride > 0 ? a.thr_stride : 1)] - kF16Tiny) * qinv : __builtin_inff();
-    fqk[g] = qvalid ? a.qk[qr] * qinv : 0.0f;
+    flo[g] = qvalid ? (thr_ld - kF16Tiny) * qinv : __builtin_inff();
+    fqk[g] = qvalid ? qk_ld * qinv : 0.0f;
     qsc[g] = qs;
   }
   wg_cnt[tid] = 0u;   // 512 threads, 512 counters
@@ -1113,7 +1115,8 @@ __global__ void __launch_bounds__((CW + 4) * 64) rawscan16pc_kernel(const RawSca
       const int64_t qrow_g = (int64_t)qrow0 + 32 * g;
       const bool qvalid = qrow_g < a.nq;
       const int64_t qr = qvalid ? qrow_g : 0;
-      const float qs = qvalid ? a.qscale[qr] : 1.0f;
+      const float qs_ld = a.qscale[qr], thr_ld = a.thr[qr * (a.thr_stride > 0 ? a.thr_stride : 1)], qk_ld = a.qk[qr];   // unconditional: counted loads
+      const float qs = qvalid ? qs_ld : 1.0f;
       const float qinv = 1.0f / qs;   // exact: power of two
       const f32x4 *q4 = reinterpret_cast<const f32x4 *>(a.q + qr * DP);
 #pragma unroll
@@ -1128,8 +1131,8 @@ __global__ void __launch_bounds__((CW + 4) * 64) rawscan16pc_kernel(const RawSca
         if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // eight loads at a time
       }
       qconst[g * 64 + lane] = make_float4(
-          qvalid ? (a.thr[qr * (a.thr_stride > 0 ? a.thr_stride : 1)] - kF16Tiny) * qinv : __builtin_inff(),
-          qvalid ? a.qk[qr] * qinv : 0.0f, qs, 0.0f);
+          qvalid ? (thr_ld - kF16Tiny) * qinv : __builtin_inff(),
+          qvalid ? qk_ld * qinv : 0.0f, qs, 0.0f);
       __builtin_amdgcn_sched_barrier(0);   // one group's sixteen loads at a time (all 64 issued up front spilled 50 registers)
     }
     const bool wave_active = (int64_t)qt * kRawWQueries + wave * (kRawPcQG * 32) < a.nq;   // (uniform)

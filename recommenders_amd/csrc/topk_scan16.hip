@@ -188,23 +188,40 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
   int64_t qrow[kQG];
   uint2 *wp[kQG];  // FILTER: next free slot of this lane's segment (stride nseg entries)
   uint32_t mycnt[kQG];
+  // Every load of this prologue is UNCONDITIONAL (a padding lane re-reads the last query and drops it) and all of them
+  // are issued before the first conversion: loads under `if (qvalid)` / inside the per-step `if (vec_ok)` left the
+  // number of loads in flight unknown to the compiler, which waited for each pair -- eight serial round trips per wave
+  // where one does (the ISA of this prologue had 34 vmcnt(0) waits).
+  const bool vec_ok = (a.d == DP) && ((reinterpret_cast<uintptr_t>(a.q) & 15) == 0);  // uniform
+  float4 qlo[kQG][G::kSteps], qhi[kQG][G::kSteps];
+  int64_t qclampv[kQG];
 #pragma unroll
   for (int g = 0; g < kQG; ++g) {
     qrow[g] = (int64_t)qt * kScan16QueriesPerWg + wave * (kQG * 32) + g * 32 + j;
     qvalid[g] = qrow[g] < a.nq;
-    const float *qp = a.q + qrow[g] * a.d;
-    qs[g] = qvalid[g] ? a.qscale[qrow[g]] : 1.0f;
+    qclampv[g] = qvalid[g] ? qrow[g] : a.nq - 1;
+    qs[g] = a.qscale[qclampv[g]];
+    if (vec_ok) {
+      const float *qp = a.q + qclampv[g] * a.d;
+#pragma unroll
+      for (int m = 0; m < G::kSteps; ++m) {  // 8 consecutive features = two 16-byte loads
+        qlo[g][m] = *reinterpret_cast<const float4 *>(qp + 16 * m + 8 * h);
+        qhi[g][m] = *reinterpret_cast<const float4 *>(qp + 16 * m + 8 * h + 4);
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < kQG; ++g) {
+    const int64_t qclamp = qclampv[g];
+    const float *qp = a.q + qclamp * a.d;
+    if (!qvalid[g]) qs[g] = 1.0f;
     qinv[g] = 1.0f / qs[g];  // exact: power of two
-    const bool vec_ok = (a.d == DP) && ((reinterpret_cast<uintptr_t>(a.q) & 15) == 0);  // uniform
 #pragma unroll
     for (int m = 0; m < G::kSteps; ++m) {
       float x[8];
-      if (vec_ok) {  // 8 consecutive features = two 16-byte loads
-        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-        if (qvalid[g]) {
-          lo = *reinterpret_cast<const float4 *>(qp + 16 * m + 8 * h);
-          hi = *reinterpret_cast<const float4 *>(qp + 16 * m + 8 * h + 4);
-        }
+      if (vec_ok) {
+        float4 lo = qlo[g][m], hi = qhi[g][m];
+        if (!qvalid[g]) lo = hi = make_float4(0.f, 0.f, 0.f, 0.f);
         x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w;
         x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
       } else {
@@ -219,8 +236,13 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
       for (int i = 0; i < 4; ++i) w[i] = cvt_f16x2(x[2 * i] * qinv[g], x[2 * i + 1] * qinv[g]);
       bq[g][m] = as_f16x8(w);
     }
-    lower[g] = (MODE == kModeFilter && qvalid[g]) ? a.lower[qrow[g]] : __builtin_inff();
-    qk[g] = (MODE == kModeFilter && qvalid[g]) ? a.qk[qrow[g]] : 0.0f;
+    lower[g] = __builtin_inff();
+    qk[g] = 0.0f;
+    if (MODE == kModeFilter) {
+      const float lw = a.lower[qclamp], kq = a.qk[qclamp];
+      lower[g] = qvalid[g] ? lw : __builtin_inff();
+      qk[g] = qvalid[g] ? kq : 0.0f;
+    }
     // survivor lists are entry-major: buf[(q * cap_l + e) * nseg + seg], seg = 2 * split + h
     wp[g] = (MODE == kModeFilter)
                 ? a.buf + (qrow[g] * (int64_t)a.cap_l) * a.nseg + (2 * split + h)
@@ -506,23 +528,41 @@ __global__ void __launch_bounds__(NW * 64, NW * QG >= 32 ? 1 : (DP <= 64 ? 2 : 1
   // per (group, lane): {(lower - tiny) / qscale, qk / qscale, qscale} parked in LDS (re-read
   // once per stage: three more resident VGPR pairs do not fit under 128)
   float4 *const qconst = reinterpret_cast<float4 *>(qbase + G::kQCap * G::kEntB + QG * 64 * 4);
+  // all loads of the prologue unconditional and issued before the first conversion: see scan16_kernel
+  const bool vec_ok = (a.d == DP) && ((reinterpret_cast<uintptr_t>(a.q) & 15) == 0);  // uniform
+  float4 qlo[QG][G::kSteps], qhi[QG][G::kSteps];
+  float qscv[QG], lowv[QG], qkv[QG];
+#pragma unroll
+  for (int g = 0; g < QG; ++g) {
+    const int64_t qrow = q0 + g * 32 + j;
+    const int64_t qclamp = qrow < a.nq ? qrow : a.nq - 1;
+    qscv[g] = a.qscale[qclamp];
+    lowv[g] = a.lower[qclamp];
+    qkv[g] = a.qk[qclamp];
+    if (vec_ok) {
+      const float *qp = a.q + qclamp * a.d;
+#pragma unroll
+      for (int m = 0; m < G::kSteps; ++m) {
+        qlo[g][m] = *reinterpret_cast<const float4 *>(qp + 16 * m + 8 * h);
+        qhi[g][m] = *reinterpret_cast<const float4 *>(qp + 16 * m + 8 * h + 4);
+      }
+    }
+  }
 #pragma unroll
   for (int g = 0; g < QG; ++g) {
     const int64_t qrow = q0 + g * 32 + j;
     const bool qvalid = qrow < a.nq;
-    const float *qp = a.q + qrow * a.d;
-    const float qsc = qvalid ? a.qscale[qrow] : 1.0f;
+    const int64_t qclamp = qvalid ? qrow : a.nq - 1;
+    const float *qp = a.q + qclamp * a.d;
+    const float qsc = qvalid ? qscv[g] : 1.0f;
+    const float lower_q = lowv[g], qk_q = qkv[g];
     const float qinv = 1.0f / qsc;  // exact: power of two
-    const bool vec_ok = (a.d == DP) && ((reinterpret_cast<uintptr_t>(a.q) & 15) == 0);  // uniform
 #pragma unroll
     for (int m = 0; m < G::kSteps; ++m) {
       float x[8];
       if (vec_ok) {
-        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-        if (qvalid) {
-          lo = *reinterpret_cast<const float4 *>(qp + 16 * m + 8 * h);
-          hi = *reinterpret_cast<const float4 *>(qp + 16 * m + 8 * h + 4);
-        }
+        float4 lo = qlo[g][m], hi = qhi[g][m];
+        if (!qvalid) lo = hi = make_float4(0.f, 0.f, 0.f, 0.f);
         x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w;
         x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
       } else {
@@ -543,8 +583,8 @@ __global__ void __launch_bounds__(NW * 64, NW * QG >= 32 ? 1 : (DP <= 64 ? 2 : 1
     // .w: entry index of this (query, lane half, split) segment in the survivor buffer (the
     // launcher guarantees that the whole buffer is indexable with 32 bits)
     const uint32_t seg_base = (uint32_t)((qrow * (int64_t)a.cap_l) * a.nseg + (2 * split + h));
-    qconst[g * 64 + lane] = make_float4(qvalid ? (a.lower[qrow] - kF16Tiny) * qinv : __builtin_inff(),
-                                        qvalid ? a.qk[qrow] * qinv : 0.0f, qsc,
+    qconst[g * 64 + lane] = make_float4(qvalid ? (lower_q - kF16Tiny) * qinv : __builtin_inff(),
+                                        qvalid ? qk_q * qinv : 0.0f, qsc,
                                         __uint_as_float(seg_base));
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
