@@ -29,6 +29,7 @@ struct TopkTuning {
   int64_t prefix;  // rows scored densely before filtering starts
   int64_t rho;     // geometric growth of the filtered ranges
   int64_t target_wgs;
+  int64_t thr_wgs;       // workgroups of the threshold pass (TFRS_TOPK_WGS_THR; default: target_wgs)
   bool f16_filter;  // TFRS_TOPK_FILTER=f16 (default) | f32
   int64_t sample;   // fp16 path: the threshold pass scans every `sample`-th stage
   int64_t min_bins; // fp16 path: sampled bins required per query, in units of K
@@ -48,6 +49,7 @@ static TopkTuning tuning() {
   t.prefix = padded_rows(t.prefix);
   t.rho = std::max<int64_t>(2, env_i64("TFRS_TOPK_RHO", 8));
   t.target_wgs = std::max<int64_t>(1, env_i64("TFRS_TOPK_WGS", 512));
+  t.thr_wgs = std::max<int64_t>(1, env_i64("TFRS_TOPK_WGS_THR", t.target_wgs));
   const char *f = option("TFRS_TOPK_FILTER");
   t.f16_filter = !(f && (f[0] == 'f' || f[0] == 'F') && f[1] == '3');
   t.sample = std::max<int64_t>(1, env_i64("TFRS_TOPK_SAMPLE", 4));
@@ -528,7 +530,11 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
   if (!lower_preset) {
   s16.n_stages = (int)sp.n_stages;
   s16.stage_stride = (int)sp.stride;
-  plan_stage_splits(sp.n_stages, n_qtiles, t, &s16.stages_per_split, &s16.n_splits);
+  {
+    TopkTuning tt = t;
+    tt.target_wgs = t.thr_wgs;
+    plan_stage_splits(sp.n_stages, n_qtiles, tt, &s16.stages_per_split, &s16.n_splits);
+  }
   s16.bin_stages = (int)sp.bin_stages;
   s16.stages_per_split = (int)((s16.stages_per_split + sp.bin_stages - 1) / sp.bin_stages * sp.bin_stages);
   s16.n_splits = (int)((sp.n_stages + s16.stages_per_split - 1) / s16.stages_per_split);

@@ -43,4 +43,4 @@ for v in vals:
     for kv in v.split(","):
       _lib.set_option(kv.split("=")[0], None)
   print(json.dumps({"switch": v, "step_ms": round(dt * 1e3, 4), "filter_ms": round(res[1][0], 4),
-                    "filter_tflops": round(res[1][1], 1), "same": same}), flush=True)
+                    "filter_tflops": round(res[1][1], 1), "thr_ms": round(res[2][0], 4), "same": same}), flush=True)
