@@ -841,6 +841,14 @@ def test_hot_kernel_register_budgets(source, patterns, max_vgprs, agpr_spills_ok
     # ... and its form for 8-byte aligned rows (k % 4 == 2, eight waves per four rows): first built with a nested ternary per
     # element that compiled to a branch + vmcnt(0) behind every load (2.85 TB/s); the selects keep 4-5 loads in flight
     ("gemm16.hip", "g16_prep_rows_ksm1_kernelILi8ELb0ELb1ELi8E", 4),
+    # round 6, last session -- latency chains of short kernels that the listing showed with ONE load in flight:
+    # the in-batch softmax's record packer (one 4-byte load per round trip, eight in a row at dim 64)
+    ("softmax16.hip", "sm16_prep_kernelILi64E", 4),
+    # the row-scan Adagrad of small tables (ids, gradient rows of a row's hits, accumulator / table rows)
+    ("embedding.hip", "scatter_rowscan_multi_kernel", 16),
+    # the query prologue of the fp16 filter / threshold kernels: a wave's 16 x 16-byte query loads at once
+    ("topk_scan16.hip", "scan16f_kernelILi64ELi16ELi2ELi2E", 8),
+    ("topk_scan16.hip", "scan16_kernelILi64ELi2E", 8),
 ])
 def test_pipelined_kernels_keep_loads_in_flight(source, pattern, min_in_flight):
   """gfx950 tracks a wave's outstanding loads with ONE in-order counter; a load inside a branch makes the
