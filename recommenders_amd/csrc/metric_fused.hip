@@ -79,6 +79,9 @@ __device__ __forceinline__ void hits_fold(const HitsArgs &a, float (*part_s)[17]
 #pragma unroll
   for (int i = 0; i < 16; ++i) tot[i] = 0.0f;
   float wsum = 0.0f;
+  // (the running totals travel with the first batch of counts: read behind the fold they were a round trip of their own)
+  const int st = tid < a.nks ? tid : 0;
+  const float state_t = a.state[st], state_c = a.state[a.nks + st];
   constexpr int kB = 16;                                  // loads per thread in flight: one memory round
   for (int64_t q0 = 0; q0 < a.nq; q0 += kB * NT) {       // trip covers 4096 queries at NT = 256
     uint32_t cv[kB];
@@ -135,8 +138,8 @@ __device__ __forceinline__ void hits_fold(const HitsArgs &a, float (*part_s)[17]
       t += part_s[v][tid];
       w += part_s[v][16];
     }
-    const float total = a.state[tid] + t;
-    const float count = a.state[a.nks + tid] + w;
+    const float total = state_t + t;
+    const float count = state_c + w;
     a.state[tid] = total;
     a.state[a.nks + tid] = count;
     a.results[tid] = count > 0.0f ? total / count : 0.0f;

@@ -458,6 +458,9 @@ __global__ void __launch_bounds__(64) sm16_finalize_kernel(const Sm16Args a, flo
   const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const bool valid = row < a.q.n;
   const int64_t r = valid ? row : 0;
+  // (the positive and the weight travel with the first batch of partials: behind the loop they were a round trip of their own)
+  const float pos_ld = a.ppos[r];
+  const float w_ld = a.w ? a.w[r] : 1.0f;
   float mm = -__builtin_inff(), ll = 0.0f;
   for (int s0 = 0; s0 < a.nsplit; s0 += 16) {
     float pm[16], pl[16];
@@ -483,11 +486,11 @@ __global__ void __launch_bounds__(64) sm16_finalize_kernel(const Sm16Args a, flo
   if (valid) {
     const float lse2 = mm + log2f(ll);
     const float lse = lse2 * kLn2;
-    const float pos = a.ppos[row];
+    const float pos = pos_ld;
     out_lse[row] = lse;
     out_pos[row] = pos;
     reinterpret_cast<float *>(a.q_rec_w + (row >> 5) * RL::kBytes + RL::kLse)[row & 31] = lse * kLog2e;
-    const float w = a.w ? a.w[row] : 1.0f;
+    const float w = w_ld;
     local = (double)w * ((double)lse - (double)pos);
   }
 #pragma unroll
