@@ -222,7 +222,7 @@ __device__ __forceinline__ float raw_score(const RawTable *t, int64_t row, int d
   const float4 *c4 = reinterpret_cast<const float4 *>(raw_row_ptr(t, row, d));
   const float4 *q4 = reinterpret_cast<const float4 *>(qs);
   float acc = 0.0f;
-#pragma unroll 4
+#pragma unroll 8
   for (int m = 0; m < d / 4; ++m) {
     const float4 c = c4[m], q = q4[m];
     acc = __builtin_fmaf(c.x, q.x, acc);

@@ -132,15 +132,25 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
   const int dp = padded_dim(a.d);
 
   // ---- seed with the prior state (already sorted by construction) -----------------
-  for (int i = lane; i < KP; i += 64) {
-    uint64_t key = 0ull;
-    if (i < a.state_len) {
+  if (a.state_len > 0) {   // uniform; both loads of every slot unconditional (clamped) and in flight together
+    int32_t si[KP / 64];
+    float ss[KP / 64];
+#pragma unroll
+    for (int u = 0; u < KP / 64; ++u) {
+      const int i = u * 64 + lane;
+      const int ic = i < a.state_len ? i : 0;
+      si[u] = a.state_idx[row * K + ic];
+      ss[u] = a.state_scores[row * K + ic];
+    }
+#pragma unroll
+    for (int u = 0; u < KP / 64; ++u) {
+      const int i = u * 64 + lane;
       // (a paged search can leave a query with fewer than state_len candidates below its ceiling:
       // empty slots carry row -1 and must not come back as a real (0.0, row 0) entry)
-      const int32_t si = a.state_idx[row * K + i];
-      if (si >= 0) key = make_key(a.state_scores[row * K + i], si);
+      best[i] = (i < a.state_len && si[u] >= 0) ? make_key(ss[u], si[u]) : 0ull;
     }
-    best[i] = key;
+  } else {
+    for (int i = lane; i < KP; i += 64) best[i] = 0ull;
   }
   if (source == kSrcList || source == kSrcRecompute) {  // the query, zero-padded, for exact scoring
     for (int i = lane; i < dp; i += 64) qs[i] = (i < a.d) ? a.q[row * a.d + i] : 0.0f;
@@ -269,24 +279,30 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
     }
   } else if (source == kSrcDense) {
     if (!a.rowmap) {
-      // eight scores per lane and round trip, loaded unconditionally at a clamped column (one wave walks the row: with
-      // one conditional load per 64 scores the dense round of a single streamed query -- 65536 scores -- was 1024 serial
-      // round trips, 55 us of a 1.3 ms call); the keys are offered in the same order as before
-      constexpr int kU = 8;
+      // Sixteen scores per lane and batch, loaded unconditionally at a clamped column, the NEXT batch in flight while this
+      // one is offered (one wave walks the row: with one conditional load per 64 scores the dense round of a single
+      // streamed query -- 65536 scores -- was 1024 serial round trips, 55 us of a 1.3 ms call).  Same order of keys.
+      constexpr int kU = 16;
       const float *drow = a.dense + row * a.ld_dense;
-      for (int64_t base = 0; base < a.n_dense; base += 64 * kU) {
-        float v[kU];
+      float v[kU], nx[kU];
+      auto fetch = [&](float (&dst)[kU], int64_t base) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
           const int64_t e = base + u * 64 + lane;
-          v[u] = drow[e < a.n_dense ? e : a.n_dense - 1];
+          dst[u] = drow[e < a.n_dense ? e : a.n_dense - 1];
         }
+      };
+      if (a.n_dense > 0) fetch(v, 0);
+      for (int64_t base = 0; base < a.n_dense; base += 64 * kU) {
+        fetch(nx, base + 64 * kU);   // (unconditional: behind the row's end every lane re-reads the last score and drops it)
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
           const int64_t e = base + u * 64 + lane;
           if (base + u * 64 < a.n_dense)   // uniform
             consume(e < a.n_dense ? make_key(v[u], (int32_t)(a.idx_base + e)) : 0ull);
         }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) v[u] = nx[u];
       }
     } else {
       for (int64_t base = 0; base < a.n_dense; base += 64) {
@@ -337,18 +353,29 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
       }
     }
   } else {
+    // four entries per lane and round trip, indices and scores loaded unconditionally at a clamped entry (the merge
+    // of a range's result into the carried state -- 2 x K entries -- was four pairs of dependent conditional loads)
     const int64_t m = (int64_t)a.nparts * a.k_in;
-    for (int64_t base = 0; base < m; base += 64) {
-      const int64_t e = base + lane;
-      uint64_t key = 0ull;
-      if (e < m) {
-        const int64_t part = e / a.k_in, jj = e - part * a.k_in;
-        const int64_t pstride = a.part_stride ? a.part_stride : a.nq * (int64_t)a.k_in;
+    const int64_t pstride = a.part_stride ? a.part_stride : a.nq * (int64_t)a.k_in;
+    constexpr int kU = 4;
+    for (int64_t base = 0; base < m; base += 64 * kU) {
+      int32_t pi[kU];
+      float ps[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int64_t e = base + u * 64 + lane;
+        const int64_t ec = e < m ? e : m - 1;
+        const int64_t part = ec / a.k_in, jj = ec - part * a.k_in;
         const int64_t off = part * pstride + row * a.k_in + jj;
-        const int32_t pi = a.part_idx[off];
-        if (pi >= 0) key = make_key(a.part_scores[off], pi);
+        pi[u] = a.part_idx[off];
+        ps[u] = a.part_scores[off];
       }
-      consume(key);
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int64_t e = base + u * 64 + lane;
+        if (base + u * 64 < m)   // uniform
+          consume((e < m && pi[u] >= 0) ? make_key(ps[u], pi[u]) : 0ull);
+      }
     }
   }
   if (fill > 0) absorb_chunk<KP>(best, chunk, fill, lane);

@@ -276,7 +276,12 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
     // Large batches: one segment per lane, ~7 entries each.  Eight entries per round as one batch
     // of independent loads (the first round is issued straight behind the count), so the gather
     // costs 1 + ceil(longest segment / 8) memory latencies.
-    uint32_t c = (lane < a.nseg) ? a.cnt[row * a.nseg + lane] : 0u;
+    // (every load of this gather is UNCONDITIONAL at a clamped segment / entry and selected afterwards: under
+    // `if (e < c)` each one was awaited on its own -- the listing had 134 vmcnt(0) waits, at most 6 loads in flight)
+    const int lseg = lane < a.nseg ? lane : a.nseg - 1;
+    const uint32_t ecap = a.cap_l - 1u;
+    uint32_t c = a.cnt[row * a.nseg + lseg];
+    if (lane >= a.nseg) c = 0u;
     if (a.ovf_cnt) {   // the excess (up to kOvfPerSeg per segment) went to the overflow list
       bad = c > a.cap_l + kOvfPerSeg;
       c = min(c, a.cap_l);
@@ -287,10 +292,7 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
       for (uint32_t e0 = 0; __ballot(e0 < c) != 0ull; e0 += 8) {
         uint2 w[8];
 #pragma unroll
-        for (int x = 0; x < 8; ++x) {
-          w[x] = make_uint2(0u, 0u);
-          if (e0 + x < c) w[x] = qbuf[(int64_t)(e0 + x) * a.nseg + lane];
-        }
+        for (int x = 0; x < 8; ++x) w[x] = qbuf[(int64_t)min(e0 + x, ecap) * a.nseg + lseg];
 #pragma unroll
         for (int x = 0; x < 8; ++x) push(e0 + x < c, w[x]);
       }
@@ -301,8 +303,11 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
 #pragma unroll
     for (int b = 0; b < kCntBatch; ++b) {
       const int sg = sb0 + b * 64 + lane;
-      cnts[b] = (sg < a.nseg) ? a.cnt[row * a.nseg + sg] : 0u;
+      cnts[b] = a.cnt[row * a.nseg + (sg < a.nseg ? sg : a.nseg - 1)];   // unconditional, clamped (see above)
     }
+#pragma unroll
+    for (int b = 0; b < kCntBatch; ++b)
+      if (sb0 + b * 64 + lane >= a.nseg) cnts[b] = 0u;
 #pragma unroll
     for (int b = 0; b < kCntBatch; ++b) {
       if (a.ovf_cnt) {   // the excess (up to kOvfPerSeg per segment) went to the overflow list
@@ -322,8 +327,8 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
     for (int b = 0; b < kCntBatch; ++b)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        v[b][e] = make_uint2(0u, 0u);
-        if ((uint32_t)e < cnts[b]) v[b][e] = qbuf[(int64_t)e * a.nseg + sb0 + b * 64 + lane];
+        const int sg = sb0 + b * 64 + lane;
+        v[b][e] = qbuf[(int64_t)min((uint32_t)e, a.cap_l - 1u) * a.nseg + (sg < a.nseg ? sg : a.nseg - 1)];
       }
 #pragma unroll
     for (int b = 0; b < kCntBatch; ++b) {
@@ -337,8 +342,8 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
         uint2 w[4];
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-          w[x] = make_uint2(0u, 0u);
-          if (e0 + x < cnts[b]) w[x] = qbuf[(int64_t)(e0 + x) * a.nseg + sb0 + b * 64 + lane];
+          const int sg = sb0 + b * 64 + lane;
+          w[x] = qbuf[(int64_t)min(e0 + x, a.cap_l - 1u) * a.nseg + (sg < a.nseg ? sg : a.nseg - 1)];
         }
 #pragma unroll
         for (int x = 0; x < 4; ++x) push(e0 + x < cnts[b], w[x]);
