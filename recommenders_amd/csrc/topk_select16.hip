@@ -335,10 +335,10 @@ __global__ void __launch_bounds__(kSel16Waves * 64) list_topk16_kernel(const Lis
       if (sb0 + b * 64 >= a.nseg) break;   // uniform
 #pragma unroll
       for (int e = 0; e < 2; ++e) push((uint32_t)e < cnts[b], v[b][e]);
-      // longer segments (large batches: few splits, ~7 entries each): 4 entries per round
-      uint32_t cmax = cnts[b];
-      for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, off));
-      for (uint32_t e0 = 2; e0 < cmax; e0 += 4) {
+      // longer segments (large batches: few splits, ~7 entries each): 4 entries per round (the loop condition is a
+      // ballot: the wave-wide maximum it replaces was six dependent cross-lane shuffles per batch of 64 segments,
+      // 96 in a row for the 1024 segments of a single query)
+      for (uint32_t e0 = 2; __ballot(e0 < cnts[b]) != 0ull; e0 += 4) {
         uint2 w[4];
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
