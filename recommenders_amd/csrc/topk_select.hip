@@ -278,36 +278,51 @@ __global__ void __launch_bounds__(kSelWaves * 64) select_kernel(const SelectArgs
       }
     }
   } else if (source == kSrcDense) {
-    if (!a.rowmap) {
-      // Sixteen scores per lane and batch, loaded unconditionally at a clamped column, the NEXT batch in flight while this
-      // one is offered (one wave walks the row: with one conditional load per 64 scores the dense round of a single
-      // streamed query -- 65536 scores -- was 1024 serial round trips, 55 us of a 1.3 ms call).  Same order of keys.
-      constexpr int kU = 16;
+    if (!a.rowmap && (reinterpret_cast<uintptr_t>(a.dense + row * a.ld_dense) & 15) == 0) {
+      // One wave walks the row, so the walk is bound by how many bytes it keeps in flight: eight 16-byte loads per lane and
+      // batch (8 KB per wave), unconditional at a clamped column, the NEXT batch issued before this one is offered.  With
+      // one conditional 4-byte load per 64 scores the dense round of a single streamed query -- 65536 scores -- was 1024
+      // serial round trips (55 us of a 1.3 ms call); 4-byte loads in batches of 16 still 64 of them (43 us).  The keys
+      // carry their column, so the order in which they are offered does not matter.
+      constexpr int kU = 8;
+      typedef float f4a __attribute__((ext_vector_type(4)));
       const float *drow = a.dense + row * a.ld_dense;
-      float v[kU], nx[kU];
-      auto fetch = [&](float (&dst)[kU], int64_t base) __attribute__((always_inline)) {
+      const int64_t n4 = a.n_dense & ~(int64_t)3;          // whole 16-byte pieces; the last n % 4 scores: below
+      f4a v[kU], nx[kU];
+      auto fetch = [&](f4a (&dst)[kU], int64_t base) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-          const int64_t e = base + u * 64 + lane;
-          dst[u] = drow[e < a.n_dense ? e : a.n_dense - 1];
+          const int64_t e = base + (int64_t)(u * 64 + lane) * 4;
+          dst[u] = *reinterpret_cast<const f4a *>(drow + (e + 4 <= n4 ? e : (n4 >= 4 ? n4 - 4 : 0)));
         }
       };
-      if (a.n_dense > 0) fetch(v, 0);
-      for (int64_t base = 0; base < a.n_dense; base += 64 * kU) {
-        fetch(nx, base + 64 * kU);   // (unconditional: behind the row's end every lane re-reads the last score and drops it)
+      if (n4 >= 4) {
+        fetch(v, 0);
+        for (int64_t base = 0; base < n4; base += 256 * kU) {
+          fetch(nx, base + 256 * kU);   // (unconditional: behind the row's end every lane re-reads the last piece and drops it)
 #pragma unroll
-        for (int u = 0; u < kU; ++u) {
-          const int64_t e = base + u * 64 + lane;
-          if (base + u * 64 < a.n_dense)   // uniform
-            consume(e < a.n_dense ? make_key(v[u], (int32_t)(a.idx_base + e)) : 0ull);
+          for (int u = 0; u < kU; ++u) {
+            const int64_t e = base + (int64_t)(u * 64 + lane) * 4;
+            if (base + u * 256 < n4) {   // uniform
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                consume(e + 4 <= n4 ? make_key(v[u][c], (int32_t)(a.idx_base + e + c)) : 0ull);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < kU; ++u) v[u] = nx[u];
         }
-#pragma unroll
-        for (int u = 0; u < kU; ++u) v[u] = nx[u];
+      }
+      {
+        const int64_t e = n4 + lane;
+        if (n4 < a.n_dense) consume(e < a.n_dense ? make_key(drow[e], (int32_t)(a.idx_base + e)) : 0ull);
       }
     } else {
       for (int64_t base = 0; base < a.n_dense; base += 64) {
         const int64_t e = base + lane;
-        consume(e < a.n_dense ? make_key(a.dense[row * a.ld_dense + e], (int32_t)(a.idx_base + (int64_t)a.rowmap[e])) : 0ull);
+        consume(e < a.n_dense ? make_key(a.dense[row * a.ld_dense + e],
+                                         (int32_t)(a.idx_base + (a.rowmap ? (int64_t)a.rowmap[e] : e)))
+                              : 0ull);
       }
     }
   } else if (source == kSrcExpand) {
