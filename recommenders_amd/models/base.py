@@ -523,14 +523,33 @@ class Model(torch.nn.Module):
     if self.optimizer is None:
       raise RuntimeError("Call `compile(optimizer=...)` before training.")
     allowed = self._graph_steps_allowed(graph, training=True)
+    pending = []
     for _ in range(epochs):
       self._check_capture_fingerprint()  # a changed lr / optimizer / metric object drops the captured steps
       cache = self.__dict__.setdefault("_fit_graphs", {})
       self._reset_metrics()
       logs = self._run_epoch(dataset, self.train_step, self.make_graphed_train_step, cache, allowed)
-      for k, v in self._logs_to_floats(logs).items():
-        history.setdefault(k, []).append(v)
+      # The epoch's log values stay on the device until the last epoch has been issued (one stacked copy per epoch: the
+      # logs of a replayed step are static tensors that the next epoch overwrites): reading them back here would drain
+      # the stream once per epoch -- ~0.1 ms of a 2.2 ms epoch at the MovieLens shapes -- although nothing on the host
+      # depends on them before `fit` returns.
+      pending.append(self._logs_snapshot(logs))
+    for keys, dev_keys, stacked, host_vals in pending:
+      vals = dict(host_vals)
+      if stacked is not None:
+        vals.update(zip(dev_keys, stacked.tolist()))
+      for k in keys:
+        history.setdefault(k, []).append(vals[k])
     return history
+
+  @staticmethod
+  def _logs_snapshot(logs: Dict[str, Any]):
+    """(keys, device keys, their values stacked into ONE new device tensor, host values): no synchronisation."""
+    keys = list(logs)
+    dev = [k for k in keys if isinstance(logs[k], torch.Tensor) and logs[k].is_cuda]
+    stacked = torch.stack([logs[k].detach().to(torch.float32).reshape(()) for k in dev]) if dev else None
+    host = {k: float(logs[k]) for k in keys if k not in dev}
+    return keys, dev, stacked, host
 
   @staticmethod
   def _logs_to_floats(logs: Dict[str, Any]) -> Dict[str, float]:
