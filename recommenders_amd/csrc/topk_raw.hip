@@ -60,15 +60,32 @@ struct RawGeom {
 // Direct-to-LDS copy of 16 bytes per lane, issued from inline assembly so that the prefetch of the
 // next stage stays in flight under the MFMAs of the current one (see topk_scan16.hip); completion
 // is awaited by hand (raw_wait_dma) before the barrier that ends a stage.
+// NT: the copy carries the non-temporal hint.  The guide's LDS-DMA measurements (MI355X_MICROARCH.md, "nt-weights") put
+// issued -> landed 18-19 % lower for a stream that ONE CU reads once, and these kernels hold ONE stage of prefetch per CU
+// -- their rate is 64 KiB per memory latency -- so the hint is worth what it takes off that latency: 12.5 M x 128, one
+// query tile (same-box A/B, profiles/r06_stream_nt.txt): 1 / 32 / 64 / 128 queries 1.32 / 1.37 / 1.43 / 1.57 -> 1.23 /
+// 1.29 / 1.35 / 1.51-1.54 ms.  With TWO query tiles per split (129 .. 256 queries at dim 128) the second tile re-reads
+// the rows from the XCD's L2 and the hint costs 3 %: the launchers take NT = (n_qtiles == 1).  A compile-time choice: as
+// a run-time (wave-uniform) branch around the two instructions the SAME hint made 128 / 256 queries 5-11 % slower.
+// TFRS_RAW_NT=0 (library switch): never.
+template <bool NT>
 __device__ __forceinline__ void raw_glds_copy16(const char *gsrc_lane, const char *lds_wave_base) {
   const uint32_t m0v = (uint32_t)(uintptr_t)(
       __attribute__((address_space(3))) const char *)lds_wave_base;
   uint32_t m0_saved;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(m0_saved)
-               : "v"(gsrc_lane), "s"(m0v)
-               : "memory");
+  if constexpr (NT) {
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved)
+                 : "v"(gsrc_lane), "s"(m0v)
+                 : "memory");
+  } else {
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved)
+                 : "v"(gsrc_lane), "s"(m0v)
+                 : "memory");
+  }
 }
 __device__ __forceinline__ void raw_wait_dma() {   // s_waitcnt vmcnt(0), other counters untouched
   __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8) | (0 << 14));
@@ -109,7 +126,7 @@ int launch_raw_table_write(const RawTable &table_h, RawTable *table_dev, hipStre
   return TFRS_OK;
 }
 
-template <int DP, int QG, bool MATERIALIZE>
+template <int DP, int QG, bool MATERIALIZE, bool NT>
 __global__ void __launch_bounds__(kRawThreads) rawscan_kernel(const RawScanArgs a) {
   using G = RawGeom<DP>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -192,7 +209,7 @@ __global__ void __launch_bounds__(kRawThreads) rawscan_kernel(const RawScanArgs 
       int64_t row = v0 + r;
       if (row > c1 - 1) row = c1 - 1;
       const char *p = reinterpret_cast<const char *>(raw_row_ptr(T, row, DP)) + (byte - r * G::kRowB);
-      raw_glds_copy16(p, lds + ch * kRawChunkB);
+      raw_glds_copy16<NT>(p, lds + ch * kRawChunkB);
     }
     return nullptr;
   };
@@ -202,7 +219,7 @@ __global__ void __launch_bounds__(kRawThreads) rawscan_kernel(const RawScanArgs 
     if (src0 != nullptr) {
 #pragma unroll
       for (int i = 0; i < G::kCopies; ++i)
-        raw_glds_copy16(src0 + i * (kRawWaves * 1024), smem + (wave + kRawWaves * i) * kRawChunkB);
+        raw_glds_copy16<NT>(src0 + i * (kRawWaves * 1024), smem + (wave + kRawWaves * i) * kRawChunkB);
     }
   }
   raw_wait_dma();
@@ -235,7 +252,7 @@ __global__ void __launch_bounds__(kRawThreads) rawscan_kernel(const RawScanArgs 
 #pragma unroll
     for (int m = 0; m < DP / 8; ++m) {
       if (next_src != nullptr)   // (wave-uniform) chunk wave + 4 m of the next stage
-        raw_glds_copy16(next_src + m * (kRawWaves * 1024), next_lds + m * (kRawWaves * kRawChunkB));
+        raw_glds_copy16<NT>(next_src + m * (kRawWaves * 1024), next_lds + m * (kRawWaves * kRawChunkB));
       const f32x4 v = av[m];
       // (lo | hi) lanes: v = (d0|d4, d1|d5, d2|d6, d3|d7) -> steps (d0|d1), (d2|d3), (d4|d5), (d6|d7)
       const auto s01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);
@@ -293,14 +310,27 @@ __global__ void __launch_bounds__(kRawThreads) rawscan_kernel(const RawScanArgs 
   }
 }
 
-template <int DP, int QG, bool MAT>
-static int launch_rawscan_variant(const RawScanArgs &a, hipStream_t stream) {
+// the stage copies carry the non-temporal hint when every row is read once, by one workgroup (raw_glds_copy16)
+static bool raw_nt_copies(const RawScanArgs &a) {
+  const char *e = option("TFRS_RAW_NT");
+  return a.n_qtiles == 1 && !(e && e[0] == '0');
+}
+
+template <int DP, int QG, bool MAT, bool NT>
+static int launch_rawscan_variant_nt(const RawScanArgs &a, hipStream_t stream) {
   using G = RawGeom<DP>;
-  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&rawscan_kernel<DP, QG, MAT>), G::kLdsBytes));
+  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&rawscan_kernel<DP, QG, MAT, NT>), G::kLdsBytes));
   const dim3 grid((unsigned)(a.n_qtiles * a.n_splits));
-  hipLaunchKernelGGL((rawscan_kernel<DP, QG, MAT>), grid, dim3(kRawThreads), G::kLdsBytes, stream, a);
+  hipLaunchKernelGGL((rawscan_kernel<DP, QG, MAT, NT>), grid, dim3(kRawThreads), G::kLdsBytes, stream, a);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
+}
+template <int DP, int QG, bool MAT>
+static int launch_rawscan_variant(const RawScanArgs &a, hipStream_t stream) {
+  if constexpr (!MAT) {   // (the dense round is a few stages per workgroup: no second instantiation for it)
+    if (raw_nt_copies(a)) return launch_rawscan_variant_nt<DP, QG, MAT, true>(a, stream);
+  }
+  return launch_rawscan_variant_nt<DP, QG, MAT, false>(a, stream);
 }
 
 template <int DP>
@@ -357,7 +387,7 @@ __device__ __forceinline__ uint32_t raw_pack_f16x2(float lo, float hi) {
 typedef _Float16 f16x8r __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4r __attribute__((ext_vector_type(4)));
 
-template <int DP, int QG>
+template <int DP, int QG, bool NT>
 __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArgs a) {
   using G = RawGeom<DP>;
   constexpr int KS = DP >= 16 ? DP / 16 : 1;   // MFMA steps of 16 features
@@ -450,7 +480,7 @@ __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArg
       int64_t row = v0 + r;
       if (row > c1 - 1) row = c1 - 1;
       const char *p = reinterpret_cast<const char *>(raw_row_ptr(T, row, DP)) + (byte - r * G::kRowB);
-      raw_glds_copy16(p, lds + ch * kRawChunkB);
+      raw_glds_copy16<NT>(p, lds + ch * kRawChunkB);
     }
     return nullptr;
   };
@@ -460,7 +490,7 @@ __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArg
     constexpr int kPer = (G::kCopies + 3) / 4;
 #pragma unroll
     for (int i = part * kPer; i < (part + 1) * kPer && i < G::kCopies; ++i)
-      raw_glds_copy16(src + i * (kRawWaves * 1024), lds_wave + i * (kRawWaves * kRawChunkB));
+      raw_glds_copy16<NT>(src + i * (kRawWaves * 1024), lds_wave + i * (kRawWaves * kRawChunkB));
   };
   if (nstages > 0) {
     const char *src0 = begin_stage(0, smem);
@@ -589,15 +619,20 @@ __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArg
     atomicMax(reinterpret_cast<uint32_t *>(a.norm_max), __float_as_uint(norm_run));   // >= 0
 }
 
-template <int DP, int QG>
-static int launch_rawscan16_variant(const RawScanArgs &a, hipStream_t stream) {
+template <int DP, int QG, bool NT>
+static int launch_rawscan16_variant_nt(const RawScanArgs &a, hipStream_t stream) {
   using G = RawGeom<DP>;
   static_assert(G::kLdsBytes + 768 <= 160 * 1024, "two raw stages + the counters must fit the LDS");
-  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&rawscan16_kernel<DP, QG>), G::kLdsBytes + 768));
+  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&rawscan16_kernel<DP, QG, NT>), G::kLdsBytes + 768));
   const dim3 grid((unsigned)(a.n_qtiles * a.n_splits));
-  hipLaunchKernelGGL((rawscan16_kernel<DP, QG>), grid, dim3(kRawThreads), G::kLdsBytes + 768, stream, a);
+  hipLaunchKernelGGL((rawscan16_kernel<DP, QG, NT>), grid, dim3(kRawThreads), G::kLdsBytes + 768, stream, a);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
+}
+template <int DP, int QG>
+static int launch_rawscan16_variant(const RawScanArgs &a, hipStream_t stream) {
+  return raw_nt_copies(a) ? launch_rawscan16_variant_nt<DP, QG, true>(a, stream)
+                          : launch_rawscan16_variant_nt<DP, QG, false>(a, stream);
 }
 
 // ---- the same filter for query batches of 257 .. 2048 (round 5): ONE conversion of a stage per workgroup -------
