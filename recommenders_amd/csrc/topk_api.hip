@@ -1154,7 +1154,12 @@ static bool group_uses_raw16(int64_t nq, int d, int k, const TopkTuning &t) {
 // the rows; the tiles of a split are neighbours in the XCD-aware workgroup order, so the second one reads the
 // rows from the XCD's L2
 static int raw16_qg(int64_t nq, int d) {
-  if (nq > 256 && d >= 32) return 16;     // rawscan16w_kernel: 512 queries per workgroup
+  // the 512-query workgroup (rawscan16pc_kernel) from this many queries on (TFRS_STREAM_RAW16_WIDE_FROM): beyond what
+  // ONE resident query tile holds -- 128 queries at dim 128 (four groups per wave), 256 below.  Two tiles of rawscan16_kernel
+  // read every row twice (the second time from L2): 12.5 M x 128, 129 / 192 / 256 queries 2.64 / 2.59 / 2.61 ms against
+  // 1.94 / 1.97 / 2.03 here; at dim 64 (eight groups per wave) 129 .. 256 queries measure the same either way
+  const int64_t wide_from = env_i64("TFRS_STREAM_RAW16_WIDE_FROM", d >= 128 ? 129 : 257);
+  if (nq >= std::max<int64_t>(wide_from, 1) && d >= 32) return 16;     // rawscan16w_kernel: 512 queries per workgroup
   const int cap = d <= 64 ? 8 : 4;
   const int want = nq <= 32 ? 1 : nq <= 64 ? 2 : nq <= 128 ? 4 : 8;
   return std::min(want, cap);

@@ -319,6 +319,8 @@ def test_streaming_block_fed_filter_awkward_data(seed, monkeypatch):
   ftk = _layers()
   from recommenders_amd import _lib
   monkeypatch.setenv("TFRS_STREAM_RAW16_MIN_NQ", "1")
+  if seed % 2:   # dim 128, 129 .. 256 queries: two resident tiles of four groups (the default since round 6 is the 512-query workgroup)
+    monkeypatch.setenv("TFRS_STREAM_RAW16_WIDE_FROM", "257")
   rng = np.random.default_rng(900 + seed)
   dev = torch.device("cuda", 0)
   for case in range(7):
@@ -377,6 +379,11 @@ def test_streaming_wide_block_fed_filter(seed, form, monkeypatch):
     d = int(rng.choice([16, 32, 64, 128, 128]))
     k = int(rng.choice([1, 10, 100, 300, 512]))
     nq = int(rng.choice([257, 300, 512, 513, 1000, 1025, 2048]))
+    if case % 3 == 2:   # (dim 128 takes this kernel from 129 queries on; TFRS_STREAM_RAW16_WIDE_FROM for the other dims)
+      nq = int(rng.choice([129, 130, 200, 256]))
+      monkeypatch.setenv("TFRS_STREAM_RAW16_WIDE_FROM", "129")
+    else:
+      monkeypatch.delenv("TFRS_STREAM_RAW16_WIDE_FROM", raising=False)
     n = int(rng.integers(60_000, 500_000))
     kind = ["row_scales", "dups", "negative", "clustered", "zero_blocks", "gauss"][(case + seed) % 6]
     g = torch.Generator(device=dev).manual_seed(int(rng.integers(1 << 30)))
