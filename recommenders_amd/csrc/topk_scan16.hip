@@ -94,17 +94,31 @@ struct Scan16Geom {
 // drains it with s_waitcnt vmcnt(0) right after issue -- the prefetch then never overlaps the
 // MFMAs of the current stage.  Completion is tracked by hand: `wait_dma()` before the barrier
 // that ends a stage.
+// NT: the copy carries the non-temporal hint -- for launches with ONE query tile, where a stage is read once, by one
+// workgroup (Streaming's block-fed scans, topk_raw.hip raw_glds_copy16, have the measurements behind the hint).  Here:
+// BruteForce over 12.5 M x 128 / 25 M x 64, 1 and 64 queries 0.718 / 0.774 and 0.700 / 0.721 -> 0.695 / 0.746 and 0.667 /
+// 0.695 ms (-3.3 ... -4.7 %; 256 / 512 queries -0.5 %); with several query tiles the later ones read the stage from L2 and the
+// hint costs 3 % (8192 queries), so it is a template parameter chosen by the launchers (TFRS_SCAN16_NT=0: never).
+template <bool NT = false>
 __device__ __forceinline__ void glds_copy16(const char *gsrc_lane, const char *lds_wave_base) {
   const uint32_t m0v = (uint32_t)(uintptr_t)(
       __attribute__((address_space(3))) const char *)lds_wave_base;
   // M0 (the LDS base of the copy) is a reserved register the compiler does not track through
   // inline assembly: it is saved and restored around the instruction.
   uint32_t m0_saved;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(m0_saved)
-               : "v"(gsrc_lane), "s"(m0v)
-               : "memory");
+  if constexpr (NT) {
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved)
+                 : "v"(gsrc_lane), "s"(m0v)
+                 : "memory");
+  } else {
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved)
+                 : "v"(gsrc_lane), "s"(m0v)
+                 : "memory");
+  }
 }
 __device__ __forceinline__ void wait_dma() {   // s_waitcnt vmcnt(0), other counters untouched
   __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8) | (0 << 14));
@@ -112,14 +126,14 @@ __device__ __forceinline__ void wait_dma() {   // s_waitcnt vmcnt(0), other coun
 
 // Linear stage copy HBM/L2 -> LDS (the fp16 image already has its LDS layout): every
 // wave-instruction moves 1 KiB; the stage's 16-byte StageMeta rides along into its LDS slot.
-template <int CHUNKS, int LOADS>
+template <int CHUNKS, int LOADS, bool NT = false>
 __device__ __forceinline__ void stage16_glds(const char *gsrc, char *lds_dst, const StageMeta *meta,
                                              char *lds_meta, int tid, int wave) {
 #pragma unroll
   for (int i = 0; i < LOADS; ++i) {
     const int ch0 = i * kThreads16 + wave * 64;
     if (ch0 < CHUNKS)  // wave-uniform (CHUNKS is a multiple of 64)
-      glds_copy16(gsrc + (size_t)(i * kThreads16 + tid) * 16, lds_dst + ch0 * 16);
+      glds_copy16<NT>(gsrc + (size_t)(i * kThreads16 + tid) * 16, lds_dst + ch0 * 16);
   }
   if (tid == 0) glds_copy16(reinterpret_cast<const char *>(meta), lds_meta);
 }
@@ -150,7 +164,7 @@ __device__ __forceinline__ float max16(const f32x16 &c) {
   return __builtin_fmaxf(mx3(a, b, d), mx3(e, f, c[15]));
 }
 
-template <int DP, int MODE>
+template <int DP, int MODE, bool NT = false>
 __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(const Scan16Args a) {
   using G = Scan16Geom<DP>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -258,7 +272,7 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
   const char *gsrc = a.packed16 + first_stage * (int64_t)G::kStageB;
   const int64_t gstep = stride * (int64_t)G::kStageB;
   const StageMeta *mp = a.meta + first_stage;
-  stage16_glds<G::kChunks, G::kLoads>(gsrc, smem, mp, smem + G::kMetaOff, tid, wave);
+  stage16_glds<G::kChunks, G::kLoads, NT>(gsrc, smem, mp, smem + G::kMetaOff, tid, wave);
   wait_dma();
   __syncthreads();
 
@@ -267,7 +281,7 @@ __global__ void __launch_bounds__(kThreads16, DP <= 64 ? 4 : 2) scan16_kernel(co
     const char *tile = smem + (st & 1) * G::kStageB;
     const bool more = (st + 1 < nst);
     if (more) {  // prefetch the next stage into the other buffer (its readers passed the barrier)
-      stage16_glds<G::kChunks, G::kLoads>(gsrc + (int64_t)(st + 1) * gstep,
+      stage16_glds<G::kChunks, G::kLoads, NT>(gsrc + (int64_t)(st + 1) * gstep,
                                           smem + ((st + 1) & 1) * G::kStageB,
                                           mp + (int64_t)(st + 1) * stride,
                                           smem + G::kMetaOff + ((st + 1) & 1) * 16, tid, wave);
@@ -459,14 +473,14 @@ struct Scan16FGeom : Scan16Geom<DP> {
 };
 
 // stage copy with NW waves (see stage16_glds)
-template <int CHUNKS, int LOADS, int THREADS>
+template <int CHUNKS, int LOADS, int THREADS, bool NT = false>
 __device__ __forceinline__ void stage16f_glds(const char *gsrc, char *lds_dst, const StageMeta *meta,
                                               char *lds_meta, int tid, int wave) {
 #pragma unroll
   for (int i = 0; i < LOADS; ++i) {
     const int ch0 = i * THREADS + wave * 64;
     if (ch0 < CHUNKS)  // wave-uniform (CHUNKS is a multiple of 64)
-      glds_copy16(gsrc + (size_t)(i * THREADS + tid) * 16, lds_dst + ch0 * 16);
+      glds_copy16<NT>(gsrc + (size_t)(i * THREADS + tid) * 16, lds_dst + ch0 * 16);
   }
   if (tid == 0) glds_copy16(reinterpret_cast<const char *>(meta), lds_meta);
 }
@@ -485,7 +499,7 @@ __device__ __forceinline__ uint32_t lds_atomic_inc(uint32_t *p) {
 // (Tried and dropped, round 5: one skewed sub-tile pipeline ACROSS the two stages of a period -- next stage's first A
 // fragments fetched under the current stage's last chains, stage constants switched per group at the boundary:
 // 0.931 ms against 0.895 for the plain two-stage period on the same box, profiles/r05_scan16f_shapes.txt.)
-template <int DP, int NW, int QG, int SPB = 1>
+template <int DP, int NW, int QG, int SPB = 1, bool NT = false>
 __global__ void __launch_bounds__(NW * 64, NW * QG >= 32 ? 1 : (DP <= 64 ? 2 : 1) * NW / 4) scan16f_kernel(const Scan16Args a) {
   using G = Scan16FGeom<DP, NW, QG, SPB>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -652,7 +666,7 @@ __global__ void __launch_bounds__(NW * 64, NW * QG >= 32 ? 1 : (DP <= 64 ? 2 : 1
   // stage `st` of this split's list lives in slot (period & 1) * SPB + st % SPB
   auto copy_stage = [&](int st) __attribute__((always_inline)) {
     const int slot = ((st / SPB) & 1) * SPB + (st % SPB);
-    stage16f_glds<G::kChunks, G::kLoadsF, G::kThreads>(gsrc + (int64_t)st * gstep, smem + slot * G::kStageB,
+    stage16f_glds<G::kChunks, G::kLoadsF, G::kThreads, NT>(gsrc + (int64_t)st * gstep, smem + slot * G::kStageB,
                                                        mp + (int64_t)st * a.stage_stride,
                                                        smem + G::kMetaOffF + slot * 16, tid, wave);
   };
@@ -836,12 +850,18 @@ __global__ void __launch_bounds__(NW * 64, NW * QG >= 32 ? 1 : (DP <= 64 ? 2 : 1
 }
 
 
-template <int DP, int NW, int QG, int SPB = 1>
+// one query tile: every stage is read once, by one workgroup -> the copies carry the non-temporal hint (glds_copy16)
+static bool scan16_nt_copies(const Scan16Args &a) {
+  const char *e = option("TFRS_SCAN16_NT");
+  return a.n_qtiles == 1 && !(e && e[0] == '0');
+}
+
+template <int DP, int NW, int QG, int SPB = 1, bool NT = false>
 static int launch_scan16f(const Scan16Args &a, hipStream_t stream) {
   using G = Scan16FGeom<DP, NW, QG, SPB>;
-  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&scan16f_kernel<DP, NW, QG, SPB>), G::kLdsBytesF));
+  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&scan16f_kernel<DP, NW, QG, SPB, NT>), G::kLdsBytesF));
   const dim3 grid((unsigned)((a.n_qtiles + G::kTiles - 1) / G::kTiles * a.n_splits));
-  hipLaunchKernelGGL((scan16f_kernel<DP, NW, QG, SPB>), grid, dim3(NW * 64), G::kLdsBytesF, stream, a);
+  hipLaunchKernelGGL((scan16f_kernel<DP, NW, QG, SPB, NT>), grid, dim3(NW * 64), G::kLdsBytesF, stream, a);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
 }
@@ -866,15 +886,19 @@ static int launch_scan16f_shape(const Scan16Args &a, hipStream_t stream) {
     if (pair) return launch_scan16f<DP, 16, 2, 2>(a, stream);
   }
   // (dim 128: the 16-wave instantiation needs more than 128 registers -- 15.0 ms against 3.4 -- and stays out)
+  if (!e && scan16_nt_copies(a)) return launch_scan16f<DP, 8, 2, 1, true>(a, stream);
   return launch_scan16f<DP, 8, 2>(a, stream);
 }
 
-template <int DP, int MODE>
+template <int DP, int MODE, bool NT = false>
 static int launch_scan16_variant(const Scan16Args &a, hipStream_t stream) {
   using G = Scan16Geom<DP>;
-  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&scan16_kernel<DP, MODE>), G::kLdsBytes));
+  if constexpr (MODE == kModeBinMax && !NT) {   // (the threshold pass of a one-tile batch: the sampled stages are read once)
+    if (scan16_nt_copies(a)) return launch_scan16_variant<DP, MODE, true>(a, stream);
+  }
+  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&scan16_kernel<DP, MODE, NT>), G::kLdsBytes));
   const dim3 grid((unsigned)(a.n_qtiles * a.n_splits));
-  hipLaunchKernelGGL((scan16_kernel<DP, MODE>), grid, dim3(kThreads16), G::kLdsBytes, stream, a);
+  hipLaunchKernelGGL((scan16_kernel<DP, MODE, NT>), grid, dim3(kThreads16), G::kLdsBytes, stream, a);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
 }
