@@ -278,6 +278,8 @@ int launch_rawscan(const RawScanArgs &a, bool materialize, hipStream_t stream);
 // qg: 1, 2, 4 or 8 groups of 32 queries per workgroup (n_qtiles = ceil(nq / (32 * qg))); survivors carry
 // PREFILTER scores (re-scored by launch_list_topk16 with the table), layout [nq, cap_l, nseg = n_splits]
 int launch_rawscan16(const RawScanArgs &a, hipStream_t stream);
+// dim 128, one query tile of 65 .. 128 queries: workgroups of two waves on 64-row stages, two per CU (the caller plans twice the splits)
+bool rawscan16_half(int d, int qg, int n_qtiles);
 // fp16 prefilter image (+ StageMeta, global max row norm) of the group's rows [0, table.total_rows),
 // zero rows up to the next stage boundary, straight from the row-major blocks
 int launch_pack16_raw(const RawTable *table, int64_t n_rows, int d, char *packed16, StageMeta *meta,

@@ -453,7 +453,13 @@ static int run_raw16_range(const float *q, int64_t nq, int d, const RawTable *ra
   sa.c_end = row_lo + n;
   sa.qg = qg;
   sa.n_qtiles = (int)((nq + 32 * qg - 1) / (32 * qg));
-  plan_splits(n, sa.n_qtiles, t, &sa.split_len, &sa.n_splits);
+  if (rawscan16_half(d, qg, sa.n_qtiles)) {   // two-wave workgroups, two per CU: twice the splits (topk_raw.hip)
+    TopkTuning t2 = t;
+    t2.target_wgs = std::min<int64_t>(2 * t.target_wgs, 2 * (int64_t)max_splits(nq, t));   // (nseg <= 2 * max_splits: the list budget)
+    plan_splits(n, sa.n_qtiles, t2, &sa.split_len, &sa.n_splits);
+  } else {
+    plan_splits(n, sa.n_qtiles, t, &sa.split_len, &sa.n_splits);
+  }
   sa.nseg = sa.n_splits;
   sa.cap_l = segment_cap(k, sa.nseg, t);
   if ((int64_t)sa.nseg * sa.cap_l > w.entries || sa.nseg > 2 * max_splits(nq, t)) {

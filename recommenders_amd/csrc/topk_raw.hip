@@ -45,16 +45,19 @@ constexpr int kRawWaves = 4;
 constexpr int kRawThreads = kRawWaves * 64;
 constexpr int kRawChunkB = 1040;   // 1 KiB of rows + 16 bytes of padding
 
-template <int DP>
+// NWV waves per workgroup = 32 * NWV rows per stage (kTileN with the default four waves; rawscan16_kernel also runs as
+// TWO waves on 64-row stages: two workgroups per CU at dim 128, see there)
+template <int DP, int NWV = kRawWaves>
 struct RawGeom {
+  static constexpr int kTile = 32 * NWV;                      // rows per stage
   static constexpr int kRowB = DP * 4;
   static constexpr int kRowsPerChunk = 1024 / kRowB;          // 2 (DP = 128) .. 32 (DP = 8)
-  static constexpr int kChunks = kTileN / kRowsPerChunk;      // DP / 2
-  static constexpr int kCopies = kChunks / kRawWaves;         // copy instructions per wave and stage
+  static constexpr int kChunks = kTile / kRowsPerChunk;       // DP / 2 with four waves
+  static constexpr int kCopies = kChunks / NWV;               // copy instructions per wave and stage
   static constexpr int kStageB = kChunks * kRawChunkB;
   static constexpr int kCntOff = 2 * kStageB;                 // uint32 [64] workgroup survivor counters
   static constexpr int kLdsBytes = 2 * kStageB + 64 * 4;
-  static_assert(kChunks % kRawWaves == 0, "every wave issues the same number of stage copies");
+  static_assert(kChunks % NWV == 0 && kChunks >= NWV, "every wave issues the same number of stage copies");
 };
 
 // Direct-to-LDS copy of 16 bytes per lane, issued from inline assembly so that the prefetch of the
@@ -387,9 +390,10 @@ __device__ __forceinline__ uint32_t raw_pack_f16x2(float lo, float hi) {
 typedef _Float16 f16x8r __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4r __attribute__((ext_vector_type(4)));
 
-template <int DP, int QG, bool NT>
-__global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArgs a) {
-  using G = RawGeom<DP>;
+template <int DP, int QG, bool NT, int NWV = kRawWaves>
+__global__ void __launch_bounds__(NWV * 64) rawscan16_kernel(const RawScanArgs a) {
+  using G = RawGeom<DP, NWV>;
+  constexpr int kTile = G::kTile;   // rows per stage
   constexpr int KS = DP >= 16 ? DP / 16 : 1;   // MFMA steps of 16 features
   constexpr int NV = DP >= 16 ? DP / 8 : 2;    // 16-byte pieces a lane holds: half of its row (DP = 8: the row, lane half 0)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -415,7 +419,7 @@ __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArg
   const int64_t c0 = a.c_begin + (int64_t)split * a.split_len;
   int64_t c1 = c0 + a.split_len;
   if (c1 > a.c_end) c1 = a.c_end;
-  const int nstages = c0 < c1 ? (int)((c1 - c0 + kTileN - 1) / kTileN) : 0;
+  const int nstages = c0 < c1 ? (int)((c1 - c0 + kTile - 1) / kTile) : 0;
 
   // ---- the tile's queries -> fp16 MFMA B operands (q / qscale), resident -------------------------
   f16x8r bq[QG][KS];
@@ -447,7 +451,7 @@ __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArg
     fqk[g] = qvalid ? qk_ld * qinv : 0.0f;
     qsc[g] = qs;
   }
-  wg_cnt[tid] = 0u;   // 256 threads, 256 counters
+  for (int e = tid; e < 256; e += NWV * 64) wg_cnt[e] = 0u;   // 256 counters
 
   // ---- block cursor and stage prefetch: as in rawscan_kernel ------------------------------------
   const RawTable *T = a.table;
@@ -461,20 +465,20 @@ __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArg
   // The caller spreads them over the phases of the stage (copy_part).  Returns the lane's source address
   // of chunk `wave` (NULL: the copies were issued here).
   auto begin_stage = [&](int st, char *lds) -> const char * {
-    const int64_t v0 = c0 + (int64_t)st * kTileN;
+    const int64_t v0 = c0 + (int64_t)st * kTile;
     while (v0 >= blk_hi && blk + 1 < nblk) {
       ++blk;
       blk_lo = blk_hi;
       blk_hi = T->row_start[blk + 1];
       blk_ptr = reinterpret_cast<const char *>(T->ptr[blk]);
     }
-    if (v0 + kTileN <= blk_hi && v0 + kTileN <= c1)   // the whole stage lies in one block: a linear copy
+    if (v0 + kTile <= blk_hi && v0 + kTile <= c1)   // the whole stage lies in one block: a linear copy
       return blk_ptr + (v0 - blk_lo) * (int64_t)G::kRowB + wave * 1024 + lane * 16;
     // block boundary or the last, partly filled stage: every lane looks its row up; rows at or
     // beyond c1 re-read the last valid row (their scores are never used)
 #pragma unroll 1
     for (int i = 0; i < G::kCopies; ++i) {
-      const int ch = wave + kRawWaves * i;
+      const int ch = wave + NWV * i;
       const int byte = ch * 1024 + lane * 16;
       const int r = byte / G::kRowB;
       int64_t row = v0 + r;
@@ -490,7 +494,7 @@ __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArg
     constexpr int kPer = (G::kCopies + 3) / 4;
 #pragma unroll
     for (int i = part * kPer; i < (part + 1) * kPer && i < G::kCopies; ++i)
-      raw_glds_copy16<NT>(src + i * (kRawWaves * 1024), lds_wave + i * (kRawWaves * kRawChunkB));
+      raw_glds_copy16<NT>(src + i * (NWV * 1024), lds_wave + i * (NWV * kRawChunkB));
   };
   if (nstages > 0) {
     const char *src0 = begin_stage(0, smem);
@@ -512,7 +516,7 @@ __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArg
     const bool more = st + 1 < nstages;
     char *next_lds = smem + ((st + 1) & 1) * G::kStageB + wave * kRawChunkB;
     const char *next_src = more ? begin_stage(st + 1, smem + ((st + 1) & 1) * G::kStageB) : nullptr;
-    const int64_t stage_c = c0 + (int64_t)st * kTileN;
+    const int64_t stage_c = c0 + (int64_t)st * kTile;
 
     // ---- the lane's half row; norm and max |x| of the wave's 32 rows ------------------------------
     const char *ap = tile + a_off;
@@ -577,11 +581,11 @@ __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArg
         // (round 5, as in rawscan16w_kernel: 32-bit row arithmetic relative to the split and ONE counter round trip
         // per lane and hot tile instead of sixteen dependent ones)
         const float un = qsc[g] * cs;
-        const uint32_t rel_stage = (uint32_t)st * kTileN;
+        const uint32_t rel_stage = (uint32_t)st * kTile;
         uint32_t hits = 0u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) hits |= acc[r] > thr ? (1u << r) : 0u;
-        if (rel_stage + kTileN > rows_here) {   // (uniform) the split's last, partly filled stage: rows beyond it score nothing
+        if (rel_stage + kTile > rows_here) {   // (uniform) the split's last, partly filled stage: rows beyond it score nothing
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int t = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -611,26 +615,42 @@ __global__ void __launch_bounds__(kRawThreads) rawscan16_kernel(const RawScanArg
 
   // every (query, split) count is written: no memset needed (counts beyond cap_l flag the query for
   // the exact redo, as the image-fed filter kernel does)
-  if (tid < QG * 32) {   // (the stage loop ends with a barrier)
-    const int64_t qr = ((int64_t)qt * QG + (tid >> 5)) * 32 + (tid & 31);
-    if (qr < a.nq) a.cnt[qr * a.nseg + split] = wg_cnt[tid];
+  for (int e = tid; e < QG * 32; e += NWV * 64) {   // (the stage loop ends with a barrier)
+    const int64_t qr = ((int64_t)qt * QG + (e >> 5)) * 32 + (e & 31);
+    if (qr < a.nq) a.cnt[qr * a.nseg + split] = wg_cnt[e];
   }
   if (nstages > 0 && lane == 0 && a.norm_max)
     atomicMax(reinterpret_cast<uint32_t *>(a.norm_max), __float_as_uint(norm_run));   // >= 0
 }
 
-template <int DP, int QG, bool NT>
+template <int DP, int QG, bool NT, int NWV = kRawWaves>
 static int launch_rawscan16_variant_nt(const RawScanArgs &a, hipStream_t stream) {
-  using G = RawGeom<DP>;
+  using G = RawGeom<DP, NWV>;
   static_assert(G::kLdsBytes + 768 <= 160 * 1024, "two raw stages + the counters must fit the LDS");
-  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&rawscan16_kernel<DP, QG, NT>), G::kLdsBytes + 768));
+  TFRS_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(&rawscan16_kernel<DP, QG, NT, NWV>), G::kLdsBytes + 768));
   const dim3 grid((unsigned)(a.n_qtiles * a.n_splits));
-  hipLaunchKernelGGL((rawscan16_kernel<DP, QG, NT>), grid, dim3(kRawThreads), G::kLdsBytes + 768, stream, a);
+  hipLaunchKernelGGL((rawscan16_kernel<DP, QG, NT, NWV>), grid, dim3(NWV * 64), G::kLdsBytes + 768, stream, a);
   TFRS_LAUNCH_CHECK();
   return TFRS_OK;
 }
+// Dim 128: two 64 KiB stages fill the LDS -- ONE workgroup of four waves per CU, whose copies of the next stage are all
+// issued in the first third of a stage and awaited at its end.  Two workgroups of TWO waves on 64-row stages (2 x 33 KB
+// each) run out of step.  Measured on 12.5 M x 128 (same box, alternating): with four query groups per wave (65 .. 128
+// queries) 96 / 128 queries 1.49 / 1.55 -> 1.455 / 1.51 ms; with one or two groups the four-wave form is 2-3 % FASTER
+// (1.239 / 1.317 / 1.385 against 1.27 / 1.357 / 1.412 ms at 1 / 32 / 64 queries: twice the splits = twice the survivor
+// segments for the list kernel, and the scan was at the copy engine's rate already) -- so only four groups take it
+// (topk_api.hip doubles the number of splits for these launches; TFRS_RAW16_HALF=0: never).
+bool rawscan16_half(int d, int qg, int n_qtiles) {
+  const char *e = option("TFRS_RAW16_HALF");
+  return d == 128 && qg == 4 && n_qtiles == 1 && !(e && e[0] == '0');
+}
 template <int DP, int QG>
 static int launch_rawscan16_variant(const RawScanArgs &a, hipStream_t stream) {
+  if constexpr (DP == 128 && QG == 4) {
+    if (rawscan16_half(a.d, a.qg, a.n_qtiles))
+      return raw_nt_copies(a) ? launch_rawscan16_variant_nt<DP, QG, true, 2>(a, stream)
+                              : launch_rawscan16_variant_nt<DP, QG, false, 2>(a, stream);
+  }
   return raw_nt_copies(a) ? launch_rawscan16_variant_nt<DP, QG, true>(a, stream)
                           : launch_rawscan16_variant_nt<DP, QG, false>(a, stream);
 }
