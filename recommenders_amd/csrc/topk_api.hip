@@ -453,12 +453,16 @@ static int run_raw16_range(const float *q, int64_t nq, int d, const RawTable *ra
   sa.c_end = row_lo + n;
   sa.qg = qg;
   sa.n_qtiles = (int)((nq + 32 * qg - 1) / (32 * qg));
-  if (rawscan16_half(d, qg, sa.n_qtiles)) {   // two-wave workgroups, two per CU: twice the splits (topk_raw.hip)
+  {
+    // TFRS_TOPK_WGS (512) counts two resident workgroups per CU, which is what the image-fed filters and the block-fed
+    // ones up to dim 64 hold.  At dim 128 two raw stages fill the LDS: ONE workgroup per CU, and 512 splits ran as two
+    // rounds -- 12.5 M x 128, 1 / 64 / 128 / 512 queries 1.20 / 1.34 / 1.47 / 2.60 ms against 1.18 / 1.305 / 1.42 / 2.565 with
+    // one round (384 splits, a round and a half: 1.41 / 1.59 / 1.71 / 3.06).  The two-wave form (rawscan16_half) holds two.
     TopkTuning t2 = t;
-    t2.target_wgs = std::min<int64_t>(2 * t.target_wgs, 2 * (int64_t)max_splits(nq, t));   // (nseg <= 2 * max_splits: the list budget)
+    if (d >= 128) t2.target_wgs = std::max<int64_t>(1, t.target_wgs / 2);
+    if (rawscan16_half(d, qg, sa.n_qtiles))
+      t2.target_wgs = std::min<int64_t>(2 * t2.target_wgs, 2 * (int64_t)max_splits(nq, t));   // (nseg <= 2 * max_splits: the list budget)
     plan_splits(n, sa.n_qtiles, t2, &sa.split_len, &sa.n_splits);
-  } else {
-    plan_splits(n, sa.n_qtiles, t, &sa.split_len, &sa.n_splits);
   }
   sa.nseg = sa.n_splits;
   sa.cap_l = segment_cap(k, sa.nseg, t);
