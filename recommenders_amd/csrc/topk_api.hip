@@ -459,7 +459,9 @@ static int run_raw16_range(const float *q, int64_t nq, int d, const RawTable *ra
     // rounds -- 12.5 M x 128, 1 / 64 / 128 / 512 queries 1.20 / 1.34 / 1.47 / 2.60 ms against 1.18 / 1.305 / 1.42 / 2.565 with
     // one round (384 splits, a round and a half: 1.41 / 1.59 / 1.71 / 3.06).  The two-wave form (rawscan16_half) holds two.
     TopkTuning t2 = t;
-    if (d >= 128) t2.target_wgs = std::max<int64_t>(1, t.target_wgs / 2);
+    // (eight query groups per wave -- 129 .. 256 queries up to dim 64 -- need more than 128 registers: one workgroup per CU
+    // as well; 25 M x 64, 256 queries 2.41 -> 2.35 ms)
+    if (d >= 128 || qg == 8) t2.target_wgs = std::max<int64_t>(1, t.target_wgs / 2);
     if (rawscan16_half(d, qg, sa.n_qtiles))
       t2.target_wgs = std::min<int64_t>(2 * t2.target_wgs, 2 * (int64_t)max_splits(nq, t));   // (nseg <= 2 * max_splits: the list budget)
     plan_splits(n, sa.n_qtiles, t2, &sa.split_len, &sa.n_splits);

@@ -5,8 +5,8 @@ from recommenders_amd.layers import factorized_top_k as ftk
 from recommenders_amd import _lib
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(5)
-d = 128
-n, k, bs = 12_500_000, 100, 65536
+d = int(os.environ.get("DIM", 128))
+n, k, bs = (12_500_000 * 128 // d), 100, 65536
 corpus = torch.randn((n, d), generator=g, device=dev) / d ** 0.5
 class Blocks:
   def __iter__(self):
@@ -19,7 +19,7 @@ def t(fn, it=9):
   for a,b in ev: a.record(); fn(); b.record()
   torch.cuda.synchronize()
   return sorted(a.elapsed_time(b) for a,b in ev)[it//2]
-for nq in (1, 64, 128, 512):
+for nq in [int(x) for x in os.environ.get("NQS", "1,64,128,512").split(",")]:
   q = torch.randn((nq, d), generator=g, device=dev) / d ** 0.5
   r = {"nq": nq}
   for rep in range(2):
