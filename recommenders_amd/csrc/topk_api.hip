@@ -564,7 +564,14 @@ static int run_f16(const float *q, int64_t nq, int d, const char *packed, const 
   s16.binmax = nullptr;
   s16.n_stages = (int)all_stages;
   s16.stage_stride = 1;
-  plan_stage_splits(all_stages, n_qtiles, t, &s16.stages_per_split, &s16.n_splits);
+  {
+    // dim 128: two 34.8 KB stages + the survivor queues leave room for ONE filter workgroup per CU (scan16f_kernel<128, 8, 2>:
+    // 111 KB of LDS), so TFRS_TOPK_WGS = 512 -- two per CU -- ran as two rounds: one round measures - 3.8 / - 2.4 / - 1.8 % at
+    // 1 / 64 / 512 queries over 12.5 M x 128 and - 5 ... 6 % up to 1024 queries over 2 M x 128 (8192 queries: - 0.3 ... 0.5 %)
+    TopkTuning tf = t;
+    if (padded_dim16(d) >= 128) tf.target_wgs = std::max<int64_t>(1, t.target_wgs / 2);
+    plan_stage_splits(all_stages, n_qtiles, tf, &s16.stages_per_split, &s16.n_splits);
+  }
   s16.lower = w.thr;
   s16.cnt = w.cnt;
   s16.buf = w.buf;
